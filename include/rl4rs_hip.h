@@ -1,0 +1,243 @@
+/*
+ * rl4rs_hip.h — C ABI of librl4rs_hip.so: the MI355X (gfx950) implementation of the RL4RS batched
+ * env.step() hot path (boundary row b).
+ *
+ * The reference is pure Python; it has no FFI.  Each entry point below replaces the Python call a
+ * reference maintainer would bind through ctypes; the reference interface it
+ * replaces is cited as rl4rs/<file>:<line>.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative RL4RS_E* code on failure; the message of the
+ *     last failure on the calling thread is available from rl4rs_last_error().
+ *   - "dev" pointers are device (HBM) addresses, "host" pointers are host addresses; the caller owns
+ *     every buffer it passes in; handles own their internal state.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work on
+ *     that stream: no allocation, no host synchronisation inside step / forward calls.
+ *   - a handle is bound to the HIP device that was current when it was created and is not thread-safe.
+ *   - plain C types only: no torch / STL types cross this boundary.
+ */
+#ifndef RL4RS_HIP_H
+#define RL4RS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL4RS_ABI_VERSION 1
+
+enum {
+    RL4RS_OK = 0,
+    RL4RS_EINVAL = -1,   /* bad argument / configuration */
+    RL4RS_EHIP = -2,     /* a HIP runtime call failed */
+    RL4RS_ESTATE = -3,   /* call not valid in the handle's current state (e.g. step past the horizon) */
+    RL4RS_ENOMEM = -4
+};
+
+const char* rl4rs_last_error(void);
+int rl4rs_abi_version(void);
+/* number of HIP devices visible; <0 on error.  The library never falls back to a CPU path. */
+int rl4rs_device_count(void);
+
+/* Async device-to-device copy on `stream` (lets a host binding snapshot env-owned buffers into
+ * caller-owned ones without linking the HIP runtime itself). */
+int rl4rs_copy_d2d(void* dst_dev, const void* src_dev, int64_t n_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Env state machine: SlateState / SeqSlateState (rl4rs/env/slate.py:8-214, rl4rs/env/seqslate.py:8-126)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct rl4rs_env rl4rs_env;
+
+typedef struct rl4rs_env_cfg {
+    int32_t batch_size;            /* config['batch_size']                       slate.py:11 */
+    int32_t max_steps;             /* config['max_steps']                        slate.py:14 */
+    int32_t action_size;           /* config['action_size']                      slate.py:12 */
+    int32_t action_emb_size;       /* config['action_emb_size'] (32)             slate.py:13 */
+    int32_t page_items;            /* config['page_items'] (9)                   seqslate.py:11 */
+    int32_t item_dim;              /* len(item_vec) (40)                         slate.py:35 */
+    int32_t user_dense_dim;        /* len(user_protrait[10:]) (32)               slate.py:78 */
+    int32_t user_cat_dim;          /* len(user_protrait[:10]) (10)               slate.py:79 */
+    int32_t maxlen;                /* config['maxlen'] (64)                      datautil.py:12 */
+    int32_t dense_feature_num;     /* config['dense_feature_num'] (432)          datautil.py:15 */
+    int32_t category_feature_num;  /* config['category_feature_num'] (21)        datautil.py:16 */
+    int32_t log_steps;             /* columns of exposed_items / user_feedback in the loaded batch */
+    int32_t is_seq;                /* 0 = SlateState rules, 1 = SeqSlateState rules */
+    int32_t violation_zeroes_reward; /* slate.py:303-307 (always) / seqslate.py:154-157 (mask modes only) */
+} rl4rs_env_cfg;
+
+int rl4rs_env_create(const rl4rs_env_cfg* cfg, rl4rs_env** out);
+int rl4rs_env_destroy(rl4rs_env* env);
+
+/* Catalogue tables parsed on the host from item_info.csv
+ * (SlateState.get_iteminfo_from_file slate.py:28-53, get_mask_from_file slate.py:55-65).
+ *   item_vec_host     [action_size, item_dim] float32 (row 0 = zeros)
+ *   price_host        [action_size] float64
+ *   action_emb_host   [action_size, action_emb_size] float64
+ *   is_special_host   [action_size] uint8
+ *   location_mask_host[4, action_size] uint8
+ */
+int rl4rs_env_set_catalog(rl4rs_env* env, const float* item_vec_host, const double* price_host,
+                          const double* action_emb_host, const uint8_t* is_special_host,
+                          const uint8_t* location_mask_host, void* stream);
+
+/* One sampled batch of log records in columnar form (RecDataBase.sample base.py:92-100 +
+ * SlateState.records_to_state slate.py:67-83 + pad_sequences of the history, datautil.py:43-46).
+ * Device pointers; copied into the env (async on `stream`).
+ *   exposed_dev   [B, log_steps] int32      exposed_items
+ *   feedback_dev  [B, log_steps] int32      user_feedback
+ *   history_dev   [B, maxlen]    int32      user_seqfeature, pre-padded / pre-truncated
+ *   user_dense_dev[B, user_dense_dim] float32
+ *   user_cat_dev  [B, user_cat_dim]   int32
+ */
+int rl4rs_env_load_batch(rl4rs_env* env, const int32_t* exposed_dev, const int32_t* feedback_dev,
+                         const int32_t* history_dev, const float* user_dense_dev,
+                         const int32_t* user_cat_dev, void* stream);
+
+/* RecState.__init__ (base.py:27-31) + SlateState.__init__ (slate.py:15-19): zero prev_actions, masks
+ * to all-ones, cur_steps = 0, feature rows = the un-acted state. */
+int rl4rs_env_reset(rl4rs_env* env, void* stream);
+
+/* SlateState.act / SeqSlateState.act with integer actions (slate.py:198-214, seqslate.py:98-126). */
+int rl4rs_env_act_discrete(rl4rs_env* env, const int32_t* actions_dev, void* stream);
+
+/* Continuous actions: masked K-NN argmax in float64 (slate.py:187-197, seqslate.py:93-97) followed by
+ * act.  `actions_dev` is [B, action_emb_size] float32 (is_f64 = 0) or float64 (is_f64 = 1);
+ * `chosen_dev` (optional) receives the item ids that were played. */
+int rl4rs_env_act_conti(rl4rs_env* env, const void* actions_dev, int is_f64, int32_t* chosen_dev,
+                        void* stream);
+
+/* SlateState.get_nearest_neighbor (slate.py:180-184, static, unmasked): [n,E] -> [n]. */
+int rl4rs_knn(const void* actions_dev, int is_f64, int32_t n, const double* action_emb_dev,
+              int32_t action_size, int32_t emb_size, int32_t* out_dev, void* stream);
+
+/* get_complete_states + feature_extraction for the reward rows (slate.py:117-131,289-294;
+ * seqslate.py:27-50,141-146): fills the env's complete-state buffers ([B*n, ...], env-major). */
+int rl4rs_env_build_complete(rl4rs_env* env, void* stream);
+/* rows per env produced by build_complete: max_steps (Slate) or page_items (SeqSlate). */
+int rl4rs_env_complete_rows(const rl4rs_env* env);
+/* 1 when SlateRecEnv.forward / SeqSlateRecEnv.forward would call the reward net now
+ * (slate.py:283, seqslate.py:138). */
+int rl4rs_env_is_reward_step(const rl4rs_env* env);
+int rl4rs_env_cur_steps(const rl4rs_env* env);
+
+/* reward = sum_j price*prob in float64 (numpy pairwise order), zeroed on violation
+ * (slate.py:298-307, seqslate.py:150-157).  probs_dev [B, n] float32, reward_dev [B] float64. */
+int rl4rs_env_reward(rl4rs_env* env, const float* probs_dev, double* reward_dev, void* stream);
+
+/* get_violation (slate.py:133-147, seqslate.py:52-69): out_dev [B] int32 in {0,1}. */
+int rl4rs_env_violation(rl4rs_env* env, int32_t* out_dev, void* stream);
+
+/* state['action_mask'] = action_mask & location_mask[layer(post-increment cur_steps)] & special_mask
+ * (slate.py:92-97, seqslate.py:15-17).  out_dev [B, action_size]; dtype: 0=uint8 1=int32 2=int64 3=float32 */
+int rl4rs_env_obs_mask(rl4rs_env* env, void* out_dev, int dtype, void* stream);
+
+/* offline_action (slate.py:149-162): ids_dev [B] int32, and/or emb_dev [B, E] float64 (conti mode). */
+int rl4rs_env_offline_action(rl4rs_env* env, int32_t* ids_dev, double* emb_dev, void* stream);
+/* offline_reward (slate.py:164-174, seqslate.py:71-86): out_dev [B] float64. */
+int rl4rs_env_offline_reward(rl4rs_env* env, double* out_dev, void* stream);
+
+/* Device views of env-owned buffers (valid until destroy).  `which`: */
+enum {
+    RL4RS_BUF_PREV_ACTIONS = 0,   /* int32  [B, max_steps] */
+    RL4RS_BUF_ACTION_MASK = 1,    /* uint32 [B, ceil(A/32)] bit k of word k/32 = action_mask[b,k] */
+    RL4RS_BUF_SPECIAL_MASK = 2,   /* uint32 [B, ceil(A/32)] */
+    RL4RS_BUF_DENSE = 3,          /* float32 [B, dense_feature_num]      feature_extraction()[1] */
+    RL4RS_BUF_CATEGORY = 4,       /* int32  [B, category_feature_num]    feature_extraction()[2] */
+    RL4RS_BUF_SEQ0 = 5,           /* int32  [B, maxlen]                  sequence 0 (history)     */
+    RL4RS_BUF_SEQ1 = 6,           /* int32  [B, maxlen]                  sequence 1               */
+    RL4RS_BUF_C_DENSE = 7,        /* float32 [B*n, dense_feature_num]    complete-state rows      */
+    RL4RS_BUF_C_CATEGORY = 8,     /* int32  [B*n, category_feature_num] */
+    RL4RS_BUF_ERROR_FLAG = 9      /* int32  [1]  sticky: 1 = an action id outside [0, action_size) */
+};
+int rl4rs_env_buffer(rl4rs_env* env, int which, void** dev_ptr, int64_t* n_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * DIEN simulator net: rl4rs/nets/dien.py:8-45, rl4rs/nets/utils.py:16-25,48-54,100-129,
+ * called from SlateRecEnv.obs_fn / forward (slate.py:265-267, 295-297) as obs_layer / reward_layer.
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct rl4rs_dien rl4rs_dien;
+
+typedef struct rl4rs_dien_cfg {
+    int32_t maxlen;                /* 64  */
+    int32_t emb_size;              /* 128 */
+    int32_t hidden_units;          /* 128 */
+    int32_t dense_feature_num;     /* 432 */
+    int32_t category_feature_num;  /* 21  */
+    int32_t category_hash_size;    /* 100000 */
+    int32_t seq_num;               /* 2   */
+    int32_t class_num;             /* 2   */
+    int32_t max_rows;              /* largest R passed to rl4rs_dien_forward */
+    int32_t max_slots;             /* sequence-cache slots per sequence input */
+} rl4rs_dien_cfg;
+
+/* Host pointers to float32 arrays, shapes in rl4rs_amd/nets/dien.py (dien_spec). seq arrays have
+ * seq_num entries (max 4). */
+typedef struct rl4rs_dien_weights {
+    const float* cat_emb;
+    const float* dense_w1; const float* dense_b1;
+    const float* dense_w2; const float* dense_b2;
+    const float* seq_emb;
+    const float* gru_gate_w[4];   const float* gru_gate_b[4];
+    const float* gru_cand_w[4];   const float* gru_cand_b[4];
+    const float* att_w1[4]; const float* att_b1[4];
+    const float* att_w2[4]; const float* att_b2[4];
+    const float* att_w3[4]; const float* att_b3[4];
+    const float* augru_gate_w[4]; const float* augru_gate_b[4];
+    const float* augru_cand_w[4]; const float* augru_cand_b[4];
+    const float* obs_w; const float* obs_b;
+    const float* out_w; const float* out_b;
+} rl4rs_dien_weights;
+
+int rl4rs_dien_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, void* stream,
+                      rl4rs_dien** out);
+int rl4rs_dien_destroy(rl4rs_dien* net);
+
+/* Encode `n` id sequences of sequence input `s` into cache slots [slot_base, slot_base+n):
+ * embedding lookup + first GRU over all maxlen steps (utils.py:119-120) and the input-side
+ * projections of the attention MLP / AUGRU that depend only on it.  ids_dev [n, maxlen] int32. */
+int rl4rs_dien_encode(rl4rs_dien* net, int32_t s, const int32_t* ids_dev, int32_t n,
+                      int32_t slot_base, void* stream);
+
+/* Forward R rows (obs_layer / reward_layer, slate.py:265-267,295-297).
+ *   dense_dev [R, dense_feature_num] f32, cat_dev [R, category_feature_num] i32
+ *   slot_dev  [seq_num, R/group] int32: cache slot of sequence input s for each group of `group`
+ *             consecutive rows (rows of one env share their sequences)
+ *   obs_dev   [R, 256] f32  'simulator_obs' activations (may be NULL)
+ *   prob_dev  [R] f32       softmax('simulator_reward')[:, 1] (may be NULL)
+ */
+int rl4rs_dien_forward(rl4rs_dien* net, int32_t R, int32_t group, const float* dense_dev,
+                       const int32_t* cat_dev, const int32_t* slot_dev, float* obs_dev,
+                       float* prob_dev, void* stream);
+
+/* Intermediate activations for parity tests; `which`: */
+enum {
+    RL4RS_DIEN_ALL_FEATURE = 0,   /* float32 [max_rows, 2*2E*seq_num/2 + U + (Cn+1)E] concat input of simulator_obs */
+    RL4RS_DIEN_SCORES = 1,        /* float32 [seq_num, max_rows, maxlen] attention scores */
+    RL4RS_DIEN_QUERY = 2,         /* float32 [max_rows, E] */
+    RL4RS_DIEN_H1 = 3             /* float32 [seq_num, max_slots, maxlen, E] first-GRU states */
+};
+int rl4rs_dien_buffer(rl4rs_dien* net, int which, void** dev_ptr, int64_t* n_bytes);
+
+/* Per-kernel HIP-event timing (bench.py roofline).  With profiling enabled every kernel class launched
+ * by rl4rs_dien_encode / rl4rs_dien_forward is bracketed by an event pair on the caller's stream.
+ * rl4rs_dien_profile_read synchronises on the recorded pairs and returns the cumulative milliseconds
+ * and launch count of kernel class `which` since the last reset. */
+int rl4rs_dien_set_profiling(rl4rs_dien* net, int enable);
+int rl4rs_dien_kernel_count(void);
+const char* rl4rs_dien_kernel_name(int which);
+int rl4rs_dien_profile_read(rl4rs_dien* net, int which, double* ms_total, int64_t* launches);
+int rl4rs_dien_profile_reset(rl4rs_dien* net);
+
+/* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
+ * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */
+int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,
+                   const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                   int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL4RS_HIP_H */

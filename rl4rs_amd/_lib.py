@@ -1,0 +1,131 @@
+"""ctypes binding of librl4rs_hip.so (C ABI declared in include/rl4rs_hip.h).
+
+There is NO CPU fallback: if the shared object is missing, or no HIP device is visible when a device
+handle is created, this module raises.  Build the library with ``python -m rl4rs_amd.build`` or
+``__graft_entry__.build()``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'librl4rs_hip.so')
+
+OK = 0
+
+
+class Rl4rsHipError(RuntimeError):
+    pass
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'batch_size', 'max_steps', 'action_size', 'action_emb_size', 'page_items', 'item_dim',
+        'user_dense_dim', 'user_cat_dim', 'maxlen', 'dense_feature_num', 'category_feature_num',
+        'log_steps', 'is_seq', 'violation_zeroes_reward')]
+
+
+class DienCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num',
+        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots')]
+
+
+_FP = C.POINTER(C.c_float)
+_FP4 = _FP * 4
+
+
+class DienWeights(C.Structure):
+    _fields_ = [
+        ('cat_emb', _FP),
+        ('dense_w1', _FP), ('dense_b1', _FP), ('dense_w2', _FP), ('dense_b2', _FP),
+        ('seq_emb', _FP),
+        ('gru_gate_w', _FP4), ('gru_gate_b', _FP4), ('gru_cand_w', _FP4), ('gru_cand_b', _FP4),
+        ('att_w1', _FP4), ('att_b1', _FP4), ('att_w2', _FP4), ('att_b2', _FP4),
+        ('att_w3', _FP4), ('att_b3', _FP4),
+        ('augru_gate_w', _FP4), ('augru_gate_b', _FP4), ('augru_cand_w', _FP4), ('augru_cand_b', _FP4),
+        ('obs_w', _FP), ('obs_b', _FP), ('out_w', _FP), ('out_b', _FP),
+    ]
+
+
+class PolicyCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('obs_dim', 'hidden', 'action_size', 'max_rows')]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/rl4rs_hip.h declares
+_P = C.c_void_p
+_I = C.c_int
+_I32 = C.c_int32
+_I64 = C.c_int64
+SIGNATURES = {
+    'rl4rs_last_error': (C.c_char_p, []),
+    'rl4rs_abi_version': (_I, []),
+    'rl4rs_device_count': (_I, []),
+    'rl4rs_copy_d2d': (_I, [_P, _P, _I64, _P]),
+    'rl4rs_env_create': (_I, [C.POINTER(EnvCfg), C.POINTER(_P)]),
+    'rl4rs_env_destroy': (_I, [_P]),
+    'rl4rs_env_set_catalog': (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_env_load_batch': (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_env_reset': (_I, [_P, _P]),
+    'rl4rs_env_act_discrete': (_I, [_P, _P, _P]),
+    'rl4rs_env_act_conti': (_I, [_P, _P, _I, _P, _P]),
+    'rl4rs_knn': (_I, [_P, _I, _I32, _P, _I32, _I32, _P, _P]),
+    'rl4rs_env_build_complete': (_I, [_P, _P]),
+    'rl4rs_env_complete_rows': (_I, [_P]),
+    'rl4rs_env_is_reward_step': (_I, [_P]),
+    'rl4rs_env_cur_steps': (_I, [_P]),
+    'rl4rs_env_reward': (_I, [_P, _P, _P, _P]),
+    'rl4rs_env_violation': (_I, [_P, _P, _P]),
+    'rl4rs_env_obs_mask': (_I, [_P, _P, _I, _P]),
+    'rl4rs_env_offline_action': (_I, [_P, _P, _P, _P]),
+    'rl4rs_env_offline_reward': (_I, [_P, _P, _P]),
+    'rl4rs_env_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
+    'rl4rs_dien_create': (_I, [C.POINTER(DienCfg), C.POINTER(DienWeights), _P, C.POINTER(_P)]),
+    'rl4rs_dien_destroy': (_I, [_P]),
+    'rl4rs_dien_encode': (_I, [_P, _I32, _P, _I32, _I32, _P]),
+    'rl4rs_dien_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_dien_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
+    'rl4rs_dien_set_profiling': (_I, [_P, _I]),
+    'rl4rs_dien_kernel_count': (_I, []),
+    'rl4rs_dien_kernel_name': (C.c_char_p, [_I]),
+    'rl4rs_dien_profile_read': (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    'rl4rs_dien_profile_reset': (_I, [_P]),
+    'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
+}
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Rl4rsHipError(
+            "librl4rs_hip.so not found at %s: build it with `python -m rl4rs_amd.build` "
+            "(hipcc --offload-arch=gfx950). rl4rs_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rl4rs_abi_version() != 1:
+        raise Rl4rsHipError("librl4rs_hip.so ABI version %d, expected 1" % lib.rl4rs_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().rl4rs_last_error()
+        raise Rl4rsHipError("librl4rs_hip error %d: %s" % (rc, msg.decode() if msg else '?'))
+    return rc
+
+
+def require_device():
+    """Raise unless a HIP device is visible (called before any device handle is created)."""
+    n = load().rl4rs_device_count()
+    if n <= 0:
+        raise Rl4rsHipError("no MI355X / HIP device visible (rl4rs_device_count=%d): "
+                            "rl4rs_amd runs the env step on the GPU only" % n)
+    return n

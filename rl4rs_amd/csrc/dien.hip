@@ -1,0 +1,756 @@
+// DIEN simulator-net forward on gfx950 (rl4rs/nets/dien.py:8-45, rl4rs/nets/utils.py:16-25,48-54,100-129;
+// cell equations of TF1.15 GRUCell / deepctr-0.9.0 VecAttGRUCell + LocalActivationUnit).
+//
+// Design: exact fp32 on v_mfma_f32_32x32x2_f32.
+//   * Everything that depends only on a sequence input (embedding lookup, the first GRU, and the
+//     input-side halves of the attention MLP and of the AUGRU matmuls) is computed ONCE per sequence
+//     ("encode") into a per-slot cache in HBM: h1 [slot,L,E] and proj [slot,L, 64 | 4E | 2E].  Rows of one
+//     env share their sequences, so a forward over R rows only indexes the cache by slot.
+//         [x,h] @ W  =  x @ W[:E]  (cached, incl. bias)  +  h @ W[E:]   (per step, on the matrix cores)
+//         [q,k,q-k,q*k] @ W1 = q @ (W1a+W1c) (per row) + k @ (W1b-W1c) + b1 (cached) + (q*k) @ W1d (MFMA)
+//   * The first-GRU input projection is a table: embw1 = seq_emb @ Wx + b, [H, 3E], built at create time
+//     (HBM is 288 GB; 150 MB per sequence input buys the whole x-side GEMM of the first GRU).
+//   * Recurrences run as ONE launch for all L steps: a workgroup owns 32 rows, keeps h in LDS/registers and
+//     streams the (pre-packed, L2-resident) recurrent weights every step; no inter-workgroup traffic.
+#include <vector>
+
+#include "common.hpp"
+
+namespace rl4rs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+constexpr int ATT_H1 = 64, ATT_H2 = 16, OBS_DIM = 256;
+
+// -------------------------------------------------------------------------------------------------
+// Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
+// One wave per row; 4 rows per block.  Writes allf[row, off_c : off_c + E] = mean_i(softmax(E E^T) E),
+// allf[row, off_c+E : off_c+E+Cn*E] = flatten(E), q[row] = mean(seq_emb[cat[-10:]]).
+__global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ cat, int R, int Cn, int E, int H,
+                                                  const float* __restrict__ cat_emb,
+                                                  const float* __restrict__ seq_emb, float* __restrict__ allf,
+                                                  int ldf, int off_c, float* __restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int LE = E + 1, LS = Cn + 1;
+    float* sE = reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * LE + Cn * LS + Cn);
+    float* sS = sE + Cn * LE;
+    float* sW = sS + Cn * LS;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const int32_t* crowp = cat + (size_t)row * Cn;
+    float* frow = allf + (size_t)row * ldf + off_c;
+    for (int c = 0; c < Cn; ++c) {
+        int id = crowp[c];
+        id = min(max(id, 0), H - 1);
+        const float* src = cat_emb + (size_t)id * E;
+        for (int k = lane; k < E; k += 64) {
+            float v = src[k];
+            sE[c * LE + k] = v;
+            frow[E + c * E + k] = v;                  // Flatten()(category_emb)
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // scores = E E^T (symmetric): one (i<=j) pair per lane per pass
+    const int npairs = Cn * (Cn + 1) / 2;
+    for (int p = lane; p < npairs; p += 64) {
+        int i = 0, rem = p;
+        while (rem >= Cn - i) { rem -= Cn - i; ++i; }
+        int j = i + rem;
+        float s = 0.f;
+        for (int k = 0; k < E; ++k) s = fmaf(sE[i * LE + k], sE[j * LE + k], s);
+        sS[i * LS + j] = s;
+        sS[j * LS + i] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // row softmax (keras Attention: no scale, no mask)
+    for (int i = lane; i < Cn; i += 64) {
+        float m = -3.4e38f;
+        for (int j = 0; j < Cn; ++j) m = fmaxf(m, sS[i * LS + j]);
+        float sum = 0.f;
+        for (int j = 0; j < Cn; ++j) {
+            float ev = expf(sS[i * LS + j] - m);
+            sS[i * LS + j] = ev;
+            sum += ev;
+        }
+        float inv = 1.f / sum;
+        for (int j = 0; j < Cn; ++j) sS[i * LS + j] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // GlobalAveragePooling1D over the Cn attended rows: column weights cw_j = sum_i w_ij
+    for (int j = lane; j < Cn; j += 64) {
+        float s = 0.f;
+        for (int i = 0; i < Cn; ++i) s += sS[i * LS + j];
+        sW[j] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float invc = 1.f / (float)Cn;
+    for (int k = lane; k < E; k += 64) {
+        float s = 0.f;
+        for (int j = 0; j < Cn; ++j) s = fmaf(sW[j], sE[j * LE + k], s);
+        frow[k] = s * invc;
+    }
+    // query = reduce_mean(seq_emb[cat[-10:]]) (utils.py:114-115)
+    const int nq = min(10, Cn);
+    const float invq = 1.f / (float)nq;
+    for (int k = lane; k < E; k += 64) {
+        float s = 0.f;
+        for (int c = Cn - nq; c < Cn; ++c) {
+            int id = min(max(crowp[c], 0), H - 1);
+            s += seq_emb[(size_t)id * E + k];
+        }
+        q[(size_t)row * E + k] = s * invq;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Recurrent kernel: GRU (NH = E, first layer, writes every state) or AUGRU (NH = 2E, writes the final state).
+//   gates  [r|u] = sigmoid(xg_t + h @ Wg)      Wg packed [2*NW tiles][NH/8][64 lanes][4]
+//   cand   c     = tanh(xc_t + (r*h) @ Wc)     Wc packed [NW tiles][NH/8][64][4]
+//   GRU:   h' = u*h + (1-u)*c        AUGRU: u <- (1 - a_t) * u first (deepctr VecAttGRUCell)
+// xg_t / xc_t are the cached input projections (bias folded in):
+//   GRU  : row = table[ids[row,t]]            (xld = 3*NH, layout [2NH gates | NH cand])
+//   AUGRU: row = proj[slot(row)*L + t] + xoff (xld = proj ld)
+// Workgroup = NH/32 waves, 32 rows; wave w owns hidden columns [32w, 32w+32) of r, u, c and h.
+struct RecurArgs {
+    int n_rows, L, group;
+    const float* xbase; int64_t xld; int xoff;
+    const int32_t* ids;      // GRU: [n_rows, L]
+    const int32_t* slots;    // AUGRU: [n_rows/group]
+    const float* wg; const float* wc;
+    const float* att;        // AUGRU: [n_rows, L]
+    float* out; int64_t out_ld; int out_off;   // GRU: h1 cache rows (slot_base+row)*L + t ; AUGRU: allf
+    int slot_base;
+};
+
+template <int NH, bool AUGRU>
+__global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
+    constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hb = reinterpret_cast<float*>(smem);          // [32][LDH]
+    float* rhb = hb + 32 * LDH;                          // [32][LDH]
+    float* s_att = rhb + 32 * LDH;                       // AUGRU: [32][L+1]
+    int32_t* s_ids = reinterpret_cast<int32_t*>(rhb + 32 * LDH);   // GRU: [32][L+1]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, li = lane & 31;
+    const int row0 = blockIdx.x * 32;
+    const int L = a.L, LDT = L + 1;
+    const int col = wave * 32 + li;
+
+    for (int i = tid; i < 32 * LDH; i += NH * 2) hb[i] = 0.f;
+    for (int i = tid; i < 32 * L; i += NH * 2) {
+        int r = i / L, t = i - r * L;
+        int gr = min(row0 + r, a.n_rows - 1);
+        if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)gr * L + t];
+        else s_ids[r * LDT + t] = a.ids[(size_t)gr * L + t];
+    }
+    // per-lane row bookkeeping in C/D layout
+    int64_t xrow_base[16];
+    bool rvalid[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int lr = crow(r, half);
+        int gr = row0 + lr;
+        rvalid[r] = gr < a.n_rows;
+        gr = min(gr, a.n_rows - 1);
+        xrow_base[r] = AUGRU ? (int64_t)a.slots[gr / a.group] * L : 0;
+    }
+    f32x16 h_own;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
+    const float4* wg_r = reinterpret_cast<const float4*>(a.wg) + ((size_t)wave * KB) * 64 + lane;
+    const float4* wg_u = reinterpret_cast<const float4*>(a.wg) + ((size_t)(NW + wave) * KB) * 64 + lane;
+    const float4* wc_c = reinterpret_cast<const float4*>(a.wc) + ((size_t)wave * KB) * 64 + lane;
+    __syncthreads();
+
+    for (int t = 0; t < L; ++t) {
+        // cached input projections for this step (bias folded in) -> accumulator init
+        f32x16 acc_r, acc_u, acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t xr = AUGRU ? xrow_base[r] + t : (int64_t)s_ids[crow(r, half) * LDT + t];
+            const float* xp = a.xbase + xr * a.xld + a.xoff + col;
+            acc_r[r] = xp[0];
+            acc_u[r] = xp[NH];
+            acc_c[r] = xp[2 * NH];
+        }
+        // ---- phase 1: gates
+        const float* arow = hb + li * LDH + half * 4;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
+            float4 br = wg_r[(size_t)kb * 64];
+            float4 bu = wg_u[(size_t)kb * 64];
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, br.x, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bu.x, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, br.y, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bu.y, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, br.z, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bu.z, acc_u, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, br.w, acc_r, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bu.w, acc_u, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float rg = sigmoidf_(acc_r[r]);
+            acc_u[r] = sigmoidf_(acc_u[r]);
+            rhb[crow(r, half) * LDH + col] = rg * h_own[r];
+        }
+        __syncthreads();
+        // ---- phase 2: candidate + state update
+        const float* rrow = rhb + li * LDH + half * 4;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            float4 av = *reinterpret_cast<const float4*>(rrow + kb * 8);
+            float4 bc = wc_c[(size_t)kb * 64];
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc.x, acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc.y, acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc.z, acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc.w, acc_c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float c = tanhf(acc_c[r]);
+            float u = acc_u[r];
+            if (AUGRU) u = (1.0f - s_att[crow(r, half) * LDT + t]) * u;
+            float hn = u * h_own[r] + (1.0f - u) * c;
+            h_own[r] = hn;
+            hb[crow(r, half) * LDH + col] = hn;
+            if (!AUGRU && rvalid[r]) {
+                int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
+                a.out[orow * a.out_ld + a.out_off + col] = hn;
+            }
+        }
+        __syncthreads();
+    }
+    if (AUGRU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rvalid[r]) a.out[(int64_t)(row0 + crow(r, half)) * a.out_ld + a.out_off + col] = h_own[r];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// DIN attention scores (deepctr LocalActivationUnit, att_hidden_units=(64,16), sigmoid, raw scores).
+// Workgroup = one (group of rows sharing a slot, sequence input s); each wave scores whole rows:
+//   hid1^T [64 units x L steps] = W1d^T (q*h1_t) + qa + AK_t    as 2x2 32x32 MFMA tiles
+//   hid2 = sigmoid(hid1 W2 + b2), score = hid2 w3 + b3           in registers (+ one half-wave swap)
+struct DinArgs {
+    int R, L, E, group, n_groups;
+    const int32_t* slots;        // [n_groups]
+    const float* h1;             // [slot, L, E]
+    const float* proj; int64_t pld;   // [slot*L, pld], AK at column 0
+    const float* q;              // [R, E]
+    const float* w1ac;           // [E, 64]   (W1a + W1c)
+    const float* w1d;            // packed [2][E/8][64][4]
+    const float* w2; const float* b2; const float* w3; const float* b3;
+    float* scores;               // [R, L]
+};
+
+__global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = a.L, E = a.E, LDK = E + 4;
+    float* s_h1 = reinterpret_cast<float*>(smem);        // [L][LDK]
+    float* s_w2 = s_h1 + (size_t)L * LDK;                // [64][16]
+    float* s_misc = s_w2 + ATT_H1 * ATT_H2;              // b2[16] w3[16] b3[1] pad -> 48
+    float* s_wave = s_misc + 48;                         // per wave: q[E] + qa[64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    const int g = blockIdx.x;
+    const int slot = a.slots[g];
+    const float* h1g = a.h1 + (size_t)slot * L * E;
+    for (int i = tid; i < L * (E / 4); i += blockDim.x) {
+        int t = i / (E / 4), k4 = i - t * (E / 4);
+        *reinterpret_cast<float4*>(s_h1 + t * LDK + k4 * 4) = *reinterpret_cast<const float4*>(h1g + (size_t)t * E + k4 * 4);
+    }
+    for (int i = tid; i < ATT_H1 * ATT_H2; i += blockDim.x) s_w2[i] = a.w2[i];
+    if (tid < ATT_H2) { s_misc[tid] = a.b2[tid]; s_misc[16 + tid] = a.w3[tid]; }
+    if (tid == 0) s_misc[32] = a.b3[0];
+    __syncthreads();
+    float* s_q = s_wave + (size_t)wave * (E + ATT_H1);
+    float* s_qa = s_q + E;
+    const int KB = E / 8;
+    const float4* w1d0 = reinterpret_cast<const float4*>(a.w1d) + lane;
+    const float4* w1d1 = w1d0 + (size_t)KB * 64;
+    const int ntile = (L + 31) / 32;    // L <= 64 -> 1 or 2 N tiles
+
+    for (int j = wave; j < a.group; j += nw) {
+        const int row = g * a.group + j;
+        if (row >= a.R) break;
+        for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {   // qa = q @ (W1a + W1c): lane = hidden unit
+            float s = 0.f;
+            for (int k = 0; k < E; ++k) s = fmaf(s_q[k], a.w1ac[k * ATT_H1 + lane], s);
+            s_qa[lane] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int t0 = li, t1 = min(32 + li, L - 1);
+#pragma unroll 2
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kk = kb * 8 + half * 4;
+            float4 aw0 = w1d0[(size_t)kb * 64];
+            float4 aw1 = w1d1[(size_t)kb * 64];
+            float4 qv = *reinterpret_cast<const float4*>(s_q + kk);
+            float4 h0 = *reinterpret_cast<const float4*>(s_h1 + t0 * LDK + kk);
+            float4 h1v = *reinterpret_cast<const float4*>(s_h1 + t1 * LDK + kk);
+            float b0[4] = {h0.x * qv.x, h0.y * qv.y, h0.z * qv.z, h0.w * qv.w};
+            float b1[4] = {h1v.x * qv.x, h1v.y * qv.y, h1v.z * qv.z, h1v.w * qv.w};
+            float a0[4] = {aw0.x, aw0.y, aw0.z, aw0.w};
+            float a1[4] = {aw1.x, aw1.y, aw1.z, aw1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
+                if (ntile > 1) {
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: lane holds, for step t (= N index), 16 of the 32 hidden units of each M tile
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (n >= ntile) break;
+            const int t = n * 32 + li;
+            const int tc = min(t, L - 1);
+            const float* akp = a.proj + ((size_t)slot * L + tc) * a.pld;
+            float p[ATT_H2];
+#pragma unroll
+            for (int o = 0; o < ATT_H2; ++o) p[o] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int jr = m * 32 + 8 * r4 + 4 * half;       // hidden units jr..jr+3
+                    float4 ak = *reinterpret_cast<const float4*>(akp + jr);
+                    float akv[4] = {ak.x, ak.y, ak.z, ak.w};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float x = acc[m][n][r4 * 4 + rr] + s_qa[jr + rr] + akv[rr];
+                        float hv = sigmoidf_(x);
+                        const float* w2r = s_w2 + (jr + rr) * ATT_H2;
+#pragma unroll
+                        for (int o = 0; o < ATT_H2; ++o) p[o] = fmaf(hv, w2r[o], p[o]);
+                    }
+                }
+            }
+            float sc = 0.f;
+#pragma unroll
+            for (int o = 0; o < ATT_H2; ++o) {
+                float tot = p[o] + __shfl_xor(p[o], 32);
+                float h2 = sigmoidf_(tot + s_misc[o]);
+                sc = fmaf(h2, s_misc[16 + o], sc);
+            }
+            sc += s_misc[32];
+            if (half == 0 && t < L) a.scores[(size_t)row * L + t] = sc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// softmax(obs @ out_w + out_b)[:, 1]  (dien.py:36, slate.py:298).  One wave per row.
+__global__ __launch_bounds__(256) void k_head_prob(const float* __restrict__ obs, int R, int D, int K,
+                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                   float* __restrict__ prob) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    float logit[8];
+    for (int c = 0; c < K; ++c) {
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s = fmaf(obs[(size_t)row * D + k], w[(size_t)k * K + c], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        logit[c] = s + b[c];
+    }
+    float m = logit[0];
+    for (int c = 1; c < K; ++c) m = fmaxf(m, logit[c]);
+    float sum = 0.f;
+    for (int c = 0; c < K; ++c) sum += expf(logit[c] - m);
+    if (lane == 0) prob[row] = expf(logit[K > 1 ? 1 : 0] - m) / sum;
+}
+
+}  // namespace rl4rs
+
+// =================================================================================================
+using namespace rl4rs;
+
+namespace {
+enum { KID_CAT = 0, KID_DENSE, KID_DIN, KID_AUGRU, KID_HEAD, KID_PROB, KID_GRU1, KID_PROJ, KID_COUNT };
+const char* kKernelNames[KID_COUNT] = {"k_cat_attn", "k_gemm_f32(dense tower)", "k_din_scores",
+                                       "k_recur<256,augru>", "k_gemm_f32(simulator_obs)", "k_head_prob",
+                                       "k_recur<128,gru>", "k_gemm_f32(seq projections)"};
+struct EvPair { int id; hipEvent_t a, b; };
+}  // namespace
+
+struct rl4rs_dien {
+    rl4rs_dien_cfg c;
+    int E, U, L, S, Cn, Dn, H, K, F, PLD, NH2;
+    // weights (device)
+    float *cat_emb, *seq_emb, *dense_w1, *dense_b1, *dense_w2, *dense_b2, *obs_w, *obs_b, *out_w, *out_b;
+    float* embw1[4];       // [H, 3E]   first-GRU input projection table (bias folded)
+    float* gru_wg[4];      // packed h-side gate weights     [2*E/32][E/8][64][4]
+    float* gru_wc[4];      // packed h-side candidate weights
+    float* wproj[4];       // [E, PLD]  = [W1b - W1c | augru gate x-side | augru cand x-side]
+    float* bproj[4];       // [PLD]
+    float* w1ac[4];        // [E, 64]
+    float* w1d[4];         // packed [2][E/8][64][4]
+    float *att_w2[4], *att_b2[4], *att_w3[4], *att_b3[4];
+    float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
+    float* augru_wc[4];
+    // caches
+    float* h1[4];          // [max_slots, L, E]
+    float* proj[4];        // [max_slots*L, PLD]
+    // scratch
+    float *allf, *dh, *q, *scores, *obs_tmp;
+    std::vector<void*> owned;
+    // profiling
+    bool profiling;
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms_total[KID_COUNT];
+    long launches[KID_COUNT];
+};
+
+namespace {
+
+int upload(rl4rs_dien* n, float** dst, const float* src, size_t count, hipStream_t st) {
+    int rc = dev_alloc(dst, count);
+    if (rc) return rc;
+    n->owned.push_back(*dst);
+    RL4RS_HIP_TRY(hipMemcpyAsync(*dst, src, count * 4, hipMemcpyHostToDevice, st));
+    return RL4RS_OK;
+}
+int alloc_f(rl4rs_dien* n, float** dst, size_t count) {
+    int rc = dev_alloc(dst, count);
+    if (rc) return rc;
+    n->owned.push_back(*dst);
+    return RL4RS_OK;
+}
+
+// pack Wh [K, N] (row-major, leading dim ld, starting at row k_off) into MFMA-B fragment order
+std::vector<float> pack_frag(const float* w, int ld, int k_off, int K, int N) {
+    const int KB = K / 8, NT = N / 32;
+    std::vector<float> out((size_t)K * N);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    int k = kb * 8 + (lane >> 5) * 4 + i;
+                    int j = nt * 32 + (lane & 31);
+                    out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + i] = w[(size_t)(k_off + k) * ld + j];
+                }
+    return out;
+}
+
+struct Prof {
+    rl4rs_dien* n; int id; hipStream_t st; hipEvent_t a, b; bool on;
+    Prof(rl4rs_dien* n_, int id_, hipStream_t st_) : n(n_), id(id_), st(st_), on(n_->profiling) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!n->pool.empty()) { e = n->pool.back(); n->pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) { on = false; e = nullptr; }
+            return e;
+        };
+        a = get(); b = get();
+        if (on) (void)hipEventRecord(a, st);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        n->pending.push_back({id, a, b});
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void* stream, rl4rs_dien** out) {
+    RL4RS_REQUIRE(c && w && out, "dien_create: null argument");
+    RL4RS_REQUIRE(c->emb_size == 128 && c->hidden_units > 0 && c->hidden_units % 32 == 0,
+                  "dien: emb_size must be 128 (got %d), hidden_units a multiple of 32", c->emb_size);
+    RL4RS_REQUIRE(c->maxlen >= 1 && c->maxlen <= 64, "dien: maxlen must be in 1..64 (got %d)", c->maxlen);
+    RL4RS_REQUIRE(c->seq_num >= 1 && c->seq_num <= 4, "dien: seq_num must be in 1..4");
+    RL4RS_REQUIRE(c->class_num >= 1 && c->class_num <= 8, "dien: class_num must be in 1..8");
+    RL4RS_REQUIRE(c->category_feature_num >= 1 && c->category_feature_num <= 64, "dien: category_feature_num must be in 1..64");
+    RL4RS_REQUIRE(c->max_rows > 0 && c->max_slots > 0 && c->category_hash_size > 0 && c->dense_feature_num > 0,
+                  "dien: bad sizes");
+    int ndev = rl4rs_device_count();
+    if (ndev <= 0) {
+        set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
+        return RL4RS_EHIP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    rl4rs_dien* n = new rl4rs_dien();
+    n->c = *c;
+    const int E = c->emb_size, U = c->hidden_units, L = c->maxlen, S = c->seq_num, Cn = c->category_feature_num;
+    const int Dn = c->dense_feature_num, H = c->category_hash_size, K = c->class_num;
+    const int NH2 = 2 * E, PLD = ATT_H1 + 3 * NH2;
+    const int F = S * NH2 + U + (Cn + 1) * E;
+    n->E = E; n->U = U; n->L = L; n->S = S; n->Cn = Cn; n->Dn = Dn; n->H = H; n->K = K; n->F = F;
+    n->PLD = PLD; n->NH2 = NH2;
+    n->profiling = false;
+    for (int i = 0; i < KID_COUNT; ++i) { n->ms_total[i] = 0; n->launches[i] = 0; }
+    int rc;
+#define UP(dst, src, cnt) if ((rc = upload(n, &n->dst, (src), (size_t)(cnt), st)) != RL4RS_OK) return rc
+#define AL(dst, cnt) if ((rc = alloc_f(n, &n->dst, (size_t)(cnt))) != RL4RS_OK) return rc
+    UP(cat_emb, w->cat_emb, (size_t)H * E);
+    UP(seq_emb, w->seq_emb, (size_t)H * E);
+    UP(dense_w1, w->dense_w1, (size_t)Dn * U);
+    UP(dense_b1, w->dense_b1, U);
+    UP(dense_w2, w->dense_w2, (size_t)U * U);
+    UP(dense_b2, w->dense_b2, U);
+    UP(obs_w, w->obs_w, (size_t)F * OBS_DIM);
+    UP(obs_b, w->obs_b, OBS_DIM);
+    UP(out_w, w->out_w, (size_t)OBS_DIM * K);
+    UP(out_b, w->out_b, K);
+    std::vector<std::vector<float>> keep;    // host staging must outlive the async copies
+    for (int s = 0; s < S; ++s) {
+        RL4RS_REQUIRE(w->gru_gate_w[s] && w->gru_cand_w[s] && w->att_w1[s] && w->augru_gate_w[s] && w->augru_cand_w[s],
+                      "dien_create: weights of sequence input %d missing", s);
+        // ---- first GRU: x-side table weights [E, 3E] + bias, h-side packed
+        std::vector<float> wx((size_t)E * 3 * E), bx(3 * E);
+        for (int k = 0; k < E; ++k) {
+            for (int j = 0; j < 2 * E; ++j) wx[(size_t)k * 3 * E + j] = w->gru_gate_w[s][(size_t)k * 2 * E + j];
+            for (int j = 0; j < E; ++j) wx[(size_t)k * 3 * E + 2 * E + j] = w->gru_cand_w[s][(size_t)k * E + j];
+        }
+        for (int j = 0; j < 2 * E; ++j) bx[j] = w->gru_gate_b[s][j];
+        for (int j = 0; j < E; ++j) bx[2 * E + j] = w->gru_cand_b[s][j];
+        float *d_wx, *d_bx;
+        if ((rc = upload(n, &d_wx, wx.data(), wx.size(), st))) return rc;
+        if ((rc = upload(n, &d_bx, bx.data(), bx.size(), st))) return rc;
+        AL(embw1[s], (size_t)H * 3 * E);
+        if ((rc = launch_gemm_f32(n->seq_emb, E, d_wx, 3 * E, d_bx, n->embw1[s], 3 * E, H, 3 * E, E, 0, st))) return rc;
+        keep.push_back(std::move(wx)); keep.push_back(std::move(bx));
+        keep.push_back(pack_frag(w->gru_gate_w[s], 2 * E, E, E, 2 * E));
+        UP(gru_wg[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_frag(w->gru_cand_w[s], E, E, E, E));
+        UP(gru_wc[s], keep.back().data(), keep.back().size());
+        // ---- projections of h1: [W1b - W1c | augru gate x-side | augru cand x-side], bias [b1 | bg | bc]
+        std::vector<float> wp((size_t)E * PLD), bp(PLD), wac((size_t)E * ATT_H1);
+        const float* w1 = w->att_w1[s];    // rows: q [0,E) | k [E,2E) | q-k [2E,3E) | q*k [3E,4E)
+        for (int k = 0; k < E; ++k) {
+            for (int j = 0; j < ATT_H1; ++j) {
+                wp[(size_t)k * PLD + j] = w1[(size_t)(E + k) * ATT_H1 + j] - w1[(size_t)(2 * E + k) * ATT_H1 + j];
+                wac[(size_t)k * ATT_H1 + j] = w1[(size_t)k * ATT_H1 + j] + w1[(size_t)(2 * E + k) * ATT_H1 + j];
+            }
+            for (int j = 0; j < 2 * NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + j] = w->augru_gate_w[s][(size_t)k * 2 * NH2 + j];
+            for (int j = 0; j < NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + 2 * NH2 + j] = w->augru_cand_w[s][(size_t)k * NH2 + j];
+        }
+        for (int j = 0; j < ATT_H1; ++j) bp[j] = w->att_b1[s][j];
+        for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j];
+        for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
+        keep.push_back(std::move(wp)); UP(wproj[s], keep.back().data(), keep.back().size());
+        keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
+        keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
+        UP(w1d[s], keep.back().data(), keep.back().size());
+        UP(att_w2[s], w->att_w2[s], ATT_H1 * ATT_H2);
+        UP(att_b2[s], w->att_b2[s], ATT_H2);
+        UP(att_w3[s], w->att_w3[s], ATT_H2);
+        UP(att_b3[s], w->att_b3[s], 1);
+        keep.push_back(pack_frag(w->augru_gate_w[s], 2 * NH2, E, NH2, 2 * NH2));
+        UP(augru_wg[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_frag(w->augru_cand_w[s], NH2, E, NH2, NH2));
+        UP(augru_wc[s], keep.back().data(), keep.back().size());
+        AL(h1[s], (size_t)c->max_slots * L * E);
+        AL(proj[s], (size_t)c->max_slots * L * PLD);
+    }
+    AL(allf, (size_t)c->max_rows * F);
+    AL(dh, (size_t)c->max_rows * U);
+    AL(q, (size_t)c->max_rows * E);
+    AL(scores, (size_t)S * c->max_rows * L);
+    AL(obs_tmp, (size_t)c->max_rows * OBS_DIM);
+#undef UP
+#undef AL
+    // LDS opt-in above the 64 KB default where needed
+    {
+        size_t sm_aug = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1)) * 4;
+        size_t sm_gru = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1)) * 4;
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<256, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));   // host staging (keep) may now be released
+    *out = n;
+    return RL4RS_OK;
+}
+
+int rl4rs_dien_destroy(rl4rs_dien* n) {
+    if (!n) return RL4RS_OK;
+    for (void* p : n->owned) (void)hipFree(p);
+    for (auto& e : n->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : n->pool) (void)hipEventDestroy(e);
+    delete n;
+    return RL4RS_OK;
+}
+
+int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt, int32_t slot_base, void* stream) {
+    RL4RS_REQUIRE(n && ids, "dien_encode: null argument");
+    RL4RS_REQUIRE(s >= 0 && s < n->S, "dien_encode: sequence input %d out of range", s);
+    RL4RS_REQUIRE(cnt > 0 && slot_base >= 0 && slot_base + cnt <= n->c.max_slots,
+                  "dien_encode: slots [%d,%d) exceed max_slots=%d", slot_base, slot_base + cnt, n->c.max_slots);
+    hipStream_t st = (hipStream_t)stream;
+    const int E = n->E, L = n->L;
+    {
+        Prof p(n, KID_GRU1, st);
+        RecurArgs a;
+        a.n_rows = cnt; a.L = L; a.group = 1;
+        a.xbase = n->embw1[s]; a.xld = 3 * E; a.xoff = 0;
+        a.ids = ids; a.slots = nullptr;
+        a.wg = n->gru_wg[s]; a.wc = n->gru_wc[s]; a.att = nullptr;
+        a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.slot_base = slot_base;
+        size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1)) * 4;
+        hipLaunchKernelGGL((k_recur<128, false>), dim3((cnt + 31) / 32), dim3(256), smem, st, a);
+        RL4RS_LAUNCH_CHECK();
+    }
+    {
+        Prof p(n, KID_PROJ, st);
+        int rc = launch_gemm_f32(n->h1[s] + (size_t)slot_base * L * E, E, n->wproj[s], n->PLD, n->bproj[s],
+                                 n->proj[s] + (size_t)slot_base * L * n->PLD, n->PLD, cnt * L, n->PLD, E, 0, st);
+        if (rc) return rc;
+    }
+    return RL4RS_OK;
+}
+
+int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* dense, const int32_t* cat,
+                       const int32_t* slots, float* obs, float* prob, void* stream) {
+    RL4RS_REQUIRE(n && dense && cat && slots, "dien_forward: null argument");
+    RL4RS_REQUIRE(R > 0 && R <= n->c.max_rows, "dien_forward: R=%d exceeds max_rows=%d", R, n->c.max_rows);
+    RL4RS_REQUIRE(group >= 1 && R % group == 0, "dien_forward: R=%d is not a multiple of group=%d", R, group);
+    hipStream_t st = (hipStream_t)stream;
+    const int E = n->E, U = n->U, L = n->L, S = n->S, Cn = n->Cn, F = n->F, NH2 = n->NH2;
+    const int off_d = S * NH2, off_c = off_d + U;
+    const int ngroups = R / group;
+    int rc;
+    {
+        Prof p(n, KID_CAT, st);
+        size_t smem = (size_t)4 * (Cn * (E + 1) + Cn * (Cn + 1) + Cn) * 4;
+        hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
+                           n->seq_emb, n->allf, F, off_c, n->q);
+        RL4RS_LAUNCH_CHECK();
+    }
+    {
+        Prof p(n, KID_DENSE, st);
+        if ((rc = launch_gemm_f32(dense, n->Dn, n->dense_w1, U, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
+        if ((rc = launch_gemm_f32(n->dh, U, n->dense_w2, U, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
+    }
+    {
+        Prof p(n, KID_DIN, st);
+        int nw = group < 4 ? group : 4;
+        size_t smem = ((size_t)L * (E + 4) + ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+        for (int s = 0; s < S; ++s) {
+            DinArgs a;
+            a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
+            a.slots = slots + (size_t)s * ngroups;
+            a.h1 = n->h1[s]; a.proj = n->proj[s]; a.pld = n->PLD; a.q = n->q;
+            a.w1ac = n->w1ac[s]; a.w1d = n->w1d[s];
+            a.w2 = n->att_w2[s]; a.b2 = n->att_b2[s]; a.w3 = n->att_w3[s]; a.b3 = n->att_b3[s];
+            a.scores = n->scores + (size_t)s * n->c.max_rows * L;
+            hipLaunchKernelGGL(k_din_scores, dim3(ngroups), dim3(64 * nw), smem, st, a);
+            RL4RS_LAUNCH_CHECK();
+        }
+    }
+    {
+        Prof p(n, KID_AUGRU, st);
+        size_t smem = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1)) * 4;
+        for (int s = 0; s < S; ++s) {
+            RecurArgs a;
+            a.n_rows = R; a.L = L; a.group = group;
+            a.xbase = n->proj[s]; a.xld = n->PLD; a.xoff = ATT_H1;
+            a.ids = nullptr; a.slots = slots + (size_t)s * ngroups;
+            a.wg = n->augru_wg[s]; a.wc = n->augru_wc[s];
+            a.att = n->scores + (size_t)s * n->c.max_rows * L;
+            a.out = n->allf; a.out_ld = F; a.out_off = s * NH2; a.slot_base = 0;
+            hipLaunchKernelGGL((k_recur<256, true>), dim3((R + 31) / 32), dim3(512), smem, st, a);
+            RL4RS_LAUNCH_CHECK();
+        }
+    }
+    float* obs_out = obs ? obs : n->obs_tmp;
+    {
+        Prof p(n, KID_HEAD, st);
+        if ((rc = launch_gemm_f32(n->allf, F, n->obs_w, OBS_DIM, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
+    }
+    if (prob) {
+        Prof p(n, KID_PROB, st);
+        hipLaunchKernelGGL(k_head_prob, dim3((R + 3) / 4), dim3(256), 0, st, obs_out, R, OBS_DIM, n->K, n->out_w,
+                           n->out_b, prob);
+        RL4RS_LAUNCH_CHECK();
+    }
+    return RL4RS_OK;
+}
+
+int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
+    RL4RS_REQUIRE(n && p, "dien_buffer: null argument");
+    int64_t b = 0;
+    void* ptr = nullptr;
+    switch (which) {
+        case RL4RS_DIEN_ALL_FEATURE: ptr = n->allf; b = (int64_t)n->c.max_rows * n->F * 4; break;
+        case RL4RS_DIEN_SCORES: ptr = n->scores; b = (int64_t)n->S * n->c.max_rows * n->L * 4; break;
+        case RL4RS_DIEN_QUERY: ptr = n->q; b = (int64_t)n->c.max_rows * n->E * 4; break;
+        case RL4RS_DIEN_H1: ptr = n->h1[0]; b = (int64_t)n->c.max_slots * n->L * n->E * 4; break;
+        default: set_error("dien_buffer: unknown buffer id %d", which); return RL4RS_EINVAL;
+    }
+    *p = ptr;
+    if (bytes) *bytes = b;
+    return RL4RS_OK;
+}
+
+int rl4rs_dien_set_profiling(rl4rs_dien* n, int enable) {
+    RL4RS_REQUIRE(n, "dien_set_profiling: null handle");
+    n->profiling = enable != 0;
+    return RL4RS_OK;
+}
+int rl4rs_dien_kernel_count(void) { return KID_COUNT; }
+const char* rl4rs_dien_kernel_name(int which) {
+    return (which >= 0 && which < KID_COUNT) ? kKernelNames[which] : "";
+}
+// Drains the recorded event pairs (synchronises on them) and returns the cumulative time / launch count
+// of kernel class `which` since the last rl4rs_dien_profile_reset.
+int rl4rs_dien_profile_read(rl4rs_dien* n, int which, double* ms_total, int64_t* launches) {
+    RL4RS_REQUIRE(n && which >= 0 && which < KID_COUNT, "dien_profile_read: bad argument");
+    for (auto& e : n->pending) {
+        RL4RS_HIP_TRY(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        RL4RS_HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        n->ms_total[e.id] += ms;
+        n->launches[e.id] += 1;
+        n->pool.push_back(e.a);
+        n->pool.push_back(e.b);
+    }
+    n->pending.clear();
+    if (ms_total) *ms_total = n->ms_total[which];
+    if (launches) *launches = n->launches[which];
+    return RL4RS_OK;
+}
+int rl4rs_dien_profile_reset(rl4rs_dien* n) {
+    RL4RS_REQUIRE(n, "dien_profile_reset: null handle");
+    double d; int64_t l;
+    int rc = rl4rs_dien_profile_read(n, 0, &d, &l);
+    for (int i = 0; i < KID_COUNT; ++i) { n->ms_total[i] = 0; n->launches[i] = 0; }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Plain fp32 GEMM on the gfx950 matrix cores: C[M,N] = act(A[M,K] @ W[K,N] + bias).
+//
+// Used for the non-recurrent layers of the DIEN scorer (dense tower utils.py:48-54, simulator_obs head
+// dien.py:35, the input-side projections hoisted out of the recurrences) and the policy net.
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD, MI355X_MICROARCH.md): a 32x32 output tile per
+// wave, lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  The K order inside an 8-wide block is
+// permuted (lower half-wave takes k0..k0+3, upper half k0+4..k0+7) so each lane fetches its four A
+// values with ONE 16-byte LDS read; the sum over k is order-independent as long as A and B agree.
+//
+// Block = 256 threads = 2x2 waves, tile 128(M) x 64(N), BK = 32.  A is staged global -> registers ->
+// LDS (double buffered, rows padded to 36 floats: conflict-free for ds_read_b128); W is small and
+// L1/L2 resident, so B fragments come straight from global memory (128-byte coalesced per half-wave).
+#include "common.hpp"
+
+namespace rl4rs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+
+constexpr int GBM = 128, GBN = 64, GBK = 32, GLD = GBK + 4;
+
+__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int64_t lda,
+                                                  const float* __restrict__ W, int64_t ldw,
+                                                  const float* __restrict__ bias, float* __restrict__ C,
+                                                  int64_t ldc, int M, int N, int K, int act) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBM][GLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    const int col = n0 + wn * 32 + li;
+    const bool col_ok = col < N;
+    const bool vec_ok = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    // staging map: thread -> (row, 4-float chunk); 128 rows x 8 chunks = 1024 chunks, 4 per thread
+    float4 stage[4];
+    auto load_tile = [&](int kt) {
+        for (int p = 0; p < 4; ++p) {
+            int c = tid + p * 256;
+            int r = c >> 3, kq = (c & 7) << 2;
+            int gr = m0 + r, gk = kt * GBK + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < M) {
+                const float* src = A + (size_t)gr * lda + gk;
+                if (vec_ok && gk + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (gk + 0 < K) v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
+                }
+            }
+            stage[p] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        for (int p = 0; p < 4; ++p) {
+            int c = tid + p * 256;
+            int r = c >> 3, kq = (c & 7) << 2;
+            *reinterpret_cast<float4*>(&As[buf][r][kq]) = stage[p];
+        }
+    };
+
+    const int nkt = (K + GBK - 1) / GBK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int arow = wm * 64 + li;
+#pragma unroll
+        for (int kb = 0; kb < GBK / 8; ++kb) {
+            const int kk = kb * 8 + half * 4;
+            float4 a0 = *reinterpret_cast<const float4*>(&As[cur][arow][kk]);
+            float4 a1 = *reinterpret_cast<const float4*>(&As[cur][arow + 32][kk]);
+            const int gk = kt * GBK + kk;
+            float b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                b[i] = (col_ok && gk + i < K) ? W[(size_t)(gk + i) * ldw + col] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[3], acc1, 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (col_ok) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            int g0 = m0 + wm * 64 + row;
+            int g1 = g0 + 32;
+            if (g0 < M) C[(size_t)g0 * ldc + col] = apply_act(acc0[r] + bv, act);
+            if (g1 < M) C[(size_t)g1 * ldc + col] = apply_act(acc1[r] + bv, act);
+        }
+    }
+}
+
+int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* c,
+                    int64_t ldc, int M, int N, int K, int act, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
+    dim3 grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN);
+    if (grid.y > 65535u) {
+        set_error("gemm: N=%d too large", N);
+        return RL4RS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+}  // namespace rl4rs
+
+extern "C" int rl4rs_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
+                              float* c, int64_t ldc, int32_t M, int32_t N, int32_t K, int act, void* stream) {
+    RL4RS_REQUIRE(a && w && c && M > 0 && N > 0 && K > 0, "rl4rs_gemm_f32: bad argument");
+    RL4RS_REQUIRE(lda >= K && ldw >= N && ldc >= N, "rl4rs_gemm_f32: leading dimension too small");
+    return rl4rs::launch_gemm_f32(a, lda, w, ldw, bias, c, ldc, M, N, K, act, (hipStream_t)stream);
+}

@@ -1,0 +1,334 @@
+"""Thin object wrappers over the C-ABI handles of librl4rs_hip.so.
+
+PyTorch is used for device memory and stream handles only (``tensor.data_ptr()``,
+``torch.cuda.current_stream().cuda_stream``); all compute goes through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+# rl4rs_env_buffer ids (include/rl4rs_hip.h)
+BUF_PREV_ACTIONS, BUF_ACTION_MASK, BUF_SPECIAL_MASK, BUF_DENSE, BUF_CATEGORY, BUF_SEQ0, BUF_SEQ1, \
+    BUF_C_DENSE, BUF_C_CATEGORY, BUF_ERROR_FLAG = range(10)
+DIEN_ALL_FEATURE, DIEN_SCORES, DIEN_QUERY, DIEN_H1 = range(4)
+
+_MASK_DTYPES = {torch.uint8: 0, torch.int32: 1, torch.int64: 2, torch.float32: 3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev_tensor(x, dtype, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device=device, dtype=dtype).contiguous()
+
+
+class DeviceEnv(object):
+    """rl4rs_env handle: SlateState / SeqSlateState device state for one batch."""
+
+    def __init__(self, config, catalog, is_seq, log_steps, violation_zeroes_reward, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.B = int(config['batch_size'])
+        self.T = int(config['max_steps'])
+        self.A = int(config['action_size'])
+        self.E = int(catalog.action_emb.shape[1])
+        self.P = int(config.get('page_items', 9))
+        self.L = int(config['maxlen'])
+        self.Dn = int(config['dense_feature_num'])
+        self.Cn = int(config['category_feature_num'])
+        self.W = (self.A + 31) // 32
+        self.is_seq = bool(is_seq)
+        self.log_steps = int(log_steps)
+        cfg = _lib.EnvCfg(self.B, self.T, self.A, self.E, self.P, int(catalog.item_dim), 32, 10, self.L,
+                          self.Dn, self.Cn, self.log_steps, 1 if is_seq else 0,
+                          1 if violation_zeroes_reward else 0)
+        self.user_dense_dim, self.user_cat_dim = 32, 10
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_env_create(C.byref(cfg), C.byref(h)))
+            self.h = h
+            loc = np.ascontiguousarray(catalog.location_mask.astype(np.uint8))
+            check(self.lib.rl4rs_env_set_catalog(
+                self.h, catalog.item_vec.ctypes.data_as(C.c_void_p), catalog.price.ctypes.data_as(C.c_void_p),
+                catalog.action_emb.ctypes.data_as(C.c_void_p), catalog.is_special.ctypes.data_as(C.c_void_p),
+                loc.ctypes.data_as(C.c_void_p), _stream()))
+        self.n_complete = self.lib.rl4rs_env_complete_rows(self.h)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_env_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- batch / reset
+    def load_batch(self, exposed, feedback, history, user_dense, user_cat):
+        d = self.device
+        ex = _dev_tensor(exposed, torch.int32, d)
+        fb = _dev_tensor(feedback, torch.int32, d)
+        hi = _dev_tensor(history, torch.int32, d)
+        ud = _dev_tensor(user_dense, torch.float32, d)
+        uc = _dev_tensor(user_cat, torch.int32, d)
+        assert ex.shape == (self.B, self.log_steps) and fb.shape == ex.shape, (ex.shape, self.log_steps)
+        assert hi.shape == (self.B, self.L) and ud.shape == (self.B, 32) and uc.shape == (self.B, 10)
+        check(self.lib.rl4rs_env_load_batch(self.h, _ptr(ex), _ptr(fb), _ptr(hi), _ptr(ud), _ptr(uc), _stream()))
+        self._keep = (ex, fb, hi, ud, uc)     # keep sources alive until the async copies ran
+
+    def reset(self):
+        check(self.lib.rl4rs_env_reset(self.h, _stream()))
+
+    # ------------------------------------------------------------------------ act
+    def act_discrete(self, actions):
+        a = _dev_tensor(actions, torch.int32, self.device).reshape(-1)
+        assert a.numel() == self.B, (a.shape, self.B)
+        check(self.lib.rl4rs_env_act_discrete(self.h, _ptr(a), _stream()))
+        return a
+
+    def act_conti(self, actions):
+        if isinstance(actions, torch.Tensor):
+            a = actions.to(self.device)
+            if a.dtype not in (torch.float32, torch.float64):
+                a = a.to(torch.float64)
+            a = a.contiguous()
+        else:
+            a = np.asarray(actions)
+            a = a.astype(np.float32 if a.dtype == np.float32 else np.float64)
+            a = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        assert a.shape == (self.B, self.E), (a.shape, (self.B, self.E))
+        chosen = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_env_act_conti(self.h, _ptr(a), 1 if a.dtype == torch.float64 else 0,
+                                           _ptr(chosen), _stream()))
+        return chosen
+
+    # -------------------------------------------------------------------- queries
+    @property
+    def cur_steps(self):
+        return self.lib.rl4rs_env_cur_steps(self.h)
+
+    def is_reward_step(self):
+        return bool(self.lib.rl4rs_env_is_reward_step(self.h))
+
+    def buffer_ptr(self, which):
+        p = C.c_void_p()
+        n = C.c_int64()
+        check(self.lib.rl4rs_env_buffer(self.h, which, C.byref(p), C.byref(n)))
+        return p, n.value
+
+    def snapshot(self, which):
+        """Copy an env-owned buffer into a fresh torch tensor (device)."""
+        p, n = self.buffer_ptr(which)
+        B, nc = self.B, self.n_complete
+        shapes = {
+            BUF_PREV_ACTIONS: ((B, self.T), torch.int32), BUF_ACTION_MASK: ((B, self.W), torch.int32),
+            BUF_SPECIAL_MASK: ((B, self.W), torch.int32), BUF_DENSE: ((B, self.Dn), torch.float32),
+            BUF_CATEGORY: ((B, self.Cn), torch.int32), BUF_SEQ0: ((B, self.L), torch.int32),
+            BUF_SEQ1: ((B, self.L), torch.int32), BUF_C_DENSE: ((B * nc, self.Dn), torch.float32),
+            BUF_C_CATEGORY: ((B * nc, self.Cn), torch.int32), BUF_ERROR_FLAG: ((1,), torch.int32),
+        }
+        shape, dt = shapes[which]
+        out = torch.empty(shape, dtype=dt, device=self.device)
+        assert out.numel() * out.element_size() == n, (which, shape, n)
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p, n, _stream()))
+        return out
+
+    def bits_to_mask(self, bits):
+        """uint32 bit rows [B,W] -> int64 [B,A] (numpy), the reference's mask layout."""
+        b = bits.cpu().numpy().view(np.uint32)
+        k = np.arange(self.A)
+        return ((b[:, k >> 5] >> (k & 31).astype(np.uint32)) & 1).astype(np.int64)
+
+    def build_complete(self):
+        check(self.lib.rl4rs_env_build_complete(self.h, _stream()))
+
+    def reward(self, probs):
+        out = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        assert probs.dtype == torch.float32 and probs.numel() == self.B * self.n_complete
+        check(self.lib.rl4rs_env_reward(self.h, _ptr(probs), _ptr(out), _stream()))
+        return out
+
+    def violation(self):
+        out = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_env_violation(self.h, _ptr(out), _stream()))
+        return out
+
+    def obs_mask(self, dtype=torch.int64):
+        out = torch.empty((self.B, self.A), dtype=dtype, device=self.device)
+        check(self.lib.rl4rs_env_obs_mask(self.h, _ptr(out), _MASK_DTYPES[dtype], _stream()))
+        return out
+
+    def offline_action(self, conti=False):
+        ids = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        emb = torch.empty((self.B, self.E), dtype=torch.float64, device=self.device) if conti else None
+        check(self.lib.rl4rs_env_offline_action(self.h, _ptr(ids), _ptr(emb), _stream()))
+        return emb if conti else ids
+
+    def offline_reward(self):
+        out = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        check(self.lib.rl4rs_env_offline_reward(self.h, _ptr(out), _stream()))
+        return out
+
+    def check_error_flag(self):
+        flag = int(self.snapshot(BUF_ERROR_FLAG).item())
+        if flag:
+            raise IndexError("an action id outside [0, action_size) was passed to act() "
+                             "(numpy would raise at rl4rs/env/slate.py:199)")
+
+
+def knn(actions, action_emb_dev):
+    """SlateState.get_nearest_neighbor on device: actions [n,E] (f32/f64) -> int32 [n]."""
+    lib = _lib.load()
+    dev = action_emb_dev.device
+    a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(actions)))
+    if a.dtype not in (torch.float32, torch.float64):
+        a = a.to(torch.float64)
+    a = a.to(dev).contiguous()
+    n, E = a.shape
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib.rl4rs_knn(_ptr(a), 1 if a.dtype == torch.float64 else 0, n, _ptr(action_emb_dev),
+                        action_emb_dev.shape[0], E, _ptr(out), _stream()))
+    return out
+
+
+class DeviceDien(object):
+    """rl4rs_dien handle: DIEN scorer with its sequence cache."""
+
+    def __init__(self, config, weights, max_rows, max_slots, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.S = int(config['seq_num'])
+        self.L = int(config['maxlen'])
+        self.E = int(config['emb_size'])
+        self.U = int(config['hidden_units'])
+        self.Cn = int(config['category_feature_num'])
+        self.Dn = int(config['dense_feature_num'])
+        self.K = int(config['class_num'])
+        self.max_rows, self.max_slots = int(max_rows), int(max_slots)
+        self.F = self.S * 2 * self.E + self.U + (self.Cn + 1) * self.E
+        cfg = _lib.DienCfg(self.L, self.E, self.U, self.Dn, self.Cn, int(config['category_hash_size']),
+                           self.S, self.K, self.max_rows, self.max_slots)
+        w = _lib.DienWeights()
+        keep = []
+
+        def fp(name):
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(arr)
+            return arr.ctypes.data_as(_lib._FP)
+
+        for name in ('cat_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'seq_emb', 'obs_w', 'obs_b',
+                     'out_w', 'out_b'):
+            setattr(w, name, fp(name))
+        for i in range(self.S):
+            w.gru_gate_w[i] = fp('gru%d_gate_w' % i)
+            w.gru_gate_b[i] = fp('gru%d_gate_b' % i)
+            w.gru_cand_w[i] = fp('gru%d_cand_w' % i)
+            w.gru_cand_b[i] = fp('gru%d_cand_b' % i)
+            w.att_w1[i] = fp('att%d_w1' % i)
+            w.att_b1[i] = fp('att%d_b1' % i)
+            w.att_w2[i] = fp('att%d_w2' % i)
+            w.att_b2[i] = fp('att%d_b2' % i)
+            w.att_w3[i] = fp('att%d_w3' % i)
+            w.att_b3[i] = fp('att%d_b3' % i)
+            w.augru_gate_w[i] = fp('augru%d_gate_w' % i)
+            w.augru_gate_b[i] = fp('augru%d_gate_b' % i)
+            w.augru_cand_w[i] = fp('augru%d_cand_w' % i)
+            w.augru_cand_b[i] = fp('augru%d_cand_b' % i)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_dien_create(C.byref(cfg), C.byref(w), _stream(), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_dien_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, s, ids, slot_base=0):
+        """ids: int32 device tensor [n, L] (or a raw (ptr, n) pair)."""
+        if isinstance(ids, tuple):
+            ptr, n = ids
+        else:
+            ids = _dev_tensor(ids, torch.int32, self.device)
+            assert ids.dim() == 2 and ids.shape[1] == self.L
+            ptr, n = _ptr(ids), ids.shape[0]
+            self._keep_ids = ids
+        check(self.lib.rl4rs_dien_encode(self.h, s, ptr, n, slot_base, _stream()))
+
+    def forward(self, R, group, dense, cat, slots, want_obs=True, want_prob=False, obs_out=None):
+        """dense/cat: device tensors or raw c_void_p pointers; slots: int32 device tensor [S, R/group]."""
+        dp = dense if isinstance(dense, C.c_void_p) else _ptr(dense)
+        cp = cat if isinstance(cat, C.c_void_p) else _ptr(cat)
+        assert slots.dtype == torch.int32 and slots.numel() == self.S * (R // group)
+        obs = None
+        if want_obs:
+            obs = obs_out if obs_out is not None else torch.empty((R, 256), dtype=torch.float32, device=self.device)
+        prob = torch.empty(R, dtype=torch.float32, device=self.device) if want_prob else None
+        check(self.lib.rl4rs_dien_forward(self.h, R, group, dp, cp, _ptr(slots), _ptr(obs), _ptr(prob), _stream()))
+        return obs, prob
+
+    def snapshot(self, which, rows):
+        p = C.c_void_p()
+        n = C.c_int64()
+        check(self.lib.rl4rs_dien_buffer(self.h, which, C.byref(p), C.byref(n)))
+        if which == DIEN_ALL_FEATURE:
+            shape = (self.max_rows, self.F)
+        elif which == DIEN_SCORES:
+            shape = (self.S, self.max_rows, self.L)
+        elif which == DIEN_QUERY:
+            shape = (self.max_rows, self.E)
+        else:
+            shape = (self.max_slots, self.L, self.E)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        assert out.numel() * 4 == n.value
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p, n.value, _stream()))
+        return out
+
+    # profiling (bench.py roofline)
+    def set_profiling(self, on):
+        check(self.lib.rl4rs_dien_set_profiling(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.rl4rs_dien_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        for k in range(self.lib.rl4rs_dien_kernel_count()):
+            ms = C.c_double()
+            n = C.c_int64()
+            check(self.lib.rl4rs_dien_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[self.lib.rl4rs_dien_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+
+def gemm_f32(a, w, bias=None, act=0):
+    """C = act(a @ w + bias) through rl4rs_gemm_f32 (tests)."""
+    lib = _lib.load()
+    M, K = a.shape
+    K2, N = w.shape
+    assert K == K2
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.rl4rs_gemm_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(c), N, M, N, K, act, _stream()))
+    return c

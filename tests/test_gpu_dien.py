@@ -1,0 +1,107 @@
+"""GPU parity of the HIP DIEN scorer against the numpy oracle restatement (fp64) with seeded synthetic
+weights.  Tolerances (fp32 kernel vs fp64 oracle): obs 5e-5 abs (activations are O(1..10)),
+probabilities 5e-6 abs; the fp32 oracle itself differs from the fp64 one by ~1e-5 / 1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"maxlen": 64, "batch_size": 8, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+       "category_feature_num": 21, "category_hash_size": 3000, "seq_num": 2, "emb_size": 128,
+       "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32}
+
+
+def _inputs(R, rs, hash_size):
+    seq = rs.randint(0, 284, size=(R, 2, 64)).astype(np.int32)
+    seq[: R // 3, 0, :20] = 0            # left padding like short histories
+    seq[::2, 1, :] = 0                   # the constant all-zero second sequence of SlateState
+    dense = np.abs(rs.randn(R, 432) * 3).astype(np.float32)
+    cat = rs.randint(0, hash_size, size=(R, 21)).astype(np.int32)
+    cat[:, 10:] = rs.randint(0, 284, size=(R, 11))
+    return seq, dense, cat
+
+
+@pytest.mark.parametrize('R', [5, 64, 333])
+def test_dien_rowwise_matches_oracle(R):
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien, DIEN_ALL_FEATURE, DIEN_SCORES, DIEN_QUERY, DIEN_H1
+    from oracle.dien import OracleDien
+    w = init_dien_weights(CFG, seed=3, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(R)
+    seq, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+    net = DeviceDien(CFG, w, max_rows=R, max_slots=R)
+    for s in range(2):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    slots = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+    obs, prob = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots,
+                            want_obs=True, want_prob=True)
+    torch.cuda.synchronize()
+    orc = OracleDien(w, CFG, np.float64)
+    allf, parts = orc.features(seq, dense, cat, return_parts=True)
+    h1 = net.snapshot(DIEN_H1, R).cpu().numpy()[:R]
+    assert np.abs(h1 - parts['h1_0']).max() < 2e-6
+    q = net.snapshot(DIEN_QUERY, R).cpu().numpy()[:R]
+    assert np.abs(q - parts['query']).max() < 1e-6
+    sc = net.snapshot(DIEN_SCORES, R).cpu().numpy()
+    assert np.abs(sc[0, :R] - parts['score_0']).max() < 2e-6
+    assert np.abs(sc[1, :R] - parts['score_1']).max() < 2e-6
+    af = net.snapshot(DIEN_ALL_FEATURE, R).cpu().numpy()[:R]
+    assert np.abs(af[:, :256] - parts['h2_0']).max() < 5e-6
+    assert np.abs(af[:, 256:512] - parts['h2_1']).max() < 5e-6
+    assert np.abs(af[:, 512:640] - parts['dense_feat']).max() < 2e-5 * max(1.0, np.abs(parts['dense_feat']).max())
+    assert np.abs(af[:, 640:] - parts['cat_feat']).max() < 2e-6
+    obs_ref = orc.obs(seq, dense, cat)
+    prob_ref = orc.reward_probs(seq, dense, cat)[:, 1]
+    assert np.abs(obs.cpu().numpy() - obs_ref).max() < 5e-5
+    assert np.abs(prob.cpu().numpy() - prob_ref).max() < 5e-6
+    net.close()
+
+
+def test_dien_grouped_slots_and_obs_only():
+    """Rows of one env share cache slots (group = 9 reward rows); also obs-only / prob-only calls."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from oracle.dien import OracleDien
+    w = init_dien_weights(CFG, seed=11, emb_scale=0.5, bias_noise=0.2)
+    B, G = 7, 9
+    R = B * G
+    rs = np.random.RandomState(1)
+    seq_env, _, _ = _inputs(B, rs, CFG['category_hash_size'])
+    _, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+    net = DeviceDien(CFG, w, max_rows=R + 3, max_slots=B + 2)
+    # sequence 0 in slots 2..B+1, sequence 1 shares ONE slot (all-zero ids) like SlateState
+    net.encode(0, torch.from_numpy(np.ascontiguousarray(seq_env[:, 0])).cuda(), 2)
+    net.encode(1, torch.zeros((1, 64), dtype=torch.int32).cuda(), 1)
+    slots = torch.stack([torch.arange(2, B + 2, dtype=torch.int32),
+                         torch.full((B,), 1, dtype=torch.int32)]).contiguous().cuda()
+    obs, prob = net.forward(R, G, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots,
+                            want_obs=True, want_prob=True)
+    _, prob2 = net.forward(R, G, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots,
+                           want_obs=False, want_prob=True)
+    seq_rows = np.repeat(seq_env, G, axis=0).copy()
+    seq_rows[:, 1, :] = 0
+    orc = OracleDien(w, CFG, np.float64)
+    assert np.abs(obs.cpu().numpy() - orc.obs(seq_rows, dense, cat)).max() < 5e-5
+    pr = orc.reward_probs(seq_rows, dense, cat)[:, 1]
+    assert np.abs(prob.cpu().numpy() - pr).max() < 5e-6
+    assert np.array_equal(prob.cpu().numpy(), prob2.cpu().numpy())   # deterministic
+    net.close()
+
+
+def test_dien_bad_arguments():
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from rl4rs_amd._lib import Rl4rsHipError
+    import torch
+    w = init_dien_weights(CFG, seed=3)
+    net = DeviceDien(CFG, w, max_rows=8, max_slots=4)
+    with pytest.raises(Rl4rsHipError):
+        net.encode(0, torch.zeros((5, 64), dtype=torch.int32).cuda(), 0)      # exceeds max_slots
+    slots = torch.zeros((2, 16), dtype=torch.int32).cuda()
+    with pytest.raises(Rl4rsHipError):
+        net.forward(16, 1, torch.zeros((16, 432)).cuda(), torch.zeros((16, 21), dtype=torch.int32).cuda(), slots)
+    bad = dict(CFG, emb_size=64)
+    with pytest.raises((Rl4rsHipError, KeyError, ValueError)):
+        DeviceDien(bad, w, max_rows=8, max_slots=4)
