@@ -108,9 +108,11 @@ int rl4rs_env_act_discrete(rl4rs_env* env, const int32_t* actions_dev, void* str
 int rl4rs_env_act_conti(rl4rs_env* env, const void* actions_dev, int is_f64, int32_t* chosen_dev,
                         void* stream);
 
-/* SlateState.get_nearest_neighbor (slate.py:180-184, static, unmasked): [n,E] -> [n]. */
+/* SlateState.get_nearest_neighbor / get_nearest_neighbor_with_mask (slate.py:180-191, static):
+ * [n,E] -> [n].  mask_dev: optional uint8 [n, action_size] (0 = score forced to -2**31). */
 int rl4rs_knn(const void* actions_dev, int is_f64, int32_t n, const double* action_emb_dev,
-              int32_t action_size, int32_t emb_size, int32_t* out_dev, void* stream);
+              int32_t action_size, int32_t emb_size, const uint8_t* mask_dev, int32_t* out_dev,
+              void* stream);
 
 /* get_complete_states + feature_extraction for the reward rows (slate.py:117-131,289-294;
  * seqslate.py:27-50,141-146): fills the env's complete-state buffers ([B*n, ...], env-major). */

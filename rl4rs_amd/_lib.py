@@ -70,7 +70,7 @@ SIGNATURES = {
     'rl4rs_env_reset': (_I, [_P, _P]),
     'rl4rs_env_act_discrete': (_I, [_P, _P, _P]),
     'rl4rs_env_act_conti': (_I, [_P, _P, _I, _P, _P]),
-    'rl4rs_knn': (_I, [_P, _I, _I32, _P, _I32, _I32, _P, _P]),
+    'rl4rs_knn': (_I, [_P, _I, _I32, _P, _I32, _I32, _P, _P, _P]),
     'rl4rs_env_build_complete': (_I, [_P, _P]),
     'rl4rs_env_complete_rows': (_I, [_P]),
     'rl4rs_env_is_reward_step': (_I, [_P]),

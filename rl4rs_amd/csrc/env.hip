@@ -231,7 +231,8 @@ template <typename TA>
 __global__ __launch_bounds__(256) void k_knn(const TA* __restrict__ actions, int n, const double* __restrict__ emb,
                                              int A, int E, const uint32_t* __restrict__ amask,
                                              const uint32_t* __restrict__ smask, const uint32_t* __restrict__ loc,
-                                             int W, int32_t* __restrict__ out) {
+                                             int W, const uint8_t* __restrict__ dense_mask,
+                                             int32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_act = reinterpret_cast<double*>(smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void k_knn(const TA* __restrict__ actions, int
             uint32_t m = amask[(size_t)b * W + (k >> 5)] & smask[(size_t)b * W + (k >> 5)] & loc[k >> 5];
             if (!((m >> (k & 31)) & 1u)) s = -2147483648.0;     // action_score[mask < 0.5] = -2**31
         }
+        if (dense_mask && !dense_mask[(size_t)b * A + k]) s = -2147483648.0;
         if (best_k == 0x7fffffff || s > best) { best = s; best_k = k; }
     }
     // first-max wins: lower index on ties (np.argmax)
@@ -591,14 +593,14 @@ int rl4rs_env_act_discrete(rl4rs_env* e, const int32_t* actions, void* stream) {
 }
 
 static int knn_launch(const void* actions, int is_f64, int n, const double* emb, int A, int E,
-                      const uint32_t* amask, const uint32_t* smask, const uint32_t* loc, int W, int32_t* out,
-                      hipStream_t st) {
+                      const uint32_t* amask, const uint32_t* smask, const uint32_t* loc, int W,
+                      const uint8_t* dense_mask, int32_t* out, hipStream_t st) {
     dim3 grid((n + 3) / 4), block(256);
     size_t smem = (size_t)4 * E * sizeof(double);
     if (is_f64)
-        hipLaunchKernelGGL(k_knn<double>, grid, block, smem, st, (const double*)actions, n, emb, A, E, amask, smask, loc, W, out);
+        hipLaunchKernelGGL(k_knn<double>, grid, block, smem, st, (const double*)actions, n, emb, A, E, amask, smask, loc, W, dense_mask, out);
     else
-        hipLaunchKernelGGL(k_knn<float>, grid, block, smem, st, (const float*)actions, n, emb, A, E, amask, smask, loc, W, out);
+        hipLaunchKernelGGL(k_knn<float>, grid, block, smem, st, (const float*)actions, n, emb, A, E, amask, smask, loc, W, dense_mask, out);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
@@ -614,16 +616,16 @@ int rl4rs_env_act_conti(rl4rs_env* e, const void* actions, int is_f64, int32_t* 
     int layer = d.is_seq ? (e->cur_steps % d.P) / 3 : e->cur_steps / 3;   // PRE-increment (slate.py:195)
     RL4RS_REQUIRE(layer < 4, "location layer %d out of range (cur_steps=%d)", layer, e->cur_steps);
     int rc = knn_launch(actions, is_f64, d.B, d.action_emb, d.A, d.E, d.amask, d.smask, d.loc_bits + layer * d.W,
-                        d.W, e->knn_tmp, st);
+                        d.W, nullptr, e->knn_tmp, st);
     if (rc) return rc;
     if (chosen) RL4RS_HIP_TRY(hipMemcpyAsync(chosen, e->knn_tmp, (size_t)d.B * 4, hipMemcpyDeviceToDevice, st));
     return rl4rs_env_act_discrete(e, e->knn_tmp, stream);
 }
 
-int rl4rs_knn(const void* actions, int is_f64, int32_t n, const double* emb, int32_t A, int32_t E, int32_t* out,
-              void* stream) {
+int rl4rs_knn(const void* actions, int is_f64, int32_t n, const double* emb, int32_t A, int32_t E,
+              const uint8_t* mask, int32_t* out, void* stream) {
     RL4RS_REQUIRE(actions && emb && out && n > 0 && A > 0 && E > 0, "rl4rs_knn: bad argument");
-    return knn_launch(actions, is_f64, n, emb, A, E, nullptr, nullptr, nullptr, 0, out, (hipStream_t)stream);
+    return knn_launch(actions, is_f64, n, emb, A, E, nullptr, nullptr, nullptr, 0, mask, out, (hipStream_t)stream);
 }
 
 int rl4rs_env_complete_rows(const rl4rs_env* e) { return e ? e->n_complete : RL4RS_EINVAL; }

@@ -191,8 +191,8 @@ class DeviceEnv(object):
                              "(numpy would raise at rl4rs/env/slate.py:199)")
 
 
-def knn(actions, action_emb_dev):
-    """SlateState.get_nearest_neighbor on device: actions [n,E] (f32/f64) -> int32 [n]."""
+def knn(actions, action_emb_dev, mask=None):
+    """SlateState.get_nearest_neighbor(_with_mask) on device: actions [n,E] (f32/f64) -> int32 [n]."""
     lib = _lib.load()
     dev = action_emb_dev.device
     a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(actions)))
@@ -201,8 +201,13 @@ def knn(actions, action_emb_dev):
     a = a.to(dev).contiguous()
     n, E = a.shape
     out = torch.empty(n, dtype=torch.int32, device=dev)
+    m = None
+    if mask is not None:
+        m = (torch.as_tensor(np.asarray(mask) >= 0.5) if not isinstance(mask, torch.Tensor) else (mask >= 0.5))
+        m = m.to(device=dev, dtype=torch.uint8).contiguous()
+        assert m.shape == (n, action_emb_dev.shape[0])
     check(lib.rl4rs_knn(_ptr(a), 1 if a.dtype == torch.float64 else 0, n, _ptr(action_emb_dev),
-                        action_emb_dev.shape[0], E, _ptr(out), _stream()))
+                        action_emb_dev.shape[0], E, _ptr(m), _ptr(out), _stream()))
     return out
 
 

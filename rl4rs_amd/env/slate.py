@@ -1,0 +1,421 @@
+"""SlateState / SlateRecEnv with the reference's names and behaviour, executing on the GPU.
+
+Mirrors ``rl4rs/env/slate.py``: ``SlateState`` (slate.py:8-218) keeps its per-batch state machine in
+HBM behind ``librl4rs_hip.so``; ``SlateRecEnv`` (slate.py:220-308) scores with the HIP DIEN.  Public
+attributes scripts read (``prev_actions``, ``action_mask``, ``special_mask``, ``cur_steps``,
+``action_emb``, ``records``, ``item_info_d``, ``location_mask``, ``special_items``) are materialised
+from device memory on access.
+
+Config keys are the reference's; two additions select the zero-copy mode:
+``return_tensors`` (bool, default False): return torch CUDA tensors instead of numpy/list objects;
+``model_seed`` (int): seed for synthetic DIEN weights when ``model_file`` is empty.
+"""
+import numpy as np
+
+from .base import RecSimBase, RecState, RecordBatch
+from ..data import CatalogTables, RecordColumns
+from ..utils.datautil import FeatureUtil
+from .. import device as D
+
+_CATALOG_CACHE = {}
+
+
+def _catalog(iteminfo_file, action_size, action_emb_size, onehot):
+    key = (iteminfo_file, action_size, action_emb_size, bool(onehot))
+    if key not in _CATALOG_CACHE:
+        _CATALOG_CACHE[key] = CatalogTables(iteminfo_file, action_size, action_emb_size, onehot)
+    return _CATALOG_CACHE[key]
+
+
+class StateRows(object):
+    """What ``SlateState.state`` / ``get_complete_states`` hand to ``obs_fn`` / ``feature_extraction``:
+    a view of R feature rows that live in the env's device buffers (``kind`` 'state' or 'complete')."""
+
+    def __init__(self, owner, kind):
+        self.owner = owner
+        self.kind = kind
+
+    @property
+    def rows(self):
+        return self.owner.batch_size * (1 if self.kind == 'state' else self.owner._env.n_complete)
+
+    def __len__(self):
+        return self.rows
+
+    def numpy_features(self):
+        env = self.owner._env
+        B, L = env.B, env.L
+        s0 = env.snapshot(D.BUF_SEQ0).cpu().numpy()
+        s1 = env.snapshot(D.BUF_SEQ1).cpu().numpy()
+        if self.kind == 'state':
+            dense = env.snapshot(D.BUF_DENSE).cpu().numpy()
+            cat = env.snapshot(D.BUF_CATEGORY).cpu().numpy()
+            seq = np.stack([s0, s1], axis=1)
+        else:
+            n = env.n_complete
+            dense = env.snapshot(D.BUF_C_DENSE).cpu().numpy()
+            cat = env.snapshot(D.BUF_C_CATEGORY).cpu().numpy()
+            seq = np.repeat(np.stack([s0, s1], axis=1), n, axis=0)
+        return seq, dense, cat
+
+
+class SlateState(RecState):
+    is_seq = False
+
+    def __init__(self, config, records, _ctx=None):
+        RecState.__init__(self, config, records)
+        self.batch_size = self.config["batch_size"]
+        self.action_size = self.config["action_size"]
+        self.action_emb_size = self.config.get("action_emb_size", 32)
+        self.max_steps = config['max_steps']
+        self.page_items = config.get("page_items", 9)
+        self.infos = [{} for _ in range(self.batch_size)]
+        onehot = config.get('support_onehot_action', False)
+        self._catalog = _catalog(config["iteminfo_file"], self.action_size, self.action_emb_size, onehot)
+        if onehot:                      # slate.py:22-25
+            config['action_emb_size'] = self.action_size
+            self.action_emb_size = self.action_size
+        self.action_emb = self._catalog.action_emb
+        self.location_mask = self._catalog.location_mask
+        self.special_items = self._catalog.special_items
+        if len(records) != self.batch_size:
+            raise ValueError('got %d records for batch_size=%d' % (len(records), self.batch_size))
+        self._ctx = _ctx if _ctx is not None else {}
+        self._bind_device(records)
+
+    # ------------------------------------------------------------------ device plumbing
+    def _violation_zeroes_reward(self):
+        return True                     # slate.py:303-307: unconditional
+
+    def _bind_device(self, records):
+        import torch
+        store = getattr(records, 'store', None)
+        if store is not None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+            cols = store.gather(records.rows, dev)
+            log_steps = store.log_steps
+            self._exposed_len_min = int(store.exposed_len[np.asarray(records.rows)].min())
+            self._users = None
+        else:
+            rc = RecordColumns(list(records), self.config['maxlen'])
+            cols = dict(exposed=rc.exposed, feedback=rc.feedback, history=rc.history,
+                        user_dense=rc.user_dense, user_cat=rc.user_cat)
+            log_steps = rc.log_steps
+            self._exposed_len_min = int(rc.exposed_len.min())
+            self._users = rc.users
+        key = ('env', self.is_seq, log_steps, self.batch_size, self.max_steps, self._violation_zeroes_reward())
+        env = self._ctx.get(key)
+        if env is None:
+            env = D.DeviceEnv(self.config, self._catalog, self.is_seq, log_steps, self._violation_zeroes_reward())
+            self._ctx[key] = env
+        self._env = env
+        self._ctx['owner'] = self
+        env.load_batch(cols['exposed'], cols['feedback'], cols['history'], cols['user_dense'], cols['user_cat'])
+        env.reset()
+        self._seq1_version = 0
+        self._batch_version = self._ctx.get('batch_version', 0) + 1
+        self._ctx['batch_version'] = self._batch_version
+
+    def _live(self):
+        if self._ctx.get('owner') is not self:
+            raise RuntimeError('this SlateState was replaced by a newer sample() on the same device env')
+        return self._env
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def cur_steps(self):
+        return self._live().cur_steps
+
+    @property
+    def prev_actions(self):
+        return self._live().snapshot(D.BUF_PREV_ACTIONS).cpu().numpy().astype(np.int64)
+
+    @property
+    def action_mask(self):
+        env = self._live()
+        return env.bits_to_mask(env.snapshot(D.BUF_ACTION_MASK))
+
+    @property
+    def special_mask(self):
+        env = self._live()
+        return env.bits_to_mask(env.snapshot(D.BUF_SPECIAL_MASK))
+
+    @property
+    def item_info_d(self):
+        return self._catalog.item_info_dict()
+
+    @staticmethod
+    def get_iteminfo_from_file(iteminfo_file, action_size, action_emb_size=32):
+        t = _catalog(iteminfo_file, action_size, action_emb_size, False)
+        return t.item_info_dict(), t.action_emb
+
+    @staticmethod
+    def get_mask_from_file(iteminfo_file, action_size):
+        t = _catalog(iteminfo_file, action_size, 32, False)
+        return t.location_mask, t.special_items
+
+    @staticmethod
+    def records_to_state(records):
+        """The reference's nested-list state (slate.py:67-83), kept for API parity."""
+        out = []
+        for rec in records:
+            parts = FeatureUtil.record_split(rec)
+            hist, portrait = parts[5], parts[6]
+            out.append([0, [hist, [0]], portrait[10:], portrait[:10], [0] * 9, 0])
+        return out
+
+    def get_location_mask(self, location_mask, cur_layer):
+        return np.repeat(location_mask[cur_layer][np.newaxis, :], self.batch_size, 0)
+
+    # ------------------------------------------------------------------ state / obs views
+    def _tensor_mode(self):
+        return bool(self.config.get('return_tensors', False))
+
+    def _obs_mask(self):
+        import torch
+        m = self._live().obs_mask(torch.int64)
+        return m if self._tensor_mode() else m.cpu().numpy()
+
+    def _masked_actions(self):
+        """slate.py:98-104"""
+        import torch
+        env = self._live()
+        pa = env.snapshot(D.BUF_PREV_ACTIONS).to(torch.int64)
+        cur = torch.full((self.batch_size, 1), env.cur_steps, dtype=torch.int64, device=pa.device)
+        return pa, cur
+
+    @property
+    def state(self):
+        rows = StateRows(self, 'state')
+        if self.config.get("support_rllib_mask", False):
+            return {"state": rows, "action_mask": self._obs_mask()}
+        elif self.config.get("support_d3rl_mask", False):
+            pa, cur = self._masked_actions()
+            if not self._tensor_mode():
+                pa, cur = pa.cpu().numpy(), cur.cpu().numpy()
+            return {"state": rows, "masked_actions": pa, "cur_steps": cur}
+        return rows
+
+    @property
+    def user(self):
+        if self._users is None:
+            self._users = [x.split('@')[1] for x in self.records]
+        return self._users
+
+    @property
+    def info(self):
+        return self.infos
+
+    def to_string(self):
+        return '\n'.join(self.records)
+
+    # ------------------------------------------------------------------ dynamics
+    def get_price(self, actions):
+        return self._catalog.price[np.asarray(actions)]
+
+    def get_complete_states(self):
+        self._live().build_complete()
+        return StateRows(self, 'complete')
+
+    def get_violation(self):
+        return self._live().violation().cpu().numpy().astype(np.int64)
+
+    @property
+    def offline_action(self):
+        env = self._live()
+        if env.cur_steps < self.max_steps and env.cur_steps >= self._exposed_len_min:
+            raise IndexError('list index out of range')       # exposed_items[cur_step], slate.py:154-156
+        conti = bool(self.config.get("support_conti_env", False))
+        out = env.offline_action(conti=conti)
+        if self._tensor_mode():
+            return out
+        out = out.cpu().numpy()
+        return [row for row in out] if conti else out.tolist()
+
+    @property
+    def offline_reward(self):
+        env = self._live()
+        if env.cur_steps < self.max_steps:
+            return [0, ] * self.batch_size
+        r = env.offline_reward()
+        return r if self._tensor_mode() else r.cpu().numpy().tolist()
+
+    @staticmethod
+    def get_nearest_neighbor(actions, action_emb, temperature=None):
+        import torch
+        emb = torch.from_numpy(np.ascontiguousarray(action_emb, dtype=np.float64)).cuda()
+        return D.knn(actions, emb).cpu().numpy().astype(np.int64)
+
+    @staticmethod
+    def get_nearest_neighbor_with_mask(actions, action_emb, action_mask, temperature=None):
+        import torch
+        emb = torch.from_numpy(np.ascontiguousarray(action_emb, dtype=np.float64)).cuda()
+        return D.knn(actions, emb, mask=np.asarray(action_mask)).cpu().numpy().astype(np.int64)
+
+    def act(self, actions):
+        env = self._live()
+        if self.config.get("support_conti_env", False):
+            self.last_actions = env.act_conti(actions)
+        else:
+            self.last_actions = env.act_discrete(actions)
+        if not self._tensor_mode():
+            env.check_error_flag()
+
+
+class DienModel(object):
+    """What ``SlateRecEnv.get_model`` returns: host weights + (lazily) the device scorer."""
+
+    def __init__(self, config, weights=None):
+        self.config = config
+        self.weights = weights
+        self.device_net = None
+        self.max_rows = 0
+        self.max_slots = 0
+
+    def ensure_device(self, max_rows, max_slots):
+        if self.device_net is None or max_rows > self.max_rows or max_slots > self.max_slots:
+            if self.device_net is not None:
+                self.device_net.close()
+            if self.weights is None:
+                raise RuntimeError("no simulator weights: set config['model_file'] to an .npz with the "
+                                   "rl4rs_amd.nets.dien.dien_spec arrays or config['model_seed'] for synthetic ones")
+            self.max_rows, self.max_slots = max(max_rows, self.max_rows), max(max_slots, self.max_slots)
+            self.device_net = D.DeviceDien(self.config, self.weights, self.max_rows, self.max_slots)
+            self.zero_slot_ready = False
+        return self.device_net
+
+
+class SlateRecEnv(RecSimBase):
+    """Core simulator (slate.py:220-308) on the GPU."""
+    default_state_seq = False
+
+    def __init__(self, config, state_cls):
+        if not (isinstance(state_cls, type) and issubclass(state_cls, SlateState)):
+            raise NotImplementedError(
+                "state_cls must be rl4rs_amd SlateState/SeqSlateState (or a subclass): the env step runs on "
+                "the GPU and there is no CPU fallback for arbitrary RecState plugins")
+        self.max_steps = config['max_steps']
+        self.batch_size = config['batch_size']
+        self.FeatureUtil = FeatureUtil(config)
+        self._ctx = {}
+        RecSimBase.__init__(self, config, state_cls)
+        self._recData.state_kwargs = {'_ctx': self._ctx}
+        self._encoded_batch = None
+        self._encoded_seq1 = None
+        self._slots = None
+
+    # -- model ---------------------------------------------------------------------------------
+    def get_model(self, config):
+        model_type = config.get('algo', 'dien')
+        if model_type != 'dien':
+            raise NotImplementedError("only the DIEN simulator ('algo': 'dien') runs on the GPU path; got %r" % model_type)
+        from ..nets import dien
+        model = DienModel(config)
+        if not config.get('model_file', None):
+            model.weights = dien.init_dien_weights(config, seed=config.get('model_seed', 7))
+        return model
+
+    def reload_model(self, model_file):
+        from ..nets import dien
+        if not str(model_file).endswith('.npz'):
+            raise NotImplementedError(
+                "model_file=%r: TF1 checkpoints cannot be read here (no TensorFlow); export the variables to an "
+                ".npz with the names of rl4rs_amd.nets.dien.dien_spec" % (model_file,))
+        self.model.weights = dien.load_weights(model_file, self.config)
+        if self.model.device_net is not None:
+            self.model.device_net.close()
+            self.model.device_net = None
+
+    # -- sequence cache ------------------------------------------------------------------------
+    def _net_for(self, samples):
+        import torch
+        B = self.batch_size
+        env = samples._live()
+        net = self.model.ensure_device(B * env.n_complete, B + 1)
+        if self._encoded_batch != (id(net), samples._batch_version):
+            p0, _ = env.buffer_ptr(D.BUF_SEQ0)
+            net.encode(0, (p0, B), 0)                       # history: one slot per env
+            self._encoded_batch = (id(net), samples._batch_version)
+            self._encoded_seq1 = None
+        if samples.is_seq:
+            if self._encoded_seq1 != samples._seq1_version:
+                p1, _ = env.buffer_ptr(D.BUF_SEQ1)
+                for s in range(1, net.S):
+                    net.encode(s, (p1, B), 0)
+                self._encoded_seq1 = samples._seq1_version
+            if self._slots is None or self._slots[0] != 'seq':
+                self._slots = ('seq', torch.arange(B, dtype=torch.int32, device=env.device).repeat(net.S, 1).contiguous())
+        else:
+            if not getattr(self.model, 'zero_slot_ready', False):
+                z = torch.zeros((1, net.L), dtype=torch.int32, device=env.device)
+                for s in range(1, net.S):
+                    net.encode(s, z, B)                     # the constant [0] sequence: ONE shared slot
+                self.model.zero_slot_ready = True
+            if self._slots is None or self._slots[0] != 'slate':
+                sl = torch.full((net.S, B), B, dtype=torch.int32, device=env.device)
+                sl[0] = torch.arange(B, dtype=torch.int32, device=env.device)
+                self._slots = ('slate', sl.contiguous())
+        return net, self._slots[1]
+
+    # -- obs -----------------------------------------------------------------------------------
+    def obs_fn(self, state):
+        masked = self.config.get("support_rllib_mask", False)
+        d3rl = self.config.get("support_d3rl_mask", False)
+        rows = state["state"] if (masked or d3rl) else state
+        samples = rows.owner
+        tensor_mode = samples._tensor_mode()
+        B = self.batch_size
+        if self.config.get("rawstate_as_obs", False):
+            feat, _ = self.FeatureUtil.feature_extraction(rows)
+            obs = [{"category_feature": feat[2][i], "dense_feature": feat[1][i], "sequence_feature": feat[0][i]}
+                   for i in range(B)]
+            if masked:
+                am = state["action_mask"]
+                am = am.cpu().numpy() if hasattr(am, 'cpu') else am
+                return [dict(action_mask=am[i], **obs[i]) for i in range(B)]
+            return obs
+        env = samples._live()
+        net, slots = self._net_for(samples)
+        dp, _ = env.buffer_ptr(D.BUF_DENSE)
+        cp, _ = env.buffer_ptr(D.BUF_CATEGORY)
+        obs, _ = net.forward(B, 1, dp, cp, slots, want_obs=True, want_prob=False)
+        if tensor_mode:
+            if masked:
+                return {"action_mask": state["action_mask"], "obs": obs}
+            if d3rl:
+                import torch
+                return torch.cat([obs.double(), state["masked_actions"].double(), state["cur_steps"].double()], dim=-1)
+            return obs
+        obs = obs.cpu().numpy()
+        if masked:
+            am = state["action_mask"]
+            return [{"action_mask": am[i], "obs": obs[i]} for i in range(B)]
+        if d3rl:
+            return np.concatenate([obs, state["masked_actions"], state["cur_steps"]], axis=-1)
+        return obs
+
+    # -- reward --------------------------------------------------------------------------------
+    def _reward_due(self, samples):
+        return samples.cur_steps >= self.max_steps        # slate.py:283
+
+    def forward(self, model, samples):
+        import torch
+        B = self.batch_size
+        tensor_mode = samples._tensor_mode()
+        if not self._reward_due(samples):
+            if tensor_mode:
+                return torch.zeros(B, dtype=torch.float64, device=samples._env.device)
+            return [0] * B
+        env = samples._live()
+        samples.get_complete_states()
+        n = env.n_complete
+        net, slots = self._net_for(samples)
+        dp, _ = env.buffer_ptr(D.BUF_C_DENSE)
+        cp, _ = env.buffer_ptr(D.BUF_C_CATEGORY)
+        _, probs = net.forward(B * n, n, dp, cp, slots, want_obs=False, want_prob=True)
+        if self.config.get("simulator_info_fetch", False):
+            pr = probs.reshape(B, n).cpu().numpy()
+            for i in range(B):
+                samples.info[i].update({'click_p': pr[i]})
+        reward = env.reward(probs)
+        return reward if tensor_mode else reward.cpu().numpy().tolist()

@@ -38,34 +38,58 @@ def make_catalog_text(action_size=284, item_dim=40, n_special=113, seed=1234):
     return "\n".join(lines)
 
 
+def special_ids_from_text(catalog_text):
+    """ids whose ``special_item`` column is 2 (slate.py:58)."""
+    out = []
+    for line in catalog_text.split('\n')[1:]:
+        f = line.split(' ')
+        if int(f[4]) == 2:
+            out.append(int(f[0]))
+    return out
+
+
 def make_records(n, pages=1, page_items=9, action_size=284, hash_size=100000, seed=1000,
-                 illegal_frac=0.05, max_hist=128, short_frac=0.0):
+                 illegal_frac=0.05, max_hist=128, special_ids=()):
     """Return ``n`` synthetic log records (list of str).
 
-    exposed_items per page: 3 ids from each location layer (legal by construction); a fraction of
-    records gets a duplicate / wrong-layer item injected so that ``get_violation`` fires.
-    ``short_frac`` of records get an exposed_items list shorter than the horizon is NOT generated:
-    the reference indexes ``exposed_items[cur_step]`` unguarded (slate.py:154-156).
+    exposed_items per page: 3 distinct ids from each location layer with at most ONE special item per
+    page (legal by construction, like logged slates); a fraction ``illegal_frac`` of records gets a
+    duplicate / wrong-layer / second-special item injected so that ``get_violation`` fires.
     """
     rs = np.random.RandomState(seed)
+    special = set(int(x) for x in special_ids)
     out = []
     T = pages * page_items
+    per_layer = page_items // 3
     for r in range(n):
         exposed = []
         for _ in range(pages):
+            page = []
             for (lo, hi) in LAYER_BOUNDS:
                 hi = min(hi, action_size)
-                exposed.extend(rs.randint(lo, hi, size=page_items // 3).tolist())
+                plain = [i for i in range(lo, hi) if i not in special]
+                page.extend(rs.choice(plain, size=per_layer, replace=False).tolist())
+            if special and rs.rand() < 0.5:          # one special item somewhere it is legal
+                pos = int(rs.randint(0, len(page)))
+                lo, hi = LAYER_BOUNDS[pos // per_layer]
+                cands = [i for i in range(lo, min(hi, action_size)) if i in special]
+                if cands:
+                    page[pos] = int(rs.choice(cands))
+            exposed.extend(page)
         if rs.rand() < illegal_frac:
-            k = rs.randint(0, 3)
+            k = rs.randint(0, 4)
             pos = rs.randint(1, T)
             if k == 0:      # adjacent duplicate
                 exposed[pos] = exposed[pos - 1]
             elif k == 1:    # wrong layer
                 exposed[pos] = int(rs.randint(1, action_size))
-            else:           # distance-2 duplicate
+            elif k == 2:    # distance-2 duplicate
                 if pos >= 2:
                     exposed[pos] = exposed[pos - 2]
+            elif special:   # two different special items on the first page
+                sp = sorted(special)
+                exposed[page_items - 1] = sp[-1]
+                exposed[page_items - 2] = sp[-2]
         feedback = (rs.rand(T) < 0.3).astype(int).tolist()
         hist_len = int(rs.randint(1, max_hist + 1))
         hist = rs.randint(1, action_size, size=hist_len).tolist()

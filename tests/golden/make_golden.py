@@ -191,9 +191,11 @@ def main():
 
     # ---------------- inputs (committed next to the expected outputs)
     cat_path = os.path.join(HERE, 'catalog_synth.csv')
-    synth.write_text(cat_path, synth.make_catalog_text(seed=1234))
-    rec_a = synth.make_records(6, pages=1, seed=1000, illegal_frac=0.5)
-    rec_b = synth.make_records(6, pages=4, seed=2000, illegal_frac=0.5)
+    cat_text = synth.make_catalog_text(seed=1234)
+    synth.write_text(cat_path, cat_text)
+    sp = synth.special_ids_from_text(cat_text)
+    rec_a = synth.make_records(6, pages=1, seed=1000, illegal_frac=0.5, special_ids=sp)
+    rec_b = synth.make_records(6, pages=4, seed=2000, illegal_frac=0.5, special_ids=sp)
     synth.write_records(os.path.join(HERE, 'records_slate.txt'), rec_a)
     synth.write_records(os.path.join(HERE, 'records_seq.txt'), rec_b)
 

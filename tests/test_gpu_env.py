@@ -93,8 +93,10 @@ def test_hip_env_matches_oracle_large(tmp_path, seq, T, B):
     from oracle.state import OracleState
     from oracle.env import reward_from_probs, is_reward_step
     cat_path = os.path.join(str(tmp_path), 'item_info.csv')
-    synth.write_text(cat_path, synth.make_catalog_text(seed=99))
-    records = synth.make_records(B, pages=4 if seq else 1, seed=5, illegal_frac=0.3)
+    cat_text = synth.make_catalog_text(seed=99)
+    synth.write_text(cat_path, cat_text)
+    records = synth.make_records(B, pages=4 if seq else 1, seed=5, illegal_frac=0.3,
+                                 special_ids=synth.special_ids_from_text(cat_text))
     for conti in (False, True):
         cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
                "category_feature_num": 21, "category_hash_size": 100000, "seq_num": 2, "emb_size": 128,

@@ -1,0 +1,192 @@
+"""End-to-end parity through the reference-shaped API: ``SlateRecEnv``/``SeqSlateRecEnv`` + ``RecEnvBase``
+on the GPU against the oracle env (numpy state machine + fp64 DIEN) on the same files and weights.
+
+Integer quantities (chosen items, masks, done) must be identical; observations within 5e-5 abs;
+rewards within rtol 1e-5 + atol 1e-5 (north star: fp32 rewards within 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, seq, B, T, **flags):
+    from rl4rs_amd import synth
+    from rl4rs_amd.nets.dien import init_dien_weights, save_weights
+    d = str(tmp_path)
+    cat_path = os.path.join(d, 'item_info.csv')
+    cat_text = synth.make_catalog_text(seed=21)
+    synth.write_text(cat_path, cat_text)
+    records = synth.make_records(B + 5, pages=4 if seq else 1, seed=8, illegal_frac=0.3, hash_size=5000,
+                                 special_ids=synth.special_ids_from_text(cat_text))
+    log_path = os.path.join(d, 'log.csv')
+    synth.write_records(log_path, records)
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 5000, "seq_num": 2, "emb_size": 128,
+           "page_items": 9, "hidden_units": 128, "max_steps": T, "action_emb_size": 32,
+           "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": True, "cache_size": B}
+    cfg.update(flags)
+    w = init_dien_weights(cfg, seed=5, emb_scale=0.5, bias_noise=0.2)
+    wpath = os.path.join(d, 'dien.npz')
+    save_weights(wpath, w)
+    cfg['model_file'] = wpath
+    return cfg, records, w
+
+
+def _make(cfg, seq):
+    import rl4rs_amd
+    if seq:
+        from rl4rs.env.seqslate import SeqSlateRecEnv, SeqSlateState
+        sim = SeqSlateRecEnv(cfg, state_cls=SeqSlateState)
+        return rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=sim)
+    from rl4rs.env.slate import SlateRecEnv, SlateState
+    sim = SlateRecEnv(cfg, state_cls=SlateState)
+    return rl4rs_amd.make('SlateRecEnv-v0', recsim=sim)
+
+
+def _oracle(cfg, records, w, seq):
+    from oracle.dien import OracleDien
+    from oracle.env import OracleEnv
+    return OracleEnv(cfg, records[:cfg['batch_size']], OracleDien(w, cfg, np.float64), seq=seq)
+
+
+@pytest.mark.parametrize('seq,T', [(False, 9), (True, 36), (True, 32)])
+@pytest.mark.parametrize('mode', ['plain', 'rllib', 'd3rl', 'conti'])
+def test_episode_matches_oracle(tmp_path, seq, T, mode):
+    flags = {'plain': {}, 'rllib': {'support_rllib_mask': True}, 'd3rl': {'support_d3rl_mask': True},
+             'conti': {'support_conti_env': True}}[mode]
+    B = 12
+    cfg, records, w = _setup(tmp_path, seq, B, T, **flags)
+    env = _make(cfg, seq)
+    orc = _oracle(cfg, records, w, seq)
+    obs = env.reset(reset_file=True)
+    o_obs = orc.reset()
+    assert list(env.user_id) == list(orc.samples.user)
+
+    def check_obs(obs, o_obs):
+        if mode == 'rllib':
+            assert isinstance(obs, list) and len(obs) == B and set(obs[0]) == {'action_mask', 'obs'}
+            got = np.stack([x['obs'] for x in obs])
+            assert np.array_equal(np.stack([x['action_mask'] for x in obs]), o_obs['action_mask'])
+            assert obs[0]['action_mask'].dtype == np.int64
+        elif mode == 'd3rl':
+            assert obs.shape == (B, 256 + o_obs['masked_actions'].shape[1] + 1)
+            got = obs[:, :256]
+            assert np.array_equal(obs[:, 256:-1], o_obs['masked_actions'])
+            assert np.array_equal(obs[:, -1:], o_obs['cur_steps'])
+        else:
+            got = obs
+        assert got.shape == (B, 256)
+        assert np.abs(got - o_obs['obs']).max() < 5e-5
+
+    check_obs(obs, o_obs)
+    rs = np.random.RandomState(4)
+    for t in range(T):
+        if mode == 'conti':
+            a = rs.randn(B, 32).astype(np.float32)
+        else:
+            a = env.offline_action
+            assert a == orc.samples.offline_action
+            if t % 4 == 3:
+                # off-policy ids (duplicates / wrong layers -> violations) for the second half of the batch
+                a = list(a[:B // 2]) + [int(x) for x in rs.randint(0, 284, size=B - B // 2)]
+        obs, reward, done, info = env.step(a)
+        o_obs, o_reward, o_done, chosen = orc.step(a)
+        check_obs(obs, o_obs)
+        assert isinstance(reward, list) and len(reward) == B
+        assert np.allclose(reward, o_reward, rtol=1e-5, atol=1e-5), (t, reward, o_reward)
+        assert done == o_done and isinstance(done, list)
+        assert isinstance(info, list) and len(info) == B
+        assert np.array_equal(env.samples.prev_actions, orc.samples.prev_actions)
+        assert np.allclose(np.asarray(env.offline_reward, dtype=np.float64),
+                           np.asarray(orc.samples.offline_reward, dtype=np.float64), rtol=0, atol=0)
+    assert seq or mode == 'conti' or any(r != 0 for r in reward)
+    assert np.array_equal(env.samples.get_violation(), orc.samples.get_violation())
+    assert np.array_equal(env.samples.action_mask, orc.samples.action_mask)
+    assert np.array_equal(env.samples.special_mask, orc.samples.special_mask)
+
+
+def test_rawstate_and_tensor_modes(tmp_path):
+    import torch
+    B, T = 6, 9
+    cfg, records, w = _setup(tmp_path, False, B, T, support_rllib_mask=True, rawstate_as_obs=True)
+    env = _make(cfg, False)
+    orc = _oracle(dict(cfg, rawstate_as_obs=True), records, w, False)
+    obs = env.reset(reset_file=True)
+    o = orc.reset()
+    assert set(obs[0]) == {'action_mask', 'category_feature', 'dense_feature', 'sequence_feature'}
+    assert obs[0]['sequence_feature'].shape == (2, 64) and len(obs[0]['dense_feature']) == 432
+    for t in range(T):
+        a = env.offline_action
+        obs, reward, done, info = env.step(a)
+        o, o_reward, _, _ = orc.step(a)
+        assert np.array_equal(np.stack([x['dense_feature'] for x in obs]), o['dense_feature'])
+        assert np.array_equal(np.stack([x['category_feature'] for x in obs]), o['category_feature'])
+        assert np.array_equal(np.stack([x['sequence_feature'] for x in obs]), o['sequence_feature'])
+        assert np.array_equal(np.stack([x['action_mask'] for x in obs]), o['action_mask'])
+        assert np.allclose(reward, o_reward, rtol=1e-5, atol=1e-5)
+    # zero-copy mode: torch tensors, no host round trip
+    cfg2, records, w = _setup(tmp_path, False, B, T, return_tensors=True, simulator_info_fetch=True)
+    env2 = _make(cfg2, False)
+    orc2 = _oracle(cfg2, records, w, False)
+    obs = env2.reset(reset_file=True)
+    o = orc2.reset()
+    assert isinstance(obs, torch.Tensor) and obs.is_cuda and obs.shape == (B, 256)
+    for t in range(T):
+        a = env2.offline_action
+        assert isinstance(a, torch.Tensor)
+        obs, reward, done, info = env2.step(a)
+        o, o_reward, _, _ = orc2.step(a.cpu().numpy())
+        assert np.abs(obs.cpu().numpy() - o['obs']).max() < 5e-5
+        assert isinstance(reward, torch.Tensor) and reward.dtype == torch.float64
+        assert np.allclose(reward.cpu().numpy(), o_reward, rtol=1e-5, atol=1e-5)
+    assert 'click_p' in info[0] and info[0]['click_p'].shape == (9,)
+
+
+def test_batch_of_one_and_sampling_semantics(tmp_path):
+    """single_elem_support unwrapping (base.py:9-23) and RecDataBase cache/wrap/sampling (base.py:82-108)."""
+    cfg, records, w = _setup(tmp_path, False, 1, 9)
+    env = _make(cfg, False)
+    obs = env.reset(reset_file=True)
+    assert obs.shape == (256,)
+    a = env.offline_action
+    assert isinstance(a, int)
+    obs, reward, done, info = env.step(a)
+    assert obs.shape == (256,) and reward == 0 and done == 0 and info == {}
+    # train-mode sampling draws np.random.choice from the global RNG exactly like the reference
+    cfg, records, w = _setup(tmp_path, False, 4, 9, is_eval=False, cache_size=6)
+    env = _make(cfg, False)
+    env.seed(123)
+    env.reset(reset_file=True)
+    np.random.seed(123)
+    cache = records[:6]
+    expect = np.random.choice(cache, 4)
+    assert list(env.samples.records) == list(expect)
+    # the file has 9 lines + trailing newline: the next reset wraps (base.py:84-88: skip line 0, take line 1)
+    env.reset()
+    assert env.sim._recData.sample_list == records[6:9] + [records[1]] + records[2:4]
+
+
+def test_vector_env_wrapper(tmp_path):
+    from rl4rs.utils.rllib_vector_env import MyVectorEnvWrapper
+    cfg, records, w = _setup(tmp_path, False, 5, 9, support_rllib_mask=True)
+    env = _make(cfg, False)
+    venv = MyVectorEnvWrapper(env, 5)
+    assert venv.num_envs == 5 and len(venv.get_unwrapped()) == 5
+    first = venv.reset_at(0)
+    assert set(first) == {'action_mask', 'obs'}
+    assert venv.reset_at(3)['obs'].shape == (256,)
+    obs, rew, done, info = venv.vector_step(env.offline_action)
+    assert len(obs) == 5 and len(rew) == 5
+
+
+def test_custom_state_cls_is_rejected_loudly(tmp_path):
+    from rl4rs.env.slate import SlateRecEnv
+    from rl4rs.env import RecState
+    cfg, records, w = _setup(tmp_path, False, 2, 9)
+
+    class Mine(RecState):
+        pass
+    with pytest.raises(NotImplementedError):
+        SlateRecEnv(cfg, state_cls=Mine)
