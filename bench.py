@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/s of the batched SlateRecEnv env.step() hot path on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run, one
+rank per GPU).  A "step" is ONE episode-batch of the workload BASELINE.json's metric is quoted on
+(configs[1]: SlateRecEnv-v0, batch 4096, 284-item catalogue, 9-slot slate, DIEN simulator scorer):
+``env.reset()`` + 9 x ``env.step(offline_action)`` including the reward forward, i.e. B*T = 36 864
+env-steps.  Inputs (parsed log + catalogue + weights) are resident in HBM before the timed region.
+Ranks run independent env batches (weak scaling, no collective on the data path); rank 0 prints ONE
+JSON line with the whole-job env-steps/s, the roofline of the dominant kernel (the AUGRU recurrence,
+MFMA-bound, timed live with HIP events on the launch stream) and a CPU baseline (the numpy oracle port
+timed on this box's host cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
+
+
+def make_config(args, workdir, rank):
+    from rl4rs_amd import synth
+    cat_path = os.path.join(workdir, 'item_info.csv')
+    log_path = os.path.join(workdir, 'log_rank%d.csv' % rank)
+    cat_text = synth.make_catalog_text(seed=1234)
+    synth.write_text(cat_path, cat_text)
+    seq = args.env == 'seq'
+    records = synth.make_records(args.log_records, pages=4 if seq else 1, seed=1000 + rank, illegal_frac=0.05,
+                                 special_ids=synth.special_ids_from_text(cat_text))
+    synth.write_records(log_path, records)
+    cfg = {"maxlen": 64, "batch_size": args.batch, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 100000, "seq_num": 2, "emb_size": 128,
+           "page_items": 9, "hidden_units": 128, "max_steps": args.horizon, "action_emb_size": 32,
+           "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": False, "cache_size": 2048,
+           "model_seed": 7, "return_tensors": True}
+    return cfg, records
+
+
+def build_env(cfg, seq):
+    import rl4rs_amd
+    if seq:
+        from rl4rs_amd.env.seqslate import SeqSlateRecEnv, SeqSlateState
+        return rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=SeqSlateRecEnv(cfg, state_cls=SeqSlateState))
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    return rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
+
+
+def episode(env, T):
+    """reset + T steps of offline_action replay (the reference's canonical loop, simulator_eval.py:34-48)."""
+    env.reset()
+    total = None
+    for _ in range(T):
+        a = env.offline_action
+        obs, reward, done, info = env.step(a)
+        total = reward if total is None else total + reward
+    return obs, total
+
+
+def cpu_baseline(cfg, records, seq, sample_batch):
+    """The oracle port (vectorised numpy state machine + float32 numpy DIEN) on the host cores."""
+    import numpy as np
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from oracle.dien import OracleDien
+    from oracle.env import OracleEnv
+    c = dict(cfg, batch_size=sample_batch)
+    w = init_dien_weights(c, seed=c.get('model_seed', 7))
+    scorer = OracleDien(w, c, np.float32)
+    env = OracleEnv(c, records[:sample_batch], scorer, seq=seq)
+    T = c['max_steps']
+    t0 = time.time()
+    env.reset()
+    for _ in range(T):
+        env.step(np.asarray(env.samples.offline_action))
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs, numpy oracle "
+                      "(float32 DIEN), %.1f s" % (T, sample_batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--env', choices=['slate', 'seq'], default='slate')
+    ap.add_argument('--horizon', type=int, default=None)
+    ap.add_argument('--log-records', type=int, default=8193)
+    ap.add_argument('--cpu-batch', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    if args.horizon is None:
+        args.horizon = 9 if args.env == 'slate' else 32
+    seq = args.env == 'seq'
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+
+    workdir = tempfile.mkdtemp(prefix='rl4rs_bench_')
+    cfg, records = make_config(args, workdir, rank)
+    env = build_env(cfg, seq)
+    env.seed(1000 + rank)
+    # inputs resident in HBM before the timed region: parse the whole log once
+    env.sim._recData.store.preload(torch.device('cuda', local_rank))
+    B, T = args.batch, args.horizon
+    for _ in range(args.warmup):
+        episode(env, T)
+    net = env.sim.model.device_net
+    net.set_profiling(True)
+    net.profile_reset()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obs, total = episode(env, T)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = net.profile()
+    net.set_profiling(False)
+
+    if rank == 0:
+        env_steps = world * B * T * args.steps
+        # dominant kernel: AUGRU recurrence.  Executed (= algorithmic after the exact input-projection hoist)
+        # FLOPs per row per sequence input: L steps x (2E x 6E) MACs x 2.
+        L, E = cfg['maxlen'], cfg['emb_size']
+        flop_row_seq = L * (2 * E) * (6 * E) * 2
+        ms, launches = prof['k_recur<256,augru>']
+        n_complete = T if not seq else cfg['page_items']
+        reward_calls = 1 if not seq else T // cfg['page_items']
+        rows_per_episode = (T + 1) * B + reward_calls * n_complete * B
+        flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "k_recur<256,augru>", "achieved": achieved,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
+                    "kernel_ms_share": ms / (elapsed * 1e3)}
+        kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
+        # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
+        samples = env.samples
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        samples._env.build_complete()
+        ev0.record()
+        for _ in range(reps):
+            samples._env.build_complete()
+        ev1.record()
+        torch.cuda.synchronize()
+        g_ms = ev0.elapsed_time(ev1) / reps
+        g_rows = B * samples._env.n_complete
+        g_bytes = g_rows * (cfg['dense_feature_num'] * 4 + cfg['category_feature_num'] * 4 + 32 * 4 + 10 * 4 + 36)
+        g_gbs = g_bytes / (g_ms * 1e-3) / 1e9
+        gather = {"bound": "hbm", "kernel": "k_env_rows<complete>", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_ms,
+                  "rows": g_rows}
+        out = {
+            "metric": "env-steps/s (batch=%d, %d-slot slate)" % (B, 9),
+            "value": env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s batch=%d per GPU, 284-item catalogue, 9-slot slate, %d-step horizon, "
+                                   "DIEN simulator scorer, offline_action replay"
+                                   % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T),
+                       "step": "one episode-batch = reset + %d env.step incl. reward forward" % T,
+                       "parallelism": "independent env batches per GPU (no data-path collective)"},
+            "roofline": roofline,
+            "roofline_gather": gather,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, records, seq, args.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -104,6 +104,9 @@ def load():
         raise Rl4rsHipError(
             "librl4rs_hip.so not found at %s: build it with `python -m rl4rs_amd.build` "
             "(hipcc --offload-arch=gfx950). rl4rs_amd has no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime this process uses, so import it
+    # before dlopen()ing the library (two HIP runtimes in one process cannot see each other's devices).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
