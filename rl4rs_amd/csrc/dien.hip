@@ -25,6 +25,10 @@ __device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x)
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 constexpr int ATT_H1 = 64, ATT_H2 = 16, OBS_DIM = 256;
+#ifndef RL4RS_AUGRU_U
+#define RL4RS_AUGRU_U 2
+#endif
+constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-ring slot
 
 // -------------------------------------------------------------------------------------------------
 // Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
@@ -120,20 +124,50 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
 //   GRU  : row = table[ids[row,t]]            (xld = 3*NH, layout [2NH gates | NH cand])
 //   AUGRU: row = proj[slot(row)*L + t] + xoff (xld = proj ld)
 // Workgroup = NH/32 waves, 32 rows; wave w owns hidden columns [32w, 32w+32) of r, u, c and h.
+// grid = (row tiles, sequence inputs): all sequence inputs of a forward share ONE launch.
+//
+// Schedule (per step, two phases separated by one barrier each):
+//   * the h-side weight fragments stream from L2 through a 2-deep register ring, U k-blocks (8 k each) per
+//     slot: the loads of group g+1 are issued before the MFMAs of group g, and the first group of the NEXT
+//     phase is issued during the last group of the current one (weights do not depend on the recurrence);
+//   * the cached input projections of a phase are requested right after its first weight group and added in
+//     the phase's epilogue (thousands of MFMA cycles later), so their HBM latency never sits in front of an MFMA.
 struct RecurArgs {
     int n_rows, L, group;
-    const float* xbase; int64_t xld; int xoff;
+    const float* xbase[4]; int64_t xld; int xoff;
     const int32_t* ids;      // GRU: [n_rows, L]
-    const int32_t* slots;    // AUGRU: [n_rows/group]
-    const float* wg; const float* wc;
-    const float* att;        // AUGRU: [n_rows, L]
-    float* out; int64_t out_ld; int out_off;   // GRU: h1 cache rows (slot_base+row)*L + t ; AUGRU: allf
+    const int32_t* slots; int64_t slots_stride;    // AUGRU: [n_seq][n_rows/group]
+    const float* wg[4]; const float* wc[4];
+    const float* att; int64_t att_stride;          // AUGRU: [n_seq][att_stride] rows of L
+    float* out; int64_t out_ld; int out_off; int out_seq_off;   // GRU: h1 cache rows ; AUGRU: allf
     int slot_base;
 };
 
-template <int NH, bool AUGRU>
+#ifndef RL4RS_FAST_ACT
+#define RL4RS_FAST_ACT 1
+#endif
+// sigmoid / tanh on the hardware exp2 + rcp (abs error ~1e-7; the gates are convex-combined into h, so
+// absolute error is what propagates).  -DRL4RS_FAST_ACT=0 selects the libm-accurate forms.
+__device__ __forceinline__ float gate_sigmoid(float x) {
+#if RL4RS_FAST_ACT
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#else
+    return 1.f / (1.f + expf(-x));
+#endif
+}
+__device__ __forceinline__ float gate_tanh(float x) {
+#if RL4RS_FAST_ACT
+    // 1 - 2/(exp(2x)+1); exp2 saturates cleanly to 0 / inf
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+#else
+    return tanhf(x);
+#endif
+}
+
+template <int NH, bool AUGRU, int U>
 __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
-    constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4;
+    constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4, NG = KB / U, NP = NG / 2;
+    static_assert(KB % U == 0 && (NG % 2) == 0 && NP >= 2, "need an even number (>= 4) of k-block groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hb = reinterpret_cast<float*>(smem);          // [32][LDH]
     float* rhb = hb + 32 * LDH;                          // [32][LDH]
@@ -142,99 +176,173 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, li = lane & 31;
     const int row0 = blockIdx.x * 32;
+    const int sq = blockIdx.y;
     const int L = a.L, LDT = L + 1;
     const int col = wave * 32 + li;
+    const float* __restrict__ xbase = a.xbase[sq] + a.xoff + col;
+    const uint32_t xld = (uint32_t)a.xld;
 
     for (int i = tid; i < 32 * LDH; i += NH * 2) hb[i] = 0.f;
     for (int i = tid; i < 32 * L; i += NH * 2) {
         int r = i / L, t = i - r * L;
         int gr = min(row0 + r, a.n_rows - 1);
-        if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)gr * L + t];
+        if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
         else s_ids[r * LDT + t] = a.ids[(size_t)gr * L + t];
     }
-    // per-lane row bookkeeping in C/D layout
-    int64_t xrow_base[16];
-    bool rvalid[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int lr = crow(r, half);
-        int gr = row0 + lr;
-        rvalid[r] = gr < a.n_rows;
-        gr = min(gr, a.n_rows - 1);
-        xrow_base[r] = AUGRU ? (int64_t)a.slots[gr / a.group] * L : 0;
+    // element offset of each row's x-projection at t = 0 (AUGRU: slot * L * xld)
+    uint32_t* s_xoff = reinterpret_cast<uint32_t*>(s_att + 32 * LDT);
+    if (tid < 32) {
+        int gr = min(row0 + tid, a.n_rows - 1);
+        s_xoff[tid] = AUGRU ? (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * xld : 0u;
     }
     f32x16 h_own;
 #pragma unroll
     for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
-    const float4* wg_r = reinterpret_cast<const float4*>(a.wg) + ((size_t)wave * KB) * 64 + lane;
-    const float4* wg_u = reinterpret_cast<const float4*>(a.wg) + ((size_t)(NW + wave) * KB) * 64 + lane;
-    const float4* wc_c = reinterpret_cast<const float4*>(a.wc) + ((size_t)wave * KB) * 64 + lane;
+    const float4* __restrict__ wg_r = reinterpret_cast<const float4*>(a.wg[sq]) + ((size_t)wave * KB) * 64 + lane;
+    const float4* __restrict__ wg_u = reinterpret_cast<const float4*>(a.wg[sq]) + ((size_t)(NW + wave) * KB) * 64 + lane;
+    const float4* __restrict__ wc_c = reinterpret_cast<const float4*>(a.wc[sq]) + ((size_t)wave * KB) * 64 + lane;
+    const float* arow = hb + li * LDH + half * 4;
+    const float* rrow = rhb + li * LDH + half * 4;
     __syncthreads();
 
+    auto xaddr = [&](int r, int t) -> const float* {
+        uint32_t off = AUGRU ? s_xoff[crow(r, half)] + (uint32_t)t * xld : (uint32_t)s_ids[crow(r, half) * LDT + t] * xld;
+        return xbase + off;
+    };
+    f32x16 xr_, xu_, xc_;
+    // 2-deep register ring of weight / operand fragments, U k-blocks per slot
+    float4 wA[U], wB[U], uA[U], uB[U], cA[U], cB[U], aA[U], aB[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) { wA[i] = wg_r[(size_t)i * 64]; uA[i] = wg_u[(size_t)i * 64]; }
+
+#define RL4RS_MFMA_RU(AV, WR, WU)                                                         \
+    _Pragma("unroll") for (int i = 0; i < U; ++i) {                                      \
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WR[i].x, acc_r, 0, 0, 0);  \
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WU[i].x, acc_u, 0, 0, 0);  \
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WR[i].y, acc_r, 0, 0, 0);  \
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WU[i].y, acc_u, 0, 0, 0);  \
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WR[i].z, acc_r, 0, 0, 0);  \
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WU[i].z, acc_u, 0, 0, 0);  \
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WR[i].w, acc_r, 0, 0, 0);  \
+        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WU[i].w, acc_u, 0, 0, 0);  \
+    }
+#define RL4RS_MFMA_C(AV, WC)                                                              \
+    _Pragma("unroll") for (int i = 0; i < U; ++i) {                                      \
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WC[i].x, acc_c, 0, 0, 0);  \
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WC[i].y, acc_c, 0, 0, 0);  \
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WC[i].z, acc_c, 0, 0, 0);  \
+        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WC[i].w, acc_c, 0, 0, 0);  \
+    }
+
     for (int t = 0; t < L; ++t) {
-        // cached input projections for this step (bias folded in) -> accumulator init
-        f32x16 acc_r, acc_u, acc_c;
+        f32x16 acc_r, acc_u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_u[r] = 0.f; }
+        // ---- phase 1: gates.  Groups are consumed in pairs (slot A, slot B); wA/uA of group 0 are resident.
+#pragma unroll
+        for (int i = 0; i < U; ++i) aA[i] = *reinterpret_cast<const float4*>(arow + i * 8);
+#pragma unroll 1
+        for (int gp = 0; gp < NP; ++gp) {
+            const float4* pr = wg_r + (size_t)(2 * gp + 1) * U * 64;
+            const float4* pu = wg_u + (size_t)(2 * gp + 1) * U * 64;
+            const float* pa = arow + (2 * gp + 1) * U * 8;
+#pragma unroll
+            for (int i = 0; i < U; ++i) {                      // slot B <- group 2gp+1
+                wB[i] = pr[(size_t)i * 64];
+                uB[i] = pu[(size_t)i * 64];
+                aB[i] = *reinterpret_cast<const float4*>(pa + i * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_MFMA_RU(aA, wA, uA)
+            __builtin_amdgcn_sched_barrier(0);
+            if (gp + 1 < NP) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {                  // slot A <- group 2gp+2
+                    wA[i] = pr[(size_t)(U + i) * 64];
+                    uA[i] = pu[(size_t)(U + i) * 64];
+                    aA[i] = *reinterpret_cast<const float4*>(pa + (U + i) * 8);
+                }
+                if (gp == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {             // consumed by this phase's epilogue
+                        const float* xp = xaddr(r, t);
+                        xr_[r] = xp[0];
+                        xu_[r] = xp[NH];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < U; ++i) cA[i] = wc_c[(size_t)i * 64];         // first group of phase 2
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_MFMA_RU(aB, wB, uB)
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int64_t xr = AUGRU ? xrow_base[r] + t : (int64_t)s_ids[crow(r, half) * LDT + t];
-            const float* xp = a.xbase + xr * a.xld + a.xoff + col;
-            acc_r[r] = xp[0];
-            acc_u[r] = xp[NH];
-            acc_c[r] = xp[2 * NH];
-        }
-        // ---- phase 1: gates
-        const float* arow = hb + li * LDH + half * 4;
-#pragma unroll 4
-        for (int kb = 0; kb < KB; ++kb) {
-            float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
-            float4 br = wg_r[(size_t)kb * 64];
-            float4 bu = wg_u[(size_t)kb * 64];
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, br.x, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bu.x, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, br.y, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bu.y, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, br.z, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bu.z, acc_u, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, br.w, acc_r, 0, 0, 0);
-            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bu.w, acc_u, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float rg = sigmoidf_(acc_r[r]);
-            acc_u[r] = sigmoidf_(acc_u[r]);
+            float rg = gate_sigmoid(acc_r[r] + xr_[r]);
+            acc_u[r] = gate_sigmoid(acc_u[r] + xu_[r]);
             rhb[crow(r, half) * LDH + col] = rg * h_own[r];
         }
         __syncthreads();
         // ---- phase 2: candidate + state update
-        const float* rrow = rhb + li * LDH + half * 4;
-#pragma unroll 4
-        for (int kb = 0; kb < KB; ++kb) {
-            float4 av = *reinterpret_cast<const float4*>(rrow + kb * 8);
-            float4 bc = wc_c[(size_t)kb * 64];
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc.x, acc_c, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc.y, acc_c, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc.z, acc_c, 0, 0, 0);
-            acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc.w, acc_c, 0, 0, 0);
+        f32x16 acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_c[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < U; ++i) aA[i] = *reinterpret_cast<const float4*>(rrow + i * 8);
+#pragma unroll 1
+        for (int gp = 0; gp < NP; ++gp) {
+            const float4* pc = wc_c + (size_t)(2 * gp + 1) * U * 64;
+            const float* pa = rrow + (2 * gp + 1) * U * 8;
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                cB[i] = pc[(size_t)i * 64];
+                aB[i] = *reinterpret_cast<const float4*>(pa + i * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_MFMA_C(aA, cA)
+            __builtin_amdgcn_sched_barrier(0);
+            if (gp + 1 < NP) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    cA[i] = pc[(size_t)(U + i) * 64];
+                    aA[i] = *reinterpret_cast<const float4*>(pa + (U + i) * 8);
+                }
+                if (gp == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xc_[r] = xaddr(r, t)[2 * NH];   // consumed by this phase's epilogue
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < U; ++i) { wA[i] = wg_r[(size_t)i * 64]; uA[i] = wg_u[(size_t)i * 64]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_MFMA_C(aB, cB)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float c = tanhf(acc_c[r]);
+            float c = gate_tanh(acc_c[r] + xc_[r]);
             float u = acc_u[r];
             if (AUGRU) u = (1.0f - s_att[crow(r, half) * LDT + t]) * u;
             float hn = u * h_own[r] + (1.0f - u) * c;
             h_own[r] = hn;
             hb[crow(r, half) * LDH + col] = hn;
-            if (!AUGRU && rvalid[r]) {
+            if (!AUGRU && row0 + crow(r, half) < a.n_rows) {
                 int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
                 a.out[orow * a.out_ld + a.out_off + col] = hn;
             }
         }
         __syncthreads();
     }
+#undef RL4RS_MFMA_RU
+#undef RL4RS_MFMA_C
     if (AUGRU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (rvalid[r]) a.out[(int64_t)(row0 + crow(r, half)) * a.out_ld + a.out_off + col] = h_own[r];
+            if (row0 + crow(r, half) < a.n_rows)
+                a.out[(int64_t)(row0 + crow(r, half)) * a.out_ld + a.out_off + sq * a.out_seq_off + col] = h_own[r];
     }
 }
 
@@ -584,11 +692,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
 #undef AL
     // LDS opt-in above the 64 KB default where needed
     {
-        size_t sm_aug = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1)) * 4;
-        size_t sm_gru = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1)) * 4;
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<256, true>),
+        size_t sm_aug = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1) + 32) * 4;
+        size_t sm_gru = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false>),
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -617,13 +725,14 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
     {
         Prof p(n, KID_GRU1, st);
         RecurArgs a;
+        memset(&a, 0, sizeof(a));
         a.n_rows = cnt; a.L = L; a.group = 1;
-        a.xbase = n->embw1[s]; a.xld = 3 * E; a.xoff = 0;
-        a.ids = ids; a.slots = nullptr;
-        a.wg = n->gru_wg[s]; a.wc = n->gru_wc[s]; a.att = nullptr;
-        a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.slot_base = slot_base;
-        size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1)) * 4;
-        hipLaunchKernelGGL((k_recur<128, false>), dim3((cnt + 31) / 32), dim3(256), smem, st, a);
+        a.xbase[0] = n->embw1[s]; a.xld = 3 * E; a.xoff = 0;
+        a.ids = ids; a.slots = nullptr; a.slots_stride = 0;
+        a.wg[0] = n->gru_wg[s]; a.wc[0] = n->gru_wc[s]; a.att = nullptr; a.att_stride = 0;
+        a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.out_seq_off = 0; a.slot_base = slot_base;
+        size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
+        hipLaunchKernelGGL((k_recur<128, false, GRU_U>), dim3((cnt + 31) / 32, 1), dim3(256), smem, st, a);
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -675,18 +784,17 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     }
     {
         Prof p(n, KID_AUGRU, st);
-        size_t smem = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1)) * 4;
-        for (int s = 0; s < S; ++s) {
-            RecurArgs a;
-            a.n_rows = R; a.L = L; a.group = group;
-            a.xbase = n->proj[s]; a.xld = n->PLD; a.xoff = ATT_H1;
-            a.ids = nullptr; a.slots = slots + (size_t)s * ngroups;
-            a.wg = n->augru_wg[s]; a.wc = n->augru_wc[s];
-            a.att = n->scores + (size_t)s * n->c.max_rows * L;
-            a.out = n->allf; a.out_ld = F; a.out_off = s * NH2; a.slot_base = 0;
-            hipLaunchKernelGGL((k_recur<256, true>), dim3((R + 31) / 32), dim3(512), smem, st, a);
-            RL4RS_LAUNCH_CHECK();
-        }
+        size_t smem = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1) + 32) * 4;
+        RecurArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n_rows = R; a.L = L; a.group = group;
+        a.xld = n->PLD; a.xoff = ATT_H1;
+        a.ids = nullptr; a.slots = slots; a.slots_stride = ngroups;
+        for (int s = 0; s < S; ++s) { a.xbase[s] = n->proj[s]; a.wg[s] = n->augru_wg[s]; a.wc[s] = n->augru_wc[s]; }
+        a.att = n->scores; a.att_stride = (int64_t)n->c.max_rows * L;
+        a.out = n->allf; a.out_ld = F; a.out_off = 0; a.out_seq_off = NH2; a.slot_base = 0;
+        hipLaunchKernelGGL((k_recur<256, true, AUGRU_U>), dim3((R + 31) / 32, S), dim3(512), smem, st, a);
+        RL4RS_LAUNCH_CHECK();
     }
     float* obs_out = obs ? obs : n->obs_tmp;
     {
