@@ -239,6 +239,12 @@ int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t 
                    const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
                    int act, void* stream);
 
+/* Same GEMM through the pre-packed-weight kernel the scorer uses (w_host is a HOST pointer; packs, uploads,
+ * runs and synchronises: test entry point only). */
+int rl4rs_gemm_f32_packed(const float* a_dev, int64_t lda, const float* w_host, int64_t ldw,
+                          const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                          int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

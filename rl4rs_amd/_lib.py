@@ -91,6 +91,7 @@ SIGNATURES = {
     'rl4rs_dien_kernel_name': (C.c_char_p, [_I]),
     'rl4rs_dien_profile_read': (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_I64)]),
     'rl4rs_dien_profile_reset': (_I, [_P]),
+    'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
 }
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/rl4rs_hip.h"
 
@@ -50,5 +51,10 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // Launches of the generic fp32 MFMA GEMM (gemm.hip); ldw = leading dim of W [K,N].
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
                     float* c, int64_t ldc, int M, int N, int K, int act, hipStream_t st);
+
+// GEMM against a weight matrix pre-packed by pack_gemm_weight (gemm.hip)
+int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
+                       int M, int N, int K, int act, hipStream_t st);
+std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N);
 
 }  // namespace rl4rs

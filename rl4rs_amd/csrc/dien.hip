@@ -348,98 +348,131 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 
 // -------------------------------------------------------------------------------------------------
 // DIN attention scores (deepctr LocalActivationUnit, att_hidden_units=(64,16), sigmoid, raw scores).
-// Workgroup = one (group of rows sharing a slot, sequence input s); each wave scores whole rows:
-//   hid1^T [64 units x L steps] = W1d^T (q*h1_t) + qa + AK_t    as 2x2 32x32 MFMA tiles
+//   hid1^T [64 units x L steps] = W1d^T (q*h1_t) + qa + AK_t    as 2x2 32x32 MFMA tiles per row
 //   hid2 = sigmoid(hid1 W2 + b2), score = hid2 w3 + b3           in registers (+ one half-wave swap)
+// grid.y = sequence input.  STAGE = true: a workgroup owns one group of rows that share a cache slot (the 9
+// reward rows of an env), stages the slot's h1 tile [L,E] in LDS once and its waves take the rows round-robin.
+// STAGE = false (group == 1, obs rows): one row per wave, 4 rows per workgroup, the (q*h1_t) operand is read
+// straight from the cache (every byte is used exactly once, LDS staging would only cost occupancy).
+// Weight / operand fragments run through a 2-deep register ring like k_recur.
 struct DinArgs {
     int R, L, E, group, n_groups;
-    const int32_t* slots;        // [n_groups]
-    const float* h1;             // [slot, L, E]
-    const float* proj; int64_t pld;   // [slot*L, pld], AK at column 0
+    const int32_t* slots; int64_t slots_stride;     // [n_seq][n_groups]
+    const float* h1[4];          // [slot, L, E]
+    const float* proj[4]; int64_t pld;   // [slot*L, pld], AK at column 0
     const float* q;              // [R, E]
-    const float* w1ac;           // [E, 64]   (W1a + W1c)
-    const float* w1d;            // packed [2][E/8][64][4]
-    const float* w2; const float* b2; const float* w3; const float* b3;
-    float* scores;               // [R, L]
+    const float* w1ac[4];        // [E, 64]   (W1a + W1c)
+    const float* w1d[4];         // packed [2][E/8][64][4]
+    const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
+    float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
 };
 
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = a.L, E = a.E, LDK = E + 4;
-    float* s_h1 = reinterpret_cast<float*>(smem);        // [L][LDK]
-    float* s_w2 = s_h1 + (size_t)L * LDK;                // [64][16]
+    const int sq = blockIdx.y;
+    float* s_w2 = reinterpret_cast<float*>(smem);        // [64][16]
     float* s_misc = s_w2 + ATT_H1 * ATT_H2;              // b2[16] w3[16] b3[1] pad -> 48
     float* s_wave = s_misc + 48;                         // per wave: q[E] + qa[64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    float* s_h1 = s_wave + (size_t)nw * (E + ATT_H1);    // STAGE: [L][LDK]
     const int half = lane >> 5, li = lane & 31;
-    const int g = blockIdx.x;
-    const int slot = a.slots[g];
-    const float* h1g = a.h1 + (size_t)slot * L * E;
-    for (int i = tid; i < L * (E / 4); i += blockDim.x) {
-        int t = i / (E / 4), k4 = i - t * (E / 4);
-        *reinterpret_cast<float4*>(s_h1 + t * LDK + k4 * 4) = *reinterpret_cast<const float4*>(h1g + (size_t)t * E + k4 * 4);
+    for (int i = tid; i < ATT_H1 * ATT_H2; i += blockDim.x) s_w2[i] = a.w2[sq][i];
+    if (tid < ATT_H2) { s_misc[tid] = a.b2[sq][tid]; s_misc[16 + tid] = a.w3[sq][tid]; }
+    if (tid == 0) s_misc[32] = a.b3[sq][0];
+    int g0, slot0 = 0;
+    if (STAGE) {
+        g0 = blockIdx.x;
+        slot0 = a.slots[(size_t)sq * a.slots_stride + g0];
+        const float* h1g = a.h1[sq] + (size_t)slot0 * L * E;
+        for (int i = tid; i < L * (E / 4); i += blockDim.x) {
+            int t = i / (E / 4), k4 = i - t * (E / 4);
+            *reinterpret_cast<float4*>(s_h1 + t * LDK + k4 * 4) = *reinterpret_cast<const float4*>(h1g + (size_t)t * E + k4 * 4);
+        }
+    } else {
+        g0 = blockIdx.x * nw;
     }
-    for (int i = tid; i < ATT_H1 * ATT_H2; i += blockDim.x) s_w2[i] = a.w2[i];
-    if (tid < ATT_H2) { s_misc[tid] = a.b2[tid]; s_misc[16 + tid] = a.w3[tid]; }
-    if (tid == 0) s_misc[32] = a.b3[0];
     __syncthreads();
     float* s_q = s_wave + (size_t)wave * (E + ATT_H1);
     float* s_qa = s_q + E;
     const int KB = E / 8;
-    const float4* w1d0 = reinterpret_cast<const float4*>(a.w1d) + lane;
-    const float4* w1d1 = w1d0 + (size_t)KB * 64;
+    const float4* __restrict__ w1d0 = reinterpret_cast<const float4*>(a.w1d[sq]) + lane;
+    const float4* __restrict__ w1d1 = w1d0 + (size_t)KB * 64;
+    const float* __restrict__ w1ac = a.w1ac[sq];
     const int ntile = (L + 31) / 32;    // L <= 64 -> 1 or 2 N tiles
+    const int t0 = li, t1 = min(32 + li, L - 1);
+    const int nrows = STAGE ? a.group : 1;
+    const int jstep = STAGE ? nw : 1;
 
-    for (int j = wave; j < a.group; j += nw) {
-        const int row = g * a.group + j;
+    for (int j = STAGE ? wave : 0; j < nrows; j += jstep) {
+        const int row = STAGE ? g0 * a.group + j : g0 + wave;
         if (row >= a.R) break;
+        const int slot = STAGE ? slot0 : a.slots[(size_t)sq * a.slots_stride + row];
         for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         {   // qa = q @ (W1a + W1c): lane = hidden unit
             float s = 0.f;
-            for (int k = 0; k < E; ++k) s = fmaf(s_q[k], a.w1ac[k * ATT_H1 + lane], s);
+#pragma unroll 8
+            for (int k = 0; k < E; ++k) s = fmaf(s_q[k], w1ac[k * ATT_H1 + lane], s);
             s_qa[lane] = s;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        f32x16 acc[2][2];
+        // B-operand source rows for this lane's two steps
+        const float* hsrc0 = STAGE ? s_h1 + t0 * LDK + half * 4 : a.h1[sq] + ((size_t)slot * L + t0) * E + half * 4;
+        const float* hsrc1 = STAGE ? s_h1 + t1 * LDK + half * 4 : a.h1[sq] + ((size_t)slot * L + t1) * E + half * 4;
+        const float* qsrc = s_q + half * 4;
+        f32x16 acc00, acc10, acc01, acc11;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        const int t0 = li, t1 = min(32 + li, L - 1);
-#pragma unroll 2
-        for (int kb = 0; kb < KB; ++kb) {
-            const int kk = kb * 8 + half * 4;
-            float4 aw0 = w1d0[(size_t)kb * 64];
-            float4 aw1 = w1d1[(size_t)kb * 64];
-            float4 qv = *reinterpret_cast<const float4*>(s_q + kk);
-            float4 h0 = *reinterpret_cast<const float4*>(s_h1 + t0 * LDK + kk);
-            float4 h1v = *reinterpret_cast<const float4*>(s_h1 + t1 * LDK + kk);
-            float b0[4] = {h0.x * qv.x, h0.y * qv.y, h0.z * qv.z, h0.w * qv.w};
-            float b1[4] = {h1v.x * qv.x, h1v.y * qv.y, h1v.z * qv.z, h1v.w * qv.w};
-            float a0[4] = {aw0.x, aw0.y, aw0.z, aw0.w};
-            float a1[4] = {aw1.x, aw1.y, aw1.z, aw1.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
-                if (ntile > 1) {
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
-                }
-            }
+        for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc10[r] = 0.f; acc01[r] = 0.f; acc11[r] = 0.f; }
+        float4 aA0, aA1, hA0, hA1, qA, aB0, aB1, hB0, hB1, qB;
+        aA0 = w1d0[0]; aA1 = w1d1[0];
+        hA0 = *reinterpret_cast<const float4*>(hsrc0); hA1 = *reinterpret_cast<const float4*>(hsrc1);
+        qA = *reinterpret_cast<const float4*>(qsrc);
+#define RL4RS_DIN_MFMA(A0, A1, H0, H1, Q)                                                         \
+        {                                                                                         \
+            const float b0[4] = {H0.x * Q.x, H0.y * Q.y, H0.z * Q.z, H0.w * Q.w};                  \
+            const float b1[4] = {H1.x * Q.x, H1.y * Q.y, H1.z * Q.z, H1.w * Q.w};                  \
+            const float a0[4] = {A0.x, A0.y, A0.z, A0.w};                                         \
+            const float a1[4] = {A1.x, A1.y, A1.z, A1.w};                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc00, 0, 0, 0);       \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc10, 0, 0, 0);       \
+                if (ntile > 1) {                                                                  \
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc01, 0, 0, 0);   \
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc11, 0, 0, 0);   \
+                }                                                                                 \
+            }                                                                                     \
         }
+#pragma unroll 1
+        for (int kp = 0; kp < KB / 2; ++kp) {
+            const int kb1 = 2 * kp + 1;
+            aB0 = w1d0[(size_t)kb1 * 64]; aB1 = w1d1[(size_t)kb1 * 64];
+            hB0 = *reinterpret_cast<const float4*>(hsrc0 + kb1 * 8); hB1 = *reinterpret_cast<const float4*>(hsrc1 + kb1 * 8);
+            qB = *reinterpret_cast<const float4*>(qsrc + kb1 * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_DIN_MFMA(aA0, aA1, hA0, hA1, qA)
+            __builtin_amdgcn_sched_barrier(0);
+            if (kp + 1 < KB / 2) {
+                const int kb2 = kb1 + 1;
+                aA0 = w1d0[(size_t)kb2 * 64]; aA1 = w1d1[(size_t)kb2 * 64];
+                hA0 = *reinterpret_cast<const float4*>(hsrc0 + kb2 * 8); hA1 = *reinterpret_cast<const float4*>(hsrc1 + kb2 * 8);
+                qA = *reinterpret_cast<const float4*>(qsrc + kb2 * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RL4RS_DIN_MFMA(aB0, aB1, hB0, hB1, qB)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef RL4RS_DIN_MFMA
         // epilogue: lane holds, for step t (= N index), 16 of the 32 hidden units of each M tile
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             if (n >= ntile) break;
             const int t = n * 32 + li;
             const int tc = min(t, L - 1);
-            const float* akp = a.proj + ((size_t)slot * L + tc) * a.pld;
+            const float* akp = a.proj[sq] + ((size_t)slot * L + tc) * a.pld;
             float p[ATT_H2];
 #pragma unroll
             for (int o = 0; o < ATT_H2; ++o) p[o] = 0.f;
@@ -452,8 +485,9 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                     float akv[4] = {ak.x, ak.y, ak.z, ak.w};
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        float x = acc[m][n][r4 * 4 + rr] + s_qa[jr + rr] + akv[rr];
-                        float hv = sigmoidf_(x);
+                        const float accv = (n == 0) ? (m == 0 ? acc00[r4 * 4 + rr] : acc10[r4 * 4 + rr])
+                                                    : (m == 0 ? acc01[r4 * 4 + rr] : acc11[r4 * 4 + rr]);
+                        float hv = gate_sigmoid(accv + s_qa[jr + rr] + akv[rr]);
                         const float* w2r = s_w2 + (jr + rr) * ATT_H2;
 #pragma unroll
                         for (int o = 0; o < ATT_H2; ++o) p[o] = fmaf(hv, w2r[o], p[o]);
@@ -464,11 +498,11 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
 #pragma unroll
             for (int o = 0; o < ATT_H2; ++o) {
                 float tot = p[o] + __shfl_xor(p[o], 32);
-                float h2 = sigmoidf_(tot + s_misc[o]);
+                float h2 = gate_sigmoid(tot + s_misc[o]);
                 sc = fmaf(h2, s_misc[16 + o], sc);
             }
             sc += s_misc[32];
-            if (half == 0 && t < L) a.scores[(size_t)row * L + t] = sc;
+            if (half == 0 && t < L) a.scores[(size_t)sq * a.scores_stride + (size_t)row * L + t] = sc;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -621,17 +655,18 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     int rc;
 #define UP(dst, src, cnt) if ((rc = upload(n, &n->dst, (src), (size_t)(cnt), st)) != RL4RS_OK) return rc
 #define AL(dst, cnt) if ((rc = alloc_f(n, &n->dst, (size_t)(cnt))) != RL4RS_OK) return rc
+    std::vector<std::vector<float>> keep;    // host staging must outlive the async copies
+    keep.reserve(64);
     UP(cat_emb, w->cat_emb, (size_t)H * E);
     UP(seq_emb, w->seq_emb, (size_t)H * E);
-    UP(dense_w1, w->dense_w1, (size_t)Dn * U);
+    { auto pk = pack_gemm_weight(w->dense_w1, U, Dn, U); keep.push_back(std::move(pk)); UP(dense_w1, keep.back().data(), keep.back().size()); }
     UP(dense_b1, w->dense_b1, U);
-    UP(dense_w2, w->dense_w2, (size_t)U * U);
+    { auto pk = pack_gemm_weight(w->dense_w2, U, U, U); keep.push_back(std::move(pk)); UP(dense_w2, keep.back().data(), keep.back().size()); }
     UP(dense_b2, w->dense_b2, U);
-    UP(obs_w, w->obs_w, (size_t)F * OBS_DIM);
+    { auto pk = pack_gemm_weight(w->obs_w, OBS_DIM, F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
     UP(obs_b, w->obs_b, OBS_DIM);
     UP(out_w, w->out_w, (size_t)OBS_DIM * K);
     UP(out_b, w->out_b, K);
-    std::vector<std::vector<float>> keep;    // host staging must outlive the async copies
     for (int s = 0; s < S; ++s) {
         RL4RS_REQUIRE(w->gru_gate_w[s] && w->gru_cand_w[s] && w->att_w1[s] && w->augru_gate_w[s] && w->augru_cand_w[s],
                       "dien_create: weights of sequence input %d missing", s);
@@ -667,7 +702,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (int j = 0; j < ATT_H1; ++j) bp[j] = w->att_b1[s][j];
         for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j];
         for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
-        keep.push_back(std::move(wp)); UP(wproj[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_gemm_weight(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
@@ -698,7 +733,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores),
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
     RL4RS_HIP_TRY(hipStreamSynchronize(st));   // host staging (keep) may now be released
@@ -737,8 +772,8 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
     }
     {
         Prof p(n, KID_PROJ, st);
-        int rc = launch_gemm_f32(n->h1[s] + (size_t)slot_base * L * E, E, n->wproj[s], n->PLD, n->bproj[s],
-                                 n->proj[s] + (size_t)slot_base * L * n->PLD, n->PLD, cnt * L, n->PLD, E, 0, st);
+        int rc = launch_gemm_packed(n->h1[s] + (size_t)slot_base * L * E, E, n->wproj[s], n->bproj[s],
+                                    n->proj[s] + (size_t)slot_base * L * n->PLD, n->PLD, cnt * L, n->PLD, E, 0, st);
         if (rc) return rc;
     }
     return RL4RS_OK;
@@ -763,24 +798,30 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     }
     {
         Prof p(n, KID_DENSE, st);
-        if ((rc = launch_gemm_f32(dense, n->Dn, n->dense_w1, U, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
-        if ((rc = launch_gemm_f32(n->dh, U, n->dense_w2, U, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
+        if ((rc = launch_gemm_packed(dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
+        if ((rc = launch_gemm_packed(n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
     }
     {
         Prof p(n, KID_DIN, st);
-        int nw = group < 4 ? group : 4;
-        size_t smem = ((size_t)L * (E + 4) + ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+        DinArgs a;
+        memset(&a, 0, sizeof(a));
+        a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
+        a.slots = slots; a.slots_stride = ngroups; a.pld = n->PLD; a.q = n->q;
         for (int s = 0; s < S; ++s) {
-            DinArgs a;
-            a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
-            a.slots = slots + (size_t)s * ngroups;
-            a.h1 = n->h1[s]; a.proj = n->proj[s]; a.pld = n->PLD; a.q = n->q;
-            a.w1ac = n->w1ac[s]; a.w1d = n->w1d[s];
-            a.w2 = n->att_w2[s]; a.b2 = n->att_b2[s]; a.w3 = n->att_w3[s]; a.b3 = n->att_b3[s];
-            a.scores = n->scores + (size_t)s * n->c.max_rows * L;
-            hipLaunchKernelGGL(k_din_scores, dim3(ngroups), dim3(64 * nw), smem, st, a);
-            RL4RS_LAUNCH_CHECK();
+            a.h1[s] = n->h1[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s];
+            a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];
         }
+        a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
+        if (group == 1) {
+            const int nw = 4;
+            size_t smem = ((size_t)ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+            hipLaunchKernelGGL(k_din_scores<false>, dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
+        } else {
+            int nw = group % 4 == 0 ? 4 : (group % 3 == 0 ? 3 : (group % 2 == 0 ? 2 : (group < 4 ? group : 4)));
+            size_t smem = ((size_t)L * (E + 4) + ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+            hipLaunchKernelGGL(k_din_scores<true>, dim3(ngroups, S), dim3(64 * nw), smem, st, a);
+        }
+        RL4RS_LAUNCH_CHECK();
     }
     {
         Prof p(n, KID_AUGRU, st);
@@ -799,7 +840,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     float* obs_out = obs ? obs : n->obs_tmp;
     {
         Prof p(n, KID_HEAD, st);
-        if ((rc = launch_gemm_f32(n->allf, F, n->obs_w, OBS_DIM, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
+        if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
     }
     if (prob) {
         Prof p(n, KID_PROB, st);

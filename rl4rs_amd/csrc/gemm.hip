@@ -11,6 +11,8 @@
 // Block = 256 threads = 2x2 waves, tile 128(M) x 64(N), BK = 32.  A is staged global -> registers ->
 // LDS (double buffered, rows padded to 36 floats: conflict-free for ds_read_b128); W is small and
 // L1/L2 resident, so B fragments come straight from global memory (128-byte coalesced per half-wave).
+#include <vector>
+
 #include "common.hpp"
 
 namespace rl4rs {
@@ -120,6 +122,146 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Same GEMM with the weight matrix PRE-PACKED into MFMA B-fragment order (done once when a model is
+// loaded): Wp[ntile][kb][lane] is the float4 {W[kb*8 + (lane>>5)*4 + i][ntile*32 + (lane&31)], i=0..3},
+// K zero-padded to a multiple of 8, N to a multiple of 32.  One 16-byte load feeds four MFMAs; the next
+// k-block's fragment is requested before the current block's MFMAs (register ring).
+// WM = 32-row tiles per wave: block tile = (64*WM) x 64, 2x2 waves.
+template <int WM>
+__global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, int64_t lda,
+                                                 const float4* __restrict__ Wp, int KB,
+                                                 const float* __restrict__ bias, float* __restrict__ C,
+                                                 int64_t ldc, int M, int N, int K, int act) {
+    constexpr int BM = 64 * WM;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][GLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * BM;
+    const int nt = blockIdx.y * 2 + wn;
+    const int col = nt * 32 + li;
+    const bool tile_ok = nt * 32 < N;
+    const bool vec_ok = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const float4* __restrict__ wp = Wp + ((size_t)(tile_ok ? nt : 0) * KB) * 64 + lane;
+
+    f32x16 acc[WM];
+#pragma unroll
+    for (int w = 0; w < WM; ++w)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[w][i] = 0.f;
+
+    constexpr int NST = BM * 8 / 256;     // float4 chunks per thread per A tile
+    float4 stage[NST];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < NST; ++p) {
+            int c = tid + p * 256;
+            int r = c >> 3, kq = (c & 7) << 2;
+            int gr = m0 + r, gk = kt * GBK + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < M) {
+                const float* src = A + (size_t)gr * lda + gk;
+                if (vec_ok && gk + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (gk + 0 < K) v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
+                }
+            }
+            stage[p] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NST; ++p) {
+            int c = tid + p * 256;
+            int r = c >> 3, kq = (c & 7) << 2;
+            *reinterpret_cast<float4*>(&As[buf][r][kq]) = stage[p];
+        }
+    };
+
+    const int nkt = (K + GBK - 1) / GBK;
+    load_tile(0);
+    store_tile(0);
+    float4 b_cur = wp[0];
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int arow = wm * 32 * WM + li;
+#pragma unroll
+        for (int j = 0; j < GBK / 8; ++j) {
+            const int g = kt * (GBK / 8) + j;
+            if (g < KB) {
+                float4 b_next = (g + 1 < KB) ? wp[(size_t)(g + 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 av[WM];
+#pragma unroll
+                for (int w = 0; w < WM; ++w)
+                    av[w] = *reinterpret_cast<const float4*>(&As[cur][arow + 32 * w][j * 8 + half * 4]);
+#pragma unroll
+                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].x, b_cur.x, acc[w], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].y, b_cur.y, acc[w], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].z, b_cur.z, acc[w], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].w, b_cur.w, acc[w], 0, 0, 0);
+                b_cur = b_next;
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    if (tile_ok && col < N) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * 32 * WM + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv, act);
+            }
+    }
+}
+
+// host: pack W [K,N] (leading dim ldw) into fragment order; returns floats ( NT * KB * 64 * 4 )
+std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N) {
+    const int KB = (K + 7) / 8, NT = (N + 31) / 32;
+    std::vector<float> out((size_t)NT * KB * 256, 0.f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    int k = kb * 8 + (lane >> 5) * 4 + i;
+                    int j = nt * 32 + (lane & 31);
+                    if (k < K && j < N) out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + i] = w[(size_t)k * ldw + j];
+                }
+    return out;
+}
+
+int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
+                       int M, int N, int K, int act, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
+    const int KB = (K + 7) / 8;
+    const int ny = ((N + 31) / 32 + 1) / 2;
+    // small problems: 64-row block tiles so that the grid still covers the 256 CUs
+    const bool small = ((M + 127) / 128) * ny < 512;
+    if (small) {
+        dim3 grid((M + 63) / 64, ny);
+        hipLaunchKernelGGL(k_gemm_pk<1>, grid, dim3(256), 0, st, a, lda, reinterpret_cast<const float4*>(wp), KB, bias, c,
+                           ldc, M, N, K, act);
+    } else {
+        dim3 grid((M + 127) / 128, ny);
+        hipLaunchKernelGGL(k_gemm_pk<2>, grid, dim3(256), 0, st, a, lda, reinterpret_cast<const float4*>(wp), KB, bias, c,
+                           ldc, M, N, K, act);
+    }
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* c,
                     int64_t ldc, int M, int N, int K, int act, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
@@ -140,4 +282,21 @@ extern "C" int rl4rs_gemm_f32(const float* a, int64_t lda, const float* w, int64
     RL4RS_REQUIRE(a && w && c && M > 0 && N > 0 && K > 0, "rl4rs_gemm_f32: bad argument");
     RL4RS_REQUIRE(lda >= K && ldw >= N && ldc >= N, "rl4rs_gemm_f32: leading dimension too small");
     return rl4rs::launch_gemm_f32(a, lda, w, ldw, bias, c, ldc, M, N, K, act, (hipStream_t)stream);
+}
+
+// Packed-weight variant exposed for tests: packs W on the host, uploads, runs, frees (synchronous).
+extern "C" int rl4rs_gemm_f32_packed(const float* a_dev, int64_t lda, const float* w_host, int64_t ldw,
+                                     const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N,
+                                     int32_t K, int act, void* stream) {
+    RL4RS_REQUIRE(a_dev && w_host && c_dev && M > 0 && N > 0 && K > 0, "rl4rs_gemm_f32_packed: bad argument");
+    std::vector<float> pk = rl4rs::pack_gemm_weight(w_host, ldw, K, N);
+    float* d = nullptr;
+    int rc = rl4rs::dev_alloc(&d, pk.size());
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    RL4RS_HIP_TRY(hipMemcpyAsync(d, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, st));
+    rc = rl4rs::launch_gemm_packed(a_dev, lda, d, bias_dev, c_dev, ldc, M, N, K, act, st);
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    return rc;
 }

@@ -337,3 +337,16 @@ def gemm_f32(a, w, bias=None, act=0):
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     check(lib.rl4rs_gemm_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(c), N, M, N, K, act, _stream()))
     return c
+
+
+def gemm_f32_packed(a, w_host, bias=None, act=0):
+    """Same through the packed-weight kernel (w_host: numpy [K,N] float32)."""
+    lib = _lib.load()
+    M, K = a.shape
+    w_host = np.ascontiguousarray(w_host, dtype=np.float32)
+    K2, N = w_host.shape
+    assert K == K2
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.rl4rs_gemm_f32_packed(_ptr(a), a.stride(0), w_host.ctypes.data_as(C.c_void_p), N, _ptr(bias), _ptr(c), N,
+                                    M, N, K, act, _stream()))
+    return c

@@ -25,6 +25,9 @@ def test_gemm_f32(M, N, K, act):
         ref = torch.tanh(ref)
     err = (c.double() - ref).abs().max().item()
     assert err < 2e-5, err
+    from rl4rs_amd.device import gemm_f32_packed
+    cp = gemm_f32_packed(a, w.cpu().numpy(), b, act)
+    assert (cp.double() - ref).abs().max().item() < 2e-5
     # strided A (a column slice of a wider matrix) and no bias
     wide = torch.randn(M, K + 8, generator=g).cuda()
     c2 = gemm_f32(wide[:, 4:4 + K], w, None, 0)
