@@ -33,7 +33,7 @@ def make_config(args, workdir, rank):
     cat_text = synth.make_catalog_text(seed=1234)
     synth.write_text(cat_path, cat_text)
     seq = args.env == 'seq'
-    records = synth.make_records(args.log_records, pages=4 if seq else 1, seed=1000 + rank, illegal_frac=0.05,
+    records = synth.make_records(args.log_records, pages=4 if seq else 1, seed=1000 + rank, illegal_frac=0.05,   # rdist.shard_seed(1000, rank)
                                  special_ids=synth.special_ids_from_text(cat_text))
     synth.write_records(log_path, records)
     cfg = {"maxlen": 64, "batch_size": args.batch, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
@@ -108,18 +108,15 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    from rl4rs_amd import dist as rdist
+    rank, local_rank, world = rdist.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+    rdist.init('nccl')
 
     workdir = tempfile.mkdtemp(prefix='rl4rs_bench_')
-    cfg, records = make_config(args, workdir, rank)
+    cfg, records = make_config(args, workdir, rank)     # log shard / RNG stream of this rank: seed 1000 + rank
     env = build_env(cfg, seq)
     env.seed(1000 + rank)
     # inputs resident in HBM before the timed region: parse the whole log once
@@ -131,22 +128,12 @@ def main():
     net.set_profiling(True)
     net.profile_reset()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    barrier()
+    rdist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         obs, total = episode(env, T)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rdist.barrier()
+    elapsed = rdist.max_over_ranks(time.perf_counter() - t0, device='cuda')
     prof = net.profile()
     net.set_profiling(False)
 

@@ -1,0 +1,57 @@
+"""CPU: the N>1 plumbing with world_size 2 over gloo (sharding, max-over-ranks timing, gradient mean)."""
+import os
+import socket
+
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from rl4rs_amd import dist as D
+    r, lr, w = D.init('gloo')
+    assert (r, w) == (rank, world)
+    lo, hi = D.shard_rows(4097, r, w)
+    t = D.max_over_ranks(1.0 + r)
+    total = D.sum_over_ranks(hi - lo)
+    g = torch.full((34973,), float(r + 1))
+    D.allreduce_mean_(g)
+    D.barrier()
+    out.put((r, lo, hi, t, total, float(g[0]), float(g[-1]), D.shard_seed(1000, r)))
+
+
+def test_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1:3] for r in res] == [(0, 2049), (2049, 4097)]          # contiguous, covering, balanced
+    assert all(r[3] == 2.0 for r in res)                               # MAX over ranks
+    assert all(r[4] == 4097.0 for r in res)                            # every env row owned exactly once
+    assert all(r[5] == 1.5 and r[6] == 1.5 for r in res)               # gradient mean
+    assert [r[7] for r in res] == [1000, 1001]
+
+
+def test_single_process_is_a_noop():
+    from rl4rs_amd import dist as D
+    import torch
+    assert D.shard_rows(10, 0, 1) == (0, 10)
+    assert D.max_over_ranks(3.5) == 3.5
+    g = torch.ones(4)
+    assert D.allreduce_mean_(g) is g

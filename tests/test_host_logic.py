@@ -1,0 +1,146 @@
+"""CPU: host-side logic of the product (parsers, sampler, FeatureUtil list path, API surface) against the
+golden fixtures / the oracle.  No GPU, no compute calls into the library."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_scenario
+
+
+def test_catalog_tables_match_reference_golden():
+    from rl4rs_amd.data import CatalogTables
+    for name, path in (('slate_discrete', 'catalog_synth.csv'), ('real_discrete', 'item_info_real.csv')):
+        g = np.load(os.path.join(GOLDEN, name + '.npz'))
+        t = CatalogTables(os.path.join(GOLDEN, path), 284)
+        assert np.array_equal(t.action_emb, g['action_emb'])          # bit-exact float64
+        assert t.item_vec.dtype == np.float32 and t.item_vec.shape == (284, 40)
+        assert not t.item_vec[0].any() and t.price[0] == 0.0
+        assert t.location_mask.sum(1).tolist() == [39, 108, 136, 1]
+    assert len(t.special_items) == 113 and t.price.max() == 1478.1
+    d = t.item_info_dict()
+    assert d['0']['price'] == 0.0 and len(d['1']['item_vec']) == 40 and len(d) == 284
+
+
+def test_record_columns_match_oracle_parser():
+    from rl4rs_amd.data import RecordColumns
+    from oracle.records import ParsedRecords, pad_sequences
+    for name in ('slate_discrete', 'seq36_discrete', 'real_discrete'):
+        m, cfg, records, g = load_scenario(name)
+        c = RecordColumns(records, 64)
+        p = ParsedRecords(records)
+        assert np.array_equal(c.exposed, np.array(p.exposed))
+        assert np.array_equal(c.feedback, np.array(p.feedback))
+        assert np.array_equal(c.history, pad_sequences(p.history, 64))
+        assert np.array_equal(c.user_cat, p.user_cat)
+        assert np.array_equal(c.user_dense, p.user_dense.astype(np.float32))
+        assert c.users == p.users
+        # the un-acted state of the reference = user features padded
+        assert np.array_equal(c.user_dense, g['dense_init'][:, :32])
+        assert np.array_equal(c.user_cat, g['cat_init'][:, :10])
+        assert np.array_equal(c.history, g['seq_init'][:, 0])
+
+
+class _CaptureState(object):
+    def __init__(self, config, records, **kw):
+        self.records = records
+        self.kw = kw
+
+
+def test_recdatabase_cache_wrap_and_rng(tmp_path):
+    """base.py:82-100: cache window, wrap-around (skip line 0, take line 1), np.random.choice stream."""
+    from rl4rs_amd.env.base import RecDataBase
+    lines = ['rec%d' % i for i in range(7)]
+    p = tmp_path / 'log.csv'
+    p.write_text('\n'.join(lines) + '\n')
+    cfg = {'sample_file': str(p), 'maxlen': 64, 'cache_size': 5, 'is_eval': False}
+    db = RecDataBase(cfg, _CaptureState)
+    db.reset()
+    assert db.sample_list == lines[:5]
+    db.reset()
+    assert db.sample_list == lines[5:7] + [lines[1], lines[2], lines[3]]
+    db.reset(reset_file=True)
+    assert db.sample_list == lines[:5]
+    db.seed(42)
+    st = db.sample(3)
+    np.random.seed(42)
+    assert list(st.records) == list(np.random.choice(lines[:5], 3))
+    assert st.records.rows == [lines.index(x) for x in st.records]
+    # eval mode: the first B cached lines, cache_size must equal B (base.py:93-96)
+    ev = RecDataBase(dict(cfg, is_eval=True), _CaptureState)
+    ev.reset()
+    assert list(ev.sample(5).records) == lines[:5]
+    with pytest.raises(AssertionError):
+        ev.sample(4)
+
+
+def test_featureutil_list_path_matches_reference_golden():
+    """feature_extraction on the reference's nested-list rows (datautil.py:34-69)."""
+    from rl4rs_amd.utils.datautil import FeatureUtil
+    from rl4rs_amd.env.slate import SlateState
+    m, cfg, records, g = load_scenario('slate_discrete')
+    fu = FeatureUtil(cfg)
+    rows = SlateState.records_to_state(records)
+    (seq, dense, cat, labels), y = fu.feature_extraction(rows)
+    assert np.array_equal(seq, g['seq_init']) and seq.dtype == np.int32
+    assert np.array_equal(dense, g['dense_init']) and dense.dtype == np.float32
+    assert np.array_equal(cat, g['cat_init']) and cat.dtype == np.int32
+    assert labels.shape == (len(records), 9) and y == [0] * len(records)
+    parts = FeatureUtil.record_split(records[0])
+    assert len(parts) == 9 and isinstance(parts[3], list) and isinstance(parts[6][0], float)
+    with pytest.raises(ValueError):
+        FeatureUtil.record_split('a@b')
+
+
+def test_single_elem_support_semantics():
+    from rl4rs_amd.env.base import single_elem_support
+
+    @single_elem_support
+    def f(x):
+        return x
+    assert f([5]) == 5
+    assert f(np.array([[1, 2]])).tolist() == [1, 2]
+    assert f(([[1, 2]], [3.0], [0], [{}])) == [[1, 2], 3.0, 0, {}]
+    assert f([1, 2]) == [1, 2]
+    out = f((np.zeros((2, 3)), [0.0, 1.0], [0, 0], [{}, {}]))
+    assert isinstance(out, tuple) and out[0].shape == (2, 3)
+
+
+def test_reference_import_paths_and_spaces():
+    import rl4rs  # noqa: F401
+    from rl4rs.env import RecState, RecSimBase, RecDataBase, RecEnvBase
+    from rl4rs.env.slate import SlateRecEnv, SlateState
+    from rl4rs.env.seqslate import SeqSlateRecEnv, SeqSlateState
+    from rl4rs.utils.datautil import FeatureUtil  # noqa: F401
+    from rl4rs.utils.rllib_vector_env import MyVectorEnvWrapper  # noqa: F401
+    from rl4rs_amd.env.base import _observation_space, _action_space
+    assert issubclass(SeqSlateState, SlateState) and issubclass(SlateState, RecState)
+    assert issubclass(SeqSlateRecEnv, SlateRecEnv) and issubclass(SlateRecEnv, RecSimBase)
+    for cls in (RecState, RecSimBase):
+        with pytest.raises(TypeError):
+            cls({}, [])
+    assert RecDataBase and RecEnvBase
+    sp = _observation_space({'support_rllib_mask': True}, {'action_mask': np.zeros(284), 'obs': np.zeros(256)})
+    assert sp.spaces['action_mask'].shape == (284,) and sp.spaces['obs'].shape == (256,)
+    assert _observation_space({}, np.zeros(256)).shape == (256,)
+    assert _action_space({'support_conti_env': True, 'action_emb_size': 32}).shape == (32,)
+    assert _action_space({'action_size': 284}).n == 284
+
+
+def test_synthetic_logs_are_legal_by_construction(tmp_path):
+    from rl4rs_amd import synth
+    from oracle.state import OracleState
+    text = synth.make_catalog_text(seed=5)
+    p = str(tmp_path / 'c.csv')
+    synth.write_text(p, text)
+    recs = synth.make_records(64, pages=4, seed=3, illegal_frac=0.0, special_ids=synth.special_ids_from_text(text))
+    cfg = {"maxlen": 64, "batch_size": 64, "action_size": 284, "dense_feature_num": 432, "category_feature_num": 21,
+           "max_steps": 36, "iteminfo_file": p}
+    st = OracleState(cfg, recs, seq=True)
+    for t in range(36):
+        st.act(st.offline_action)
+    cfg2 = dict(cfg, max_steps=9)
+    st2 = OracleState(cfg2, recs)
+    for t in range(9):
+        st2.act(st2.offline_action)
+    assert st2.get_violation().all()

@@ -1,0 +1,82 @@
+"""CPU: properties of the DIEN oracle restatement, and the algebraic identities the HIP scorer relies on
+(input-projection hoisting of the GRU/AUGRU matmuls, the split of the attention MLP's first layer)."""
+import numpy as np
+
+CFG = {"maxlen": 64, "batch_size": 4, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+       "category_feature_num": 21, "category_hash_size": 500, "seq_num": 2, "emb_size": 128,
+       "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32}
+
+
+def _inputs(R, rs):
+    seq = rs.randint(0, 284, size=(R, 2, 64))
+    dense = np.abs(rs.randn(R, 432)).astype(np.float32)
+    cat = rs.randint(0, 500, size=(R, 21))
+    return seq, dense, cat
+
+
+def test_shapes_dtypes_and_fp32_vs_fp64():
+    from rl4rs_amd.nets.dien import init_dien_weights, dien_spec, check_weights
+    from oracle.dien import OracleDien
+    w = init_dien_weights(CFG, seed=1, emb_scale=0.5, bias_noise=0.1)
+    check_weights(w, CFG)
+    assert dien_spec(CFG)['obs_w'] == (3456, 256)
+    rs = np.random.RandomState(0)
+    seq, dense, cat = _inputs(16, rs)
+    o64 = OracleDien(w, CFG, np.float64)
+    o32 = OracleDien(w, CFG, np.float32)
+    obs64, obs32 = o64.obs(seq, dense, cat), o32.obs(seq, dense, cat)
+    assert obs64.shape == (16, 256) and obs32.dtype == np.float32
+    assert np.abs(obs64 - obs32).max() < 1e-4
+    p = o64.reward_probs(seq, dense, cat)
+    assert p.shape == (16, 2) and np.allclose(p.sum(1), 1.0)
+    assert o64.prob(seq, dense, cat).dtype == np.float32
+    # rows are independent: scoring a subset gives the same rows (no cross-row term anywhere)
+    assert np.allclose(o64.obs(seq[3:7], dense[3:7], cat[3:7]), obs64[3:7], rtol=0, atol=1e-12)
+
+
+def test_hoisting_identities_fp64():
+    """[x,h] W = x W[:E] + h W[E:]  and  [q,k,q-k,q*k] W1 = q(W1a+W1c) + k(W1b-W1c) + (q*k) W1d."""
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from oracle.dien import OracleDien, _sigmoid
+    w = init_dien_weights(CFG, seed=2, emb_scale=0.5, bias_noise=0.1)
+    o = OracleDien(w, CFG, np.float64)
+    rs = np.random.RandomState(1)
+    seq, dense, cat = _inputs(6, rs)
+    _, parts = o.features(seq, dense, cat, return_parts=True)
+    E = 128
+    H1, q = parts['h1_0'], parts['query']
+    # attention split
+    W1, b1 = o.w['att0_w1'], o.w['att0_b1']
+    qa = q @ (W1[:E] + W1[2 * E:3 * E])
+    ak = H1 @ (W1[E:2 * E] - W1[2 * E:3 * E]) + b1
+    qk = (q[:, None, :] * H1) @ W1[3 * E:]
+    h1 = _sigmoid(qa[:, None, :] + ak + qk)
+    h2 = _sigmoid(h1 @ o.w['att0_w2'] + o.w['att0_b2'])
+    score = (h2 @ o.w['att0_w3'] + o.w['att0_b3'])[..., 0]
+    assert np.abs(score - parts['score_0']).max() < 1e-12
+    # AUGRU with the x-side projections hoisted out of the recurrence
+    Wg, bg = o.w['augru0_gate_w'], o.w['augru0_gate_b']
+    Wc, bc = o.w['augru0_cand_w'], o.w['augru0_cand_b']
+    xg = H1 @ Wg[:E] + bg
+    xc = H1 @ Wc[:E] + bc
+    N = 2 * E
+    h = np.zeros((6, N))
+    for t in range(64):
+        g = _sigmoid(xg[:, t] + h @ Wg[E:])
+        r, u = g[:, :N], g[:, N:]
+        c = np.tanh(xc[:, t] + (r * h) @ Wc[E:])
+        u = (1.0 - score[:, t:t + 1]) * u
+        h = u * h + (1.0 - u) * c
+    assert np.abs(h - parts['h2_0']).max() < 1e-12
+    # first GRU through the per-id projection table seq_emb @ Wx + b
+    Wg1, bg1 = o.w['gru0_gate_w'], o.w['gru0_gate_b']
+    Wc1, bc1 = o.w['gru0_cand_w'], o.w['gru0_cand_b']
+    table = np.concatenate([o.w['seq_emb'] @ Wg1[:E] + bg1, o.w['seq_emb'] @ Wc1[:E] + bc1], axis=1)
+    h = np.zeros((6, E))
+    for t in range(64):
+        x = table[seq[:, 0, t]]
+        g = _sigmoid(x[:, :2 * E] + h @ Wg1[E:])
+        r, u = g[:, :E], g[:, E:]
+        c = np.tanh(x[:, 2 * E:] + (r * h) @ Wc1[E:])
+        h = u * h + (1.0 - u) * c
+        assert np.abs(h - H1[:, t]).max() < 1e-12
