@@ -12,6 +12,7 @@
 //     (HBM is 288 GB; 150 MB per sequence input buys the whole x-side GEMM of the first GRU).
 //   * Recurrences run as ONE launch for all L steps: a workgroup owns 32 rows, keeps h in LDS/registers and
 //     streams the (pre-packed, L2-resident) recurrent weights every step; no inter-workgroup traffic.
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
 //     the phase's epilogue (thousands of MFMA cycles later), so their HBM latency never sits in front of an MFMA.
 struct RecurArgs {
     int n_rows, L, group;
-    const float* xbase[4]; int64_t xld; int xoff;
+    const float* xbase[4]; int64_t xld; int xoff; int64_t xbytes;   // xbytes = size of one x table (< 4 GB)
     const int32_t* ids;      // GRU: [n_rows, L]
     const int32_t* slots; int64_t slots_stride;    // AUGRU: [n_seq][n_rows/group]
     const float* wg[4]; const float* wc[4];
@@ -164,23 +165,47 @@ __device__ __forceinline__ float gate_tanh(float x) {
 #endif
 }
 
-template <int NH, bool AUGRU, int U>
+// AB = ablation bits for timing experiments only (results are wrong when non-zero):
+//   1 no activation math, 2 weight fragments loaded once (no streaming), 4 no x-projection loads, 8 no barriers
+struct f4bits { float x, y, z, w; };
+// NOTE: the b128 builtin's result type is a 128-bit value that does NOT convert element-wise to an
+// ext_vector typedef on this compiler (it splats the low dword): bit_cast the `auto` result instead.
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    static_assert(sizeof(v) == 16, "b128");
+    f4bits f = __builtin_bit_cast(f4bits, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+}
+
+template <int NH, bool AUGRU, int U, int AB = 0>
 __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
-    constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4, NG = KB / U, NP = NG / 2;
-    static_assert(KB % U == 0 && (NG % 2) == 0 && NP >= 2, "need an even number (>= 4) of k-block groups");
+    constexpr int U2 = 2 * U;
+    constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4, NG = KB / U, NG2 = KB / U2;
+    static_assert(KB % U2 == 0 && NG >= 2 && NG2 >= 2, "k-block groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hb = reinterpret_cast<float*>(smem);          // [32][LDH]
     float* rhb = hb + 32 * LDH;                          // [32][LDH]
     float* s_att = rhb + 32 * LDH;                       // AUGRU: [32][L+1]
     int32_t* s_ids = reinterpret_cast<int32_t*>(rhb + 32 * LDH);   // GRU: [32][L+1]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, li = lane & 31;
     const int row0 = blockIdx.x * 32;
     const int sq = blockIdx.y;
     const int L = a.L, LDT = L + 1;
     const int col = wave * 32 + li;
-    const float* __restrict__ xbase = a.xbase[sq] + a.xoff + col;
-    const uint32_t xld = (uint32_t)a.xld;
+    const int xld4 = (int)a.xld * 4;
+
+    // buffer descriptors: all streamed operands are addressed as (SGPR base, 32-bit lane offset, scalar offset),
+    // so no load costs address VGPRs and the unrolled ring below stays inside the register budget
+    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
+    const int vl16 = lane * 16;
+    const int so_r = wave * KB * 1024, so_u = (NW + wave) * KB * 1024, so_c = wave * KB * 1024;   // + kb * 1024
 
     for (int i = tid; i < 32 * LDH; i += NH * 2) hb[i] = 0.f;
     for (int i = tid; i < 32 * L; i += NH * 2) {
@@ -189,141 +214,129 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
         if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
         else s_ids[r * LDT + t] = a.ids[(size_t)gr * L + t];
     }
-    // element offset of each row's x-projection at t = 0 (AUGRU: slot * L * xld)
+    // byte offset of each row's x-projection at t = 0 (AUGRU: slot * L * xld)
     uint32_t* s_xoff = reinterpret_cast<uint32_t*>(s_att + 32 * LDT);
     if (tid < 32) {
         int gr = min(row0 + tid, a.n_rows - 1);
-        s_xoff[tid] = AUGRU ? (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * xld : 0u;
+        s_xoff[tid] = AUGRU ? (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4 : 0u;
     }
     f32x16 h_own;
 #pragma unroll
     for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
-    const float4* __restrict__ wg_r = reinterpret_cast<const float4*>(a.wg[sq]) + ((size_t)wave * KB) * 64 + lane;
-    const float4* __restrict__ wg_u = reinterpret_cast<const float4*>(a.wg[sq]) + ((size_t)(NW + wave) * KB) * 64 + lane;
-    const float4* __restrict__ wc_c = reinterpret_cast<const float4*>(a.wc[sq]) + ((size_t)wave * KB) * 64 + lane;
     const float* arow = hb + li * LDH + half * 4;
     const float* rrow = rhb + li * LDH + half * 4;
+    const int xcol4 = (a.xoff + col) * 4;
     __syncthreads();
 
-    auto xaddr = [&](int r, int t) -> const float* {
-        uint32_t off = AUGRU ? s_xoff[crow(r, half)] + (uint32_t)t * xld : (uint32_t)s_ids[crow(r, half) * LDT + t] * xld;
-        return xbase + off;
+    // x-projection fetch of one gate block (0 = r, 1 = u, 2 = c) of step t into dst
+    auto load_x = [&](f32x16& dst, int t, int block) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int voff = AUGRU ? (int)s_xoff[crow(r, half)] + xcol4
+                             : s_ids[crow(r, half) * LDT + t] * xld4 + xcol4;
+            dst[r] = buf_load1(rs_x, voff, (AUGRU ? t * xld4 : 0) + block * NH * 4);
+        }
     };
     f32x16 xr_, xu_, xc_;
-    // 2-deep register ring of weight / operand fragments, U k-blocks per slot
-    float4 wA[U], wB[U], uA[U], uB[U], cA[U], cB[U], aA[U], aB[U];
+    float4 wr[2][U], wu[2][U], a1[2][U], wc[2][U2], a2[2][U2];
 #pragma unroll
-    for (int i = 0; i < U; ++i) { wA[i] = wg_r[(size_t)i * 64]; uA[i] = wg_u[(size_t)i * 64]; }
-
-#define RL4RS_MFMA_RU(AV, WR, WU)                                                         \
-    _Pragma("unroll") for (int i = 0; i < U; ++i) {                                      \
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WR[i].x, acc_r, 0, 0, 0);  \
-        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WU[i].x, acc_u, 0, 0, 0);  \
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WR[i].y, acc_r, 0, 0, 0);  \
-        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WU[i].y, acc_u, 0, 0, 0);  \
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WR[i].z, acc_r, 0, 0, 0);  \
-        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WU[i].z, acc_u, 0, 0, 0);  \
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WR[i].w, acc_r, 0, 0, 0);  \
-        acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WU[i].w, acc_u, 0, 0, 0);  \
+    for (int i = 0; i < U; ++i) {
+        wr[0][i] = buf_load4(rs_wg, vl16, so_r + i * 1024);
+        wu[0][i] = buf_load4(rs_wg, vl16, so_u + i * 1024);
     }
-#define RL4RS_MFMA_C(AV, WC)                                                              \
-    _Pragma("unroll") for (int i = 0; i < U; ++i) {                                      \
-        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].x, WC[i].x, acc_c, 0, 0, 0);  \
-        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].y, WC[i].y, acc_c, 0, 0, 0);  \
-        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].z, WC[i].z, acc_c, 0, 0, 0);  \
-        acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i].w, WC[i].w, acc_c, 0, 0, 0);  \
-    }
+    load_x(xr_, 0, 0);
+    load_x(xu_, 0, 1);
 
     for (int t = 0; t < L; ++t) {
         f32x16 acc_r, acc_u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_u[r] = 0.f; }
-        // ---- phase 1: gates.  Groups are consumed in pairs (slot A, slot B); wA/uA of group 0 are resident.
+        // ---- phase 1: gates.  Fully unrolled 2-deep ring: group g+1 is requested before group g is consumed.
 #pragma unroll
-        for (int i = 0; i < U; ++i) aA[i] = *reinterpret_cast<const float4*>(arow + i * 8);
-#pragma unroll 1
-        for (int gp = 0; gp < NP; ++gp) {
-            const float4* pr = wg_r + (size_t)(2 * gp + 1) * U * 64;
-            const float4* pu = wg_u + (size_t)(2 * gp + 1) * U * 64;
-            const float* pa = arow + (2 * gp + 1) * U * 8;
+        for (int i = 0; i < U; ++i) a1[0][i] = *reinterpret_cast<const float4*>(arow + i * 8);
 #pragma unroll
-            for (int i = 0; i < U; ++i) {                      // slot B <- group 2gp+1
-                wB[i] = pr[(size_t)i * 64];
-                uB[i] = pu[(size_t)i * 64];
-                aB[i] = *reinterpret_cast<const float4*>(pa + i * 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            RL4RS_MFMA_RU(aA, wA, uA)
-            __builtin_amdgcn_sched_barrier(0);
-            if (gp + 1 < NP) {
+        for (int g = 0; g < NG; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g + 1 < NG) {
 #pragma unroll
-                for (int i = 0; i < U; ++i) {                  // slot A <- group 2gp+2
-                    wA[i] = pr[(size_t)(U + i) * 64];
-                    uA[i] = pu[(size_t)(U + i) * 64];
-                    aA[i] = *reinterpret_cast<const float4*>(pa + (U + i) * 8);
-                }
-                if (gp == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {             // consumed by this phase's epilogue
-                        const float* xp = xaddr(r, t);
-                        xr_[r] = xp[0];
-                        xu_[r] = xp[NH];
+                for (int i = 0; i < U; ++i) {
+                    const int kb = (g + 1) * U + i;
+                    if (!(AB & 2)) {
+                        wr[nb][i] = buf_load4(rs_wg, vl16, so_r + kb * 1024);
+                        wu[nb][i] = buf_load4(rs_wg, vl16, so_u + kb * 1024);
                     }
+                    a1[nb][i] = *reinterpret_cast<const float4*>(arow + kb * 8);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < U; ++i) cA[i] = wc_c[(size_t)i * 64];         // first group of phase 2
+                for (int i = 0; i < U2; ++i)
+                    if (!(AB & 2) || t == 0) wc[0][i] = buf_load4(rs_wc, vl16, so_c + i * 1024);   // first group of phase 2
+                // candidate x-projection: consumed after phase 2.  vmcnt retires in order; the next wait that
+                // covers these loads is a full epilogue + barrier + one MFMA group away.
+                if (!(AB & 4) || t == 0) load_x(xc_, t, 2);
             }
             __builtin_amdgcn_sched_barrier(0);
-            RL4RS_MFMA_RU(aB, wB, uB)
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].x, wr[cb][i].x, acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].x, wu[cb][i].x, acc_u, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].y, wr[cb][i].y, acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].y, wu[cb][i].y, acc_u, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].z, wr[cb][i].z, acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].z, wu[cb][i].z, acc_u, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].w, wr[cb][i].w, acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cb][i].w, wu[cb][i].w, acc_u, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float rg = gate_sigmoid(acc_r[r] + xr_[r]);
-            acc_u[r] = gate_sigmoid(acc_u[r] + xu_[r]);
+            float rg = (AB & 1) ? acc_r[r] + xr_[r] : gate_sigmoid(acc_r[r] + xr_[r]);
+            acc_u[r] = (AB & 1) ? acc_u[r] + xu_[r] : gate_sigmoid(acc_u[r] + xu_[r]);
             rhb[crow(r, half) * LDH + col] = rg * h_own[r];
         }
-        __syncthreads();
+        if (!(AB & 8)) __syncthreads();
         // ---- phase 2: candidate + state update
         f32x16 acc_c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_c[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < U; ++i) aA[i] = *reinterpret_cast<const float4*>(rrow + i * 8);
-#pragma unroll 1
-        for (int gp = 0; gp < NP; ++gp) {
-            const float4* pc = wc_c + (size_t)(2 * gp + 1) * U * 64;
-            const float* pa = rrow + (2 * gp + 1) * U * 8;
+        for (int i = 0; i < U2; ++i) a2[0][i] = *reinterpret_cast<const float4*>(rrow + i * 8);
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                cB[i] = pc[(size_t)i * 64];
-                aB[i] = *reinterpret_cast<const float4*>(pa + i * 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            RL4RS_MFMA_C(aA, cA)
-            __builtin_amdgcn_sched_barrier(0);
-            if (gp + 1 < NP) {
+        for (int g = 0; g < NG2; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g + 1 < NG2) {
 #pragma unroll
-                for (int i = 0; i < U; ++i) {
-                    cA[i] = pc[(size_t)(U + i) * 64];
-                    aA[i] = *reinterpret_cast<const float4*>(pa + (U + i) * 8);
-                }
-                if (gp == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) xc_[r] = xaddr(r, t)[2 * NH];   // consumed by this phase's epilogue
+                for (int i = 0; i < U2; ++i) {
+                    const int kb = (g + 1) * U2 + i;
+                    if (!(AB & 2)) wc[nb][i] = buf_load4(rs_wc, vl16, so_c + kb * 1024);
+                    a2[nb][i] = *reinterpret_cast<const float4*>(rrow + kb * 8);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < U; ++i) { wA[i] = wg_r[(size_t)i * 64]; uA[i] = wg_u[(size_t)i * 64]; }
+                for (int i = 0; i < U; ++i)
+                    if (!(AB & 2)) {                                              // first group of the next phase 1
+                        wr[0][i] = buf_load4(rs_wg, vl16, so_r + i * 1024);
+                        wu[0][i] = buf_load4(rs_wg, vl16, so_u + i * 1024);
+                    }
+                if (t + 1 < L && !(AB & 4)) {                                     // consumed after the next phase 1
+                    load_x(xr_, t + 1, 0);
+                    load_x(xu_, t + 1, 1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            RL4RS_MFMA_C(aB, cB)
+#pragma unroll
+            for (int i = 0; i < U2; ++i) {
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[cb][i].x, wc[cb][i].x, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[cb][i].y, wc[cb][i].y, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[cb][i].z, wc[cb][i].z, acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[cb][i].w, wc[cb][i].w, acc_c, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float c = gate_tanh(acc_c[r] + xc_[r]);
+            float c = (AB & 1) ? acc_c[r] + xc_[r] : gate_tanh(acc_c[r] + xc_[r]);
             float u = acc_u[r];
             if (AUGRU) u = (1.0f - s_att[crow(r, half) * LDT + t]) * u;
             float hn = u * h_own[r] + (1.0f - u) * c;
@@ -334,10 +347,8 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
                 a.out[orow * a.out_ld + a.out_off + col] = hn;
             }
         }
-        __syncthreads();
+        if (!(AB & 8)) __syncthreads();
     }
-#undef RL4RS_MFMA_RU
-#undef RL4RS_MFMA_C
     if (AUGRU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -636,6 +647,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     RL4RS_REQUIRE(c->category_feature_num >= 1 && c->category_feature_num <= 64, "dien: category_feature_num must be in 1..64");
     RL4RS_REQUIRE(c->max_rows > 0 && c->max_slots > 0 && c->category_hash_size > 0 && c->dense_feature_num > 0,
                   "dien: bad sizes");
+    RL4RS_REQUIRE((int64_t)c->max_slots * c->maxlen * (ATT_H1 + 6 * c->emb_size) * 4 < (int64_t)0x7fffffff * 2,
+                  "dien: max_slots=%d too large: the per-input sequence cache must stay below 4 GB (32-bit buffer offsets)",
+                  c->max_slots);
+    RL4RS_REQUIRE((int64_t)c->category_hash_size * 3 * c->emb_size * 4 < (int64_t)0x7fffffff * 2,
+                  "dien: category_hash_size too large for 32-bit buffer offsets");
     int ndev = rl4rs_device_count();
     if (ndev <= 0) {
         set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
@@ -729,8 +745,12 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     {
         size_t sm_aug = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1) + 32) * 4;
         size_t sm_gru = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
+        const void* augru_variants[] = {
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 0>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 1>),
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 2>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 4>),
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 8>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 15>)};
+        for (const void* f : augru_variants)
+            RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true>),
@@ -762,7 +782,7 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
         RecurArgs a;
         memset(&a, 0, sizeof(a));
         a.n_rows = cnt; a.L = L; a.group = 1;
-        a.xbase[0] = n->embw1[s]; a.xld = 3 * E; a.xoff = 0;
+        a.xbase[0] = n->embw1[s]; a.xld = 3 * E; a.xoff = 0; a.xbytes = (int64_t)n->H * 3 * E * 4;
         a.ids = ids; a.slots = nullptr; a.slots_stride = 0;
         a.wg[0] = n->gru_wg[s]; a.wc[0] = n->gru_wc[s]; a.att = nullptr; a.att_stride = 0;
         a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.out_seq_off = 0; a.slot_base = slot_base;
@@ -829,12 +849,21 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         RecurArgs a;
         memset(&a, 0, sizeof(a));
         a.n_rows = R; a.L = L; a.group = group;
-        a.xld = n->PLD; a.xoff = ATT_H1;
+        a.xld = n->PLD; a.xoff = ATT_H1; a.xbytes = (int64_t)n->c.max_slots * L * n->PLD * 4;
         a.ids = nullptr; a.slots = slots; a.slots_stride = ngroups;
         for (int s = 0; s < S; ++s) { a.xbase[s] = n->proj[s]; a.wg[s] = n->augru_wg[s]; a.wc[s] = n->augru_wc[s]; }
         a.att = n->scores; a.att_stride = (int64_t)n->c.max_rows * L;
         a.out = n->allf; a.out_ld = F; a.out_off = 0; a.out_seq_off = NH2; a.slot_base = 0;
-        hipLaunchKernelGGL((k_recur<256, true, AUGRU_U>), dim3((R + 31) / 32, S), dim3(512), smem, st, a);
+        static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;
+        dim3 grid((R + 31) / 32, S), block(512);
+        switch (ablate) {      // timing experiments only
+            case 1: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 1>), grid, block, smem, st, a); break;
+            case 2: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 2>), grid, block, smem, st, a); break;
+            case 4: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 4>), grid, block, smem, st, a); break;
+            case 8: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 8>), grid, block, smem, st, a); break;
+            case 15: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 15>), grid, block, smem, st, a); break;
+            default: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 0>), grid, block, smem, st, a); break;
+        }
         RL4RS_LAUNCH_CHECK();
     }
     float* obs_out = obs ? obs : n->obs_tmp;
