@@ -128,22 +128,36 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
 // K zero-padded to a multiple of 8, N to a multiple of 32.  One 16-byte load feeds four MFMAs; the next
 // k-block's fragment is requested before the current block's MFMAs (register ring).
 // WM = 32-row tiles per wave: block tile = (64*WM) x 64, 2x2 waves.
+struct f4bits_g { float x, y, z, w; };
+__device__ __forceinline__ float4 gbuf_load4(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);   // result must be bit_cast (see dien.hip)
+    f4bits_g f = __builtin_bit_cast(f4bits_g, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
 template <int WM>
 __global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, int64_t lda,
                                                  const float4* __restrict__ Wp, int KB,
                                                  const float* __restrict__ bias, float* __restrict__ C,
                                                  int64_t ldc, int M, int N, int K, int act) {
     constexpr int BM = 64 * WM;
+    constexpr int KPT = GBK / 8;          // k-blocks per k-tile
     __shared__ __attribute__((aligned(16))) float As[2][BM][GLD];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, li = lane & 31;
     const int m0 = blockIdx.x * BM;
     const int nt = blockIdx.y * 2 + wn;
+    const int NT = (N + 31) / 32;
     const int col = nt * 32 + li;
-    const bool tile_ok = nt * 32 < N;
+    const bool tile_ok = nt < NT;
     const bool vec_ok = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    const float4* __restrict__ wp = Wp + ((size_t)(tile_ok ? nt : 0) * KB) * 64 + lane;
+    // this wave's B-fragment stream: [KB][64 lanes] float4, addressed through a buffer descriptor so that reads
+    // past the last k-block return zeros (K tail) and no load costs address VGPRs
+    const float4* wtile = Wp + (size_t)(tile_ok ? nt : 0) * KB * 64;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wtile), 0, KB * 1024, 0x00020000);
+    const int vl16 = lane * 16;
 
     f32x16 acc[WM];
 #pragma unroll
@@ -152,69 +166,90 @@ __global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, in
         for (int i = 0; i < 16; ++i) acc[w][i] = 0.f;
 
     constexpr int NST = BM * 8 / 256;     // float4 chunks per thread per A tile
-    float4 stage[NST];
-    auto load_tile = [&](int kt) {
+    float4 stage[3][NST];                 // A tiles kt+1 .. kt+3 in flight (HBM / Infinity-Cache latency >> one tile)
+    auto load_tile = [&](float4 (&st)[NST], int kt) {
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             int c = tid + p * 256;
             int r = c >> 3, kq = (c & 7) << 2;
             int gr = m0 + r, gk = kt * GBK + kq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr < M) {
+            if (gr < M && gk < K) {
                 const float* src = A + (size_t)gr * lda + gk;
                 if (vec_ok && gk + 3 < K) {
                     v = *reinterpret_cast<const float4*>(src);
                 } else {
-                    if (gk + 0 < K) v.x = src[0];
+                    v.x = src[0];
                     if (gk + 1 < K) v.y = src[1];
                     if (gk + 2 < K) v.z = src[2];
                     if (gk + 3 < K) v.w = src[3];
                 }
             }
-            stage[p] = v;
+            st[p] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const float4 (&st)[NST], int buf) {
 #pragma unroll
         for (int p = 0; p < NST; ++p) {
             int c = tid + p * 256;
             int r = c >> 3, kq = (c & 7) << 2;
-            *reinterpret_cast<float4*>(&As[buf][r][kq]) = stage[p];
+            *reinterpret_cast<float4*>(&As[buf][r][kq]) = st[p];
+        }
+    };
+    float4 bcur[KPT], bnext[KPT];
+    auto load_b = [&](float4 (&b)[KPT], int kt) {
+        const int voff = vl16 + kt * (KPT * 1024);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) b[j] = gbuf_load4(rs_w, voff + j * 1024, 0);
+    };
+    const int arow = wm * 32 * WM + li;
+    auto compute = [&](const float4 (&b)[KPT], int buf) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            float4 av[WM];
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+                av[w] = *reinterpret_cast<const float4*>(&As[buf][arow + 32 * w][j * 8 + half * 4]);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].x, b[j].x, acc[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].y, b[j].y, acc[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].z, b[j].z, acc[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].w, b[j].w, acc[w], 0, 0, 0);
         }
     };
 
     const int nkt = (K + GBK - 1) / GBK;
-    load_tile(0);
-    store_tile(0);
-    float4 b_cur = wp[0];
+    // prologue: tile 0 -> LDS[0]; tiles 1..3 in flight; B fragments of tile 0
+    load_tile(stage[0], 0);
+    load_b(bcur, 0);
+    load_tile(stage[1], 1);
+    load_tile(stage[2], 2);
+    store_tile(stage[0], 0);
+    load_tile(stage[0], 3);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const int arow = wm * 32 * WM + li;
-#pragma unroll
-        for (int j = 0; j < GBK / 8; ++j) {
-            const int g = kt * (GBK / 8) + j;
-            if (g < KB) {
-                float4 b_next = (g + 1 < KB) ? wp[(size_t)(g + 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 av[WM];
-#pragma unroll
-                for (int w = 0; w < WM; ++w)
-                    av[w] = *reinterpret_cast<const float4*>(&As[cur][arow + 32 * w][j * 8 + half * 4]);
-#pragma unroll
-                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].x, b_cur.x, acc[w], 0, 0, 0);
-#pragma unroll
-                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].y, b_cur.y, acc[w], 0, 0, 0);
-#pragma unroll
-                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].z, b_cur.z, acc[w], 0, 0, 0);
-#pragma unroll
-                for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[w].w, b_cur.w, acc[w], 0, 0, 0);
-                b_cur = b_next;
-            }
-        }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
-        __syncthreads();
+    // steady state, unrolled by 6 so the LDS buffer (kt & 1) and the register stage ((kt + 1) % 3) are static:
+    // at the top of iteration kt: LDS[kt&1] = tile kt; stage[(kt+1)%3] = tile kt+1, stage[(kt+2)%3] = tile kt+2,
+    // stage[kt%3] = tile kt+3 (all possibly still in flight); bcur = B fragments of tile kt.
+#define RL4RS_GEMM_STEP(KT, S1, S0, BC, BN)                                        \
+    if ((KT) < nkt) {                                                              \
+        load_b(BN, (KT) + 1);                                                      \
+        compute(BC, (KT) & 1);                                                     \
+        store_tile(stage[S1], ((KT) + 1) & 1);     /* tile kt+1 (issued >= 2 tiles ago) */ \
+        load_tile(stage[S1], (KT) + 4);            /* refill the freed stage */     \
+        __syncthreads();                                                           \
     }
+    for (int kt = 0; kt < nkt; kt += 6) {
+        RL4RS_GEMM_STEP(kt + 0, 1, 0, bcur, bnext)
+        RL4RS_GEMM_STEP(kt + 1, 2, 1, bnext, bcur)
+        RL4RS_GEMM_STEP(kt + 2, 0, 2, bcur, bnext)
+        RL4RS_GEMM_STEP(kt + 3, 1, 0, bnext, bcur)
+        RL4RS_GEMM_STEP(kt + 4, 2, 1, bcur, bnext)
+        RL4RS_GEMM_STEP(kt + 5, 0, 2, bnext, bcur)
+    }
+#undef RL4RS_GEMM_STEP
     if (tile_ok && col < N) {
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
