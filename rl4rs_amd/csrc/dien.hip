@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     float* s_q = s_wave + (size_t)wave * (E + ATT_H1);
     float* s_qa = s_q + E;
     const int KB = E / 8;
-    const float4* __restrict__ w1d0 = reinterpret_cast<const float4*>(a.w1d[sq]) + lane;
-    const float4* __restrict__ w1d1 = w1d0 + (size_t)KB * 64;
+    const __amdgpu_buffer_rsrc_t rs_w1d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1d[sq]), 0, 2 * KB * 1024, 0x00020000);
+    const int vl16 = lane * 16;
     const float* __restrict__ w1ac = a.w1ac[sq];
     const int ntile = (L + 31) / 32;    // L <= 64 -> 1 or 2 N tiles
     const int t0 = li, t1 = min(32 + li, L - 1);
@@ -438,45 +438,42 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
         f32x16 acc00, acc10, acc01, acc11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc10[r] = 0.f; acc01[r] = 0.f; acc11[r] = 0.f; }
-        float4 aA0, aA1, hA0, hA1, qA, aB0, aB1, hB0, hB1, qB;
-        aA0 = w1d0[0]; aA1 = w1d1[0];
-        hA0 = *reinterpret_cast<const float4*>(hsrc0); hA1 = *reinterpret_cast<const float4*>(hsrc1);
-        qA = *reinterpret_cast<const float4*>(qsrc);
-#define RL4RS_DIN_MFMA(A0, A1, H0, H1, Q)                                                         \
-        {                                                                                         \
-            const float b0[4] = {H0.x * Q.x, H0.y * Q.y, H0.z * Q.z, H0.w * Q.w};                  \
-            const float b1[4] = {H1.x * Q.x, H1.y * Q.y, H1.z * Q.z, H1.w * Q.w};                  \
-            const float a0[4] = {A0.x, A0.y, A0.z, A0.w};                                         \
-            const float a1[4] = {A1.x, A1.y, A1.z, A1.w};                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc00, 0, 0, 0);       \
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc10, 0, 0, 0);       \
-                if (ntile > 1) {                                                                  \
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc01, 0, 0, 0);   \
-                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc11, 0, 0, 0);   \
-                }                                                                                 \
-            }                                                                                     \
-        }
-#pragma unroll 1
-        for (int kp = 0; kp < KB / 2; ++kp) {
-            const int kb1 = 2 * kp + 1;
-            aB0 = w1d0[(size_t)kb1 * 64]; aB1 = w1d1[(size_t)kb1 * 64];
-            hB0 = *reinterpret_cast<const float4*>(hsrc0 + kb1 * 8); hB1 = *reinterpret_cast<const float4*>(hsrc1 + kb1 * 8);
-            qB = *reinterpret_cast<const float4*>(qsrc + kb1 * 8);
-            __builtin_amdgcn_sched_barrier(0);
-            RL4RS_DIN_MFMA(aA0, aA1, hA0, hA1, qA)
-            __builtin_amdgcn_sched_barrier(0);
-            if (kp + 1 < KB / 2) {
-                const int kb2 = kb1 + 1;
-                aA0 = w1d0[(size_t)kb2 * 64]; aA1 = w1d1[(size_t)kb2 * 64];
-                hA0 = *reinterpret_cast<const float4*>(hsrc0 + kb2 * 8); hA1 = *reinterpret_cast<const float4*>(hsrc1 + kb2 * 8);
-                qA = *reinterpret_cast<const float4*>(qsrc + kb2 * 8);
+        // fully unrolled 2-deep ring over the E/8 k-blocks: weights through a buffer descriptor, (q*h1_t) operand
+        // from LDS (STAGE) or straight from the cache (immediate offsets off two per-lane row pointers)
+        float4 aw0[2], aw1[2], hv0[2], hv1[2], qv[2];
+        aw0[0] = buf_load4(rs_w1d, vl16, 0);
+        aw1[0] = buf_load4(rs_w1d, vl16, KB * 1024);
+        hv0[0] = *reinterpret_cast<const float4*>(hsrc0);
+        hv1[0] = *reinterpret_cast<const float4*>(hsrc1);
+        qv[0] = *reinterpret_cast<const float4*>(qsrc);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const int cb = kb & 1, nb = cb ^ 1;
+            if (kb + 1 < 16) {
+                aw0[nb] = buf_load4(rs_w1d, vl16, (kb + 1) * 1024);
+                aw1[nb] = buf_load4(rs_w1d, vl16, (KB + kb + 1) * 1024);
+                hv0[nb] = *reinterpret_cast<const float4*>(hsrc0 + (kb + 1) * 8);
+                hv1[nb] = *reinterpret_cast<const float4*>(hsrc1 + (kb + 1) * 8);
+                qv[nb] = *reinterpret_cast<const float4*>(qsrc + (kb + 1) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);
-            RL4RS_DIN_MFMA(aB0, aB1, hB0, hB1, qB)
+            {
+                const float b0[4] = {hv0[cb].x * qv[cb].x, hv0[cb].y * qv[cb].y, hv0[cb].z * qv[cb].z, hv0[cb].w * qv[cb].w};
+                const float b1[4] = {hv1[cb].x * qv[cb].x, hv1[cb].y * qv[cb].y, hv1[cb].z * qv[cb].z, hv1[cb].w * qv[cb].w};
+                const float a0[4] = {aw0[cb].x, aw0[cb].y, aw0[cb].z, aw0[cb].w};
+                const float a1[4] = {aw1[cb].x, aw1[cb].y, aw1[cb].z, aw1[cb].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc10, 0, 0, 0);
+                    if (ntile > 1) {
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc11, 0, 0, 0);
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-#undef RL4RS_DIN_MFMA
         // epilogue: lane holds, for step t (= N index), 16 of the 32 hidden units of each M tile
 #pragma unroll
         for (int n = 0; n < 2; ++n) {

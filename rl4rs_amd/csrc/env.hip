@@ -11,6 +11,8 @@
 //
 // Bound: HBM writes.  Algorithmic bytes per built row = Dn*4 + Cn*4 written + UD*4 + UC*4 + 36 read
 // = 2016 B at the reference config.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace rl4rs {
@@ -127,101 +129,96 @@ __device__ __forceinline__ void stage_items(const EnvDev& e, float* s_item) {
 }
 
 // mode 0: un-acted state rows (reset);  mode 1: act(actions) then state rows;  mode 2: complete rows.
-// Each wave owns one row per iteration; all waves of a block run the same trip count so the two
-// __syncthreads() per iteration are uniform.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_env_rows(EnvDev e, const int32_t* __restrict__ actions,
-                                                  int cur, int n_complete, int j_base) {
+// One wave assembles one row; waves are independent (each keeps its env's prev_actions row in a wave-private
+// LDS slot, ordered by wave-level fences only), so after the one-time catalogue staging there is no
+// workgroup barrier on the row loop.  USE_LDS = false reads the 45 KB catalogue through L1/L2 instead of
+// staging it (kept for A/B measurements).
+template <int MODE, bool USE_LDS>
+__global__ __launch_bounds__(1024) void k_env_rows(EnvDev e, const int32_t* __restrict__ actions,
+                                                   int cur, int n_complete, int j_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_item = reinterpret_cast<float*>(smem);
-    int32_t* s_prev_all = reinterpret_cast<int32_t*>(smem + (((size_t)e.A * e.D * 4 + 15) & ~size_t(15)));
+    float* s_item_lds = reinterpret_cast<float*>(smem);
+    const size_t item_bytes = USE_LDS ? (((size_t)e.A * e.D * 4 + 15) & ~size_t(15)) : 0;
+    int32_t* s_prev_all = reinterpret_cast<int32_t*>(smem + item_bytes);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     int32_t* s_prev = s_prev_all + wave * e.T;
-    if (MODE != 0) stage_items(e, s_item);
+    if (USE_LDS && MODE != 0) {
+        stage_items(e, s_item_lds);
+        __syncthreads();
+    }
+    const float* s_item = USE_LDS ? s_item_lds : e.item_vec;
     const int R = (MODE == 2) ? e.B * n_complete : e.B;
-    const int rows_per_block = (R + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int iters = (rows_per_block + nw - 1) / nw;
-    for (int it = 0; it < iters; ++it) {
-        const int rloc = it * nw + wave;
-        const int r = r0 + rloc;
-        const bool valid = (rloc < rows_per_block) && (r < R);
+    const int total_waves = gridDim.x * nw;
+    for (int r = blockIdx.x * nw + wave; r < R; r += total_waves) {
         const int b = (MODE == 2) ? r / n_complete : r;
         int a = 0;
-        if (valid) {
-            for (int j = lane; j < e.T; j += 64) s_prev[j] = e.prev[(size_t)b * e.T + j];
-            if (MODE == 1) {
-                a = actions[b];
-                if (a < 0 || a >= e.A) {      // numpy would raise IndexError (slate.py:199)
-                    if (lane == 0) atomicExch(e.err, 1);
-                    a = 0;
+        for (int j = lane; j < e.T; j += 64) s_prev[j] = e.prev[(size_t)b * e.T + j];
+        if (MODE == 1) {
+            a = actions[b];
+            if (a < 0 || a >= e.A) {      // numpy would raise IndexError (slate.py:199)
+                if (lane == 0) atomicExch(e.err, 1);
+                a = 0;
+            }
+            s_prev[cur] = a;   // every lane writes the same value
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (MODE == 0) {
+            // RecState.__init__: dense = user_dense, category = user_cat, both padded (base.py:30-31)
+            build_row(e, s_item, s_prev, b, 0, -1, 0, 0, e.dense + (size_t)b * e.Dn, e.cat + (size_t)b * e.Cn, lane);
+            for (int l = lane; l < e.L; l += 64) e.seq1[(size_t)b * e.L + l] = 0;
+        } else if (MODE == 1) {
+            // ---- act (slate.py:198-202 / seqslate.py:98-102)
+            if (lane == 0) {
+                e.prev[(size_t)b * e.T + cur] = a;
+                e.amask[(size_t)b * e.W + (a >> 5)] &= ~(1u << (a & 31));
+            }
+            bool hit = false;
+            for (int j = lane; j < e.T; j += 64) hit |= (e.is_special[s_prev[j]] != 0);
+            const bool any_hit = __any(hit);
+            const bool page_end = e.is_seq && ((cur + 1) % e.P == 0);
+            for (int w = lane; w < e.W; w += 64) {
+                if (page_end) {          // seqslate.py:124-126
+                    uint32_t f = full_word(e.A, w);
+                    e.amask[(size_t)b * e.W + w] = f;
+                    e.smask[(size_t)b * e.W + w] = f;
+                } else if (any_hit) {
+                    e.smask[(size_t)b * e.W + w] &= ~e.special_bits[w];
                 }
             }
-        }
-        __syncthreads();   // s_item staged (first iteration), s_prev rows loaded
-        if (valid) {
-            if (MODE == 0) {
-                // RecState.__init__: dense = user_dense, category = user_cat, both padded (base.py:30-31)
-                build_row(e, s_item, s_prev, b, 0, -1, 0, 0, e.dense + (size_t)b * e.Dn,
-                          e.cat + (size_t)b * e.Cn, lane);
-                // npage = -1 -> no item slots, sequence_id slot = 0: plain zero padding
-                for (int l = lane; l < e.L; l += 64) e.seq1[(size_t)b * e.L + l] = 0;
-            } else if (MODE == 1) {
-                // ---- act (slate.py:198-202 / seqslate.py:98-102)
-                s_prev[cur] = a;   // every lane writes the same value: its own later reads are ordered
-                if (lane == 0) {
-                    e.prev[(size_t)b * e.T + cur] = a;
-                    e.amask[(size_t)b * e.W + (a >> 5)] &= ~(1u << (a & 31));
-                }
-                bool hit = false;
-                for (int j = lane; j < e.T; j += 64) {
-                    int id = (j == cur) ? a : s_prev[j];
-                    hit |= (e.is_special[id] != 0);
-                }
-                const bool any_hit = __any(hit);
-                const bool page_end = e.is_seq && ((cur + 1) % e.P == 0);
-                for (int w = lane; w < e.W; w += 64) {
-                    if (page_end) {          // seqslate.py:124-126
-                        uint32_t f = full_word(e.A, w);
-                        e.amask[(size_t)b * e.W + w] = f;
-                        e.smask[(size_t)b * e.W + w] = f;
-                    } else if (any_hit) {
-                        e.smask[(size_t)b * e.W + w] &= ~e.special_bits[w];
+            // ---- rebuild the state row (slate.py:203-213 / seqslate.py:103-122)
+            int page_init = 0, npage = e.T, seq_id = 1;
+            if (e.is_seq) {
+                page_init = cur / e.P * e.P;
+                npage = min(e.P, e.T - page_init);
+                seq_id = cur / e.P + 1;
+                // second sequence = items of the previous pages, pre-padded (seqslate.py:107-108)
+                for (int l = lane; l < e.L; l += 64) {
+                    int v = 0;
+                    if (page_init > 0) {
+                        int idx = page_init - e.L + l;
+                        if (idx >= 0) v = s_prev[idx];
                     }
+                    e.seq1[(size_t)b * e.L + l] = v;
                 }
-                // ---- rebuild the state row (slate.py:203-213 / seqslate.py:103-122)
-                int page_init = 0, npage = e.T, seq_id = 1;
-                if (e.is_seq) {
-                    page_init = cur / e.P * e.P;
-                    npage = min(e.P, e.T - page_init);
-                    seq_id = cur / e.P + 1;
-                    // second sequence = items of the previous pages, pre-padded (seqslate.py:107-108)
-                    for (int l = lane; l < e.L; l += 64) {
-                        int v = 0;
-                        if (page_init > 0) {
-                            int idx = page_init - e.L + l;
-                            if (idx >= 0) v = (idx == cur) ? a : s_prev[idx];
-                        }
-                        e.seq1[(size_t)b * e.L + l] = v;
-                    }
-                }
-                build_row(e, s_item, s_prev, b, page_init, npage, seq_id, a, e.dense + (size_t)b * e.Dn,
-                          e.cat + (size_t)b * e.Cn, lane);
-            } else {
-                // ---- complete-state row j of env b (slate.py:117-131 / seqslate.py:27-50)
-                const int j = j_base + (r - b * n_complete);
-                int page_init = 0, npage = e.T, seq_id = 1;
-                if (e.is_seq) {
-                    page_init = j / e.P * e.P;
-                    npage = min(e.P, e.T - page_init);
-                    seq_id = j / e.P + 1;
-                }
-                a = s_prev[j];
-                build_row(e, s_item, s_prev, b, page_init, npage, seq_id, a, e.c_dense + (size_t)r * e.Dn,
-                          e.c_cat + (size_t)r * e.Cn, lane);
             }
+            build_row(e, s_item, s_prev, b, page_init, npage, seq_id, a, e.dense + (size_t)b * e.Dn,
+                      e.cat + (size_t)b * e.Cn, lane);
+        } else {
+            // ---- complete-state row j of env b (slate.py:117-131 / seqslate.py:27-50)
+            const int j = j_base + (r - b * n_complete);
+            int page_init = 0, npage = e.T, seq_id = 1;
+            if (e.is_seq) {
+                page_init = j / e.P * e.P;
+                npage = min(e.P, e.T - page_init);
+                seq_id = j / e.P + 1;
+            }
+            a = s_prev[j];
+            build_row(e, s_item, s_prev, b, page_init, npage, seq_id, a, e.c_dense + (size_t)r * e.Dn,
+                      e.c_cat + (size_t)r * e.Cn, lane);
         }
-        __syncthreads();   // s_prev reused next iteration
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // s_prev is rewritten by the next row
     }
 }
 
@@ -415,21 +412,49 @@ struct rl4rs_env {
     float* c_dense; int32_t* c_cat; int32_t* err; int32_t* knn_tmp;
 };
 
-static size_t rows_smem(const rl4rs_env* e, int waves) {
-    return (((size_t)e->d.A * e->d.D * 4 + 15) & ~size_t(15)) + (size_t)waves * e->d.T * 4;
+static int g_rows_variant = -1;     // RL4RS_ENV_ROWS_VARIANT: 0 = LDS-staged catalogue (default), 1 = catalogue via L1/L2
+static int rows_variant() {
+    if (g_rows_variant < 0) {
+        const char* v = getenv("RL4RS_ENV_ROWS_VARIANT");
+        g_rows_variant = v ? atoi(v) : 0;
+    }
+    return g_rows_variant;
+}
+static size_t rows_smem(const rl4rs_env* e, int waves, bool lds) {
+    return (lds ? (((size_t)e->d.A * e->d.D * 4 + 15) & ~size_t(15)) : 0) + (size_t)waves * e->d.T * 4;
 }
 static int check_rows_smem(const rl4rs_env* e) {
-    if (rows_smem(e, 4) > 65536) {
+    if (rows_smem(e, 16, true) > 65536) {
         set_error("catalogue of %d x %d floats does not fit the 64 KB LDS staging buffer", e->d.A, e->d.D);
         return RL4RS_EINVAL;
     }
     return RL4RS_OK;
 }
-static int rows_grid(int R) {
-    int g = (R + 15) / 16;          // >= 16 rows per block so the 45 KB catalogue staging amortises
-    if (g > 1024) g = 1024;
-    if (g < 1) g = 1;
-    return g;
+// launch geometry: persistent workgroups of `waves` waves, each wave strides over the rows
+struct RowsLaunch { int grid, threads; size_t smem; bool lds; };
+static RowsLaunch rows_launch(const rl4rs_env* e, int R, int mode) {
+    RowsLaunch L;
+    L.lds = (rows_variant() == 0) && mode != 0;
+    int waves = 16;
+    if (R < 256 * 16) waves = 4;                 // small batches: more, smaller workgroups
+    int grid = (R + waves - 1) / waves;
+    const int cap = L.lds ? 256 * (waves == 16 ? 2 : 3) : 256 * 8;   // LDS staging: amortise the 45 KB copy
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    L.grid = grid;
+    L.threads = waves * 64;
+    L.smem = rows_smem(e, waves, L.lds);
+    return L;
+}
+template <int MODE>
+static int launch_rows(rl4rs_env* e, int R, const int32_t* actions, int cur, int n_complete, int j_base, hipStream_t st) {
+    RowsLaunch L = rows_launch(e, R, MODE);
+    if (L.lds)
+        hipLaunchKernelGGL((k_env_rows<MODE, true>), dim3(L.grid), dim3(L.threads), L.smem, st, e->d, actions, cur, n_complete, j_base);
+    else
+        hipLaunchKernelGGL((k_env_rows<MODE, false>), dim3(L.grid), dim3(L.threads), L.smem, st, e->d, actions, cur, n_complete, j_base);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
 }
 
 extern "C" {
@@ -572,10 +597,7 @@ int rl4rs_env_reset(rl4rs_env* e, void* stream) {
     RL4RS_HIP_TRY(hipMemsetAsync(e->amask, 0xff, (size_t)d.B * d.W * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(e->smask, 0xff, (size_t)d.B * d.W * 4, st));
     e->cur_steps = 0;
-    hipLaunchKernelGGL(k_env_rows<0>, dim3(rows_grid(d.B)), dim3(256), rows_smem(e, 4), st, e->d,
-                       (const int32_t*)nullptr, 0, 0, 0);
-    RL4RS_LAUNCH_CHECK();
-    return RL4RS_OK;
+    return launch_rows<0>(e, d.B, nullptr, 0, 0, 0, st);
 }
 
 int rl4rs_env_act_discrete(rl4rs_env* e, const int32_t* actions, void* stream) {
@@ -585,9 +607,8 @@ int rl4rs_env_act_discrete(rl4rs_env* e, const int32_t* actions, void* stream) {
         return RL4RS_ESTATE;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_env_rows<1>, dim3(rows_grid(e->d.B)), dim3(256), rows_smem(e, 4), st, e->d,
-                       actions, e->cur_steps, 0, 0);
-    RL4RS_LAUNCH_CHECK();
+    int rc = launch_rows<1>(e, e->d.B, actions, e->cur_steps, 0, 0, st);
+    if (rc) return rc;
     e->cur_steps += 1;
     return RL4RS_OK;
 }
@@ -650,10 +671,7 @@ int rl4rs_env_build_complete(rl4rs_env* e, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     int R = e->d.B * e->n_complete;
-    hipLaunchKernelGGL(k_env_rows<2>, dim3(rows_grid(R)), dim3(256), rows_smem(e, 4), st, e->d,
-                       (const int32_t*)nullptr, e->cur_steps, e->n_complete, jb);
-    RL4RS_LAUNCH_CHECK();
-    return RL4RS_OK;
+    return launch_rows<2>(e, R, nullptr, e->cur_steps, e->n_complete, jb, st);
 }
 
 int rl4rs_env_reward(rl4rs_env* e, const float* probs, double* reward, void* stream) {
