@@ -233,6 +233,50 @@ const char* rl4rs_dien_kernel_name(int which);
 int rl4rs_dien_profile_read(rl4rs_dien* net, int which, double* ms_total, int64_t* launches);
 int rl4rs_dien_profile_reset(rl4rs_dien* net);
 
+/* ------------------------------------------------------------------------------------------------
+ * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size
+ * logits, value head on the shared hidden layer, logits + max(log(action_mask), float32.min)).
+ * Parameters, gradients and Adam state are ONE flat float32 buffer each:
+ *   [ W1 (obs_dim x hidden) | b1 (hidden) | W2e (hidden x (action_size+1)) | b2e (action_size+1) ]
+ * (column action_size of layer 2 is the value head), so a data-parallel trainer all-reduces one buffer.
+ * mask_bits_dev: uint32 [N, ceil(action_size/32)] bit rows in the layout of RL4RS_BUF_ACTION_MASK, or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rl4rs_policy rl4rs_policy;
+
+int rl4rs_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t action_size);
+int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, int32_t max_rows,
+                        const float* params_host, void* stream, rl4rs_policy** out);
+int rl4rs_policy_destroy(rl4rs_policy* pol);
+/* device pointer of the flat parameter buffer (owned by the handle) */
+int rl4rs_policy_params(rl4rs_policy* pol, float** params_dev, int32_t* count);
+
+/* Sample actions ~ Categorical(softmax(masked logits)) by Gumbel-max with a counter-based RNG keyed on
+ * (seed, step, row, action); outputs (each may be NULL except actions): log-prob of the draw, value, entropy,
+ * masked logits [N, action_size]. */
+int rl4rs_policy_act(rl4rs_policy* pol, int32_t N, const float* obs_dev, const uint32_t* mask_bits_dev,
+                     uint32_t seed, uint32_t step, int32_t* actions_dev, float* logp_dev, float* value_dev,
+                     float* entropy_dev, float* logits_dev, void* stream);
+/* Same forward for GIVEN actions (no sampling). */
+int rl4rs_policy_evaluate(rl4rs_policy* pol, int32_t N, const float* obs_dev, const uint32_t* mask_bits_dev,
+                          const int32_t* actions_dev, float* logp_dev, float* value_dev, float* entropy_dev,
+                          float* logits_dev, void* stream);
+
+/* Loss + gradient over N samples into grad_dev (flat, same layout as the parameters).
+ *   algo 0 = A2C (RLlib a3c_tf_policy: -sum(logp*adv) + vf_coeff*0.5*sum((V-R)^2) - ent_coeff*sum(H))
+ *   algo 1 = PPO (RLlib ppo_tf_policy: mean(-min(adv*r, adv*clip(r,1-c,1+c)) + kl_coeff*KL(old||new)
+ *                 + vf_coeff*max((V-R)^2, (Vclip-R)^2) - ent_coeff*H)); needs old_logp / old_value / old_logits
+ * stats_dev (optional) float[4] = sums over samples of {policy loss, value loss, entropy, kl}.
+ * Gradients are bit-reproducible (fixed sample chunks, fixed summation order). */
+int rl4rs_policy_loss_grad(rl4rs_policy* pol, int32_t algo, int32_t N, const float* obs_dev,
+                           const uint32_t* mask_bits_dev, const int32_t* actions_dev, const float* adv_dev,
+                           const float* ret_dev, const float* old_logp_dev, const float* old_value_dev,
+                           const float* old_logits_dev, float vf_coeff, float ent_coeff, float clip,
+                           float vf_clip, float kl_coeff, float* grad_dev, float* stats_dev, void* stream);
+/* Adam update of the handle's parameters from grad_dev (tf.train.AdamOptimizer form); grad_clip > 0 applies
+ * tf.clip_by_global_norm first. */
+int rl4rs_policy_adam_step(rl4rs_policy* pol, const float* grad_dev, float lr, float beta1, float beta2,
+                           float eps, float grad_clip, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

@@ -1,0 +1,81 @@
+"""Policy-net restatement.  ORACLE — test infrastructure only (see oracle/__init__.py).
+
+PARITY UNPINNED: the model is RLlib 1.5.1's ``FullyConnectedNetwork`` + ``ParametricActionsModel`` and the
+losses are RLlib's ``a3c_tf_policy`` / ``ppo_tf_policy`` (ray==1.5.1, environment.yml:199, not vendored); only the
+masking formula is in-tree (rl4rs/nets/rllib/rllib_mask_model.py:61-62).  Forward in numpy; loss + gradients by
+torch float64 autograd (the checker for the hand-written HIP backward)."""
+import numpy as np
+
+F32_MIN = float(np.finfo(np.float32).min)
+
+
+def _split(flat, od, hid, A):
+    ae = A + 1
+    o = 0
+    W1 = flat[o:o + od * hid].reshape(od, hid); o += od * hid
+    b1 = flat[o:o + hid]; o += hid
+    W2 = flat[o:o + hid * ae].reshape(hid, ae); o += hid * ae
+    b2 = flat[o:o + ae]
+    return W1, b1, W2, b2
+
+
+def forward(flat, obs, mask, od=256, hid=64, A=284):
+    """-> masked logits [N,A] (float64), value [N].  mask: [N,A] in {0,1} or None."""
+    W1, b1, W2, b2 = _split(np.asarray(flat, dtype=np.float64), od, hid, A)
+    h = np.tanh(np.asarray(obs, dtype=np.float64) @ W1 + b1)
+    out = h @ W2 + b2
+    logits = out[:, :A]
+    if mask is not None:
+        with np.errstate(divide='ignore'):
+            logits = logits + np.maximum(np.log(np.asarray(mask, dtype=np.float64)), F32_MIN)   # rllib_mask_model.py:61-62
+    return logits, out[:, A]
+
+
+def log_softmax(l):
+    m = l.max(axis=1, keepdims=True)
+    return l - (m + np.log(np.exp(l - m).sum(axis=1, keepdims=True)))
+
+
+def loss_and_grad(algo, flat, obs, mask, actions, adv, ret, old_logp=None, old_value=None, old_logits=None,
+                  vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2, od=256, hid=64, A=284):
+    """float64 autograd of the A2C (algo 0) / PPO (algo 1) loss -> (grad flat, stats[4] sums)."""
+    import torch
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    p = t(flat).clone().requires_grad_(True)
+    ae = A + 1
+    o = 0
+    W1 = p[o:o + od * hid].reshape(od, hid); o += od * hid
+    b1 = p[o:o + hid]; o += hid
+    W2 = p[o:o + hid * ae].reshape(hid, ae); o += hid * ae
+    b2 = p[o:o + ae]
+    h = torch.tanh(t(obs) @ W1 + b1)
+    out = h @ W2 + b2
+    logits, v = out[:, :A], out[:, A]
+    if mask is not None:
+        logits = logits + torch.clamp(torch.log(t(mask)), min=F32_MIN)
+    lsm = torch.log_softmax(logits, dim=1)
+    pr = torch.exp(lsm)
+    ent = -(torch.where(pr > 0, pr * lsm, torch.zeros_like(pr))).sum(1)
+    a = torch.as_tensor(np.asarray(actions), dtype=torch.int64)
+    lp = lsm.gather(1, a[:, None])[:, 0]
+    adv_t, ret_t = t(adv), t(ret)
+    N = lp.shape[0]
+    if algo == 0:
+        pi = -(lp * adv_t)
+        vf = 0.5 * (v - ret_t) ** 2
+        kl = torch.zeros_like(lp)
+        total = pi.sum() + vf_coeff * vf.sum() - ent_coeff * ent.sum()
+    else:
+        ratio = torch.exp(lp - t(old_logp))
+        pi = -torch.minimum(adv_t * ratio, adv_t * torch.clamp(ratio, 1 - clip, 1 + clip))
+        pv = t(old_value)
+        l1 = (v - ret_t) ** 2
+        vc = pv + torch.clamp(v - pv, -vf_clip, vf_clip)
+        vf = torch.maximum(l1, (vc - ret_t) ** 2)
+        olsm = torch.log_softmax(t(old_logits), dim=1)
+        q = torch.exp(olsm)
+        kl = torch.where(q > 0, q * (olsm - lsm), torch.zeros_like(q)).sum(1)
+        total = (pi + kl_coeff * kl + vf_coeff * vf - ent_coeff * ent).mean()
+    total.backward()
+    stats = np.array([pi.sum().item(), vf.sum().item(), ent.sum().item(), kl.sum().item()])
+    return p.grad.numpy(), stats

@@ -47,10 +47,6 @@ class DienWeights(C.Structure):
     ]
 
 
-class PolicyCfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('obs_dim', 'hidden', 'action_size', 'max_rows')]
-
-
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/rl4rs_hip.h declares
@@ -91,6 +87,15 @@ SIGNATURES = {
     'rl4rs_dien_kernel_name': (C.c_char_p, [_I]),
     'rl4rs_dien_profile_read': (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_I64)]),
     'rl4rs_dien_profile_reset': (_I, [_P]),
+    'rl4rs_policy_param_count': (_I, [_I32, _I32, _I32]),
+    'rl4rs_policy_create': (_I, [_I32, _I32, _I32, _I32, _P, _P, C.POINTER(_P)]),
+    'rl4rs_policy_destroy': (_I, [_P]),
+    'rl4rs_policy_params': (_I, [_P, C.POINTER(_P), C.POINTER(_I32)]),
+    'rl4rs_policy_act': (_I, [_P, _I32, _P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_policy_evaluate': (_I, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_policy_loss_grad': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, _P, _P, _P]),
+    'rl4rs_policy_adam_step': (_I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
 }

@@ -1,0 +1,502 @@
+// Action-masked policy net on gfx950: forward + sampling, loss + backward (A2C / PPO), Adam.
+//
+// Reference: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (getMaskActionsModel): FullyConnectedNetwork with
+// fcnet_hiddens=[64] (tanh, RLlib default), num_outputs = action_size, value head sharing the hidden layer
+// (vf_share_layers=True, :34), and  logits + max(log(action_mask), float32.min)  (:61-62).
+// Losses restate RLlib 1.5.1's a3c_tf_policy / ppo_tf_policy (third-party, not vendored: parity unpinned,
+// checked against an fp64 autograd restatement in tests).  Hyper-parameters: script/modelfree_train.py:179-304.
+//
+// Parameters live in ONE flat fp32 buffer (= the all-reduce unit, rl4rs_amd/dist.py):
+//   [ W1 (OD x HID) | b1 (HID) | W2e (HID x (A+1)) | b2e (A+1) ]      the value head is output column A of layer 2.
+// Per-sample work is tiny (34.6 K MAC), so forward/backward run one wave per sample; the batch reductions of the
+// parameter gradients are "A^T B" GEMMs over the sample axis on the matrix cores (exact fp32, split over samples
+// into fixed chunks and summed in a fixed order => bit-reproducible gradients).
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "common.hpp"
+
+namespace rl4rs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PolDims { int OD, HID, A, AE, W; };   // AE = A + 1 (logits | value), W = mask words
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// counter-based uniform in (0,1): a pure function of (seed, step, row, action)
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t row, uint32_t a) {
+    uint32_t h = mix32(seed ^ mix32(step * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32(row * 0xC2B2AE35U + a * 0x27D4EB2FU + 1U));
+    h = mix32(h + a);
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Shared forward of one sample by one wave.  s_obs[OD], s_h[HID], s_out[AE] are this wave's LDS slots.
+// On return: s_h = tanh hidden, s_out[0..A) = masked logits, s_out[A] = value; returns log-sum-exp of the logits.
+__device__ __forceinline__ float policy_row_forward(const PolDims& d, const float* __restrict__ prm,
+                                                    const float* __restrict__ obs_row,
+                                                    const uint32_t* __restrict__ mask_row,
+                                                    float* s_obs, float* s_h, float* s_out, int lane) {
+    const float* W1 = prm;
+    const float* b1 = W1 + (size_t)d.OD * d.HID;
+    const float* W2 = b1 + d.HID;
+    const float* b2 = W2 + (size_t)d.HID * d.AE;
+    for (int k = lane; k < d.OD; k += 64) s_obs[k] = obs_row[k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = lane; j < d.HID; j += 64) {
+        float s = b1[j];
+        for (int k = 0; k < d.OD; ++k) s = fmaf(s_obs[k], W1[(size_t)k * d.HID + j], s);
+        s_h[j] = tanhf(s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float mx = -3.4028235e38f;
+    for (int a = lane; a < d.AE; a += 64) {
+        float s = b2[a];
+        for (int j = 0; j < d.HID; ++j) s = fmaf(s_h[j], W2[(size_t)j * d.AE + a], s);
+        if (a < d.A) {
+            // logits + max(log(mask), float32.min): 0 for allowed actions, -3.4028235e38 for masked ones
+            bool ok = mask_row ? ((mask_row[a >> 5] >> (a & 31)) & 1u) : true;
+            if (!ok) s = s + (-3.4028235e38f);
+            mx = fmaxf(mx, s);
+        }
+        s_out[a] = s;
+    }
+    mx = wave_max(mx);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float se = 0.f;
+    for (int a = lane; a < d.A; a += 64) se += expf(s_out[a] - mx);
+    se = wave_sum(se);
+    return mx + logf(se);
+}
+
+// act / evaluate: one wave per sample.  SAMPLE: Gumbel-max draw from the masked categorical.
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_policy_forward(PolDims d, const float* __restrict__ prm, int N,
+                                                        const float* __restrict__ obs, const uint32_t* __restrict__ mask,
+                                                        uint32_t seed, uint32_t step, int32_t* __restrict__ actions,
+                                                        float* __restrict__ logp, float* __restrict__ value,
+                                                        float* __restrict__ entropy, float* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = d.OD + d.HID + d.AE;
+    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
+    float* s_h = s_obs + d.OD;
+    float* s_out = s_h + d.HID;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
+    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+    float ent = 0.f, best = -3.4028235e38f;
+    int best_a = 0x7fffffff;
+    for (int a = lane; a < d.A; a += 64) {
+        const float l = s_out[a];
+        const float lp = l - lse;
+        const float p = expf(lp);
+        if (p > 0.f) ent -= p * lp;
+        if (logits_out) logits_out[(size_t)n * d.A + a] = l;
+        if (SAMPLE) {
+            const float u = uniform01(seed, step, (uint32_t)n, (uint32_t)a);
+            const float g = l - logf(-logf(u));
+            if (best_a == 0x7fffffff || g > best) { best = g; best_a = a; }
+        }
+    }
+    ent = wave_sum(ent);
+    int act;
+    if (SAMPLE) {
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o);
+            int oa = __shfl_xor(best_a, o);
+            if (oa != 0x7fffffff && (best_a == 0x7fffffff || ob > best || (ob == best && oa < best_a))) { best = ob; best_a = oa; }
+        }
+        act = best_a;
+    } else {
+        act = actions[n];
+    }
+    if (lane == 0) {
+        if (SAMPLE) actions[n] = act;
+        if (logp) logp[n] = s_out[act] - lse;
+        if (value) value[n] = s_out[d.A];
+        if (entropy) entropy[n] = ent;
+    }
+}
+
+struct LossArgs {
+    int algo;            // 0 = A2C (a3c_tf_policy), 1 = PPO (ppo_tf_policy)
+    float vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, scale;   // scale = 1 (A2C: sums) or 1/N (PPO: means)
+    const int32_t* actions; const float* adv; const float* ret;
+    const float* old_logp; const float* old_value; const float* old_logits;   // PPO
+};
+
+// Training forward + per-sample backward down to the pre-activation of the hidden layer.
+// Writes H [N,HID], dOut [N,AE] (d loss / d [logits | value]), dHpre [N,HID] and per-sample loss terms
+// terms[n] = {pi_loss, vf_loss, entropy, kl}.
+__global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __restrict__ prm, int N,
+                                                      const float* __restrict__ obs, const uint32_t* __restrict__ mask,
+                                                      LossArgs L, float* __restrict__ H, float* __restrict__ dOut,
+                                                      float* __restrict__ dHpre, float4* __restrict__ terms) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = d.OD + d.HID + 2 * d.AE;
+    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
+    float* s_h = s_obs + d.OD;
+    float* s_out = s_h + d.HID;
+    float* s_d = s_out + d.AE;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
+    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+    const int act = L.actions[n];
+    const float adv = L.adv[n], ret = L.ret[n];
+    const float v = s_out[d.A];
+    const float lp_a = s_out[act] - lse;
+    // entropy and (PPO) KL(old || new) need full sums first
+    float ent = 0.f, kl = 0.f, old_lse = 0.f;
+    if (L.algo == 1) {
+        float om = -3.4028235e38f;
+        for (int a = lane; a < d.A; a += 64) om = fmaxf(om, L.old_logits[(size_t)n * d.A + a]);
+        om = wave_max(om);
+        float os = 0.f;
+        for (int a = lane; a < d.A; a += 64) os += expf(L.old_logits[(size_t)n * d.A + a] - om);
+        old_lse = om + logf(wave_sum(os));
+    }
+    for (int a = lane; a < d.A; a += 64) {
+        const float lp = s_out[a] - lse;
+        const float p = expf(lp);
+        if (p > 0.f) ent -= p * lp;
+        if (L.algo == 1) {
+            const float olp = L.old_logits[(size_t)n * d.A + a] - old_lse;
+            const float q = expf(olp);
+            if (q > 0.f) kl += q * (olp - lp);
+        }
+    }
+    ent = wave_sum(ent);
+    kl = wave_sum(kl);
+    // d loss / d logp(action), d loss / d value
+    float g_lp, g_v, pi_loss, vf_loss;
+    if (L.algo == 0) {
+        pi_loss = -lp_a * adv;
+        vf_loss = 0.5f * (v - ret) * (v - ret);
+        g_lp = -adv;
+        g_v = L.vf_coeff * (v - ret);
+    } else {
+        const float ratio = expf(lp_a - L.old_logp[n]);
+        const float clipped = fminf(fmaxf(ratio, 1.f - L.clip), 1.f + L.clip);
+        const float s1 = adv * ratio, s2 = adv * clipped;
+        pi_loss = -fminf(s1, s2);
+        g_lp = (s1 <= s2) ? -adv * ratio : 0.f;        // the clipped branch has zero gradient
+        const float pv = L.old_value[n];
+        const float l1 = (v - ret) * (v - ret);
+        const float vc = pv + fminf(fmaxf(v - pv, -L.vf_clip), L.vf_clip);
+        const float l2 = (vc - ret) * (vc - ret);
+        vf_loss = fmaxf(l1, l2);
+        float dv = (l1 >= l2) ? 2.f * (v - ret) : ((fabsf(v - pv) < L.vf_clip) ? 2.f * (vc - ret) : 0.f);
+        g_v = L.vf_coeff * dv;
+    }
+    g_lp *= L.scale;
+    g_v *= L.scale;
+    const float ce = L.ent_coeff * L.scale, ck = (L.algo == 1) ? L.kl_coeff * L.scale : 0.f;
+    for (int a = lane; a < d.AE; a += 64) {
+        float g;
+        if (a < d.A) {
+            const float lp = s_out[a] - lse;
+            const float p = expf(lp);
+            // d logp_act/dl_a = [a==act] - p ; dH/dl_a = -p (log p + H) ; dKL/dl_a = p - q
+            g = g_lp * ((a == act ? 1.f : 0.f) - p);
+            if (p > 0.f) g += ce * p * (lp + ent);
+            if (L.algo == 1) {
+                const float q = expf(L.old_logits[(size_t)n * d.A + a] - old_lse);
+                g += ck * (p - q);
+            }
+        } else {
+            g = g_v;
+        }
+        s_d[a] = g;
+        dOut[(size_t)n * d.AE + a] = g;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float* W2 = prm + (size_t)d.OD * d.HID + d.HID;
+    for (int j = lane; j < d.HID; j += 64) {
+        float s = 0.f;
+        const float* wr = W2 + (size_t)j * d.AE;
+        for (int a = 0; a < d.AE; ++a) s = fmaf(s_d[a], wr[a], s);
+        const float h = s_h[j];
+        H[(size_t)n * d.HID + j] = h;
+        dHpre[(size_t)n * d.HID + j] = s * (1.f - h * h);
+    }
+    if (lane == 0) terms[n] = make_float4(pi_loss, vf_loss, ent, kl);
+}
+
+// C_part[z][M][Nc] = sum over samples n in chunk z of A[n][m] * B[n][j]   ("A^T B" over the sample axis).
+// One wave = one 32x32 tile; lane (i, half) feeds A[n = n0 + 2s + half][m0 + i] and B[..][j0 + i]: both are
+// 128-byte coalesced reads of row-major sample-major matrices, no transpose needed.
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, int M,
+                                                 const float* __restrict__ B, int ldb, int Nc, int Ns, int chunk,
+                                                 float* __restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, li = lane & 31;
+    const int tiles_n = (Nc + 31) / 32;
+    const int tile = blockIdx.x * 4 + wave;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    if (tm * 32 >= M) return;
+    const int m = tm * 32 + li, j = tn * 32 + li;
+    const bool m_ok = m < M, j_ok = j < Nc;
+    const int z = blockIdx.y;
+    const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int n = n_lo; n < n_hi; n += 2) {
+        const int nn = n + half;
+        float a = (m_ok && nn < n_hi) ? A[(size_t)nn * lda + m] : 0.f;
+        float b = (j_ok && nn < n_hi) ? B[(size_t)nn * ldb + j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float* out = part + (size_t)z * M * Nc;
+    for (int r = 0; r < 16; ++r) {
+        int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M && j_ok) out[(size_t)row * Nc + j] = acc[r];
+    }
+}
+
+// column sums of X [Ns, ld] (first Nc columns) per sample chunk: part[z][Nc]
+__global__ void k_colsum(const float* __restrict__ X, int ld, int Nc, int Ns, int chunk, float* __restrict__ part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = blockIdx.y;
+    if (j >= Nc) return;
+    const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
+    float s = 0.f;
+    for (int n = n_lo; n < n_hi; ++n) s += X[(size_t)n * ld + j];
+    part[(size_t)z * Nc + j] = s;
+}
+
+// dst[i] = sum_z part[z][i] in chunk order (fixed order => reproducible)
+__global__ void k_reduce_chunks(const float* __restrict__ part, int count, int nz, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += part[(size_t)z * count + i];
+    dst[i] = s;
+}
+
+// stats[0..3] = sum over samples of {pi_loss, vf_loss, entropy, kl}; single block, fixed order
+__global__ __launch_bounds__(256) void k_reduce_terms(const float4* __restrict__ terms, int N, float* __restrict__ stats) {
+    __shared__ float4 sm[256];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float4 t = terms[n];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            float4 a = sm[threadIdx.x], b = sm[threadIdx.x + o];
+            sm[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { stats[0] = sm[0].x; stats[1] = sm[0].y; stats[2] = sm[0].z; stats[3] = sm[0].w; }
+}
+
+// sum of squares of a flat buffer -> out[0] (single block, fixed order)
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int count, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) s += g[i] * g[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// Adam (tf.train.AdamOptimizer semantics: lr_t = lr * sqrt(1-b2^t)/(1-b1^t)); optional global-norm clipping
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int count, float lr_t, float b1, float b2, float eps, const float* __restrict__ sumsq, float clip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float gi = g[i];
+    if (clip > 0.f) {
+        const float norm = sqrtf(sumsq[0]);
+        if (norm > clip) gi *= clip / norm;      // tf.clip_by_global_norm
+    }
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+}  // namespace rl4rs
+
+using namespace rl4rs;
+
+struct rl4rs_policy {
+    PolDims d;
+    int max_rows, n_params, nz, chunk;
+    float *params, *adam_m, *adam_v;
+    float *H, *dOut, *dHpre, *part, *sumsq;
+    float4* terms;
+    int64_t adam_t;
+    std::vector<void*> owned;
+};
+
+extern "C" {
+
+int rl4rs_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t action_size) {
+    return obs_dim * hidden + hidden + hidden * (action_size + 1) + (action_size + 1);
+}
+
+int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, int32_t max_rows,
+                        const float* params_host, void* stream, rl4rs_policy** out) {
+    RL4RS_REQUIRE(out && params_host && obs_dim > 0 && hidden > 0 && hidden <= 1024 && action_size > 1 && max_rows > 0,
+                  "policy_create: bad argument");
+    if (rl4rs_device_count() <= 0) {
+        set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
+        return RL4RS_EHIP;
+    }
+    rl4rs_policy* p = new rl4rs_policy();
+    p->d.OD = obs_dim; p->d.HID = hidden; p->d.A = action_size; p->d.AE = action_size + 1; p->d.W = (action_size + 31) / 32;
+    p->max_rows = max_rows;
+    p->n_params = rl4rs_policy_param_count(obs_dim, hidden, action_size);
+    p->chunk = 512;
+    p->nz = (max_rows + p->chunk - 1) / p->chunk;
+    p->adam_t = 0;
+    int rc;
+    auto alloc = [&](float** dst, size_t n) {
+        int r = dev_alloc(dst, n);
+        if (r == RL4RS_OK) p->owned.push_back(*dst);
+        return r;
+    };
+    if ((rc = alloc(&p->params, p->n_params))) return rc;
+    if ((rc = alloc(&p->adam_m, p->n_params))) return rc;
+    if ((rc = alloc(&p->adam_v, p->n_params))) return rc;
+    if ((rc = alloc(&p->H, (size_t)max_rows * hidden))) return rc;
+    if ((rc = alloc(&p->dOut, (size_t)max_rows * p->d.AE))) return rc;
+    if ((rc = alloc(&p->dHpre, (size_t)max_rows * hidden))) return rc;
+    size_t part_n = (size_t)p->nz * ((size_t)obs_dim * hidden > (size_t)hidden * p->d.AE ? (size_t)obs_dim * hidden : (size_t)hidden * p->d.AE);
+    if ((rc = alloc(&p->part, part_n))) return rc;
+    if ((rc = alloc(&p->sumsq, 4))) return rc;
+    float* t4;
+    if ((rc = alloc(&t4, (size_t)max_rows * 4))) return rc;
+    p->terms = reinterpret_cast<float4*>(t4);
+    hipStream_t st = (hipStream_t)stream;
+    RL4RS_HIP_TRY(hipMemcpyAsync(p->params, params_host, (size_t)p->n_params * 4, hipMemcpyHostToDevice, st));
+    RL4RS_HIP_TRY(hipMemsetAsync(p->adam_m, 0, (size_t)p->n_params * 4, st));
+    RL4RS_HIP_TRY(hipMemsetAsync(p->adam_v, 0, (size_t)p->n_params * 4, st));
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));
+    *out = p;
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_destroy(rl4rs_policy* p) {
+    if (!p) return RL4RS_OK;
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_params(rl4rs_policy* p, float** params_dev, int32_t* count) {
+    RL4RS_REQUIRE(p && params_dev, "policy_params: null argument");
+    *params_dev = p->params;
+    if (count) *count = p->n_params;
+    return RL4RS_OK;
+}
+
+static size_t fwd_smem(const PolDims& d, int extra) { return (size_t)4 * (d.OD + d.HID + d.AE + extra) * 4; }
+
+int rl4rs_policy_act(rl4rs_policy* p, int32_t N, const float* obs, const uint32_t* mask_bits, uint32_t seed,
+                     uint32_t step, int32_t* actions, float* logp, float* value, float* entropy, float* logits,
+                     void* stream) {
+    RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_act: bad argument");
+    hipLaunchKernelGGL(k_policy_forward<true>, dim3((N + 3) / 4), dim3(256), fwd_smem(p->d, 0), (hipStream_t)stream, p->d,
+                       p->params, N, obs, mask_bits, seed, step, actions, logp, value, entropy, logits);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_evaluate(rl4rs_policy* p, int32_t N, const float* obs, const uint32_t* mask_bits,
+                          const int32_t* actions, float* logp, float* value, float* entropy, float* logits,
+                          void* stream) {
+    RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_evaluate: bad argument");
+    hipLaunchKernelGGL(k_policy_forward<false>, dim3((N + 3) / 4), dim3(256), fwd_smem(p->d, 0), (hipStream_t)stream, p->d,
+                       p->params, N, obs, mask_bits, 0u, 0u, const_cast<int32_t*>(actions), logp, value, entropy, logits);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float* obs, const uint32_t* mask_bits,
+                           const int32_t* actions, const float* adv, const float* ret, const float* old_logp,
+                           const float* old_value, const float* old_logits, float vf_coeff, float ent_coeff,
+                           float clip, float vf_clip, float kl_coeff, float* grad_dev, float* stats_dev,
+                           void* stream) {
+    RL4RS_REQUIRE(p && obs && actions && adv && ret && grad_dev && N > 0 && N <= p->max_rows,
+                  "policy_loss_grad: bad argument (N=%d, max_rows=%d)", N, p ? p->max_rows : -1);
+    RL4RS_REQUIRE(algo == 0 || (algo == 1 && old_logp && old_value && old_logits), "policy_loss_grad: PPO needs old_* inputs");
+    hipStream_t st = (hipStream_t)stream;
+    const PolDims& d = p->d;
+    LossArgs L;
+    L.algo = algo; L.vf_coeff = vf_coeff; L.ent_coeff = ent_coeff; L.clip = clip; L.vf_clip = vf_clip; L.kl_coeff = kl_coeff;
+    L.scale = algo == 0 ? 1.0f : 1.0f / (float)N;
+    L.actions = actions; L.adv = adv; L.ret = ret; L.old_logp = old_logp; L.old_value = old_value; L.old_logits = old_logits;
+    hipLaunchKernelGGL(k_policy_train, dim3((N + 3) / 4), dim3(256), fwd_smem(d, d.AE), st, d, p->params, N, obs, mask_bits, L,
+                       p->H, p->dOut, p->dHpre, p->terms);
+    RL4RS_LAUNCH_CHECK();
+    const int nz = (N + p->chunk - 1) / p->chunk;
+    float* gW1 = grad_dev;
+    float* gb1 = gW1 + (size_t)d.OD * d.HID;
+    float* gW2 = gb1 + d.HID;
+    float* gb2 = gW2 + (size_t)d.HID * d.AE;
+    auto tn = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst) {
+        int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
+        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, N, p->chunk, p->part);
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, p->part, M * Nc, nz, dst);
+    };
+    auto cs = [&](const float* X, int ld, int Nc, float* dst) {
+        hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, N, p->chunk, p->part);
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, p->part, Nc, nz, dst);
+    };
+    tn(obs, d.OD, d.OD, p->dHpre, d.HID, d.HID, gW1);      // dW1  = obs^T dHpre
+    cs(p->dHpre, d.HID, d.HID, gb1);                        // db1
+    tn(p->H, d.HID, d.HID, p->dOut, d.AE, d.AE, gW2);       // dW2e = H^T dOut
+    cs(p->dOut, d.AE, d.AE, gb2);                           // db2e
+    RL4RS_LAUNCH_CHECK();
+    if (stats_dev) {
+        hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms, N, stats_dev);
+        RL4RS_LAUNCH_CHECK();
+    }
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_adam_step(rl4rs_policy* p, const float* grad_dev, float lr, float beta1, float beta2, float eps,
+                           float grad_clip, void* stream) {
+    RL4RS_REQUIRE(p && grad_dev, "policy_adam_step: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    p->adam_t += 1;
+    const double t = (double)p->adam_t;
+    const float lr_t = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    if (grad_clip > 0.f) hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(256), 0, st, grad_dev, p->n_params, p->sumsq);
+    hipLaunchKernelGGL(k_adam, dim3((p->n_params + 255) / 256), dim3(256), 0, st, p->params, grad_dev, p->adam_m, p->adam_v,
+                       p->n_params, lr_t, beta1, beta2, eps, p->sumsq, grad_clip);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+}  // extern "C"

@@ -350,3 +350,103 @@ def gemm_f32_packed(a, w_host, bias=None, act=0):
     check(lib.rl4rs_gemm_f32_packed(_ptr(a), a.stride(0), w_host.ctypes.data_as(C.c_void_p), N, _ptr(bias), _ptr(c), N,
                                     M, N, K, act, _stream()))
     return c
+
+
+class DevicePolicy(object):
+    """rl4rs_policy handle: action-masked policy net (rllib_mask_model.py:7-64) with flat parameters."""
+    A2C, PPO = 0, 1
+
+    def __init__(self, obs_dim, hidden, action_size, max_rows, params=None, seed=0, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.obs_dim, self.hidden, self.action_size, self.max_rows = int(obs_dim), int(hidden), int(action_size), int(max_rows)
+        self.n_params = self.lib.rl4rs_policy_param_count(self.obs_dim, self.hidden, self.action_size)
+        if params is None:
+            from .nets.policy import init_policy_params
+            params = init_policy_params(self.obs_dim, self.hidden, self.action_size, seed)
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        assert params.shape == (self.n_params,), (params.shape, self.n_params)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_policy_create(self.obs_dim, self.hidden, self.action_size, self.max_rows,
+                                               params.ctypes.data_as(C.c_void_p), _stream(), C.byref(h)))
+        self.h = h
+        self.W = (self.action_size + 31) // 32
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_policy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def params(self):
+        """Copy of the flat parameter buffer (device tensor)."""
+        p = C.c_void_p()
+        n = C.c_int32()
+        check(self.lib.rl4rs_policy_params(self.h, C.byref(p), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p, n.value * 4, _stream()))
+        return out
+
+    def set_params(self, flat):
+        p = C.c_void_p()
+        n = C.c_int32()
+        check(self.lib.rl4rs_policy_params(self.h, C.byref(p), C.byref(n)))
+        flat = flat.to(device=self.device, dtype=torch.float32).contiguous()
+        assert flat.numel() == n.value
+        check(self.lib.rl4rs_copy_d2d(p, _ptr(flat), n.value * 4, _stream()))
+        self._keep = flat
+
+    def _mask(self, mask_bits, N):
+        if mask_bits is None:
+            return None
+        assert mask_bits.dtype == torch.int32 and mask_bits.shape == (N, self.W) and mask_bits.is_contiguous()
+        return mask_bits
+
+    def act(self, obs, mask_bits=None, seed=0, step=0, want_logits=False):
+        N = obs.shape[0]
+        assert obs.dtype == torch.float32 and obs.shape == (N, self.obs_dim) and obs.is_contiguous()
+        m = self._mask(mask_bits, N)
+        a = torch.empty(N, dtype=torch.int32, device=self.device)
+        lp = torch.empty(N, dtype=torch.float32, device=self.device)
+        v = torch.empty(N, dtype=torch.float32, device=self.device)
+        ent = torch.empty(N, dtype=torch.float32, device=self.device)
+        lg = torch.empty((N, self.action_size), dtype=torch.float32, device=self.device) if want_logits else None
+        check(self.lib.rl4rs_policy_act(self.h, N, _ptr(obs), _ptr(m), seed & 0xffffffff, step & 0xffffffff, _ptr(a),
+                                        _ptr(lp), _ptr(v), _ptr(ent), _ptr(lg), _stream()))
+        return a, lp, v, ent, lg
+
+    def evaluate(self, obs, actions, mask_bits=None, want_logits=False):
+        N = obs.shape[0]
+        m = self._mask(mask_bits, N)
+        actions = actions.to(torch.int32).contiguous()
+        lp = torch.empty(N, dtype=torch.float32, device=self.device)
+        v = torch.empty(N, dtype=torch.float32, device=self.device)
+        ent = torch.empty(N, dtype=torch.float32, device=self.device)
+        lg = torch.empty((N, self.action_size), dtype=torch.float32, device=self.device) if want_logits else None
+        check(self.lib.rl4rs_policy_evaluate(self.h, N, _ptr(obs), _ptr(m), _ptr(actions), _ptr(lp), _ptr(v), _ptr(ent),
+                                             _ptr(lg), _stream()))
+        return lp, v, ent, lg
+
+    def loss_grad(self, algo, obs, actions, adv, ret, mask_bits=None, old_logp=None, old_value=None, old_logits=None,
+                  vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2, grad_out=None):
+        N = obs.shape[0]
+        m = self._mask(mask_bits, N)
+        g = grad_out if grad_out is not None else torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        stats = torch.empty(4, dtype=torch.float32, device=self.device)
+        f = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        actions = actions.to(torch.int32).contiguous()
+        adv, ret, old_logp, old_value, old_logits = f(adv), f(ret), f(old_logp), f(old_value), f(old_logits)
+        check(self.lib.rl4rs_policy_loss_grad(self.h, algo, N, _ptr(obs), _ptr(m), _ptr(actions), _ptr(adv), _ptr(ret),
+                                              _ptr(old_logp), _ptr(old_value), _ptr(old_logits), vf_coeff, ent_coeff, clip,
+                                              vf_clip, kl_coeff, _ptr(g), _ptr(stats), _stream()))
+        return g, stats
+
+    def adam_step(self, grad, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_clip=0.0):
+        check(self.lib.rl4rs_policy_adam_step(self.h, _ptr(grad), lr, beta1, beta2, eps, grad_clip, _stream()))

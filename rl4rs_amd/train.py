@@ -1,0 +1,99 @@
+"""On-device policy training loop over the GPU env (A2C / PPO with the reference's RLlib hyper-parameters,
+script/modelfree_train.py:179-304: gamma = 1, GAE lambda = 1, lr 1e-4, vf_loss_coeff 0.5; A2C entropy 0.01 and
+grad_clip 10; PPO clip 0.3, kl_coeff 0.2, vf_clip 500, one SGD pass over minibatches of 256).
+
+Rollout, policy forward/backward and Adam run through librl4rs_hip.so; torch is used for buffers, the reversed
+cumulative sum of rewards and (data-parallel) the single RCCL all-reduce of the flat gradient buffer."""
+import numpy as np
+import torch
+
+from . import dist as rdist
+from . import device as D
+
+
+class Trainer(object):
+    def __init__(self, env, algo='A2C', hidden=64, seed=0, lr=1e-4, minibatch=256):
+        cfg = env.config
+        assert cfg.get('return_tensors', False) and not cfg.get('support_conti_env', False), \
+            "Trainer needs the zero-copy discrete-action env (config['return_tensors'] = True)"
+        self.env = env
+        self.algo = {'A2C': D.DevicePolicy.A2C, 'PPO': D.DevicePolicy.PPO}[algo]
+        self.B, self.T, self.A = cfg['batch_size'], cfg['max_steps'], cfg['action_size']
+        self.seed, self.lr, self.minibatch = seed, lr, minibatch
+        self.policy = D.DevicePolicy(256, hidden, self.A, max_rows=self.B * self.T, seed=seed)
+        self.iteration = 0
+        dev = self.policy.device
+        N = self.B * self.T
+        self.buf = dict(obs=torch.empty((N, 256), dtype=torch.float32, device=dev),
+                        mask=torch.empty((N, self.policy.W), dtype=torch.int32, device=dev),
+                        act=torch.empty(N, dtype=torch.int32, device=dev),
+                        logp=torch.empty(N, dtype=torch.float32, device=dev),
+                        val=torch.empty(N, dtype=torch.float32, device=dev),
+                        rew=torch.empty(N, dtype=torch.float64, device=dev),
+                        logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
+        self.grad = torch.empty(self.policy.n_params, dtype=torch.float32, device=dev)
+
+    def _mask_bits(self):
+        """Packed obs-side action mask (action_mask & location_mask[layer] & special_mask, slate.py:92-97)."""
+        env = self.env.samples._live()
+        m = env.obs_mask(torch.uint8).to(torch.int32)                      # [B, A] in {0,1}
+        W = self.policy.W
+        pad = W * 32 - self.A
+        if pad:
+            m = torch.nn.functional.pad(m, (0, pad))
+        w = (m.view(self.B, W, 32) << torch.arange(32, device=m.device, dtype=torch.int32)).sum(dim=2, dtype=torch.int64)
+        return (w & 0xffffffff).to(torch.int32).contiguous()
+
+    def rollout(self):
+        B, T = self.B, self.T
+        obs = self.env.reset()
+        b = self.buf
+        for t in range(T):
+            obs_t = obs['obs'] if isinstance(obs, dict) else obs
+            sl = slice(t * B, (t + 1) * B)
+            mask = self._mask_bits()
+            a, lp, v, ent, lg = self.policy.act(obs_t.contiguous(), mask, seed=self.seed, step=self.iteration * T + t,
+                                                want_logits=self.algo == D.DevicePolicy.PPO)
+            b['obs'][sl] = obs_t
+            b['mask'][sl] = mask
+            b['act'][sl] = a
+            b['logp'][sl] = lp
+            b['val'][sl] = v
+            if lg is not None:
+                b['logits'][sl] = lg
+            obs, reward, done, info = self.env.step(a)
+            b['rew'][sl] = reward
+        # gamma = 1, lambda = 1: advantage = (sum of future rewards) - V
+        rew = b['rew'].view(T, B)
+        ret = torch.flip(torch.cumsum(torch.flip(rew, dims=[0]), dim=0), dims=[0]).reshape(-1).to(torch.float32)
+        adv = ret - b['val']
+        return ret, adv, float(rew.sum(dim=0).mean().item())
+
+    def train_iteration(self):
+        ret, adv, mean_reward = self.rollout()
+        b = self.buf
+        N = self.B * self.T
+        stats_out = None
+        if self.algo == D.DevicePolicy.A2C:
+            g, stats = self.policy.loss_grad(self.algo, b['obs'], b['act'], adv, ret, mask_bits=b['mask'],
+                                             vf_coeff=0.5, ent_coeff=0.01, grad_out=self.grad)
+            rdist.allreduce_mean_(g)                         # the ONE collective: flat policy gradient over RCCL
+            self.policy.adam_step(g, lr=self.lr, grad_clip=10.0)
+            stats_out = stats
+        else:
+            adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)      # RLlib standardises PPO advantages
+            perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration).permutation(N)).to(b['obs'].device)
+            for lo in range(0, N - self.minibatch + 1, self.minibatch):
+                idx = perm[lo:lo + self.minibatch]
+                g, stats = self.policy.loss_grad(self.algo, b['obs'][idx].contiguous(), b['act'][idx], adv_n[idx], ret[idx],
+                                                 mask_bits=b['mask'][idx].contiguous(), old_logp=b['logp'][idx],
+                                                 old_value=b['val'][idx], old_logits=b['logits'][idx].contiguous(),
+                                                 vf_coeff=0.5, ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2,
+                                                 grad_out=self.grad)
+                rdist.allreduce_mean_(g)
+                self.policy.adam_step(g, lr=self.lr)
+                stats_out = stats
+        self.iteration += 1
+        s = stats_out.cpu().numpy()
+        return {'episode_reward_mean': mean_reward, 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
+                'entropy': float(s[2]), 'kl': float(s[3]), 'iteration': self.iteration}
