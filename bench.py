@@ -101,6 +101,9 @@ def main():
     ap.add_argument('--log-records', type=int, default=8193)
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train', choices=['none', 'a2c', 'ppo'], default='none',
+                    help='none: offline_action replay (BASELINE configs[1]); a2c/ppo: policy rollout + update with the '
+                         'flat-gradient all-reduce over RCCL (configs[2]/[3])')
     args = ap.parse_args()
     if args.horizon is None:
         args.horizon = 9 if args.env == 'slate' else 32
@@ -122,8 +125,13 @@ def main():
     # inputs resident in HBM before the timed region: parse the whole log once
     env.sim._recData.store.preload(torch.device('cuda', local_rank))
     B, T = args.batch, args.horizon
+    trainer = None
+    if args.train != 'none':
+        from rl4rs_amd.train import Trainer
+        trainer = Trainer(env, algo=args.train.upper(), seed=1000 + rank)
+    run_step = (lambda: trainer.train_iteration()) if trainer else (lambda: episode(env, T))
     for _ in range(args.warmup):
-        episode(env, T)
+        run_step()
     net = env.sim.model.device_net
     net.set_profiling(True)
     net.profile_reset()
@@ -131,7 +139,7 @@ def main():
     rdist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        obs, total = episode(env, T)
+        run_step()
     rdist.barrier()
     elapsed = rdist.max_over_ranks(time.perf_counter() - t0, device='cuda')
     prof = net.profile()
@@ -146,7 +154,7 @@ def main():
         ms, launches = prof['k_recur<256,augru>']
         n_complete = T if not seq else cfg['page_items']
         reward_calls = 1 if not seq else T // cfg['page_items']
-        rows_per_episode = (T + 1) * B + reward_calls * n_complete * B
+        rows_per_episode = (T + 1) * B + reward_calls * n_complete * B      # reset obs + T step obs + reward rows
         flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "k_recur<256,augru>", "achieved": achieved,
@@ -187,7 +195,8 @@ def main():
             "config": {"workload": "%s batch=%d per GPU, 284-item catalogue, 9-slot slate, %d-step horizon, "
                                    "DIEN simulator scorer, offline_action replay"
                                    % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T),
-                       "step": "one episode-batch = reset + %d env.step incl. reward forward" % T,
+                       "step": "one episode-batch = reset + %d env.step incl. reward forward" % T +
+                               ("" if not trainer else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()),
                        "parallelism": "independent env batches per GPU (no data-path collective)"},
             "roofline": roofline,
             "roofline_gather": gather,
