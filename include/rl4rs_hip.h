@@ -140,6 +140,13 @@ int rl4rs_env_offline_action(rl4rs_env* env, int32_t* ids_dev, double* emb_dev, 
 /* offline_reward (slate.py:164-174, seqslate.py:71-86): out_dev [B] float64. */
 int rl4rs_env_offline_reward(rl4rs_env* env, double* out_dev, void* stream);
 
+/* policy_model.predict_with_mask (rl4rs/policy/policy_model.py:17-41; same mask rule as
+ * CustomVectorEncoder.forward, rl4rs/nets/cql/encoder.py:42-67): masked argmax where the mask is re-derived
+ * from the observation tail.  scores_dev [N, action_size] f32, prev_dev [N, prev_cols] int32 (the obs tail's
+ * previous actions), cur_step_dev [N] int32, out_dev [N] int32.  Uses the env's catalogue tables only. */
+int rl4rs_env_predict_with_mask(rl4rs_env* env, int32_t N, const float* scores_dev, const int32_t* prev_dev,
+                                int32_t prev_cols, const int32_t* cur_step_dev, int32_t* out_dev, void* stream);
+
 /* Device views of env-owned buffers (valid until destroy).  `which`: */
 enum {
     RL4RS_BUF_PREV_ACTIONS = 0,   /* int32  [B, max_steps] */

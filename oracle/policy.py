@@ -79,3 +79,22 @@ def loss_and_grad(algo, flat, obs, mask, actions, adv, ret, old_logp=None, old_v
     total.backward()
     stats = np.array([pi.sum().item(), vf.sum().item(), ent.sum().item(), kl.sum().item()])
     return p.grad.numpy(), stats
+
+
+def predict_with_mask(scores, obs, location_mask, special_items, page_items=9):
+    """policy_model.predict_with_mask for a d3rlpy policy (rl4rs/policy/policy_model.py:17-41), with ``scores``
+    standing in for ``action_probs(obs)``.  obs: [N, 256 + page_items + 1]."""
+    obs = np.array(obs)
+    action_probs = np.array(scores, dtype=np.float64)
+    batch_size = len(obs)
+    mask_size = page_items + 1
+    prev_actions = obs[:, -mask_size:-1].astype(int)
+    cur_step = obs[:, -1].astype(int)
+    mask = np.array(location_mask)[(cur_step % page_items // 3).astype(int)]
+    for i in range(mask_size - 1):
+        mask[range(batch_size), prev_actions[:, i]] = 0
+    action_probs[mask < 0.01] = -2 ** 15
+    for i in range(batch_size):
+        if len(np.intersect1d(prev_actions[i], special_items)) > 0:
+            action_probs[i][special_items] = -2 ** 15
+    return action_probs.argmax(axis=1)

@@ -76,6 +76,7 @@ SIGNATURES = {
     'rl4rs_env_obs_mask': (_I, [_P, _P, _I, _P]),
     'rl4rs_env_offline_action': (_I, [_P, _P, _P, _P]),
     'rl4rs_env_offline_reward': (_I, [_P, _P, _P]),
+    'rl4rs_env_predict_with_mask': (_I, [_P, _I32, _P, _P, _I32, _P, _P, _P]),
     'rl4rs_env_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
     'rl4rs_dien_create': (_I, [C.POINTER(DienCfg), C.POINTER(DienWeights), _P, C.POINTER(_P)]),
     'rl4rs_dien_destroy': (_I, [_P]),

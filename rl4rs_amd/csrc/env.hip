@@ -264,6 +264,43 @@ __global__ __launch_bounds__(256) void k_knn(const TA* __restrict__ actions, int
     if (lane == 0) out[b] = best_k;
 }
 
+// policy_model.predict_with_mask (rl4rs/policy/policy_model.py:17-41) / CustomVectorEncoder mask rule
+// (rl4rs/nets/cql/encoder.py:42-67): the action mask is re-derived from the observation tail
+// [prev_actions (page_items) | cur_step]: mask = location_mask[cur_step % page_items // 3] with every previous
+// action zeroed; masked scores = -2**15; if a special item was already chosen, all special items = -2**15;
+// argmax (first max).  One wave per row; scores float32 [N, A].
+__global__ __launch_bounds__(256) void k_predict_with_mask(EnvDev e, int N, const float* __restrict__ scores,
+                                                            const int32_t* __restrict__ prev, int prev_cols,
+                                                            const int32_t* __restrict__ cur_step, int32_t* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int layer = (cur_step[n] % e.P) / 3;
+    const int32_t* pr = prev + (size_t)n * prev_cols;
+    bool sp = false;
+    for (int j = lane; j < prev_cols; j += 64) {
+        int id = pr[j];
+        if (id >= 0 && id < e.A) sp |= (e.is_special[id] != 0);
+    }
+    const bool any_special = __any(sp);
+    float best = 0.f;
+    int best_k = 0x7fffffff;
+    for (int k = lane; k < e.A; k += 64) {
+        bool ok = (e.loc_bits[layer * e.W + (k >> 5)] >> (k & 31)) & 1u;
+        for (int j = 0; j < prev_cols; ++j) ok = ok && (pr[j] != k);
+        float s = scores[(size_t)n * e.A + k];
+        if (!ok) s = -32768.0f;
+        if (any_special && e.is_special[k]) s = -32768.0f;
+        if (best_k == 0x7fffffff || s > best) { best = s; best_k = k; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        float os = __shfl_xor(best, off);
+        int ok = __shfl_xor(best_k, off);
+        if (ok != 0x7fffffff && (best_k == 0x7fffffff || os > best || (os == best && ok < best_k))) { best = os; best_k = ok; }
+    }
+    if (lane == 0) out[n] = best_k;
+}
+
 // numpy float64 add.reduce order (0 + pairwise_sum, loops_utils.h.src) for n <= 128
 __device__ __forceinline__ double np_pairwise(const double* a, int n) {
     if (n < 8) {
@@ -719,6 +756,19 @@ int rl4rs_env_offline_reward(rl4rs_env* e, double* out, void* stream) {
     RL4RS_REQUIRE(e && out, "offline_reward: null argument");
     hipLaunchKernelGGL(k_offline_reward, dim3((e->d.B + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d,
                        e->cur_steps, out);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_env_predict_with_mask(rl4rs_env* e, int32_t N, const float* scores, const int32_t* prev, int32_t prev_cols,
+                                const int32_t* cur_step, int32_t* out, void* stream) {
+    RL4RS_REQUIRE(e && scores && prev && cur_step && out && N > 0 && prev_cols > 0, "predict_with_mask: bad argument");
+    if (!e->catalog_set) {
+        set_error("predict_with_mask: catalogue not loaded");
+        return RL4RS_ESTATE;
+    }
+    hipLaunchKernelGGL(k_predict_with_mask, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->d, N, scores, prev,
+                       prev_cols, cur_step, out);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

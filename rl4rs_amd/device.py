@@ -184,6 +184,18 @@ class DeviceEnv(object):
         check(self.lib.rl4rs_env_offline_reward(self.h, _ptr(out), _stream()))
         return out
 
+    def predict_with_mask(self, scores, obs_tail):
+        """policy_model.predict_with_mask: scores [N,A] f32, obs_tail [N, P+1] = previous actions | cur_step."""
+        scores = scores.to(device=self.device, dtype=torch.float32).contiguous()
+        tail = obs_tail.to(device=self.device)
+        prev = tail[:, :-1].to(torch.int32).contiguous()
+        cur = tail[:, -1].to(torch.int32).contiguous()
+        N = scores.shape[0]
+        out = torch.empty(N, dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_env_predict_with_mask(self.h, N, _ptr(scores), _ptr(prev), prev.shape[1], _ptr(cur),
+                                                   _ptr(out), _stream()))
+        return out
+
     def check_error_flag(self):
         flag = int(self.snapshot(BUF_ERROR_FLAG).item())
         if flag:

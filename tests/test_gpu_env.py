@@ -165,3 +165,23 @@ def test_invalid_action_sets_error_flag():
     env.act_discrete(bad)
     with pytest.raises(IndexError):
         env.check_error_flag()
+
+
+def test_predict_with_mask_from_observation_tail():
+    """a17b: the d3rlpy-side mask rule (policy_model.py:17-41) on device vs its numpy restatement."""
+    import torch
+    from oracle.policy import predict_with_mask
+    m, cfg, records, g = load_scenario('slate_discrete')
+    env, cat, cols = _mk_env(cfg, records, False)
+    rs = np.random.RandomState(5)
+    N = 777
+    scores = rs.rand(N, 284).astype(np.float32)
+    scores[:50] = np.round(scores[:50], 1)                    # exact ties -> first max
+    prev = rs.randint(0, 284, size=(N, 9))
+    prev[::3, 4:] = 0
+    prev[1::5, :] = rs.randint(1, 62, size=(len(prev[1::5]), 9))     # rows with no special item chosen
+    cur = rs.randint(0, 36, size=(N, 1))
+    obs = np.concatenate([rs.randn(N, 256), prev, cur], axis=1)
+    ref = predict_with_mask(scores, obs, cat.location_mask, cat.special_items)
+    got = env.predict_with_mask(torch.from_numpy(scores), torch.from_numpy(obs[:, 256:])).cpu().numpy()
+    assert np.array_equal(got, ref)
