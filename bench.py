@@ -154,7 +154,8 @@ def main():
         ms, launches = prof['k_recur<256,augru>']
         n_complete = T if not seq else cfg['page_items']
         reward_calls = 1 if not seq else T // cfg['page_items']
-        rows_per_episode = (T + 1) * B + reward_calls * n_complete * B      # reset obs + T step obs + reward rows
+        # reset obs + T step obs + reward rows (the last reward row of an env reuses the state row just scored)
+        rows_per_episode = (T + 1) * B + reward_calls * (n_complete - 1) * B
         flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "k_recur<256,augru>", "achieved": achieved,

@@ -117,6 +117,10 @@ int rl4rs_knn(const void* actions_dev, int is_f64, int32_t n, const double* acti
 /* get_complete_states + feature_extraction for the reward rows (slate.py:117-131,289-294;
  * seqslate.py:27-50,141-146): fills the env's complete-state buffers ([B*n, ...], env-major). */
 int rl4rs_env_build_complete(rl4rs_env* env, void* stream);
+/* Same, emitting only the first rows_per_env (<= complete_rows) rows of each env ([B*rows_per_env, ...]).
+ * The LAST complete row of an env equals its current state row (same prev_actions, action = the item just
+ * played; slate.py:205-212 vs :119-130), so a caller that already scored the state row can skip it. */
+int rl4rs_env_build_complete_rows(rl4rs_env* env, int32_t rows_per_env, void* stream);
 /* rows per env produced by build_complete: max_steps (Slate) or page_items (SeqSlate). */
 int rl4rs_env_complete_rows(const rl4rs_env* env);
 /* 1 when SlateRecEnv.forward / SeqSlateRecEnv.forward would call the reward net now
@@ -127,6 +131,11 @@ int rl4rs_env_cur_steps(const rl4rs_env* env);
 /* reward = sum_j price*prob in float64 (numpy pairwise order), zeroed on violation
  * (slate.py:298-307, seqslate.py:150-157).  probs_dev [B, n] float32, reward_dev [B] float64. */
 int rl4rs_env_reward(rl4rs_env* env, const float* probs_dev, double* reward_dev, void* stream);
+
+/* Same with the last row's probability supplied separately: probs_dev [B, n-1], p_last_dev [B] (NULL = probs_dev
+ * holds all n). */
+int rl4rs_env_reward_split(rl4rs_env* env, const float* probs_dev, const float* p_last_dev, double* reward_dev,
+                           void* stream);
 
 /* get_violation (slate.py:133-147, seqslate.py:52-69): out_dev [B] int32 in {0,1}. */
 int rl4rs_env_violation(rl4rs_env* env, int32_t* out_dev, void* stream);
@@ -220,6 +229,10 @@ int rl4rs_dien_encode(rl4rs_dien* net, int32_t s, const int32_t* ids_dev, int32_
 int rl4rs_dien_forward(rl4rs_dien* net, int32_t R, int32_t group, const float* dense_dev,
                        const int32_t* cat_dev, const int32_t* slot_dev, float* obs_dev,
                        float* prob_dev, void* stream);
+
+/* softmax(obs @ out_w + out_b)[:, 1] of already computed 'simulator_obs' activations (dien.py:36):
+ * obs_dev [R, 256] -> prob_dev [R]. */
+int rl4rs_dien_head_prob(rl4rs_dien* net, int32_t R, const float* obs_dev, float* prob_dev, void* stream);
 
 /* Intermediate activations for parity tests; `which`: */
 enum {

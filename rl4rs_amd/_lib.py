@@ -68,6 +68,8 @@ SIGNATURES = {
     'rl4rs_env_act_conti': (_I, [_P, _P, _I, _P, _P]),
     'rl4rs_knn': (_I, [_P, _I, _I32, _P, _I32, _I32, _P, _P, _P]),
     'rl4rs_env_build_complete': (_I, [_P, _P]),
+    'rl4rs_env_build_complete_rows': (_I, [_P, _I32, _P]),
+    'rl4rs_env_reward_split': (_I, [_P, _P, _P, _P, _P]),
     'rl4rs_env_complete_rows': (_I, [_P]),
     'rl4rs_env_is_reward_step': (_I, [_P]),
     'rl4rs_env_cur_steps': (_I, [_P]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     'rl4rs_dien_destroy': (_I, [_P]),
     'rl4rs_dien_encode': (_I, [_P, _I32, _P, _I32, _I32, _P]),
     'rl4rs_dien_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_dien_head_prob': (_I, [_P, _I32, _P, _P, _P]),
     'rl4rs_dien_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
     'rl4rs_dien_set_profiling': (_I, [_P, _I]),
     'rl4rs_dien_kernel_count': (_I, []),

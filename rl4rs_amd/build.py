@@ -27,7 +27,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
                '-c', os.path.join(CSRC, src), '-o', obj] + list(extra_flags)
         if verbose:
             print(' '.join(cmd))

@@ -877,6 +877,15 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     return RL4RS_OK;
 }
 
+int rl4rs_dien_head_prob(rl4rs_dien* n, int32_t R, const float* obs, float* prob, void* stream) {
+    RL4RS_REQUIRE(n && obs && prob && R > 0, "dien_head_prob: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    Prof p(n, KID_PROB, st);
+    hipLaunchKernelGGL(k_head_prob, dim3((R + 3) / 4), dim3(256), 0, st, obs, R, OBS_DIM, n->K, n->out_w, n->out_b, prob);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
     RL4RS_REQUIRE(n && p, "dien_buffer: null argument");
     int64_t b = 0;

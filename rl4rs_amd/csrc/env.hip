@@ -366,14 +366,17 @@ __global__ void k_violation(EnvDev e, int cur, int32_t* out) {
 }
 
 // reward = np.sum(price * probs, axis=1); reward[violation < 0.5] = 0 (slate.py:294-307, seqslate.py:147-157)
+// p_last (optional): probability of the LAST row of each env supplied separately; probs then holds n-1 per env
 __global__ void k_reward(EnvDev e, int cur, int n, int j_base, int zero_on_violation,
-                         const float* __restrict__ probs, double* __restrict__ out) {
+                         const float* __restrict__ probs, const float* __restrict__ p_last, double* __restrict__ out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= e.B) return;
     double terms[128];
+    const int m = p_last ? n - 1 : n;
     for (int j = 0; j < n; ++j) {
         int id = e.prev[(size_t)b * e.T + j_base + j];
-        terms[j] = __dmul_rn(e.price[id], (double)probs[(size_t)b * n + j]);
+        float pj = (j < m) ? probs[(size_t)b * m + j] : p_last[b];
+        terms[j] = __dmul_rn(e.price[id], (double)pj);
     }
     double r = np_pairwise(terms, n);
     if (zero_on_violation && violation_of(e, b, cur) == 0) r = 0.0;
@@ -699,19 +702,32 @@ static int complete_base(const rl4rs_env* e) {
     return e->d.is_seq ? e->cur_steps - e->d.P : 0;
 }
 
+int rl4rs_env_build_complete_rows(rl4rs_env* e, int32_t rows_per_env, void* stream);
 int rl4rs_env_build_complete(rl4rs_env* e, void* stream) {
     RL4RS_REQUIRE(e, "build_complete: null env");
+    return rl4rs_env_build_complete_rows(e, e->n_complete, stream);
+}
+
+int rl4rs_env_build_complete_rows(rl4rs_env* e, int32_t rows_per_env, void* stream) {
+    RL4RS_REQUIRE(e, "build_complete: null env");
+    RL4RS_REQUIRE(rows_per_env >= 1 && rows_per_env <= e->n_complete, "build_complete: rows_per_env=%d not in 1..%d",
+                  rows_per_env, e->n_complete);
     int jb = complete_base(e);
     if (jb < 0 || jb + e->n_complete > e->d.T) {
         set_error("build_complete: cur_steps=%d has no complete page", e->cur_steps);
         return RL4RS_ESTATE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int R = e->d.B * e->n_complete;
-    return launch_rows<2>(e, R, nullptr, e->cur_steps, e->n_complete, jb, st);
+    int R = e->d.B * rows_per_env;
+    return launch_rows<2>(e, R, nullptr, e->cur_steps, rows_per_env, jb, st);
 }
 
+int rl4rs_env_reward_split(rl4rs_env* e, const float* probs, const float* p_last, double* reward, void* stream);
 int rl4rs_env_reward(rl4rs_env* e, const float* probs, double* reward, void* stream) {
+    return rl4rs_env_reward_split(e, probs, nullptr, reward, stream);
+}
+
+int rl4rs_env_reward_split(rl4rs_env* e, const float* probs, const float* p_last, double* reward, void* stream) {
     RL4RS_REQUIRE(e && probs && reward, "reward: null argument");
     int jb = complete_base(e);
     if (jb < 0 || jb + e->n_complete > e->d.T) {
@@ -719,7 +735,7 @@ int rl4rs_env_reward(rl4rs_env* e, const float* probs, double* reward, void* str
         return RL4RS_ESTATE;
     }
     hipLaunchKernelGGL(k_reward, dim3((e->d.B + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d,
-                       e->cur_steps, e->n_complete, jb, e->cfg.violation_zeroes_reward, probs, reward);
+                       e->cur_steps, e->n_complete, jb, e->cfg.violation_zeroes_reward, probs, p_last, reward);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

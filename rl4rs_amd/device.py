@@ -154,13 +154,18 @@ class DeviceEnv(object):
         k = np.arange(self.A)
         return ((b[:, k >> 5] >> (k & 31).astype(np.uint32)) & 1).astype(np.int64)
 
-    def build_complete(self):
-        check(self.lib.rl4rs_env_build_complete(self.h, _stream()))
+    def build_complete(self, rows_per_env=None):
+        if rows_per_env is None:
+            check(self.lib.rl4rs_env_build_complete(self.h, _stream()))
+        else:
+            check(self.lib.rl4rs_env_build_complete_rows(self.h, rows_per_env, _stream()))
 
-    def reward(self, probs):
+    def reward(self, probs, p_last=None):
         out = torch.empty(self.B, dtype=torch.float64, device=self.device)
-        assert probs.dtype == torch.float32 and probs.numel() == self.B * self.n_complete
-        check(self.lib.rl4rs_env_reward(self.h, _ptr(probs), _ptr(out), _stream()))
+        m = self.n_complete - (1 if p_last is not None else 0)
+        assert probs.dtype == torch.float32 and probs.numel() == self.B * m
+        assert p_last is None or (p_last.dtype == torch.float32 and p_last.numel() == self.B)
+        check(self.lib.rl4rs_env_reward_split(self.h, _ptr(probs), _ptr(p_last), _ptr(out), _stream()))
         return out
 
     def violation(self):
@@ -305,6 +310,13 @@ class DeviceDien(object):
         prob = torch.empty(R, dtype=torch.float32, device=self.device) if want_prob else None
         check(self.lib.rl4rs_dien_forward(self.h, R, group, dp, cp, _ptr(slots), _ptr(obs), _ptr(prob), _stream()))
         return obs, prob
+
+    def head_prob(self, obs):
+        R = obs.shape[0]
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == 256
+        prob = torch.empty(R, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_dien_head_prob(self.h, R, _ptr(obs), _ptr(prob), _stream()))
+        return prob
 
     def snapshot(self, which, rows):
         p = C.c_void_p()

@@ -379,6 +379,9 @@ class SlateRecEnv(RecSimBase):
         dp, _ = env.buffer_ptr(D.BUF_DENSE)
         cp, _ = env.buffer_ptr(D.BUF_CATEGORY)
         obs, _ = net.forward(B, 1, dp, cp, slots, want_obs=True, want_prob=False)
+        # the state row just scored IS the last complete-state row of the reward forward (same prev_actions,
+        # action = the item just played): keep its activations so forward() scores one row less per env
+        self._last_obs = (samples._batch_version, env.cur_steps, obs if not tensor_mode else obs.clone())
         if tensor_mode:
             if masked:
                 return {"action_mask": state["action_mask"], "obs": obs}
@@ -407,15 +410,23 @@ class SlateRecEnv(RecSimBase):
                 return torch.zeros(B, dtype=torch.float64, device=samples._env.device)
             return [0] * B
         env = samples._live()
-        samples.get_complete_states()
         n = env.n_complete
         net, slots = self._net_for(samples)
+        last = getattr(self, '_last_obs', None)
+        reuse = (last is not None and last[0] == samples._batch_version and last[1] == env.cur_steps and n > 1
+                 and not self.config.get('no_state_row_reuse', False))
+        m = n - 1 if reuse else n
+        env.build_complete(m)
         dp, _ = env.buffer_ptr(D.BUF_C_DENSE)
         cp, _ = env.buffer_ptr(D.BUF_C_CATEGORY)
-        _, probs = net.forward(B * n, n, dp, cp, slots, want_obs=False, want_prob=True)
+        _, probs = net.forward(B * m, m, dp, cp, slots, want_obs=False, want_prob=True)
+        p_last = net.head_prob(last[2]) if reuse else None
         if self.config.get("simulator_info_fetch", False):
-            pr = probs.reshape(B, n).cpu().numpy()
+            pr = probs.reshape(B, m)
+            if reuse:
+                pr = torch.cat([pr, p_last[:, None]], dim=1)
+            pr = pr.cpu().numpy()
             for i in range(B):
                 samples.info[i].update({'click_p': pr[i]})
-        reward = env.reward(probs)
+        reward = env.reward(probs, p_last)
         return reward if tensor_mode else reward.cpu().numpy().tolist()

@@ -105,3 +105,31 @@ def test_dien_bad_arguments():
     bad = dict(CFG, emb_size=64)
     with pytest.raises((Rl4rsHipError, KeyError, ValueError)):
         DeviceDien(bad, w, max_rows=8, max_slots=4)
+
+
+def test_dien_is_batch_position_invariant():
+    """Size-independent property: a row's result does not depend on where it sits in the batch, on the group size,
+    or on the run (every kernel is deterministic and row-local; the library is built with -ffp-contract=off so all
+    accumulator elements follow one operation sequence)."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    B, G = 10, 8
+    w = init_dien_weights(CFG, seed=3, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(0)
+    seq, dense, cat = _inputs(B, rs, CFG['category_hash_size'])
+    net = DeviceDien(CFG, w, max_rows=B * G, max_slots=B + 1)
+    net.encode(0, torch.from_numpy(np.ascontiguousarray(seq[:, 0])).cuda(), 0)
+    net.encode(1, torch.zeros((1, 64), dtype=torch.int32).cuda(), B)
+    sl = torch.full((2, B), B, dtype=torch.int32).cuda()
+    sl[0] = torch.arange(B, dtype=torch.int32).cuda()
+    sl = sl.contiguous()
+    d1, c1 = torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda()
+    obs1, p1 = net.forward(B, 1, d1, c1, sl, True, True)
+    obs1b, p1b = net.forward(B, 1, d1, c1, sl, True, True)
+    assert torch.equal(obs1, obs1b) and torch.equal(p1, p1b)                       # run to run
+    dG, cG = d1.repeat_interleave(G, dim=0).contiguous(), c1.repeat_interleave(G, dim=0).contiguous()
+    obsG, pG = net.forward(B * G, G, dG, cG, sl, True, True)
+    assert torch.equal(obsG.reshape(B, G, 256), obs1[:, None, :].expand(B, G, 256))  # position / group size
+    assert torch.equal(pG.reshape(B, G), p1[:, None].expand(B, G))
+    net.close()

@@ -190,3 +190,24 @@ def test_custom_state_cls_is_rejected_loudly(tmp_path):
         pass
     with pytest.raises(NotImplementedError):
         SlateRecEnv(cfg, state_cls=Mine)
+
+
+@pytest.mark.parametrize('seq,T', [(False, 9), (True, 36)])
+def test_state_row_reuse_is_bit_identical(tmp_path, seq, T):
+    """The reward forward skips the last complete-state row of each env and takes its click probability from the
+    state row scored one call earlier: results must be bit-identical to scoring all 9 rows."""
+    import torch
+    out = []
+    for reuse_off in (False, True):
+        cfg, records, w = _setup(tmp_path, seq, 10, T, return_tensors=True, simulator_info_fetch=True,
+                                 no_state_row_reuse=reuse_off)
+        env = _make(cfg, seq)
+        env.reset(reset_file=True)
+        rewards = []
+        for t in range(T):
+            obs, reward, done, info = env.step(env.offline_action)
+            rewards.append(reward.clone())
+        out.append((torch.stack(rewards), np.stack([i['click_p'] for i in info])))
+    assert torch.equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][0].abs().sum() > 0
