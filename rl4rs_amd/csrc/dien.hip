@@ -38,7 +38,7 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ cat, int R, int Cn, int E, int H,
                                                   const float* __restrict__ cat_emb,
                                                   const float* __restrict__ seq_emb, float* __restrict__ allf,
-                                                  int ldf, int off_c, float* __restrict__ q) {
+                                                  int ldf, int off_c, float* __restrict__ q, int write_flat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int LE = E + 1, LS = Cn + 1;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
         for (int k = lane; k < E; k += 64) {
             float v = src[k];
             sE[c * LE + k] = v;
-            frow[E + c * E + k] = v;                  // Flatten()(category_emb)
+            if (write_flat) frow[E + c * E + k] = v;  // Flatten()(category_emb)
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -537,6 +537,29 @@ __global__ __launch_bounds__(256) void k_head_prob(const float* __restrict__ obs
     if (lane == 0) prob[row] = expf(logit[K > 1 ? 1 : 0] - m) / sum;
 }
 
+// 'simulator_obs' epilogue for the table form of the head (dien.py:35):
+//   obs[row] = ELU( pre[row] + b + sum_j P_j[cat[row, j]] ),   P_j = cat_emb @ W_obs[flatten slot j]  ([H, 256], built at load)
+// i.e. the Flatten(category_emb) slice of the concat (Cn*E of the 3456 inputs) never goes through the GEMM: its
+// contribution is Cn row gathers of 1 KB.  One wave per row, each lane owns 4 consecutive outputs (float4).
+__global__ __launch_bounds__(256) void k_head_finish(float* __restrict__ obs, int R, const int32_t* __restrict__ cat, int Cn,
+                                                     int H, const float* __restrict__ ptab, const float* __restrict__ bias) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    float4* o = reinterpret_cast<float4*>(obs + (size_t)row * OBS_DIM) + lane;
+    float4 acc = *o;
+    const float4 b = reinterpret_cast<const float4*>(bias)[lane];
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    const int32_t* crowp = cat + (size_t)row * Cn;
+    for (int j = 0; j < Cn; ++j) {
+        int id = min(max(crowp[j], 0), H - 1);
+        const float4 v = reinterpret_cast<const float4*>(ptab + ((size_t)j * H + id) * OBS_DIM)[lane];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x = eluf_(acc.x); acc.y = eluf_(acc.y); acc.z = eluf_(acc.z); acc.w = eluf_(acc.w);
+    *o = acc;
+}
+
 }  // namespace rl4rs
 
 // =================================================================================================
@@ -555,6 +578,7 @@ struct rl4rs_dien {
     int E, U, L, S, Cn, Dn, H, K, F, PLD, NH2;
     // weights (device)
     float *cat_emb, *seq_emb, *dense_w1, *dense_b1, *dense_w2, *dense_b2, *obs_w, *obs_b, *out_w, *out_b;
+    float* ptab;           // [Cn, H, 256] head tables of the flattened category embeddings (NULL = GEMM form)
     float* embw1[4];       // [H, 3E]   first-GRU input projection table (bias folded)
     float* gru_wg[4];      // packed h-side gate weights     [2*E/32][E/8][64][4]
     float* gru_wc[4];      // packed h-side candidate weights
@@ -676,7 +700,20 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     UP(dense_b1, w->dense_b1, U);
     { auto pk = pack_gemm_weight(w->dense_w2, U, U, U); keep.push_back(std::move(pk)); UP(dense_w2, keep.back().data(), keep.back().size()); }
     UP(dense_b2, w->dense_b2, U);
-    { auto pk = pack_gemm_weight(w->obs_w, OBS_DIM, F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
+    // head: table form unless disabled (RL4RS_HEAD_TABLES=0) or the tables would not fit a sane budget (8 GB)
+    const int Kh = S * NH2 + U + E;                       // [sequence finals | dense | pooled attention]
+    const char* ht = getenv("RL4RS_HEAD_TABLES");
+    const bool use_tables = !(ht && atoi(ht) == 0) && ((int64_t)Cn * H * OBS_DIM * 4 <= ((int64_t)8 << 30));
+    n->ptab = nullptr;
+    { auto pk = pack_gemm_weight(w->obs_w, OBS_DIM, use_tables ? Kh : F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
+    if (use_tables) {
+        float* d_wflat;      // raw rows [Kh, F) of obs_w = the Cn blocks of E rows each
+        if ((rc = upload(n, &d_wflat, w->obs_w + (size_t)Kh * OBS_DIM, (size_t)Cn * E * OBS_DIM, st))) return rc;
+        AL(ptab, (size_t)Cn * H * OBS_DIM);
+        for (int j = 0; j < Cn; ++j)
+            if ((rc = launch_gemm_f32(n->cat_emb, E, d_wflat + (size_t)j * E * OBS_DIM, OBS_DIM, nullptr,
+                                      n->ptab + (size_t)j * H * OBS_DIM, OBS_DIM, H, OBS_DIM, E, 0, st))) return rc;
+    }
     UP(obs_b, w->obs_b, OBS_DIM);
     UP(out_w, w->out_w, (size_t)OBS_DIM * K);
     UP(out_b, w->out_b, K);
@@ -810,7 +847,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         Prof p(n, KID_CAT, st);
         size_t smem = (size_t)4 * (Cn * (E + 1) + Cn * (Cn + 1) + Cn) * 4;
         hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
-                           n->seq_emb, n->allf, F, off_c, n->q);
+                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1);
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -866,7 +903,14 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     float* obs_out = obs ? obs : n->obs_tmp;
     {
         Prof p(n, KID_HEAD, st);
-        if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
+        if (n->ptab) {
+            const int Kh = S * NH2 + U + E;
+            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 0, st))) return rc;
+            hipLaunchKernelGGL(k_head_finish, dim3((R + 3) / 4), dim3(256), 0, st, obs_out, R, cat, Cn, n->H, n->ptab, n->obs_b);
+            RL4RS_LAUNCH_CHECK();
+        } else {
+            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
+        }
     }
     if (prob) {
         Prof p(n, KID_PROB, st);
