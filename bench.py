@@ -162,6 +162,12 @@ def main():
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                     "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
                     "kernel_ms_share": ms / (elapsed * 1e3)}
+        if not seq and B == 4096 and T == 9 and not trainer:
+            # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
+            # corrected as MI355X_MICROARCH.md prescribes; profiles/r01c_pmc.md): launch-weighted mean of the
+            # 10 obs-sized (897 MB) and 1 reward-sized (883 MB) launches of an episode
+            roofline["traffic"] = 8.96e8
+            roofline["traffic_unit"] = "B/launch (PMC, profiles/r01c_pmc.md)"
         kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples
