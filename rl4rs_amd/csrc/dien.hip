@@ -464,12 +464,12 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                 const float a1[4] = {aw1[cb].x, aw1[cb].y, aw1[cb].z, aw1[cb].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    // both 32-step tiles are always computed (for maxlen <= 32 the second one re-reads clamped rows and
+                    // its results are never stored): no branch inside the MFMA stream
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc00, 0, 0, 0);
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc10, 0, 0, 0);
-                    if (ntile > 1) {
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc01, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc11, 0, 0, 0);
-                    }
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc11, 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
