@@ -34,66 +34,88 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 // -------------------------------------------------------------------------------------------------
 // Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
 // One wave per row; 4 rows per block.  Writes allf[row, off_c : off_c + E] = mean_i(softmax(E E^T) E),
-// allf[row, off_c+E : off_c+E+Cn*E] = flatten(E), q[row] = mean(seq_emb[cat[-10:]]).
+// (optionally) allf[row, off_c+E : off_c+E+Cn*E] = flatten(E), q[row] = mean(seq_emb[cat[-10:]]).
+// S = E E^T (Cn <= 32 rows, K = E) is ONE 32x32 MFMA tile whose A and B fragments are the same registers.
+// S is symmetric, so the softmax over the keys of query i equals the softmax down column i of the tile: lane
+// (column) i normalises its own 16+16 register values (two half-waves), no cross-lane traffic for max / sum.
 __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ cat, int R, int Cn, int E, int H,
                                                   const float* __restrict__ cat_emb,
                                                   const float* __restrict__ seq_emb, float* __restrict__ allf,
                                                   int ldf, int off_c, float* __restrict__ q, int write_flat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int LE = E + 1, LS = Cn + 1;
-    float* sE = reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * LE + Cn * LS + Cn);
-    float* sS = sE + Cn * LE;
-    float* sW = sS + Cn * LS;
+    const int half = lane >> 5, li = lane & 31;
+    const int LE = E + 4;                                 // 16-byte aligned rows, conflict-free ds_read_b128
+    float* sE = reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * LE + 32);
+    float* sW = sE + Cn * LE;                             // [32] column weights
     const int row = blockIdx.x * 4 + wave;
     if (row >= R) return;
     const int32_t* crowp = cat + (size_t)row * Cn;
     float* frow = allf + (size_t)row * ldf + off_c;
-    for (int c = 0; c < Cn; ++c) {
-        int id = crowp[c];
-        id = min(max(id, 0), H - 1);
-        const float* src = cat_emb + (size_t)id * E;
-        for (int k = lane; k < E; k += 64) {
-            float v = src[k];
-            sE[c * LE + k] = v;
-            if (write_flat) frow[E + c * E + k] = v;  // Flatten()(category_emb)
+    // embedding gather: ids first (one coalesced load, broadcast by shuffle), then 8 rows' loads in flight at a time
+    // (a load-store-load chain per row would expose the full memory latency Cn times)
+    const int myid = (lane < Cn) ? min(max(crowp[lane], 0), H - 1) : 0;
+    for (int c0 = 0; c0 < Cn; c0 += 8) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = __shfl(myid, min(c0 + u, Cn - 1));
+            const float* src = cat_emb + (size_t)id * E;
+            v0[u] = src[lane];
+            v1[u] = src[lane + 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c < Cn) {
+                sE[c * LE + lane] = v0[u];
+                sE[c * LE + lane + 64] = v1[u];
+                if (write_flat) {                          // Flatten()(category_emb)
+                    frow[E + c * E + lane] = v0[u];
+                    frow[E + c * E + lane + 64] = v1[u];
+                }
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // scores = E E^T (symmetric): one (i<=j) pair per lane per pass
-    const int npairs = Cn * (Cn + 1) / 2;
-    for (int p = lane; p < npairs; p += 64) {
-        int i = 0, rem = p;
-        while (rem >= Cn - i) { rem -= Cn - i; ++i; }
-        int j = i + rem;
-        float s = 0.f;
-        for (int k = 0; k < E; ++k) s = fmaf(sE[i * LE + k], sE[j * LE + k], s);
-        sS[i * LS + j] = s;
-        sS[j * LS + i] = s;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool row_ok = li < Cn;
+    const float* erow = sE + (row_ok ? li : 0) * LE + half * 4;
+    for (int kb = 0; kb < E / 8; ++kb) {
+        float4 f = row_ok ? *reinterpret_cast<const float4*>(erow + kb * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, f.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, f.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, f.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, f.w, acc, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // row softmax (keras Attention: no scale, no mask)
-    for (int i = lane; i < Cn; i += 64) {
-        float m = -3.4e38f;
-        for (int j = 0; j < Cn; ++j) m = fmaxf(m, sS[i * LS + j]);
-        float sum = 0.f;
-        for (int j = 0; j < Cn; ++j) {
-            float ev = expf(sS[i * LS + j] - m);
-            sS[i * LS + j] = ev;
-            sum += ev;
-        }
-        float inv = 1.f / sum;
-        for (int j = 0; j < Cn; ++j) sS[i * LS + j] *= inv;
+    // lane = query i (column li); register r of half h = key j = crow(r, h).  keras Attention: no scale, no mask.
+    float m = -3.4e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (crow(r, half) < Cn) m = fmaxf(m, acc[r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float z = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float ev = (crow(r, half) < Cn) ? expf(acc[r] - m) : 0.f;
+        acc[r] = ev;
+        z += ev;
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // GlobalAveragePooling1D over the Cn attended rows: column weights cw_j = sum_i w_ij
-    for (int j = lane; j < Cn; j += 64) {
-        float s = 0.f;
-        for (int i = 0; i < Cn; ++i) s += sS[i * LS + j];
-        sW[j] = s;
+    z += __shfl_xor(z, 32);
+    const float inv = row_ok ? 1.f / z : 0.f;             // queries beyond Cn contribute nothing
+    // GlobalAveragePooling1D over the Cn attended rows: column weight of key j = sum over queries i of w_ij
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] * inv;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (li == 0) sW[crow(r, half)] = v;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -108,10 +130,7 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
     const float invq = 1.f / (float)nq;
     for (int k = lane; k < E; k += 64) {
         float s = 0.f;
-        for (int c = Cn - nq; c < Cn; ++c) {
-            int id = min(max(crowp[c], 0), H - 1);
-            s += seq_emb[(size_t)id * E + k];
-        }
+        for (int c = Cn - nq; c < Cn; ++c) s += seq_emb[(size_t)__shfl(myid, c) * E + k];
         q[(size_t)row * E + k] = s * invq;
     }
 }
@@ -665,7 +684,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     RL4RS_REQUIRE(c->maxlen >= 1 && c->maxlen <= 64, "dien: maxlen must be in 1..64 (got %d)", c->maxlen);
     RL4RS_REQUIRE(c->seq_num >= 1 && c->seq_num <= 4, "dien: seq_num must be in 1..4");
     RL4RS_REQUIRE(c->class_num >= 1 && c->class_num <= 8, "dien: class_num must be in 1..8");
-    RL4RS_REQUIRE(c->category_feature_num >= 1 && c->category_feature_num <= 64, "dien: category_feature_num must be in 1..64");
+    RL4RS_REQUIRE(c->category_feature_num >= 1 && c->category_feature_num <= 32, "dien: category_feature_num must be in 1..32");
     RL4RS_REQUIRE(c->max_rows > 0 && c->max_slots > 0 && c->category_hash_size > 0 && c->dense_feature_num > 0,
                   "dien: bad sizes");
     RL4RS_REQUIRE((int64_t)c->max_slots * c->maxlen * (ATT_H1 + 6 * c->emb_size) * 4 < (int64_t)0x7fffffff * 2,
@@ -845,7 +864,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     int rc;
     {
         Prof p(n, KID_CAT, st);
-        size_t smem = (size_t)4 * (Cn * (E + 1) + Cn * (Cn + 1) + Cn) * 4;
+        size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
         hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
                            n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1);
         RL4RS_LAUNCH_CHECK();
