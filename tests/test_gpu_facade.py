@@ -211,3 +211,50 @@ def test_state_row_reuse_is_bit_identical(tmp_path, seq, T):
     assert torch.equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
     assert out[0][0].abs().sum() > 0
+
+
+@pytest.mark.parametrize('seq,T', [(False, 9), (True, 36)])
+def test_offline_dataset_generation_matches_oracle_replay(tmp_path, seq, T):
+    """f1: device-side data_generate_rl4rs_* (script/batchrl_trainer.py:172-217) vs the same loop over the oracle env."""
+    from rl4rs_amd.offline import generate_offline_dataset
+    B = 6
+    cfg, records, w = _setup(tmp_path, seq, B, T, support_d3rl_mask=True, return_tensors=True)
+    env = _make(cfg, seq)
+    env.reset(reset_file=True)          # so that the generator's first reset() reads the SECOND cache window
+    ds = generate_offline_dataset(env, epochs=1, shuffle=False, to_numpy=True)
+    cfg_o = dict(cfg, return_tensors=False)
+    orc = _oracle(cfg_o, records, w, seq)
+    # eval mode + cache_size == B: the generator's reset() took lines [B, 2B) -> wraps like base.py:84-88
+    lines = records + ['']
+    cur, window = B, []
+    for _ in range(B):
+        t = lines[cur] if cur < len(lines) else ''
+        cur += 1
+        if not t:
+            cur = 2
+            t = lines[1]
+        window.append(t)
+    o = orc.reset(records=window)
+    S, P = T + 1, 9
+    obs = ds['observations'].reshape(B, S, -1)
+    act = ds['actions'].reshape(B, S)
+    rew = ds['rewards'].reshape(B, S)
+    term = ds['terminals'].reshape(B, S)
+    assert obs.shape[2] == 256 + P + 1
+
+    def check(k, o):
+        assert np.abs(obs[:, k, :256] - o['obs']).max() < 5e-5
+        assert np.array_equal(obs[:, k, 256:-1], o['masked_actions'])
+        assert np.array_equal(obs[:, k, -1:], o['cur_steps'])
+
+    check(0, o)
+    assert rew[:, 0].tolist() == [0] * B and term[:, 0].tolist() == [0] * B
+    for j in range(T):
+        a = np.asarray(orc.samples.offline_action)
+        assert np.array_equal(act[:, j], a)
+        o, _, done, _ = orc.step(a)
+        check(j + 1, o)
+        assert np.allclose(rew[:, j + 1], np.asarray(orc.samples.offline_reward, dtype=np.float64), rtol=1e-6)
+        assert term[:, j + 1].tolist() == [float(x) for x in done]
+    assert act[:, T].tolist() == [0] * B
+    assert rew[:, T].sum() > 0
