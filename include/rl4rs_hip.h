@@ -95,6 +95,15 @@ int rl4rs_env_load_batch(rl4rs_env* env, const int32_t* exposed_dev, const int32
                          const int32_t* history_dev, const float* user_dense_dev,
                          const int32_t* user_cat_dev, void* stream);
 
+/* HOST-side parser of a text buffer of '\n'-separated '@'-records (blank lines skipped) into the columnar HOST
+ * arrays above: FeatureUtil.record_split (datautil.py:20-32) + records_to_state (slate.py:67-83) + pad_sequences
+ * of the history (datautil.py:43-46), for a whole sample file at once.  exposed/feedback are zero padded /
+ * truncated to log_steps columns; exposed_len_host (optional) receives each record's true exposed_items count. */
+int rl4rs_parse_records(const char* text, int64_t len, int32_t max_records, int32_t maxlen, int32_t log_steps,
+                        int32_t user_dense_dim, int32_t user_cat_dim, int32_t* exposed_host, int32_t* feedback_host,
+                        int32_t* history_host, float* user_dense_host, int32_t* user_cat_host,
+                        int32_t* exposed_len_host, int32_t* n_parsed);
+
 /* RecState.__init__ (base.py:27-31) + SlateState.__init__ (slate.py:15-19): zero prev_actions, masks
  * to all-ones, cur_steps = 0, feature rows = the un-acted state. */
 int rl4rs_env_reset(rl4rs_env* env, void* stream);

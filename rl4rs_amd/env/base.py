@@ -156,7 +156,7 @@ class LogStore(object):
     def ensure(self, rows, device):
         """Make sure the given line numbers are parsed and resident on ``device``."""
         import torch
-        from ..data import RecordColumns
+        from ..data import parse_records_native
         rows = np.unique(np.asarray(rows, dtype=np.int64))
         self._ensure_width(rows)
         if self._dev is None:
@@ -164,7 +164,7 @@ class LogStore(object):
         todo = rows[~self._parsed[rows]]
         if len(todo) == 0:
             return
-        cols = RecordColumns([self.lines[r] for r in todo], self.maxlen, self.log_steps)
+        cols = parse_records_native([self.lines[r] for r in todo], self.maxlen, self.log_steps)
         idx = torch.from_numpy(todo).to(device)
         for name in ('exposed', 'feedback', 'history', 'user_dense', 'user_cat'):
             src = torch.from_numpy(getattr(cols, name)).to(device)

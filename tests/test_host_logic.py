@@ -144,3 +144,34 @@ def test_synthetic_logs_are_legal_by_construction(tmp_path):
     for t in range(9):
         st2.act(st2.offline_action)
     assert st2.get_violation().all()
+
+
+def test_native_record_parser_matches_python_parser():
+    """rl4rs_parse_records (host C++ in librl4rs_hip.so) == RecordColumns on golden + synthetic records; errors."""
+    import time
+    from rl4rs_amd.build import build_lib
+    build_lib()
+    from rl4rs_amd import synth, _lib
+    from rl4rs_amd.data import RecordColumns, parse_records_native
+    recs = []
+    for name in ('slate_discrete', 'seq36_discrete', 'real_discrete'):
+        recs.append(load_scenario(name)[2])
+    text = synth.make_catalog_text(seed=9)
+    recs.append(synth.make_records(500, pages=4, seed=77, special_ids=synth.special_ids_from_text(text)))
+    for rr in recs:
+        a = RecordColumns(rr, 64)
+        b = parse_records_native(rr, 64)
+        for f in ('exposed', 'feedback', 'history', 'user_cat', 'user_dense', 'exposed_len'):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert b.user_dense.dtype == np.float32 and b.history.dtype == np.int32
+    # narrower log_steps truncates like RecordColumns(log_steps=...)
+    a = RecordColumns(recs[3], 64, log_steps=9)
+    b = parse_records_native(recs[3], 64, log_steps=9)
+    assert np.array_equal(a.exposed, b.exposed) and np.array_equal(a.exposed_len, b.exposed_len)
+    for bad in ('a@b', recs[0][0].replace('@', '#', 1), recs[0][0].replace(',', ';', 1)):
+        with pytest.raises(_lib.Rl4rsHipError):
+            parse_records_native([bad], 64, log_steps=9)
+    big = synth.make_records(4000, pages=1, seed=5)
+    t = time.time(); RecordColumns(big, 64); tp = time.time() - t
+    t = time.time(); parse_records_native(big, 64); tn = time.time() - t
+    assert tn < tp
