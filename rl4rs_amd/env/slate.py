@@ -71,7 +71,9 @@ class SlateState(RecState):
         self.page_items = config.get("page_items", 9)
         self.infos = [{} for _ in range(self.batch_size)]
         onehot = config.get('support_onehot_action', False)
-        self._catalog = _catalog(config["iteminfo_file"], self.action_size, self.action_emb_size, onehot)
+        # the reference always takes the last 32 dims (get_iteminfo_from_file default, slate.py:21,29); config's
+        # action_emb_size only shapes the action space
+        self._catalog = _catalog(config["iteminfo_file"], self.action_size, 32, onehot)
         if onehot:                      # slate.py:22-25
             config['action_emb_size'] = self.action_size
             self.action_emb_size = self.action_size

@@ -15,7 +15,7 @@ def _mk_env(cfg, records, seq, log_steps=None, zero_on_violation=None):
     import torch
     from rl4rs_amd.data import CatalogTables, RecordColumns
     from rl4rs_amd.device import DeviceEnv
-    cat = CatalogTables(cfg['iteminfo_file'], cfg['action_size'], cfg.get('action_emb_size', 32))
+    cat = CatalogTables(cfg['iteminfo_file'], cfg['action_size'], 32)
     cols = RecordColumns(records, cfg['maxlen'])
     if zero_on_violation is None:
         zero_on_violation = (not seq) or cfg.get('support_rllib_mask', False) or cfg.get('support_d3rl_mask', False)
@@ -185,3 +185,89 @@ def test_predict_with_mask_from_observation_tail():
     ref = predict_with_mask(scores, obs, cat.location_mask, cat.special_items)
     got = env.predict_with_mask(torch.from_numpy(scores), torch.from_numpy(obs[:, 256:])).cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+def _write_catalog(path, A, D, rs):
+    lines = ["item_id item_vec price location special_item"]
+    for i in range(1, A):
+        vec = ",".join(repr(float(x)) for x in np.round(rs.randn(D), 3))
+        lines.append("%d %s %s %d %d" % (i, vec, repr(float(np.round(rs.uniform(1, 99), 1))), 1, 2 if rs.rand() < 0.3 else 0))
+    with open(path, 'w') as f:
+        f.write("\n".join(lines))
+
+
+@pytest.mark.parametrize('case', range(8))
+def test_hip_env_matches_oracle_odd_configurations(tmp_path, case):
+    """Non-default shapes: item_dim / feature widths that are not multiples of 4 (scalar row path), dense / category
+    widths that truncate or over-pad the rows (datautil.py:52-65), other horizons and page sizes, a 50..200-item
+    catalogue, history longer than maxlen, continuous and discrete actions, both envs."""
+    import torch
+    from rl4rs_amd import device as D
+    from oracle.state import OracleState
+    from oracle.env import reward_from_probs, is_reward_step
+    rs = np.random.RandomState(100 + case)
+    seq = bool(case % 2)
+    A = [50, 200, 284, 97][case % 4]
+    Dm = [33, 40, 37, 45][(case // 2) % 4]      # the reference needs >= 32 dims (action_emb = last 32, slate.py:29,49)
+    E = 32
+    P = [9, 6, 9, 3][(case // 2) % 4] if seq else 9
+    T = (P * [2, 4, 3][case % 3] - (1 if case == 5 else 0)) if seq else [9, 5, 12, 7][case % 4]
+    maxlen = [64, 16, 33, 8][case % 4]
+    Dn = [432, 100, 61, 333][(case + 1) % 4]
+    Cn = [21, 13, 30, 17][(case + 2) % 4]
+    B = 37
+    cat_path = os.path.join(str(tmp_path), 'c.csv')
+    _write_catalog(cat_path, A, Dm, rs)
+    records = []
+    for r in range(B):
+        exposed = rs.randint(1, A, size=T + 3).tolist()
+        fb = rs.randint(0, 2, size=T + 3).tolist()
+        hist = rs.randint(1, A, size=rs.randint(1, 3 * maxlen)).tolist()
+        portrait = [str(int(x)) for x in rs.randint(0, 1000, size=10)] + [repr(float(x)) for x in np.round(rs.rand(32) * 9, 3)]
+        records.append("@".join(["1", str(r), "1", ",".join(map(str, exposed)), ",".join(map(str, fb)),
+                                 ",".join(map(str, hist)), ",".join(portrait), "0.0;0.0", "1"]))
+    for conti in (False, True):
+        if conti and (T > 12 and not seq):
+            continue
+        cfg = {"maxlen": maxlen, "batch_size": B, "action_size": A, "class_num": 2, "dense_feature_num": Dn,
+               "category_feature_num": Cn, "category_hash_size": 1000, "seq_num": 2, "emb_size": 128,
+               "page_items": P, "hidden_units": 128, "max_steps": T, "action_emb_size": E, "iteminfo_file": cat_path,
+               "support_conti_env": conti, "support_rllib_mask": True}
+        if not seq and T > 12:
+            continue
+        env, cat, cols = _mk_env(cfg, records, seq)
+        st = OracleState(cfg, records, seq=seq)
+        s0, s1, dense, catf = (env.snapshot(D.BUF_SEQ0).cpu().numpy(), env.snapshot(D.BUF_SEQ1).cpu().numpy(),
+                               env.snapshot(D.BUF_DENSE).cpu().numpy(), env.snapshot(D.BUF_CATEGORY).cpu().numpy())
+        q, d0, c0 = st.features()
+        assert np.array_equal(np.stack([s0, s1], 1), q) and np.array_equal(dense, d0) and np.array_equal(catf, c0)
+        for t in range(T):
+            layer = (t % P // 3) if seq else t // 3
+            if layer > 3:
+                break
+            if conti:
+                a = rs.randn(B, E)
+                assert np.array_equal(env.act_conti(a).cpu().numpy(), st.act(a)), (case, t)
+            else:
+                a = np.where(rs.rand(B) < 0.6, np.asarray(st.offline_action), rs.randint(0, A, size=B))
+                env.act_discrete(a)
+                st.act(a)
+            q, dense, catf = st.features()
+            assert np.array_equal(env.snapshot(D.BUF_DENSE).cpu().numpy(), dense), (case, t)
+            assert np.array_equal(env.snapshot(D.BUF_CATEGORY).cpu().numpy(), catf), (case, t)
+            assert np.array_equal(env.snapshot(D.BUF_SEQ1).cpu().numpy(), q[:, 1]), (case, t)
+            post_layer = (st.cur_steps % P // 3) if seq else st.cur_steps // 3
+            if post_layer <= 3:
+                assert np.array_equal(env.obs_mask().cpu().numpy(), st.obs_action_mask()), (case, t)
+            assert np.array_equal(env.violation().cpu().numpy(), st.get_violation()), (case, t)
+            if is_reward_step(st):
+                env.build_complete()
+                _, cd, cc = st.complete_features()
+                assert np.array_equal(env.snapshot(D.BUF_C_DENSE).cpu().numpy(), cd), (case, t)
+                assert np.array_equal(env.snapshot(D.BUF_C_CATEGORY).cpu().numpy(), cc), (case, t)
+                probs = rs.rand(B, env.n_complete).astype(np.float32)
+                r = env.reward(torch.from_numpy(probs).cuda().reshape(-1)).cpu().numpy()
+                assert np.array_equal(r, np.asarray(reward_from_probs(st, probs), dtype=np.float64)), (case, t)
+        assert np.array_equal(env.snapshot(D.BUF_PREV_ACTIONS).cpu().numpy(), st.prev_actions)
+        env.check_error_flag()
+        env.close()
