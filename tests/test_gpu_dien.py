@@ -135,3 +135,31 @@ def test_dien_is_batch_position_invariant():
     assert torch.equal(obsG.reshape(B, G, 256), obs1[:, None, :].expand(B, G, 256))  # position / group size
     assert torch.equal(pG.reshape(B, G), p1[:, None].expand(B, G))
     net.close()
+
+
+@pytest.mark.parametrize('variant', [dict(maxlen=33, category_feature_num=13, hidden_units=96, dense_feature_num=61, seq_num=3, class_num=3),
+                                     dict(maxlen=64, category_feature_num=7, hidden_units=32, dense_feature_num=432, seq_num=1, class_num=2),
+                                     dict(maxlen=16, category_feature_num=32, hidden_units=128, dense_feature_num=40, seq_num=2, class_num=2)])
+def test_dien_other_configurations(variant):
+    """Non-default DIEN shapes (sequence length, category count, tower width, number of sequence inputs, classes)."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from oracle.dien import OracleDien
+    cfg = dict(CFG, **variant)
+    L, Cn, Dn, S = cfg['maxlen'], cfg['category_feature_num'], cfg['dense_feature_num'], cfg['seq_num']
+    w = init_dien_weights(cfg, seed=5, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(7)
+    R = 45
+    seq = rs.randint(0, 284, size=(R, S, L)).astype(np.int32)
+    dense = np.abs(rs.randn(R, Dn) * 3).astype(np.float32)
+    cat = rs.randint(0, cfg['category_hash_size'], size=(R, Cn)).astype(np.int32)
+    net = DeviceDien(cfg, w, max_rows=R, max_slots=R)
+    for s in range(S):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    slots = torch.arange(R, dtype=torch.int32).repeat(S, 1).contiguous().cuda()
+    obs, prob = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, True, True)
+    orc = OracleDien(w, cfg, np.float64)
+    assert np.abs(obs.cpu().numpy() - orc.obs(seq, dense, cat)).max() < 5e-5
+    assert np.abs(prob.cpu().numpy() - orc.reward_probs(seq, dense, cat)[:, 1]).max() < 5e-6
+    net.close()
