@@ -799,9 +799,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         size_t sm_aug = (size_t)(2 * 32 * (NH2 + 4) + 32 * (L + 1) + 32) * 4;
         size_t sm_gru = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
         const void* augru_variants[] = {
-            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 0>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 1>),
-            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 2>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 4>),
-            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 8>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 15>)};
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 0>),
+#ifdef RL4RS_ABLATE
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 1>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 2>),
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 4>), reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 8>),
+            reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 15>),
+#endif
+        };
         for (const void* f : augru_variants)
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
@@ -907,9 +911,10 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         for (int s = 0; s < S; ++s) { a.xbase[s] = n->proj[s]; a.wg[s] = n->augru_wg[s]; a.wc[s] = n->augru_wc[s]; }
         a.att = n->scores; a.att_stride = (int64_t)n->c.max_rows * L;
         a.out = n->allf; a.out_ld = F; a.out_off = 0; a.out_seq_off = NH2; a.slot_base = 0;
-        static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;
         dim3 grid((R + 31) / 32, S), block(512);
-        switch (ablate) {      // timing experiments only
+#ifdef RL4RS_ABLATE      // timing experiments only (tools/ablate_augru.sh builds with -DRL4RS_ABLATE)
+        static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;
+        switch (ablate) {
             case 1: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 1>), grid, block, smem, st, a); break;
             case 2: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 2>), grid, block, smem, st, a); break;
             case 4: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 4>), grid, block, smem, st, a); break;
@@ -917,6 +922,9 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             case 15: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 15>), grid, block, smem, st, a); break;
             default: hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 0>), grid, block, smem, st, a); break;
         }
+#else
+        hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 0>), grid, block, smem, st, a);
+#endif
         RL4RS_LAUNCH_CHECK();
     }
     float* obs_out = obs ? obs : n->obs_tmp;
