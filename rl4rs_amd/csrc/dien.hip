@@ -377,6 +377,198 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// AUGRU with fp16x2 operand splitting (OPTIONAL mode, RL4RS_SCORER=fp16x2; the default is the exact fp32 kernel).
+//   a = a_hi + a_lo,  a_hi = fp16(a), a_lo = fp16(a - a_hi)      (both operands; weights are split at load time)
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi                       (3 v_mfma_f32_32x32x16_f16 per 16-wide k-block)
+// The dropped a_lo*b_lo term and the fp16 rounding of the lo parts leave a relative error ~2^-22 per product
+// (fp32 keeps 2^-24); products are exact in the fp32 accumulator.  h and r*h live in (-1,1), so the un-scaled lo parts
+// only reach fp16 subnormals (absolute error <= 2^-25) - no scaling needed.  The matrix pipe runs this 16/3 = 5.3x
+// faster than the fp32 form at the SAME weight bytes (2 planes x 2 B), so the kernel becomes bound by the L2 weight
+// stream and the cached x-projection loads rather than by MFMA issue.  Same workgroup shape / schedule as k_recur.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+struct h8bits { half8_t v; };
+
+__device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return __builtin_bit_cast(half8_t, v);
+}
+
+template <int U>
+__global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
+    constexpr int NH = 256, NW = 8, KB = NH / 16, LDP = NH + 8, NG = KB / U;     // KB = 16-wide k-blocks
+    static_assert(KB % U == 0 && (NG % 2) == 0, "k-block groups");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* hp_hi = reinterpret_cast<_Float16*>(smem);     // [32][LDP] each
+    _Float16* hp_lo = hp_hi + 32 * LDP;
+    _Float16* rp_hi = hp_lo + 32 * LDP;
+    _Float16* rp_lo = rp_hi + 32 * LDP;
+    float* s_att = reinterpret_cast<float*>(rp_lo + 32 * LDP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, li = lane & 31;
+    const int row0 = blockIdx.x * 32;
+    const int sq = blockIdx.y;
+    const int L = a.L, LDT = L + 1;
+    const int col = wave * 32 + li;
+    const int xld4 = (int)a.xld * 4;
+    // packed fp16 planes: [ntile][KB][plane hi/lo][64 lanes][8 halfs] -> 1 KB per (ntile, kb, plane)
+    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
+    const int vl16 = lane * 16;
+    const int so_r = wave * KB * 2048, so_u = (NW + wave) * KB * 2048, so_c = wave * KB * 2048;   // + kb*2048 + plane*1024
+
+    for (int i = tid; i < 2 * 32 * LDP; i += 512) hp_hi[i] = (_Float16)0.f;     // hi and lo planes of h
+    for (int i = tid; i < 32 * L; i += 512) {
+        int r = i / L, t = i - r * L;
+        int gr = min(row0 + r, a.n_rows - 1);
+        s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
+    }
+    uint32_t* s_xoff = reinterpret_cast<uint32_t*>(s_att + 32 * LDT);
+    if (tid < 32) {
+        int gr = min(row0 + tid, a.n_rows - 1);
+        s_xoff[tid] = (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4;
+    }
+    f32x16 h_own;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
+    const int aoff = li * LDP + half * 8;
+    const int xcol4 = (a.xoff + col) * 4;
+    __syncthreads();
+
+    auto load_x = [&](f32x16& dst, int t, int block) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dst[r] = buf_load1(rs_x, (int)s_xoff[crow(r, half)] + xcol4, t * xld4 + block * NH * 4);
+    };
+    f32x16 xr_, xu_, xc_;
+    half8_t wrh[2][U], wrl[2][U], wuh[2][U], wul[2][U], ah[2][U], al[2][U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        wrh[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048);
+        wrl[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048 + 1024);
+        wuh[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048);
+        wul[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048 + 1024);
+    }
+    load_x(xr_, 0, 0);
+    load_x(xu_, 0, 1);
+
+    for (int t = 0; t < L; ++t) {
+        f32x16 acc_r, acc_u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_u[r] = 0.f; }
+        // ---- phase 1: gates
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            ah[0][i] = *reinterpret_cast<const half8_t*>(hp_hi + aoff + i * 16);
+            al[0][i] = *reinterpret_cast<const half8_t*>(hp_lo + aoff + i * 16);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int kb = (g + 1) * U + i;
+                    wrh[nb][i] = buf_load_h8(rs_wg, vl16, so_r + kb * 2048);
+                    wrl[nb][i] = buf_load_h8(rs_wg, vl16, so_r + kb * 2048 + 1024);
+                    wuh[nb][i] = buf_load_h8(rs_wg, vl16, so_u + kb * 2048);
+                    wul[nb][i] = buf_load_h8(rs_wg, vl16, so_u + kb * 2048 + 1024);
+                    ah[nb][i] = *reinterpret_cast<const half8_t*>(hp_hi + aoff + kb * 16);
+                    al[nb][i] = *reinterpret_cast<const half8_t*>(hp_lo + aoff + kb * 16);
+                }
+            } else {
+                load_x(xc_, t, 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrh[cb][i], acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wuh[cb][i], acc_u, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrl[cb][i], acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wul[cb][i], acc_u, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wrh[cb][i], acc_r, 0, 0, 0);
+                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wuh[cb][i], acc_u, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // first candidate-weight group while the epilogue runs (re-uses the gate ring registers)
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            wrh[0][i] = buf_load_h8(rs_wc, vl16, so_c + i * 2048);
+            wrl[0][i] = buf_load_h8(rs_wc, vl16, so_c + i * 2048 + 1024);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float rg = gate_sigmoid(acc_r[r] + xr_[r]);
+            acc_u[r] = gate_sigmoid(acc_u[r] + xu_[r]);
+            const float v = rg * h_own[r];
+            const _Float16 vh = (_Float16)v;
+            rp_hi[crow(r, half) * LDP + col] = vh;
+            rp_lo[crow(r, half) * LDP + col] = (_Float16)(v - (float)vh);
+        }
+        __syncthreads();
+        // ---- phase 2: candidate + state update
+        f32x16 acc_c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_c[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            ah[0][i] = *reinterpret_cast<const half8_t*>(rp_hi + aoff + i * 16);
+            al[0][i] = *reinterpret_cast<const half8_t*>(rp_lo + aoff + i * 16);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int kb = (g + 1) * U + i;
+                    wrh[nb][i] = buf_load_h8(rs_wc, vl16, so_c + kb * 2048);
+                    wrl[nb][i] = buf_load_h8(rs_wc, vl16, so_c + kb * 2048 + 1024);
+                    ah[nb][i] = *reinterpret_cast<const half8_t*>(rp_hi + aoff + kb * 16);
+                    al[nb][i] = *reinterpret_cast<const half8_t*>(rp_lo + aoff + kb * 16);
+                }
+            } else if (t + 1 < L) {
+                load_x(xr_, t + 1, 0);
+                load_x(xu_, t + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrh[cb][i], acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrl[cb][i], acc_c, 0, 0, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wrh[cb][i], acc_c, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // first gate-weight group of the next step
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            wrh[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048);
+            wrl[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048 + 1024);
+            wuh[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048);
+            wul[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048 + 1024);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float c = gate_tanh(acc_c[r] + xc_[r]);
+            float u = (1.0f - s_att[crow(r, half) * LDT + t]) * acc_u[r];
+            float hn = u * h_own[r] + (1.0f - u) * c;
+            h_own[r] = hn;
+            const _Float16 vh = (_Float16)hn;
+            hp_hi[crow(r, half) * LDP + col] = vh;
+            hp_lo[crow(r, half) * LDP + col] = (_Float16)(hn - (float)vh);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (row0 + crow(r, half) < a.n_rows)
+            a.out[(int64_t)(row0 + crow(r, half)) * a.out_ld + a.out_off + sq * a.out_seq_off + col] = h_own[r];
+}
+
+// -------------------------------------------------------------------------------------------------
 // DIN attention scores (deepctr LocalActivationUnit, att_hidden_units=(64,16), sigmoid, raw scores).
 //   hid1^T [64 units x L steps] = W1d^T (q*h1_t) + qa + AK_t    as 2x2 32x32 MFMA tiles per row
 //   hid2 = sigmoid(hid1 W2 + b2), score = hid2 w3 + b3           in registers (+ one half-wave swap)
@@ -606,6 +798,9 @@ struct rl4rs_dien {
     float* w1ac[4];        // [E, 64]
     float* w1d[4];         // packed [2][E/8][64][4]
     float *att_w2[4], *att_b2[4], *att_w3[4], *att_b3[4];
+    float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
+    float* augru_wc16[4];
+    bool fp16x2;
     float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
     float* augru_wc[4];
     // caches
@@ -651,6 +846,62 @@ std::vector<float> pack_frag(const float* w, int ld, int k_off, int K, int N) {
                     out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + i] = w[(size_t)(k_off + k) * ld + j];
                 }
     return out;
+}
+
+// fp32 -> fp16 bits, round to nearest even (subnormals kept)
+uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // overflow -> inf
+    if (x < 0x38800000u) {                                                   // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                           // 14..24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+// pack Wh [K, N] (rows k_off..) into fp16 hi/lo B-fragment planes for v_mfma_f32_32x32x16_f16:
+// [ntile][kb16][plane][lane][8]: element i of lane (j = lane&31, kg = lane>>5) is W[kb16*16 + kg*8 + i][nt*32 + j]
+std::vector<float> pack_frag_h16(const float* w, int ld, int k_off, int K, int N) {
+    const int KB = K / 16, NT = N / 32;
+    std::vector<uint16_t> out((size_t)NT * KB * 2 * 64 * 8);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const float v = w[(size_t)(k_off + kb * 16 + (lane >> 5) * 8 + i) * ld + nt * 32 + (lane & 31)];
+                    const uint16_t hi = f32_to_f16(v);
+                    const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                    const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8 + i;
+                    out[base] = hi;
+                    out[base + 512] = lo;
+                }
+    std::vector<float> f(out.size() / 2);
+    memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
 }
 
 struct Prof {
@@ -707,6 +958,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->E = E; n->U = U; n->L = L; n->S = S; n->Cn = Cn; n->Dn = Dn; n->H = H; n->K = K; n->F = F;
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = false;
+    { const char* sp = getenv("RL4RS_SCORER"); n->fp16x2 = sp && strcmp(sp, "fp16x2") == 0; }
     for (int i = 0; i < KID_COUNT; ++i) { n->ms_total[i] = 0; n->launches[i] = 0; }
     int rc;
 #define UP(dst, src, cnt) if ((rc = upload(n, &n->dst, (src), (size_t)(cnt), st)) != RL4RS_OK) return rc
@@ -784,6 +1036,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         UP(augru_wg[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w->augru_cand_w[s], NH2, E, NH2, NH2));
         UP(augru_wc[s], keep.back().data(), keep.back().size());
+        n->augru_wg16[s] = n->augru_wc16[s] = nullptr;
+        if (n->fp16x2) {
+            keep.push_back(pack_frag_h16(w->augru_gate_w[s], 2 * NH2, E, NH2, 2 * NH2));
+            UP(augru_wg16[s], keep.back().data(), keep.back().size());
+            keep.push_back(pack_frag_h16(w->augru_cand_w[s], NH2, E, NH2, NH2));
+            UP(augru_wc16[s], keep.back().data(), keep.back().size());
+        }
         AL(h1[s], (size_t)c->max_slots * L * E);
         AL(proj[s], (size_t)c->max_slots * L * PLD);
     }
@@ -808,6 +1067,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         };
         for (const void* f : augru_variants)
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true>),
@@ -912,6 +1173,11 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         a.att = n->scores; a.att_stride = (int64_t)n->c.max_rows * L;
         a.out = n->allf; a.out_ld = F; a.out_off = 0; a.out_seq_off = NH2; a.slot_base = 0;
         dim3 grid((R + 31) / 32, S), block(512);
+        if (n->fp16x2) {
+            for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
+            size_t smem16 = (size_t)4 * 32 * (NH2 + 8) * 2 + (size_t)(32 * (L + 1) + 32) * 4;
+            hipLaunchKernelGGL((k_augru_h16<2>), grid, block, smem16, st, a);
+        } else
 #ifdef RL4RS_ABLATE      // timing experiments only (tools/ablate_augru.sh builds with -DRL4RS_ABLATE)
         static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;
         switch (ablate) {
@@ -925,6 +1191,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
 #else
         hipLaunchKernelGGL((k_recur<256, true, AUGRU_U, 0>), grid, block, smem, st, a);
 #endif
+        ;
         RL4RS_LAUNCH_CHECK();
     }
     float* obs_out = obs ? obs : n->obs_tmp;
