@@ -23,6 +23,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# HBM bytes per AUGRU launch of the default workload, from the PMC passes (None until measured for a mode)
+TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 8.41e8}
+MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -40,7 +43,7 @@ def make_config(args, workdir, rank):
            "category_feature_num": 21, "category_hash_size": 100000, "seq_num": 2, "emb_size": 128,
            "page_items": 9, "hidden_units": 128, "max_steps": args.horizon, "action_emb_size": 32,
            "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": False, "cache_size": 2048,
-           "model_seed": 7, "return_tensors": True}
+           "model_seed": 7, "return_tensors": True, "scorer_precision": args.scorer}
     return cfg, records
 
 
@@ -101,6 +104,9 @@ def main():
     ap.add_argument('--log-records', type=int, default=8193)
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scorer', choices=['auto', 'fp32', 'fp16x2'], default='auto',
+                    help='arithmetic of the AUGRU recurrence (config scorer_precision); auto = fp16x2 operand split, '
+                         'fp32 accumulate, same measured error as the exact fp32 MFMA kernel')
     ap.add_argument('--train', choices=['none', 'a2c', 'ppo'], default='none',
                     help='none: offline_action replay (BASELINE configs[1]); a2c/ppo: policy rollout + update with the '
                          'flat-gradient all-reduce over RCCL (configs[2]/[3])')
@@ -151,23 +157,29 @@ def main():
         # FLOPs per row per sequence input: L steps x (2E x 6E) MACs x 2.
         L, E = cfg['maxlen'], cfg['emb_size']
         flop_row_seq = L * (2 * E) * (6 * E) * 2
-        ms, launches = prof['k_recur<256,augru>']
+        kname = net.augru_kernel
+        ms, launches = prof[kname]
         n_complete = T if not seq else cfg['page_items']
         reward_calls = 1 if not seq else T // cfg['page_items']
         # reset obs + T step obs + reward rows (the last reward row of an env reuses the state row just scored)
         rows_per_episode = (T + 1) * B + reward_calls * (n_complete - 1) * B
         flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "k_recur<256,augru>", "achieved": achieved,
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+        if net.scorer_mode == 'fp16x2':
+            # each fp32-class product costs 3 f16 MFMAs (hi*hi + hi*lo + lo*hi): peak in algorithmic FLOPs = f16 dense / 3
+            peak, peak_note = MFMA_F16_PEAK_TFLOPS / 3.0, "v_mfma_f32_32x32x16_f16 dense 2500 TF/s / 3 MFMAs per product"
+        else:
+            peak, peak_note = MFMA_F32_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 dense"
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved,
+                    "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
                     "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
                     "kernel_ms_share": ms / (elapsed * 1e3)}
         if not seq and B == 4096 and T == 9 and not trainer:
             # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
-            # corrected as MI355X_MICROARCH.md prescribes; profiles/r01c_pmc.md): launch-weighted mean of the
-            # 10 obs-sized (897 MB) and 1 reward-sized (883 MB) launches of an episode
-            roofline["traffic"] = 8.96e8
-            roofline["traffic_unit"] = "B/launch (PMC, profiles/r01c_pmc.md)"
+            # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
+            # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 836 / 888 MB)
+            roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
+            roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01e_pmc.md fp16x2)"
         kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples
@@ -197,7 +209,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if net.scorer_mode == 'fp32' else "f32 (AUGRU operands as fp16 hi+lo pairs, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU, 284-item catalogue, 9-slot slate, %d-step horizon, "
                                    "DIEN simulator scorer, offline_action replay"

@@ -198,7 +198,15 @@ typedef struct rl4rs_dien_cfg {
     int32_t class_num;             /* 2   */
     int32_t max_rows;              /* largest R passed to rl4rs_dien_forward */
     int32_t max_slots;             /* sequence-cache slots per sequence input */
+    int32_t scorer_mode;           /* RL4RS_SCORER_* : arithmetic of the AUGRU recurrence (the dominant kernel) */
 } rl4rs_dien_cfg;
+
+/* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):
+ *   FP32   v_mfma_f32_32x32x2_f32, operands exact.
+ *   FP16X2 operands split into fp16 hi + lo, 3 v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi):
+ *          ~2^-22 relative error per product, 2.3x faster.  Needs every AUGRU weight |w| < 6e4 (fp16 range).
+ *   AUTO   environment RL4RS_SCORER=fp32|fp16x2 if set, else FP16X2 when the weights allow it, else FP32. */
+enum { RL4RS_SCORER_AUTO = 0, RL4RS_SCORER_FP32 = 1, RL4RS_SCORER_FP16X2 = 2 };
 
 /* Host pointers to float32 arrays, shapes in rl4rs_amd/nets/dien.py (dien_spec). seq arrays have
  * seq_num entries (max 4). */
@@ -221,6 +229,8 @@ typedef struct rl4rs_dien_weights {
 int rl4rs_dien_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, void* stream,
                       rl4rs_dien** out);
 int rl4rs_dien_destroy(rl4rs_dien* net);
+/* The mode the handle resolved to (RL4RS_SCORER_FP32 or RL4RS_SCORER_FP16X2). */
+int rl4rs_dien_scorer_mode(rl4rs_dien* net, int32_t* mode);
 
 /* Encode `n` id sequences of sequence input `s` into cache slots [slot_base, slot_base+n):
  * embedding lookup + first GRU over all maxlen steps (utils.py:119-120) and the input-side

@@ -27,7 +27,7 @@ class EnvCfg(C.Structure):
 class DienCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num',
-        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots')]
+        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots', 'scorer_mode')]
 
 
 _FP = C.POINTER(C.c_float)
@@ -83,6 +83,7 @@ SIGNATURES = {
     'rl4rs_env_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
     'rl4rs_dien_create': (_I, [C.POINTER(DienCfg), C.POINTER(DienWeights), _P, C.POINTER(_P)]),
     'rl4rs_dien_destroy': (_I, [_P]),
+    'rl4rs_dien_scorer_mode': (_I, [_P, C.POINTER(_I32)]),
     'rl4rs_dien_encode': (_I, [_P, _I32, _P, _I32, _I32, _P]),
     'rl4rs_dien_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'rl4rs_dien_head_prob': (_I, [_P, _I32, _P, _P, _P]),

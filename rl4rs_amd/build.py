@@ -28,6 +28,7 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
         cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
+               '-mllvm', '-pragma-unroll-threshold=200000',     # k_augru_h16: 48 weight items per step, fully unrolled
                '-c', os.path.join(CSRC, src), '-o', obj] + list(extra_flags)
         if verbose:
             print(' '.join(cmd))

@@ -30,6 +30,14 @@ constexpr int ATT_H1 = 64, ATT_H2 = 16, OBS_DIM = 256;
 #define RL4RS_AUGRU_U 2
 #endif
 constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-ring slot
+#ifndef RL4RS_H16_NRES
+#define RL4RS_H16_NRES 14        // weight items of a step kept resident in registers (k_augru_h16)
+#endif
+#ifndef RL4RS_H16_RING1
+#define RL4RS_H16_RING1 4        // weight ring depth (items) of k_augru_h16: 3 items = 9 MFMAs ahead;
+                                 // measured (ring, resident): (8,10) 60.6 ms, (6,12) 59.5, (4,14) 59.0 per 5 episodes
+#endif
+
 
 // -------------------------------------------------------------------------------------------------
 // Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
@@ -161,6 +169,7 @@ struct RecurArgs {
     const float* att; int64_t att_stride;          // AUGRU: [n_seq][att_stride] rows of L
     float* out; int64_t out_ld; int out_off; int out_seq_off;   // GRU: h1 cache rows ; AUGRU: allf
     int slot_base;
+    unsigned long long* trace;   // -DRL4RS_H16_TRACE timing experiments only
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -377,14 +386,13 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// AUGRU with fp16x2 operand splitting (OPTIONAL mode, RL4RS_SCORER=fp16x2; the default is the exact fp32 kernel).
+// AUGRU with fp16x2 operand splitting (scorer_mode RL4RS_SCORER_FP16X2, the AUTO default when the weights fit fp16 range).
 //   a = a_hi + a_lo,  a_hi = fp16(a), a_lo = fp16(a - a_hi)      (both operands; weights are split at load time)
 //   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi                       (3 v_mfma_f32_32x32x16_f16 per 16-wide k-block)
 // The dropped a_lo*b_lo term and the fp16 rounding of the lo parts leave a relative error ~2^-22 per product
 // (fp32 keeps 2^-24); products are exact in the fp32 accumulator.  h and r*h live in (-1,1), so the un-scaled lo parts
-// only reach fp16 subnormals (absolute error <= 2^-25) - no scaling needed.  The matrix pipe runs this 16/3 = 5.3x
-// faster than the fp32 form at the SAME weight bytes (2 planes x 2 B), so the kernel becomes bound by the L2 weight
-// stream and the cached x-projection loads rather than by MFMA issue.  Same workgroup shape / schedule as k_recur.
+// only reach fp16 subnormals (absolute error <= 2^-25) - no scaling needed; the weights are range-checked at load.
+// The matrix pipe runs this 16/3 = 5.3x faster than the fp32 form at the SAME weight bytes (2 planes x 2 B).
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 struct h8bits { half8_t v; };
 
@@ -393,20 +401,47 @@ __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int 
     return __builtin_bit_cast(half8_t, v);
 }
 
-template <int U>
+// Schedule ("gate-sliced", MT row tiles of 32 rows per workgroup, wave w owns hidden columns [32w, 32w+32)):
+//   one step = 3*KB weight items (gate g = r,u,c ; k-block kb), each item = 3*MT MFMAs on ONE weight fragment pair
+//     slot R  (items  0..KB-1)  : acc_r += h  Wr                    - matrix pipe only
+//     slot U  (items KB..2KB-1) : acc_u += h  Wu    || VALU: r = sigmoid(acc_r), r*h -> fp16 hi/lo planes (item kb
+//                                                      retires accumulator register kb of every tile)
+//     barrier
+//     slot C  (items 2KB..3KB-1): acc_c += (r*h) Wc || VALU: u = (1 - a_t) sigmoid(acc_u)
+//     exposed: c = tanh(acc_c), h' = u h + (1-u) c -> fp16 hi/lo planes ; barrier
+//   Two of the three epilogues execute in the shadow of the MFMAs.  The cached input projections are loaded straight
+//   INTO the accumulators (MFMA C-in), so they cost no registers; they are requested at points that are followed by a
+//   long stretch without weight waits (the in-order vmcnt makes every later weight wait also wait for them: ~5K
+//   cycles when they were issued inside slot R).  The weight fragments stream through a RING-deep register ring, LA =
+//   RING-1 items ahead, across slots and steps; the first NRES items of a step stay resident in registers.
+//   What bounds it (s_memtime marks of one workgroup, tools/h16_trace.py; PMC: matrix pipe ~41 % busy): the L1 /
+//   texture-address path.  8 waves x 2 KB of weight fragments per item at 64 B/clk = 256 cycles against 192 cycles
+//   of MFMA, plus ~3.3K cycles per step for the 384 dword-per-lane projection loads; the two waves of a SIMD
+//   therefore take ~300 cycles per item pair, the exposed epilogue ~6K cycles per step (of ~23K).  Tried and measured
+//   flat: separate accumulators for the hi*lo / lo*hi products (no dependent-MFMA stall to remove), ping-pong u/c
+//   accumulator sets with all projections requested at the start of the epilogue, 64-row workgroups (MT = 2: halves
+//   the weight bytes per row but spills at 256 registers; +2 % on the reward-sized launch).  Resident weights are the
+//   lever that worked (-6 % at 14 of 48 items).  Next: a 64-row form that fits, or LDS-DMA staging of the ring.
+#ifdef RL4RS_H16_TRACE     // s_memtime marks of workgroup (0,0), steps 8..11: [wave][step][mark]
+#define RL4RS_TR(k) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t >= 8 && t < 12) \
+        a.trace[(wave * 4 + (t - 8)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RL4RS_TR(k) do { } while (0)
+#endif
+template <int MT, int RING, int NRES>
 __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
-    constexpr int NH = 256, NW = 8, KB = NH / 16, LDP = NH + 8, NG = KB / U;     // KB = 16-wide k-blocks
-    static_assert(KB % U == 0 && (NG % 2) == 0, "k-block groups");
+    constexpr int NH = 256, NW = 8, KB = NH / 16, LDP = NH + 8, MR = MT * 32, NI = 3 * KB, LA = RING - 1;
+    static_assert(NI % RING == 0 && RING >= 2 && RING <= KB && NRES >= 0 && NRES <= KB, "weight ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* hp_hi = reinterpret_cast<_Float16*>(smem);     // [32][LDP] each
-    _Float16* hp_lo = hp_hi + 32 * LDP;
-    _Float16* rp_hi = hp_lo + 32 * LDP;
-    _Float16* rp_lo = rp_hi + 32 * LDP;
-    float* s_att = reinterpret_cast<float*>(rp_lo + 32 * LDP);
+    _Float16* hp_hi = reinterpret_cast<_Float16*>(smem);     // [MR][LDP] each
+    _Float16* hp_lo = hp_hi + MR * LDP;
+    _Float16* rp_hi = hp_lo + MR * LDP;
+    _Float16* rp_lo = rp_hi + MR * LDP;
+    float* s_att = reinterpret_cast<float*>(rp_lo + MR * LDP);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, li = lane & 31;
-    const int row0 = blockIdx.x * 32;
+    const int row0 = blockIdx.x * MR;
     const int sq = blockIdx.y;
     const int L = a.L, LDT = L + 1;
     const int col = wave * 32 + li;
@@ -418,154 +453,175 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     const int vl16 = lane * 16;
     const int so_r = wave * KB * 2048, so_u = (NW + wave) * KB * 2048, so_c = wave * KB * 2048;   // + kb*2048 + plane*1024
 
-    for (int i = tid; i < 2 * 32 * LDP; i += 512) hp_hi[i] = (_Float16)0.f;     // hi and lo planes of h
-    for (int i = tid; i < 32 * L; i += 512) {
+    for (int i = tid; i < 2 * MR * LDP; i += 512) hp_hi[i] = (_Float16)0.f;     // hi and lo planes of h
+    for (int i = tid; i < MR * L; i += 512) {
         int r = i / L, t = i - r * L;
         int gr = min(row0 + r, a.n_rows - 1);
         s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
     }
-    uint32_t* s_xoff = reinterpret_cast<uint32_t*>(s_att + 32 * LDT);
-    if (tid < 32) {
+    uint32_t* s_xoff = reinterpret_cast<uint32_t*>(s_att + MR * LDT);
+    if (tid < MR) {
         int gr = min(row0 + tid, a.n_rows - 1);
         s_xoff[tid] = (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4;
     }
-    f32x16 h_own;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
     const int aoff = li * LDP + half * 8;
     const int xcol4 = (a.xoff + col) * 4;
     __syncthreads();
 
-    auto load_x = [&](f32x16& dst, int t, int block) {
+    // weight item i of a step: gate i / KB, k-block i % KB (i is a compile-time constant after unrolling).
+    // The three scalar bases are made opaque once per step so that the 96 per-item scalar offsets are re-derived
+    // with one s_add each instead of being hoisted out of the step loop (which spills SGPRs).
+    int sb_r = so_r, sb_u = so_u, sb_c = so_c;
+    auto wload = [&](int i, half8_t& hi, half8_t& lo) {
+        const int g = i / KB, kb = i % KB;
+        if (g == 0) {
+            hi = buf_load_h8(rs_wg, vl16, sb_r + kb * 2048); lo = buf_load_h8(rs_wg, vl16, sb_r + kb * 2048 + 1024);
+        } else if (g == 1) {
+            hi = buf_load_h8(rs_wg, vl16, sb_u + kb * 2048); lo = buf_load_h8(rs_wg, vl16, sb_u + kb * 2048 + 1024);
+        } else {
+            hi = buf_load_h8(rs_wc, vl16, sb_c + kb * 2048); lo = buf_load_h8(rs_wc, vl16, sb_c + kb * 2048 + 1024);
+        }
+    };
+    // cached input projection of (tile m, step t, gate block) -> accumulator (C-in of the gate's MFMA chain)
+    // (the per-row cache offsets are re-read from LDS at every use: keeping them live would cost 16*MT registers)
+    auto load_x = [&](f32x16& dst, int m, int t, int block) {
+        const uint32_t* px = s_xoff + m * 32 + 4 * half;
+        asm volatile("" : "+v"(px));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            dst[r] = buf_load1(rs_x, (int)s_xoff[crow(r, half)] + xcol4, t * xld4 + block * NH * 4);
+            dst[r] = buf_load1(rs_x, (int)px[crow(r, 0)] + xcol4, t * xld4 + block * NH * 4);
     };
-    f32x16 xr_, xu_, xc_;
-    half8_t wrh[2][U], wrl[2][U], wuh[2][U], wul[2][U], ah[2][U], al[2][U];
+    f32x16 acc_r[MT], acc_u[MT], acc_c[MT], h_own[MT];
+    half8_t wh[RING], wl[RING], ah[2][MT], al[2][MT];
+    // The kernel is bound by the L1 / texture-address path, not by the matrix pipe: 8 waves x 2 KB of weight
+    // fragments per item at 64 B/clk = 256 cycles against 192 cycles of MFMA (s_memtime marks, tools/h16_trace.py).
+    // The first NRES items of a step therefore stay in registers for the whole kernel (NRES * 8 registers per wave).
+    half8_t res_h[NRES > 0 ? NRES : 1], res_l[NRES > 0 ? NRES : 1];
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-        wrh[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048);
-        wrl[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048 + 1024);
-        wuh[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048);
-        wul[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048 + 1024);
+    for (int i = 0; i < NRES; ++i) wload(i, res_h[i], res_l[i]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h_own[m][r] = 0.f;
+        load_x(acc_r[m], m, 0, 0);
+        load_x(acc_u[m], m, 0, 1);
+        load_x(acc_c[m], m, 0, 2);
     }
-    load_x(xr_, 0, 0);
-    load_x(xu_, 0, 1);
+#pragma unroll
+    for (int i = NRES; i < NRES + LA; ++i) wload(i, wh[i % RING], wl[i % RING]);
 
+#pragma unroll 1
     for (int t = 0; t < L; ++t) {
-        f32x16 acc_r, acc_u;
+        asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));
+        RL4RS_TR(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_u[r] = 0.f; }
-        // ---- phase 1: gates
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            ah[0][i] = *reinterpret_cast<const half8_t*>(hp_hi + aoff + i * 16);
-            al[0][i] = *reinterpret_cast<const half8_t*>(hp_lo + aoff + i * 16);
+        for (int m = 0; m < MT; ++m) {
+            ah[0][m] = *reinterpret_cast<const half8_t*>(hp_hi + m * 32 * LDP + aoff);
+            al[0][m] = *reinterpret_cast<const half8_t*>(hp_lo + m * 32 * LDP + aoff);
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int cb = g & 1, nb = cb ^ 1;
-            if (g + 1 < NG) {
+        for (int i = 0; i < NI; ++i) {
+            const int g = i / KB, kb = i % KB, cb = i & 1, nb = cb ^ 1;
+            if (i == KB) RL4RS_TR(1);
+            if (i == 2 * KB) {
+                RL4RS_TR(2);
+                // r*h planes complete; the operand fragments of item 2KB are read here (never across the barrier)
+                __syncthreads();
+                RL4RS_TR(3);
 #pragma unroll
-                for (int i = 0; i < U; ++i) {
-                    const int kb = (g + 1) * U + i;
-                    wrh[nb][i] = buf_load_h8(rs_wg, vl16, so_r + kb * 2048);
-                    wrl[nb][i] = buf_load_h8(rs_wg, vl16, so_r + kb * 2048 + 1024);
-                    wuh[nb][i] = buf_load_h8(rs_wg, vl16, so_u + kb * 2048);
-                    wul[nb][i] = buf_load_h8(rs_wg, vl16, so_u + kb * 2048 + 1024);
-                    ah[nb][i] = *reinterpret_cast<const half8_t*>(hp_hi + aoff + kb * 16);
-                    al[nb][i] = *reinterpret_cast<const half8_t*>(hp_lo + aoff + kb * 16);
+                for (int m = 0; m < MT; ++m) {
+                    ah[cb][m] = *reinterpret_cast<const half8_t*>(rp_hi + m * 32 * LDP + aoff);
+                    al[cb][m] = *reinterpret_cast<const half8_t*>(rp_lo + m * 32 * LDP + aoff);
                 }
-            } else {
-                load_x(xc_, t, 2);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // streamed items run LA ahead in the ring (the resident ones are skipped)
+            if ((i + LA) % NI >= NRES) wload((i + LA) % NI, wh[(i + LA) % RING], wl[(i + LA) % RING]);
+            if (i == 2 * KB && t + 1 < L) {
+                // next step's r-gate projection goes into the (retired) r accumulators
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrh[cb][i], acc_r, 0, 0, 0);
-                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wuh[cb][i], acc_u, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrl[cb][i], acc_r, 0, 0, 0);
-                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wul[cb][i], acc_u, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wrh[cb][i], acc_r, 0, 0, 0);
-                acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wuh[cb][i], acc_u, 0, 0, 0);
+                for (int m = 0; m < MT; ++m) load_x(acc_r[m], m, t + 1, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // first candidate-weight group while the epilogue runs (re-uses the gate ring registers)
+            if (i + 1 < NI && i + 1 != 2 * KB) {
+                const int kn = (i + 1) % KB;
+                const _Float16* ph = (i + 1 < 2 * KB) ? hp_hi : rp_hi;
+                const _Float16* pl = (i + 1 < 2 * KB) ? hp_lo : rp_lo;
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            wrh[0][i] = buf_load_h8(rs_wc, vl16, so_c + i * 2048);
-            wrl[0][i] = buf_load_h8(rs_wc, vl16, so_c + i * 2048 + 1024);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float rg = gate_sigmoid(acc_r[r] + xr_[r]);
-            acc_u[r] = gate_sigmoid(acc_u[r] + xu_[r]);
-            const float v = rg * h_own[r];
-            const _Float16 vh = (_Float16)v;
-            rp_hi[crow(r, half) * LDP + col] = vh;
-            rp_lo[crow(r, half) * LDP + col] = (_Float16)(v - (float)vh);
-        }
-        __syncthreads();
-        // ---- phase 2: candidate + state update
-        f32x16 acc_c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_c[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            ah[0][i] = *reinterpret_cast<const half8_t*>(rp_hi + aoff + i * 16);
-            al[0][i] = *reinterpret_cast<const half8_t*>(rp_lo + aoff + i * 16);
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int cb = g & 1, nb = cb ^ 1;
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int i = 0; i < U; ++i) {
-                    const int kb = (g + 1) * U + i;
-                    wrh[nb][i] = buf_load_h8(rs_wc, vl16, so_c + kb * 2048);
-                    wrl[nb][i] = buf_load_h8(rs_wc, vl16, so_c + kb * 2048 + 1024);
-                    ah[nb][i] = *reinterpret_cast<const half8_t*>(rp_hi + aoff + kb * 16);
-                    al[nb][i] = *reinterpret_cast<const half8_t*>(rp_lo + aoff + kb * 16);
+                for (int m = 0; m < MT; ++m) {
+                    ah[nb][m] = *reinterpret_cast<const half8_t*>(ph + m * 32 * LDP + aoff + kn * 16);
+                    al[nb][m] = *reinterpret_cast<const half8_t*>(pl + m * 32 * LDP + aoff + kn * 16);
                 }
-            } else if (t + 1 < L) {
-                load_x(xr_, t + 1, 0);
-                load_x(xu_, t + 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            const half8_t bh = i < NRES ? res_h[i < NRES ? i : 0] : wh[i % RING];
+            const half8_t bl = i < NRES ? res_l[i < NRES ? i : 0] : wl[i % RING];
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrh[cb][i], acc_c, 0, 0, 0);
-                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][i], wrl[cb][i], acc_c, 0, 0, 0);
-                acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][i], wrh[cb][i], acc_c, 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+                f32x16& acc = g == 0 ? acc_r[m] : (g == 1 ? acc_u[m] : acc_c[m]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][m], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][m], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][m], bh, acc, 0, 0, 0);
+            }
+            if (g == 1) {            // shadow: reset gate, accumulator register kb of every tile
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float rg = gate_sigmoid(acc_r[m][kb]);
+                    const float v = rg * h_own[m][kb];
+                    const _Float16 vh = (_Float16)v;
+                    rp_hi[(m * 32 + crow(kb, half)) * LDP + col] = vh;
+                    rp_lo[(m * 32 + crow(kb, half)) * LDP + col] = (_Float16)(v - (float)vh);
+                }
+            } else if (g == 2) {     // shadow: attentional update gate
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float pre = acc_u[m][kb];
+                    asm volatile("" : "+v"(pre));      // keeps element kb's chain in item kb (else all 16 cluster up front)
+                    acc_u[m][kb] = (1.0f - s_att[(m * 32 + crow(kb, half)) * LDT + t]) * gate_sigmoid(pre);
+                }
+            }
+            if (g != 0) {
+                // a wave issues in order: without this the VALU chunk only overlaps the last MFMA of the item
+#pragma unroll
+                for (int q = 0; q < 3 * MT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    if (g == 1) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    // VALU in its shadow
+                    else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                if (g == 1) __builtin_amdgcn_sched_group_barrier(0x200, 2 * MT, 0);   // DS writes
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // first gate-weight group of the next step
+        RL4RS_TR(4);
+        // exposed epilogue: candidate + state update, then the next step's u / c projections into the accumulators
+        // (requested here, the barrier and slot R cover their HBM latency before slot U needs them)
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            wrh[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048);
-            wrl[0][i] = buf_load_h8(rs_wg, vl16, so_r + i * 2048 + 1024);
-            wuh[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048);
-            wul[0][i] = buf_load_h8(rs_wg, vl16, so_u + i * 2048 + 1024);
-        }
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float c = gate_tanh(acc_c[r] + xc_[r]);
-            float u = (1.0f - s_att[crow(r, half) * LDT + t]) * acc_u[r];
-            float hn = u * h_own[r] + (1.0f - u) * c;
-            h_own[r] = hn;
-            const _Float16 vh = (_Float16)hn;
-            hp_hi[crow(r, half) * LDP + col] = vh;
-            hp_lo[crow(r, half) * LDP + col] = (_Float16)(hn - (float)vh);
+            for (int r = 0; r < 16; ++r) {
+                const float c = gate_tanh(acc_c[m][r]);
+                const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - c, c);     // u h + (1-u) c
+                h_own[m][r] = hn;
+                const _Float16 vh = (_Float16)hn;
+                hp_hi[(m * 32 + crow(r, half)) * LDP + col] = vh;
+                hp_lo[(m * 32 + crow(r, half)) * LDP + col] = (_Float16)(hn - (float)vh);
+            }
         }
+        if (t + 1 < L) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                load_x(acc_u[m], m, t + 1, 1);
+                load_x(acc_c[m], m, t + 1, 2);
+            }
+        }
+        RL4RS_TR(5);
         __syncthreads();
+        RL4RS_TR(6);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (row0 + crow(r, half) < a.n_rows)
-            a.out[(int64_t)(row0 + crow(r, half)) * a.out_ld + a.out_off + sq * a.out_seq_off + col] = h_own[r];
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (row0 + m * 32 + crow(r, half) < a.n_rows)
+                a.out[(int64_t)(row0 + m * 32 + crow(r, half)) * a.out_ld + a.out_off + sq * a.out_seq_off + col] = h_own[m][r];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -779,13 +835,18 @@ using namespace rl4rs;
 namespace {
 enum { KID_CAT = 0, KID_DENSE, KID_DIN, KID_AUGRU, KID_HEAD, KID_PROB, KID_GRU1, KID_PROJ, KID_COUNT };
 const char* kKernelNames[KID_COUNT] = {"k_cat_attn", "k_gemm_f32(dense tower)", "k_din_scores",
-                                       "k_recur<256,augru>", "k_gemm_f32(simulator_obs)", "k_head_prob",
+                                       "augru", "k_gemm_f32(simulator_obs)", "k_head_prob",
                                        "k_recur<128,gru>", "k_gemm_f32(seq projections)"};
 struct EvPair { int id; hipEvent_t a, b; };
 }  // namespace
 
+static size_t augru_h16_smem(int mt, int nh2, int L) {
+    return (size_t)4 * mt * 32 * (nh2 + 8) * 2 + (size_t)(mt * 32 * (L + 1) + mt * 32) * 4;
+}
+
 struct rl4rs_dien {
     rl4rs_dien_cfg c;
+    int n_cu;
     int E, U, L, S, Cn, Dn, H, K, F, PLD, NH2;
     // weights (device)
     float *cat_emb, *seq_emb, *dense_w1, *dense_b1, *dense_w2, *dense_b2, *obs_w, *obs_b, *out_w, *out_b;
@@ -943,6 +1004,39 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                   c->max_slots);
     RL4RS_REQUIRE((int64_t)c->category_hash_size * 3 * c->emb_size * 4 < (int64_t)0x7fffffff * 2,
                   "dien: category_hash_size too large for 32-bit buffer offsets");
+    bool want_fp16x2 = false;
+    {   // arithmetic of the AUGRU recurrence (include/rl4rs_hip.h RL4RS_SCORER_*)
+        RL4RS_REQUIRE(c->scorer_mode >= RL4RS_SCORER_AUTO && c->scorer_mode <= RL4RS_SCORER_FP16X2,
+                      "dien: scorer_mode must be 0 (auto), 1 (fp32) or 2 (fp16x2), got %d", c->scorer_mode);
+        const size_t e = c->emb_size, nh2 = 2 * e;
+        int mode = c->scorer_mode;
+        float wmax = 0.f;
+        bool finite = true;
+        for (int s = 0; s < c->seq_num; ++s) {
+            RL4RS_REQUIRE(w->augru_gate_w[s] && w->augru_cand_w[s], "dien_create: null AUGRU weights for sequence input %d", s);
+            for (size_t i = 0; i < (e + nh2) * 2 * nh2; ++i) {
+                float v = fabsf(w->augru_gate_w[s][i]);
+                finite = finite && v == v; wmax = fmaxf(wmax, v);
+            }
+            for (size_t i = 0; i < (e + nh2) * nh2; ++i) {
+                float v = fabsf(w->augru_cand_w[s][i]);
+                finite = finite && v == v; wmax = fmaxf(wmax, v);
+            }
+        }
+        const bool fits = finite && wmax < 6.0e4f;
+        if (mode == RL4RS_SCORER_AUTO) {
+            const char* sp = getenv("RL4RS_SCORER");
+            if (sp && strcmp(sp, "fp32") == 0) mode = RL4RS_SCORER_FP32;
+            else if (sp && strcmp(sp, "fp16x2") == 0) mode = RL4RS_SCORER_FP16X2;
+            else {
+                RL4RS_REQUIRE(!(sp && *sp), "dien: RL4RS_SCORER must be fp32 or fp16x2 (got '%s')", sp);
+                mode = fits ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
+            }
+        }
+        RL4RS_REQUIRE(mode != RL4RS_SCORER_FP16X2 || fits,
+                      "dien: the fp16x2 scorer needs finite AUGRU weights with |w| < 6e4 (max |w| = %g); use fp32", (double)wmax);
+        want_fp16x2 = mode == RL4RS_SCORER_FP16X2;
+    }
     int ndev = rl4rs_device_count();
     if (ndev <= 0) {
         set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
@@ -958,7 +1052,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->E = E; n->U = U; n->L = L; n->S = S; n->Cn = Cn; n->Dn = Dn; n->H = H; n->K = K; n->F = F;
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = false;
-    { const char* sp = getenv("RL4RS_SCORER"); n->fp16x2 = sp && strcmp(sp, "fp16x2") == 0; }
+    n->fp16x2 = want_fp16x2;
+    {
+        int dev = 0, cus = 0;
+        RL4RS_HIP_TRY(hipGetDevice(&dev));
+        RL4RS_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        n->n_cu = cus > 0 ? cus : 256;
+    }
     for (int i = 0; i < KID_COUNT; ++i) { n->ms_total[i] = 0; n->launches[i] = 0; }
     int rc;
 #define UP(dst, src, cnt) if ((rc = upload(n, &n->dst, (src), (size_t)(cnt), st)) != RL4RS_OK) return rc
@@ -1067,8 +1167,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         };
         for (const void* f : augru_variants)
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true>),
@@ -1175,8 +1275,19 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         dim3 grid((R + 31) / 32, S), block(512);
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
-            size_t smem16 = (size_t)4 * 32 * (NH2 + 8) * 2 + (size_t)(32 * (L + 1) + 32) * 4;
-            hipLaunchKernelGGL((k_augru_h16<2>), grid, block, smem16, st, a);
+#ifdef RL4RS_H16_TRACE
+            static unsigned long long* trace_buf = nullptr;
+            if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 8 * 4 * 8 * 8); (void)hipMemset(trace_buf, 0, 8 * 4 * 8 * 8); }
+            a.trace = trace_buf;
+            if (getenv("RL4RS_H16_TRACE_DUMP")) {
+                unsigned long long host[8 * 4 * 8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(host, trace_buf, sizeof(host), hipMemcpyDeviceToHost);
+                FILE* f = fopen(getenv("RL4RS_H16_TRACE_DUMP"), "wb");
+                if (f) { fwrite(host, 1, sizeof(host), f); fclose(f); }
+            }
+#endif
+            hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
         } else
 #ifdef RL4RS_ABLATE      // timing experiments only (tools/ablate_augru.sh builds with -DRL4RS_ABLATE)
         static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;
@@ -1243,6 +1354,11 @@ int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
 int rl4rs_dien_set_profiling(rl4rs_dien* n, int enable) {
     RL4RS_REQUIRE(n, "dien_set_profiling: null handle");
     n->profiling = enable != 0;
+    return RL4RS_OK;
+}
+int rl4rs_dien_scorer_mode(rl4rs_dien* n, int32_t* mode) {
+    RL4RS_REQUIRE(n && mode, "dien_scorer_mode: null argument");
+    *mode = n->fp16x2 ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
     return RL4RS_OK;
 }
 int rl4rs_dien_kernel_count(void) { return KID_COUNT; }

@@ -228,6 +228,10 @@ def knn(actions, action_emb_dev, mask=None):
     return out
 
 
+SCORER_MODES = {'auto': 0, 'fp32': 1, 'fp16x2': 2}       # include/rl4rs_hip.h RL4RS_SCORER_*
+AUGRU_KERNELS = {1: 'k_recur<256,augru>', 2: 'k_augru_h16'}
+
+
 class DeviceDien(object):
     """rl4rs_dien handle: DIEN scorer with its sequence cache."""
 
@@ -244,8 +248,13 @@ class DeviceDien(object):
         self.K = int(config['class_num'])
         self.max_rows, self.max_slots = int(max_rows), int(max_slots)
         self.F = self.S * 2 * self.E + self.U + (self.Cn + 1) * self.E
+        # config['scorer_precision']: 'auto' (default; RL4RS_SCORER env, else fp16x2 when the weights allow it),
+        # 'fp32' (exact-operand fp32 MFMA) or 'fp16x2' (fp16 hi+lo operand split, fp32 accumulate)
+        precision = str(config.get('scorer_precision', 'auto')).lower()
+        if precision not in SCORER_MODES:
+            raise ValueError("scorer_precision must be one of %s (got %r)" % (sorted(SCORER_MODES), precision))
         cfg = _lib.DienCfg(self.L, self.E, self.U, self.Dn, self.Cn, int(config['category_hash_size']),
-                           self.S, self.K, self.max_rows, self.max_slots)
+                           self.S, self.K, self.max_rows, self.max_slots, SCORER_MODES[precision])
         w = _lib.DienWeights()
         keep = []
 
@@ -348,8 +357,20 @@ class DeviceDien(object):
             ms = C.c_double()
             n = C.c_int64()
             check(self.lib.rl4rs_dien_profile_read(self.h, k, C.byref(ms), C.byref(n)))
-            out[self.lib.rl4rs_dien_kernel_name(k).decode()] = (ms.value, n.value)
+            name = self.lib.rl4rs_dien_kernel_name(k).decode()
+            out[self.augru_kernel if name == 'augru' else name] = (ms.value, n.value)
         return out
+
+    @property
+    def scorer_mode(self):
+        """'fp32' or 'fp16x2': what the handle resolved config['scorer_precision'] to."""
+        m = C.c_int32()
+        check(self.lib.rl4rs_dien_scorer_mode(self.h, C.byref(m)))
+        return 'fp16x2' if m.value == 2 else 'fp32'
+
+    @property
+    def augru_kernel(self):
+        return AUGRU_KERNELS[SCORER_MODES[self.scorer_mode]]
 
 
 def gemm_f32(a, w, bias=None, act=0):

@@ -1,6 +1,7 @@
 """GPU parity of the HIP DIEN scorer against the numpy oracle restatement (fp64) with seeded synthetic
-weights.  Tolerances (fp32 kernel vs fp64 oracle): obs 5e-5 abs (activations are O(1..10)),
-probabilities 5e-6 abs; the fp32 oracle itself differs from the fp64 one by ~1e-5 / 1e-6."""
+weights.  Tolerances (fp32-accumulating kernels vs fp64 oracle): obs 5e-5 abs (activations are O(1..10)),
+probabilities 5e-6 abs; the fp32 oracle itself differs from the fp64 one by ~1e-5 / 1e-6.  Every test runs in both
+scorer modes (exact fp32 MFMA and the fp16x2 operand split) against the SAME tolerances."""
 import numpy as np
 import pytest
 
@@ -9,6 +10,13 @@ pytestmark = pytest.mark.gpu
 CFG = {"maxlen": 64, "batch_size": 8, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
        "category_feature_num": 21, "category_hash_size": 3000, "seq_num": 2, "emb_size": 128,
        "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32}
+
+
+@pytest.fixture(autouse=True, params=['fp32', 'fp16x2'])
+def scorer_precision(request):
+    CFG['scorer_precision'] = request.param
+    yield request.param
+    CFG.pop('scorer_precision', None)
 
 
 def _inputs(R, rs, hash_size):
@@ -31,6 +39,7 @@ def test_dien_rowwise_matches_oracle(R):
     rs = np.random.RandomState(R)
     seq, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
     net = DeviceDien(CFG, w, max_rows=R, max_slots=R)
+    assert net.scorer_mode == CFG['scorer_precision']
     for s in range(2):
         net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
     slots = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
@@ -163,3 +172,41 @@ def test_dien_other_configurations(variant):
     assert np.abs(obs.cpu().numpy() - orc.obs(seq, dense, cat)).max() < 5e-5
     assert np.abs(prob.cpu().numpy() - orc.reward_probs(seq, dense, cat)[:, 1]).max() < 5e-6
     net.close()
+
+
+def test_scorer_mode_selection(monkeypatch, scorer_precision):
+    """scorer_precision / RL4RS_SCORER / fp16 weight-range rule of rl4rs_dien_create (include/rl4rs_hip.h)."""
+    if scorer_precision != 'fp32':
+        pytest.skip('mode-independent')
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from rl4rs_amd._lib import Rl4rsHipError
+    w = init_dien_weights(CFG, seed=1)
+    base = dict(CFG)
+    base.pop('scorer_precision')
+    monkeypatch.delenv('RL4RS_SCORER', raising=False)
+    net = DeviceDien(base, w, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_h16'      # auto default
+    net.close()
+    monkeypatch.setenv('RL4RS_SCORER', 'fp32')
+    net = DeviceDien(base, w, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp32' and net.augru_kernel == 'k_recur<256,augru>'
+    net.close()
+    net = DeviceDien(dict(base, scorer_precision='fp16x2'), w, max_rows=8, max_slots=4)   # explicit beats env
+    assert net.scorer_mode == 'fp16x2'
+    net.close()
+    monkeypatch.setenv('RL4RS_SCORER', 'bf16')
+    with pytest.raises(Rl4rsHipError, match='RL4RS_SCORER'):
+        DeviceDien(base, w, max_rows=8, max_slots=4)
+    monkeypatch.delenv('RL4RS_SCORER')
+    with pytest.raises(ValueError, match='scorer_precision'):
+        DeviceDien(dict(base, scorer_precision='tf32'), w, max_rows=8, max_slots=4)
+    # a weight outside fp16 range: auto falls back to fp32, explicit fp16x2 is refused
+    big = dict(w)
+    big['augru0_cand_w'] = w['augru0_cand_w'].copy()
+    big['augru0_cand_w'][5, 7] = 7.0e4
+    net = DeviceDien(base, big, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp32'
+    net.close()
+    with pytest.raises(Rl4rsHipError, match='fp16x2'):
+        DeviceDien(dict(base, scorer_precision='fp16x2'), big, max_rows=8, max_slots=4)
