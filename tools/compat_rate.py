@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import numpy as np
 import bench
 class A: pass
-a = A(); a.env = 'slate'; a.batch = 4096; a.horizon = 9; a.log_records = 8193
+a = A(); a.env = 'slate'; a.batch = 4096; a.horizon = 9; a.log_records = 8193; a.scorer = 'auto'
 cfg, records = bench.make_config(a, tempfile.mkdtemp(), 0)
 cfg['return_tensors'] = False
 env = bench.build_env(cfg, False)
