@@ -420,7 +420,9 @@ __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int 
 //   therefore take ~300 cycles per item pair, the exposed epilogue ~6K cycles per step (of ~23K).  Tried and measured
 //   flat: separate accumulators for the hi*lo / lo*hi products (no dependent-MFMA stall to remove), ping-pong u/c
 //   accumulator sets with all projections requested at the start of the epilogue, 64-row workgroups (MT = 2: halves
-//   the weight bytes per row but spills at 256 registers; +2 % on the reward-sized launch).  Resident weights are the
+//   the weight bytes per row but spills at 256 registers; +2 % on the reward-sized launch), spreading the projection
+//   loads over the items of slot C / the elements of the epilogue (2x SLOWER: every weight wait then sits behind an
+//   HBM-latency load).  Resident weights are the
 //   lever that worked (-6 % at 14 of 48 items).  Next: a 64-row form that fits, or LDS-DMA staging of the ring.
 #ifdef RL4RS_H16_TRACE     // s_memtime marks of workgroup (0,0), steps 8..11: [wave][step][mark]
 #define RL4RS_TR(k) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t >= 8 && t < 12) \
