@@ -43,7 +43,8 @@ def make_config(args, workdir, rank):
            "category_feature_num": 21, "category_hash_size": 100000, "seq_num": 2, "emb_size": 128,
            "page_items": 9, "hidden_units": 128, "max_steps": args.horizon, "action_emb_size": 32,
            "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": False, "cache_size": 2048,
-           "model_seed": 7, "return_tensors": True, "scorer_precision": args.scorer}
+           "model_seed": 7, "return_tensors": True, "scorer_precision": args.scorer,
+           "algo": getattr(args, 'algo', 'dien')}
     return cfg, records
 
 
@@ -74,8 +75,14 @@ def cpu_baseline(cfg, records, seq, sample_batch):
     from oracle.dien import OracleDien
     from oracle.env import OracleEnv
     c = dict(cfg, batch_size=sample_batch)
-    w = init_dien_weights(c, seed=c.get('model_seed', 7))
-    scorer = OracleDien(w, c, np.float32)
+    algo = c.get('algo', 'dien')
+    if algo == 'dien':
+        w = init_dien_weights(c, seed=c.get('model_seed', 7))
+        scorer = OracleDien(w, c, np.float32)
+    else:
+        from rl4rs_amd.nets.simnets import init_simnet_weights
+        from oracle.simnets import OracleSimnet
+        scorer = OracleSimnet(algo, init_simnet_weights(c, algo, seed=c.get('model_seed', 7)), c, np.float32)
     env = OracleEnv(c, records[:sample_batch], scorer, seq=seq)
     T = c['max_steps']
     t0 = time.time()
@@ -90,7 +97,7 @@ def cpu_baseline(cfg, records, seq, sample_batch):
         cores = os.cpu_count() or 1
     return {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
             "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs, numpy oracle "
-                      "(float32 DIEN), %.1f s" % (T, sample_batch, dt)}
+                      "(float32 %s scorer), %.1f s" % (T, sample_batch, algo.upper() if algo == 'dien' else algo, dt)}
 
 
 def main():
@@ -104,6 +111,8 @@ def main():
     ap.add_argument('--log-records', type=int, default=8193)
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--algo', choices=['dien', 'dnn', 'widedeep', 'lstm'], default='dien',
+                    help="simulator family (config['algo']); the headline metric is quoted on dien")
     ap.add_argument('--scorer', choices=['auto', 'fp32', 'fp16x2'], default='auto',
                     help='arithmetic of the AUGRU recurrence (config scorer_precision); auto = fp16x2 operand split, '
                          'fp32 accumulate, same measured error as the exact fp32 MFMA kernel')
@@ -153,33 +162,36 @@ def main():
 
     if rank == 0:
         env_steps = world * B * T * args.steps
-        # dominant kernel: AUGRU recurrence.  Executed (= algorithmic after the exact input-projection hoist)
-        # FLOPs per row per sequence input: L steps x (2E x 6E) MACs x 2.
-        L, E = cfg['maxlen'], cfg['emb_size']
-        flop_row_seq = L * (2 * E) * (6 * E) * 2
-        kname = net.augru_kernel
-        ms, launches = prof[kname]
-        n_complete = T if not seq else cfg['page_items']
-        reward_calls = 1 if not seq else T // cfg['page_items']
-        # reset obs + T step obs + reward rows (the last reward row of an env reuses the state row just scored)
-        rows_per_episode = (T + 1) * B + reward_calls * (n_complete - 1) * B
-        flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        if net.scorer_mode == 'fp16x2':
-            # each fp32-class product costs 3 f16 MFMAs (hi*hi + hi*lo + lo*hi): peak in algorithmic FLOPs = f16 dense / 3
-            peak, peak_note = MFMA_F16_PEAK_TFLOPS / 3.0, "v_mfma_f32_32x32x16_f16 dense 2500 TF/s / 3 MFMAs per product"
-        else:
-            peak, peak_note = MFMA_F32_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 dense"
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved,
-                    "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
-                    "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
-                    "kernel_ms_share": ms / (elapsed * 1e3)}
-        if not seq and B == 4096 and T == 9 and not trainer:
-            # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
-            # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
-            # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 836 / 888 MB)
-            roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
-            roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01e_pmc.md fp16x2)"
+        is_dien = cfg.get('algo', 'dien') == 'dien'
+        roofline = None
+        if is_dien:
+            # dominant kernel: AUGRU recurrence.  Executed (= algorithmic after the exact input-projection hoist)
+            # FLOPs per row per sequence input: L steps x (2E x 6E) MACs x 2.
+            L, E = cfg['maxlen'], cfg['emb_size']
+            flop_row_seq = L * (2 * E) * (6 * E) * 2
+            kname = net.augru_kernel
+            ms, launches = prof[kname]
+            n_complete = T if not seq else cfg['page_items']
+            reward_calls = 1 if not seq else T // cfg['page_items']
+            # reset obs + T step obs + reward rows (the last reward row of an env reuses the state row just scored)
+            rows_per_episode = (T + 1) * B + reward_calls * (n_complete - 1) * B
+            flops = args.steps * rows_per_episode * cfg['seq_num'] * flop_row_seq
+            achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            if net.scorer_mode == 'fp16x2':
+                # each fp32-class product costs 3 f16 MFMAs (hi*hi + hi*lo + lo*hi): peak in algorithmic FLOPs = f16 dense / 3
+                peak, peak_note = MFMA_F16_PEAK_TFLOPS / 3.0, "v_mfma_f32_32x32x16_f16 dense 2500 TF/s / 3 MFMAs per product"
+            else:
+                peak, peak_note = MFMA_F32_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 dense"
+            roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved,
+                        "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
+                        "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
+                        "kernel_ms_share": ms / (elapsed * 1e3)}
+            if not seq and B == 4096 and T == 9 and not trainer:
+                # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
+                # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
+                # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 836 / 888 MB)
+                roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
+                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01e_pmc.md fp16x2)"
         kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples
@@ -209,15 +221,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if net.scorer_mode == 'fp32' else "f32 (AUGRU operands as fp16 hi+lo pairs, fp32 accumulate)",
+            "dtype": "f32" if (not is_dien or net.scorer_mode == 'fp32') else "f32 (AUGRU operands as fp16 hi+lo pairs, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU, 284-item catalogue, 9-slot slate, %d-step horizon, "
-                                   "DIEN simulator scorer, offline_action replay"
-                                   % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T),
+                                   "%s simulator scorer, offline_action replay"
+                                   % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T, cfg.get('algo', 'dien').upper() if is_dien else cfg['algo']),
                        "step": "one episode-batch = reset + %d env.step incl. reward forward" % T +
                                ("" if not trainer else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()),
                        "parallelism": "independent env batches per GPU (no data-path collective)"},
-            "roofline": roofline,
+            # dien: the AUGRU recurrence; the GEMM-only families (dnn / widedeep / lstm) have no dominant matrix kernel,
+            # their line carries the HBM roofline of the feature-gather kernel
+            "roofline": roofline if roofline is not None else gather,
             "roofline_gather": gather,
             "kernels": kernels,
         }

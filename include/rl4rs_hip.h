@@ -273,6 +273,61 @@ int rl4rs_dien_profile_read(rl4rs_dien* net, int which, double* ms_total, int64_
 int rl4rs_dien_profile_reset(rl4rs_dien* net);
 
 /* ------------------------------------------------------------------------------------------------
+ * The reference's other simulator families behind the same 'simulator_obs' / 'simulator_reward' contract
+ * (SlateRecEnv.get_model, rl4rs/env/slate.py:228-241: config['algo'] = 'dnn' | 'widedeep' | 'lstm'):
+ *   DNN       rl4rs/nets/dnn.py:31-37       obs_dim 256
+ *   WIDEDEEP  rl4rs/nets/widedeep.py:31-38  obs_dim 256 + hidden_units + category_feature_num * emb_size
+ *   LSTM      rl4rs/nets/lstm.py:31-37      obs_dim 256 (keras GRU layers; needs emb_size == hidden_units == 128)
+ * Same calling pattern as rl4rs_dien: `encode` caches the per-sequence feature of a cache slot (WIDEDEEP: mean of
+ * the sequence embeddings, LSTM: final GRU state, DNN: nothing - that model never reads its sequences), `forward`
+ * scores R rows whose groups of `group` consecutive rows share their slots.
+ * Weight arrays (host float32, shapes in rl4rs_amd/nets/simnets.py); unused ones may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rl4rs_simnet rl4rs_simnet;
+enum { RL4RS_SIMNET_DNN = 1, RL4RS_SIMNET_WIDEDEEP = 2, RL4RS_SIMNET_LSTM = 3 };
+
+typedef struct rl4rs_simnet_cfg {
+    int32_t algo;                  /* RL4RS_SIMNET_* */
+    int32_t maxlen;                /* 64  */
+    int32_t emb_size;              /* 128 */
+    int32_t hidden_units;          /* 128 */
+    int32_t dense_feature_num;     /* 432 */
+    int32_t category_feature_num;  /* 21  */
+    int32_t category_hash_size;    /* 100000 */
+    int32_t seq_num;               /* 2   */
+    int32_t class_num;             /* 2   */
+    int32_t max_rows;
+    int32_t max_slots;
+} rl4rs_simnet_cfg;
+
+typedef struct rl4rs_simnet_weights {
+    const float* cat_emb;
+    const float* seq_emb;
+    const float* dense_w1; const float* dense_b1;
+    const float* dense_w2; const float* dense_b2;
+    const float* fc_w; const float* fc_b;
+    const float* obs_w; const float* obs_b;
+    const float* out_w; const float* out_b;
+    const float* cat_gru_kernel; const float* cat_gru_recurrent; const float* cat_gru_bias;
+    const float* seq_gru_kernel[4]; const float* seq_gru_recurrent[4]; const float* seq_gru_bias[4];
+} rl4rs_simnet_weights;
+
+int rl4rs_simnet_create(const rl4rs_simnet_cfg* cfg, const rl4rs_simnet_weights* w, void* stream,
+                        rl4rs_simnet** out);
+int rl4rs_simnet_destroy(rl4rs_simnet* net);
+int rl4rs_simnet_obs_dim(rl4rs_simnet* net, int32_t* dim);
+/* ids_dev [n, maxlen] int32 -> cache slots [slot_base, slot_base + n) of sequence input s */
+int rl4rs_simnet_encode(rl4rs_simnet* net, int32_t s, const int32_t* ids_dev, int32_t n, int32_t slot_base,
+                        void* stream);
+/* dense_dev [R, dense_feature_num] f32, cat_dev [R, category_feature_num] i32, slot_dev [seq_num, R/group] i32,
+ * obs_dev [R, obs_dim] f32 (may be NULL), prob_dev [R] f32 = softmax('simulator_reward')[:, 1] (may be NULL) */
+int rl4rs_simnet_forward(rl4rs_simnet* net, int32_t R, int32_t group, const float* dense_dev,
+                         const int32_t* cat_dev, const int32_t* slot_dev, float* obs_dev, float* prob_dev,
+                         void* stream);
+/* softmax(obs @ out_w + out_b)[:, 1] of already computed 'simulator_obs' rows */
+int rl4rs_simnet_head_prob(rl4rs_simnet* net, int32_t R, const float* obs_dev, float* prob_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size
  * logits, value head on the shared hidden layer, logits + max(log(action_mask), float32.min)).
  * Parameters, gradients and Adam state are ONE flat float32 buffer each:

@@ -12,6 +12,8 @@ file:line it follows:
 * ``oracle.state``    – ``SlateState`` / ``SeqSlateState`` (``rl4rs/env/slate.py``, ``seqslate.py``)
 * ``oracle.dien``     – DIEN scorer (``rl4rs/nets/dien.py``, ``rl4rs/nets/utils.py`` + deepctr 0.9.0 /
   TF 1.15 cell equations restated from their published definitions)
+* ``oracle.simnets``  – the dnn / widedeep / lstm simulators (``rl4rs/nets/dnn.py``, ``widedeep.py``, ``lstm.py``,
+  ``rl4rs/nets/utils.py:7-97``; keras GRU v1 cell restated from its published definition)
 * ``oracle.env``      – ``RecSimBase._step`` order (``rl4rs/env/base.py:157-170``) and the two
   ``forward`` reward rules (``slate.py:281-308``, ``seqslate.py:136-160``)
 * ``oracle.policy``   – action-masked policy net (``rl4rs/nets/rllib/rllib_mask_model.py:41-62``)
@@ -22,7 +24,7 @@ Pinning status
   PINNED against golden vectors captured from the reference's own numpy state machine imported in the
   build container (``tests/golden/make_golden.py``) and against the tutorial known answers
   (SURVEY.md §8c).
-* DIEN arithmetic and policy net: **parity unpinned** – the arithmetic lives in deepctr==0.9.0 +
+* DIEN / dnn / widedeep / lstm arithmetic and policy net: **parity unpinned** – the arithmetic lives in deepctr==0.9.0 +
   tensorflow-gpu==1.15.0 / ray==1.5.1, none of which are vendored or installable here, and the
   reference holds no test vector or checkpoint for them.  The restatement follows the reference's own
   topology call sites and the libraries' published cell equations; it is the checker for the HIP

@@ -47,6 +47,22 @@ class DienWeights(C.Structure):
     ]
 
 
+class SimnetCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'algo', 'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num',
+        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots')]
+
+
+class SimnetWeights(C.Structure):
+    _fields_ = [
+        ('cat_emb', _FP), ('seq_emb', _FP),
+        ('dense_w1', _FP), ('dense_b1', _FP), ('dense_w2', _FP), ('dense_b2', _FP),
+        ('fc_w', _FP), ('fc_b', _FP), ('obs_w', _FP), ('obs_b', _FP), ('out_w', _FP), ('out_b', _FP),
+        ('cat_gru_kernel', _FP), ('cat_gru_recurrent', _FP), ('cat_gru_bias', _FP),
+        ('seq_gru_kernel', _FP4), ('seq_gru_recurrent', _FP4), ('seq_gru_bias', _FP4),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/rl4rs_hip.h declares
@@ -88,6 +104,12 @@ SIGNATURES = {
     'rl4rs_dien_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'rl4rs_dien_head_prob': (_I, [_P, _I32, _P, _P, _P]),
     'rl4rs_dien_buffer': (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I64)]),
+    'rl4rs_simnet_create': (_I, [C.POINTER(SimnetCfg), C.POINTER(SimnetWeights), _P, C.POINTER(_P)]),
+    'rl4rs_simnet_destroy': (_I, [_P]),
+    'rl4rs_simnet_obs_dim': (_I, [_P, C.POINTER(_I32)]),
+    'rl4rs_simnet_encode': (_I, [_P, _I32, _P, _I32, _I32, _P]),
+    'rl4rs_simnet_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_simnet_head_prob': (_I, [_P, _I32, _P, _P, _P]),
     'rl4rs_dien_set_profiling': (_I, [_P, _I]),
     'rl4rs_dien_kernel_count': (_I, []),
     'rl4rs_dien_kernel_name': (C.c_char_p, [_I]),

@@ -170,6 +170,8 @@ struct RecurArgs {
     float* out; int64_t out_ld; int out_off; int out_seq_off;   // GRU: h1 cache rows ; AUGRU: allf
     int slot_base;
     unsigned long long* trace;   // -DRL4RS_H16_TRACE timing experiments only
+    int hard_gates;              // GRU mode: keras hard_sigmoid gates (simnet.hpp) instead of sigmoid
+    int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -319,8 +321,15 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float rg = (AB & 1) ? acc_r[r] + xr_[r] : gate_sigmoid(acc_r[r] + xr_[r]);
-            acc_u[r] = (AB & 1) ? acc_u[r] + xu_[r] : gate_sigmoid(acc_u[r] + xu_[r]);
+            float rg, ug;
+            if (!AUGRU && a.hard_gates) {          // keras recurrent_activation = hard_sigmoid (uniform branch)
+                rg = fminf(fmaxf(0.2f * (acc_r[r] + xr_[r]) + 0.5f, 0.f), 1.f);
+                ug = fminf(fmaxf(0.2f * (acc_u[r] + xu_[r]) + 0.5f, 0.f), 1.f);
+            } else {
+                rg = (AB & 1) ? acc_r[r] + xr_[r] : gate_sigmoid(acc_r[r] + xr_[r]);
+                ug = (AB & 1) ? acc_u[r] + xu_[r] : gate_sigmoid(acc_u[r] + xu_[r]);
+            }
+            acc_u[r] = ug;
             rhb[crow(r, half) * LDH + col] = rg * h_own[r];
         }
         if (!(AB & 8)) __syncthreads();
@@ -371,8 +380,12 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
             h_own[r] = hn;
             hb[crow(r, half) * LDH + col] = hn;
             if (!AUGRU && row0 + crow(r, half) < a.n_rows) {
-                int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
-                a.out[orow * a.out_ld + a.out_off + col] = hn;
+                if (!a.final_only) {
+                    int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
+                    a.out[orow * a.out_ld + a.out_off + col] = hn;
+                } else if (t == L - 1) {
+                    a.out[((int64_t)a.slot_base + row0 + crow(r, half)) * a.out_ld + a.out_off + col] = hn;
+                }
             }
         }
         if (!(AB & 8)) __syncthreads();
@@ -1394,3 +1407,5 @@ int rl4rs_dien_profile_reset(rl4rs_dien* n) {
 }
 
 }  // extern "C"
+
+#include "simnet.hpp"

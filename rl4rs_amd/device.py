@@ -373,6 +373,101 @@ class DeviceDien(object):
         return AUGRU_KERNELS[SCORER_MODES[self.scorer_mode]]
 
 
+SIMNET_ALGOS = {'dnn': 1, 'widedeep': 2, 'lstm': 3}          # include/rl4rs_hip.h RL4RS_SIMNET_*
+
+
+class DeviceSimnet(object):
+    """rl4rs_simnet handle: the dnn / widedeep / lstm simulator families (same calling pattern as DeviceDien)."""
+
+    def __init__(self, config, weights, max_rows, max_slots, algo=None, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.algo = str(algo if algo is not None else config.get('algo')).lower()
+        if self.algo not in SIMNET_ALGOS:
+            raise ValueError("algo must be one of %s (got %r)" % (sorted(SIMNET_ALGOS), self.algo))
+        self.S = int(config['seq_num'])
+        self.L = int(config['maxlen'])
+        self.max_rows, self.max_slots = int(max_rows), int(max_slots)
+        cfg = _lib.SimnetCfg(SIMNET_ALGOS[self.algo], self.L, int(config['emb_size']), int(config['hidden_units']),
+                             int(config['dense_feature_num']), int(config['category_feature_num']),
+                             int(config['category_hash_size']), self.S, int(config['class_num']), self.max_rows,
+                             self.max_slots)
+        w = _lib.SimnetWeights()
+        keep = []
+
+        def fp(name):
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(arr)
+            return arr.ctypes.data_as(_lib._FP)
+
+        for name in ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'obs_w',
+                     'obs_b', 'out_w', 'out_b', 'cat_gru_kernel', 'cat_gru_recurrent', 'cat_gru_bias'):
+            if name in weights:
+                setattr(w, name, fp(name))
+        for i in range(self.S):
+            if 'seq%d_gru_kernel' % i in weights:
+                w.seq_gru_kernel[i] = fp('seq%d_gru_kernel' % i)
+                w.seq_gru_recurrent[i] = fp('seq%d_gru_recurrent' % i)
+                w.seq_gru_bias[i] = fp('seq%d_gru_bias' % i)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_simnet_create(C.byref(cfg), C.byref(w), _stream(), C.byref(h)))
+        self.h = h
+        d = C.c_int32()
+        check(self.lib.rl4rs_simnet_obs_dim(self.h, C.byref(d)))
+        self.obs_dim = d.value
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_simnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, s, ids, slot_base=0):
+        if isinstance(ids, tuple):
+            ptr, n = ids
+        else:
+            ids = _dev_tensor(ids, torch.int32, self.device)
+            assert ids.dim() == 2 and ids.shape[1] == self.L
+            ptr, n = _ptr(ids), ids.shape[0]
+            self._keep_ids = ids
+        check(self.lib.rl4rs_simnet_encode(self.h, s, ptr, n, slot_base, _stream()))
+
+    def forward(self, R, group, dense, cat, slots, want_obs=True, want_prob=False, obs_out=None):
+        dp = dense if isinstance(dense, C.c_void_p) else _ptr(dense)
+        cp = cat if isinstance(cat, C.c_void_p) else _ptr(cat)
+        assert slots.dtype == torch.int32 and slots.numel() == self.S * (R // group)
+        obs = None
+        if want_obs:
+            obs = obs_out if obs_out is not None else torch.empty((R, self.obs_dim), dtype=torch.float32, device=self.device)
+        prob = torch.empty(R, dtype=torch.float32, device=self.device) if want_prob else None
+        check(self.lib.rl4rs_simnet_forward(self.h, R, group, dp, cp, _ptr(slots), _ptr(obs), _ptr(prob), _stream()))
+        return obs, prob
+
+    def head_prob(self, obs):
+        R = obs.shape[0]
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.obs_dim
+        prob = torch.empty(R, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_simnet_head_prob(self.h, R, _ptr(obs), _ptr(prob), _stream()))
+        return prob
+
+    # no-op profiling hooks so bench / facade code can treat every scorer alike
+    def set_profiling(self, on):
+        pass
+
+    def profile_reset(self):
+        pass
+
+    def profile(self):
+        return {}
+
+
 def gemm_f32(a, w, bias=None, act=0):
     """C = act(a @ w + bias) through rl4rs_gemm_f32 (tests)."""
     lib = _lib.load()

@@ -80,3 +80,59 @@ def test_hoisting_identities_fp64():
         c = np.tanh(x[:, 2 * E:] + (r * h) @ Wc1[E:])
         h = u * h + (1.0 - u) * c
         assert np.abs(h - H1[:, t]).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dnn / widedeep / lstm restatements (oracle/simnets.py)
+
+SIM_CFG = {"maxlen": 16, "batch_size": 4, "action_size": 284, "class_num": 2, "dense_feature_num": 40,
+           "category_feature_num": 7, "category_hash_size": 300, "seq_num": 2, "emb_size": 16, "hidden_units": 32}
+
+
+def test_simnet_oracle_shapes_and_softmax():
+    from rl4rs_amd.nets.simnets import init_simnet_weights, obs_dim, simnet_spec, check_weights
+    from oracle.simnets import OracleSimnet
+    rs = np.random.RandomState(0)
+    seq = rs.randint(0, 300, size=(6, 2, 16))
+    dense = np.abs(rs.randn(6, 40))
+    cat = rs.randint(0, 300, size=(6, 7))
+    for algo in ('dnn', 'widedeep', 'lstm'):
+        w = init_simnet_weights(SIM_CFG, algo, seed=2, bias_noise=0.1)
+        check_weights(w, SIM_CFG, algo)
+        assert list(w) == list(simnet_spec(SIM_CFG, algo))
+        o = OracleSimnet(algo, w, SIM_CFG)
+        obs = o.obs(seq, dense, cat)
+        assert obs.shape == (6, obs_dim(SIM_CFG, algo))
+        p = o.reward_probs(seq, dense, cat)
+        assert p.shape == (6, 2) and np.allclose(p.sum(axis=1), 1.0)
+        # rows are independent: scoring a subset gives the same rows
+        assert np.allclose(o.obs(seq[2:4], dense[2:4], cat[2:4]), obs[2:4], atol=1e-12)
+    # the dnn model never reads its sequences (dnn.py:33-34); widedeep and lstm do
+    w = init_simnet_weights(SIM_CFG, 'dnn', seed=2)
+    o = OracleSimnet('dnn', w, SIM_CFG)
+    assert np.array_equal(o.obs(seq, dense, cat), o.obs(seq[::-1], dense, cat))
+    w = init_simnet_weights(SIM_CFG, 'lstm', seed=2, emb_scale=0.5)
+    o = OracleSimnet('lstm', w, SIM_CFG)
+    assert not np.allclose(o.obs(seq, dense, cat), o.obs(seq[::-1], dense, cat))
+
+
+def test_keras_gru_restatement_against_step_formula():
+    """One step from h0 = 0 and the z/r/h column order of the keras kernel."""
+    from oracle.simnets import keras_gru_last
+    rs = np.random.RandomState(3)
+    E, U = 5, 4
+    k, r, b = rs.randn(E, 3 * U), rs.randn(U, 3 * U), rs.randn(3 * U)
+    x = rs.randn(2, 1, E)
+    h1 = keras_gru_last(x, k, r, b)
+    xp = x[:, 0] @ k + b
+    z = np.clip(0.2 * xp[:, :U] + 0.5, 0, 1)
+    hh = np.tanh(xp[:, 2 * U:])
+    assert np.allclose(h1, (1 - z) * hh)
+    # two steps: the reset gate multiplies h before the candidate's recurrent matmul (reset_after=False)
+    x2 = rs.randn(2, 2, E)
+    h = keras_gru_last(x2[:, :1], k, r, b)
+    xp = x2[:, 1] @ k + b
+    z = np.clip(0.2 * (xp[:, :U] + h @ r[:, :U]) + 0.5, 0, 1)
+    rr = np.clip(0.2 * (xp[:, U:2 * U] + h @ r[:, U:2 * U]) + 0.5, 0, 1)
+    hh = np.tanh(xp[:, 2 * U:] + (rr * h) @ r[:, 2 * U:])
+    assert np.allclose(keras_gru_last(x2, k, r, b), z * h + (1 - z) * hh)
