@@ -370,6 +370,15 @@ int rl4rs_policy_loss_grad(rl4rs_policy* pol, int32_t algo, int32_t N, const flo
  * tf.clip_by_global_norm first. */
 int rl4rs_policy_adam_step(rl4rs_policy* pol, const float* grad_dev, float lr, float beta1, float beta2,
                            float eps, float grad_clip, void* stream);
+/* One PPO SGD pass over N already shuffled samples in minibatches of `minibatch` consecutive rows (loss + backward
+ * + Adam per minibatch; the trailing N % minibatch rows are dropped; stats of the last minibatch).  Identical
+ * arithmetic to rl4rs_policy_loss_grad(algo 1) + rl4rs_policy_adam_step per minibatch, one host call. */
+int rl4rs_policy_ppo_epoch(rl4rs_policy* pol, int32_t N, int32_t minibatch, const float* obs_dev,
+                           const uint32_t* mask_bits_dev, const int32_t* actions_dev, const float* adv_dev,
+                           const float* ret_dev, const float* old_logp_dev, const float* old_value_dev,
+                           const float* old_logits_dev, float vf_coeff, float ent_coeff, float clip, float vf_clip,
+                           float kl_coeff, float lr, float beta1, float beta2, float eps, float grad_clip,
+                           float* grad_dev, float* stats_dev, void* stream);
 
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */

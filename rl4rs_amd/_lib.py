@@ -124,6 +124,7 @@ SIGNATURES = {
     'rl4rs_policy_loss_grad': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, _P, _P, _P]),
     'rl4rs_policy_adam_step': (_I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
 }

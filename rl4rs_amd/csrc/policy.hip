@@ -466,12 +466,13 @@ int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float
     float* gb2 = gW2 + (size_t)d.HID * d.AE;
     auto tn = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst) {
         int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
-        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, N, p->chunk, p->part);
-        hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, p->part, M * Nc, nz, dst);
+        // one chunk (PPO minibatches): the partial IS the result, no reduction pass
+        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, N, p->chunk, nz == 1 ? dst : p->part);
+        if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, p->part, M * Nc, nz, dst);
     };
     auto cs = [&](const float* X, int ld, int Nc, float* dst) {
-        hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, N, p->chunk, p->part);
-        hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, p->part, Nc, nz, dst);
+        hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, N, p->chunk, nz == 1 ? dst : p->part);
+        if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, p->part, Nc, nz, dst);
     };
     tn(obs, d.OD, d.OD, p->dHpre, d.HID, d.HID, gW1);      // dW1  = obs^T dHpre
     cs(p->dHpre, d.HID, d.HID, gb1);                        // db1
@@ -496,6 +497,32 @@ int rl4rs_policy_adam_step(rl4rs_policy* p, const float* grad_dev, float lr, flo
     hipLaunchKernelGGL(k_adam, dim3((p->n_params + 255) / 256), dim3(256), 0, st, p->params, grad_dev, p->adam_m, p->adam_v,
                        p->n_params, lr_t, beta1, beta2, eps, p->sumsq, grad_clip);
     RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// One PPO SGD pass (RLlib: num_sgd_iter passes over minibatches of sgd_minibatch_size, script/modelfree_train.py:231-254)
+// over N already shuffled samples: loss + backward + Adam per minibatch of `minibatch` consecutive rows, the trailing
+// N % minibatch rows are dropped.  Same arithmetic as calling rl4rs_policy_loss_grad + rl4rs_policy_adam_step per
+// minibatch; exists so that a single-GPU trainer pays one host call per pass instead of two per minibatch.
+int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const float* obs, const uint32_t* mask_bits,
+                           const int32_t* actions, const float* adv, const float* ret, const float* old_logp,
+                           const float* old_value, const float* old_logits, float vf_coeff, float ent_coeff, float clip,
+                           float vf_clip, float kl_coeff, float lr, float beta1, float beta2, float eps, float grad_clip,
+                           float* grad_dev, float* stats_dev, void* stream) {
+    RL4RS_REQUIRE(p && obs && actions && adv && ret && old_logp && old_value && old_logits && grad_dev,
+                  "policy_ppo_epoch: null argument");
+    RL4RS_REQUIRE(minibatch > 0 && N >= minibatch && minibatch <= p->max_rows,
+                  "policy_ppo_epoch: bad sizes (N=%d, minibatch=%d, max_rows=%d)", N, minibatch, p->max_rows);
+    const PolDims& d = p->d;
+    for (int lo = 0; lo + minibatch <= N; lo += minibatch) {
+        const bool last = lo + 2 * minibatch > N;
+        int rc = rl4rs_policy_loss_grad(p, 1, minibatch, obs + (size_t)lo * d.OD, mask_bits ? mask_bits + (size_t)lo * d.W : nullptr,
+                                        actions + lo, adv + lo, ret + lo, old_logp + lo, old_value + lo,
+                                        old_logits + (size_t)lo * d.A, vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, grad_dev,
+                                        last ? stats_dev : nullptr, stream);
+        if (rc) return rc;
+        if ((rc = rl4rs_policy_adam_step(p, grad_dev, lr, beta1, beta2, eps, grad_clip, stream))) return rc;
+    }
     return RL4RS_OK;
 }
 

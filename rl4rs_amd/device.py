@@ -588,5 +588,22 @@ class DevicePolicy(object):
                                               vf_clip, kl_coeff, _ptr(g), _ptr(stats), _stream()))
         return g, stats
 
+    def ppo_epoch(self, obs, actions, adv, ret, mask_bits, old_logp, old_value, old_logits, minibatch=256, vf_coeff=0.5,
+                  ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                  grad_clip=0.0, grad_out=None):
+        """One SGD pass over already shuffled samples (rl4rs_policy_ppo_epoch): returns the stats of the last minibatch."""
+        N = obs.shape[0]
+        m = self._mask(mask_bits, N)
+        g = grad_out if grad_out is not None else torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        stats = torch.empty(4, dtype=torch.float32, device=self.device)
+        f = lambda t: t.to(torch.float32).contiguous()
+        obs, adv, ret, old_logp, old_value, old_logits = f(obs), f(adv), f(ret), f(old_logp), f(old_value), f(old_logits)
+        actions = actions.to(torch.int32).contiguous()
+        check(self.lib.rl4rs_policy_ppo_epoch(self.h, N, minibatch, _ptr(obs), _ptr(m), _ptr(actions), _ptr(adv), _ptr(ret),
+                                              _ptr(old_logp), _ptr(old_value), _ptr(old_logits), vf_coeff, ent_coeff, clip,
+                                              vf_clip, kl_coeff, lr, beta1, beta2, eps, grad_clip, _ptr(g), _ptr(stats),
+                                              _stream()))
+        return stats
+
     def adam_step(self, grad, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_clip=0.0):
         check(self.lib.rl4rs_policy_adam_step(self.h, _ptr(grad), lr, beta1, beta2, eps, grad_clip, _stream()))

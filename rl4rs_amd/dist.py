@@ -60,6 +60,14 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def world_size():
+    """Size of the initialised process group (1 when torch.distributed is not in use)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
 def allreduce_mean_(flat):
     """In-place mean all-reduce of ONE flat fp32 gradient buffer (a single fused collective per optimiser step:
     the mask-model gradient is 140 KB, latency-bound, so bucketing would only add launches)."""

@@ -112,6 +112,39 @@ def test_loss_gradients_match_autograd(algo):
     assert np.abs(after - expect).max() < 1e-6
 
 
+def test_ppo_epoch_equals_minibatch_sequence():
+    """rl4rs_policy_ppo_epoch == loss_grad + adam_step per minibatch, bit for bit (trailing rows dropped)."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    from oracle import policy as OP
+    rs = np.random.RandomState(9)
+    N, MB = 1100, 256
+    obs, mask, bits = _data(N, rs)
+    flat = init_policy_params(seed=2) + (rs.randn(34973) * 0.05).astype(np.float32)
+    old_logits, old_value = OP.forward(flat, obs, mask)
+    old_lsm = OP.log_softmax(old_logits)
+    actions = np.array([rs.choice(np.nonzero(mask[i])[0]) for i in range(N)])
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    o, b, a = t(obs), torch.from_numpy(bits).cuda(), t(actions, torch.int32)
+    adv, ret = t(rs.randn(N) * 2), t(rs.randn(N) * 50 + 100)
+    olp, ov = t(old_lsm[np.arange(N), actions]), t(old_value)
+    ol = t(np.maximum(old_logits, -3.4e38).astype(np.float32))
+    kw = dict(vf_coeff=0.5, ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2)
+    p1 = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+    p2 = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+    stats1 = None
+    for lo in range(0, N - MB + 1, MB):
+        hi = lo + MB
+        g, stats1 = p1.loss_grad(1, o[lo:hi], a[lo:hi], adv[lo:hi], ret[lo:hi], mask_bits=b[lo:hi], old_logp=olp[lo:hi],
+                                 old_value=ov[lo:hi], old_logits=ol[lo:hi], **kw)
+        p1.adam_step(g, lr=1e-3)
+    stats2 = p2.ppo_epoch(o, a, adv, ret, b, olp, ov, ol, minibatch=MB, lr=1e-3, **kw)
+    assert torch.equal(p1.params(), p2.params())
+    assert torch.equal(stats1, stats2)
+    assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
+
+
 def test_training_loop_runs_and_improves_masked_policy(tmp_path):
     """A2C / PPO iterations over the GPU env: runs, stays finite, never plays a masked action."""
     import torch
