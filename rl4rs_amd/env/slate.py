@@ -98,6 +98,13 @@ class SlateState(RecState):
             log_steps = store.log_steps
             self._exposed_len_min = int(store.exposed_len[np.asarray(records.rows)].min())
             self._users = None
+            # RecDataBase.sample draws the batch WITH replacement from a cache window (base.py:92-100; 4096 envs from
+            # 2048 lines at the bench config), so many envs share one user history: keep the distinct histories and
+            # the env -> history map, the scorer encodes each distinct sequence once
+            uniq, first, inv = np.unique(np.asarray(records.rows, dtype=np.int64), return_index=True, return_inverse=True)
+            if len(uniq) < len(records.rows):
+                self._hist_unique = (cols['history'].index_select(0, torch.from_numpy(first).to(dev)).contiguous(),
+                                     torch.from_numpy(inv.astype(np.int32)).to(dev))
         else:
             rc = RecordColumns(list(records), self.config['maxlen'])
             cols = dict(exposed=rc.exposed, feedback=rc.feedback, history=rc.history,
@@ -358,11 +365,16 @@ class SlateRecEnv(RecSimBase):
         B = self.batch_size
         env = samples._live()
         net = self.model.ensure_device(B * env.n_complete, B + 1)
+        hu = None if self.config.get('no_history_dedup', False) else getattr(samples, '_hist_unique', None)
         if self._encoded_batch != (id(net), samples._batch_version):
-            p0, _ = env.buffer_ptr(D.BUF_SEQ0)
-            net.encode(0, (p0, B), 0)                       # history: one slot per env
+            if hu is not None:
+                net.encode(0, hu[0], 0)                     # history: one slot per DISTINCT sampled log line
+            else:
+                p0, _ = env.buffer_ptr(D.BUF_SEQ0)
+                net.encode(0, (p0, B), 0)                   # history: one slot per env
             self._encoded_batch = (id(net), samples._batch_version)
             self._encoded_seq1 = None
+            self._slots_hist = None
         if samples.is_seq:
             if self._encoded_seq1 != samples._seq1_version:
                 p1, _ = env.buffer_ptr(D.BUF_SEQ1)
@@ -371,6 +383,7 @@ class SlateRecEnv(RecSimBase):
                 self._encoded_seq1 = samples._seq1_version
             if self._slots is None or self._slots[0] != 'seq':
                 self._slots = ('seq', torch.arange(B, dtype=torch.int32, device=env.device).repeat(net.S, 1).contiguous())
+                self._slots_hist = None
         else:
             if not getattr(self.model, 'zero_slot_ready', False):
                 z = torch.zeros((1, net.L), dtype=torch.int32, device=env.device)
@@ -381,6 +394,10 @@ class SlateRecEnv(RecSimBase):
                 sl = torch.full((net.S, B), B, dtype=torch.int32, device=env.device)
                 sl[0] = torch.arange(B, dtype=torch.int32, device=env.device)
                 self._slots = ('slate', sl.contiguous())
+                self._slots_hist = None
+        if getattr(self, '_slots_hist', None) is None:      # row 0 of the slot table: env -> history slot of this batch
+            self._slots[1][0].copy_(hu[1] if hu is not None else torch.arange(B, dtype=torch.int32, device=env.device))
+            self._slots_hist = samples._batch_version
         return net, self._slots[1]
 
     # -- obs -----------------------------------------------------------------------------------

@@ -213,6 +213,31 @@ def test_state_row_reuse_is_bit_identical(tmp_path, seq, T):
     assert out[0][0].abs().sum() > 0
 
 
+@pytest.mark.parametrize('seq,T', [(False, 9), (True, 18)])
+def test_history_dedup_is_bit_identical(tmp_path, seq, T):
+    """Training-mode sampling draws the batch with replacement from a smaller cache window (base.py:92-100), so envs
+    share user histories; the scorer encodes each distinct history once.  Must equal one-slot-per-env bit for bit."""
+    import torch
+    out = []
+    for off in (False, True):
+        cfg, records, w = _setup(tmp_path, seq, 24, T, return_tensors=True, no_history_dedup=off)
+        cfg.update(is_eval=False, cache_size=7)          # 24 envs drawn from a 7-line window
+        env = _make(cfg, seq)
+        env.seed(123)
+        obs = env.reset(reset_file=True)
+        rows = list(env.samples.records.rows)
+        assert len(set(rows)) < len(rows)
+        assert (getattr(env.samples, '_hist_unique', None) is not None)
+        trace = [obs.clone()]
+        for t in range(T):
+            obs, reward, done, info = env.step(env.offline_action)
+            trace += [obs.clone(), reward.clone()]
+        out.append((rows, trace))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('seq,T', [(False, 9), (True, 36)])
 def test_offline_dataset_generation_matches_oracle_replay(tmp_path, seq, T):
     """f1: device-side data_generate_rl4rs_* (script/batchrl_trainer.py:172-217) vs the same loop over the oracle env."""
