@@ -380,6 +380,35 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* pol, int32_t N, int32_t minibatch, cons
                            float kl_coeff, float lr, float beta1, float beta2, float eps, float grad_clip,
                            float* grad_dev, float* stats_dev, void* stream);
 
+/* Raw-state policy encoder: rl4rs/nets/rllib/rllib_rawstate_model.py:25-86 (and its action-mask wrapper,
+ * rllib_mask_model.py:67-115) for envs with config['rawstate_as_obs'] (rl4rs/env/slate.py:250-262):
+ *   context = ELU([mean seq emb (per sequence, one shared table) | dense tower | mean category emb] @ ctx_w + ctx_b)  (256)
+ *   logits  = context @ out_w + out_b (+ max(log(mask), float32.min)),   value = context @ value_w + value_b
+ * Forward only (act / evaluate with the outputs of rl4rs_policy_act / rl4rs_policy_evaluate); shapes of the host
+ * float32 weights in rl4rs_amd/nets/rawpolicy.py.  seq_dev: seq_num device pointers, each int32 [N, maxlen]. */
+typedef struct rl4rs_rawpolicy rl4rs_rawpolicy;
+typedef struct rl4rs_rawpolicy_cfg {
+    int32_t maxlen, emb_size, hidden_units, dense_feature_num, category_feature_num, category_hash_size, seq_num,
+        action_size, max_rows;
+} rl4rs_rawpolicy_cfg;
+typedef struct rl4rs_rawpolicy_weights {
+    const float* cat_emb; const float* seq_emb;
+    const float* dense_w1; const float* dense_b1; const float* dense_w2; const float* dense_b2;
+    const float* ctx_w; const float* ctx_b;
+    const float* out_w; const float* out_b;
+    const float* value_w; const float* value_b;
+} rl4rs_rawpolicy_weights;
+int rl4rs_rawpolicy_create(const rl4rs_rawpolicy_cfg* cfg, const rl4rs_rawpolicy_weights* w, void* stream,
+                           rl4rs_rawpolicy** out);
+int rl4rs_rawpolicy_destroy(rl4rs_rawpolicy* pol);
+int rl4rs_rawpolicy_act(rl4rs_rawpolicy* pol, int32_t N, const int32_t* cat_dev, const float* dense_dev,
+                        const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, uint32_t seed, uint32_t step,
+                        int32_t* actions_dev, float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev,
+                        void* stream);
+int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* pol, int32_t N, const int32_t* cat_dev, const float* dense_dev,
+                             const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
+                             float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

@@ -98,3 +98,21 @@ def predict_with_mask(scores, obs, location_mask, special_items, page_items=9):
         if len(np.intersect1d(prev_actions[i], special_items)) > 0:
             action_probs[i][special_items] = -2 ** 15
     return action_probs.argmax(axis=1)
+
+
+def rawstate_forward(weights, cat, dense, seqs, mask=None):
+    """Raw-state policy encoder (rl4rs/nets/rllib/rllib_rawstate_model.py:49-76; PARITY UNPINNED like the rest of this
+    module): context = ELU([mean seq embs | dense tower | mean category emb] @ ctx_w + ctx_b); logits = context @ out_w +
+    out_b (+ the mask term of rllib_mask_model.py:61-62); value = context @ value_w + value_b.
+    cat [N,Cn] ids, dense [N,Dn], seqs = list of [N,L] ids.  -> masked logits [N,A] float64, value [N]."""
+    w = dict((k, np.asarray(v, dtype=np.float64)) for k, v in weights.items())
+    elu = lambda x: np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    seq_feat = [w['seq_emb'][np.asarray(s, dtype=np.int64)].mean(axis=1) for s in seqs]     # utils.py:57-77
+    d = elu(elu(np.asarray(dense, dtype=np.float64) @ w['dense_w1'] + w['dense_b1']) @ w['dense_w2'] + w['dense_b2'])
+    c = w['cat_emb'][np.asarray(cat, dtype=np.int64)].mean(axis=1)                          # utils.py:7-14
+    ctx = elu(np.concatenate(seq_feat + [d, c], axis=1) @ w['ctx_w'] + w['ctx_b'])
+    logits = ctx @ w['out_w'] + w['out_b']
+    if mask is not None:
+        with np.errstate(divide='ignore'):
+            logits = logits + np.maximum(np.log(np.asarray(mask, dtype=np.float64)), F32_MIN)
+    return logits, (ctx @ w['value_w'] + w['value_b'])[:, 0]

@@ -63,6 +63,17 @@ class SimnetWeights(C.Structure):
     ]
 
 
+class RawPolicyCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num', 'category_hash_size',
+        'seq_num', 'action_size', 'max_rows')]
+
+
+class RawPolicyWeights(C.Structure):
+    _fields_ = [(n, _FP) for n in ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'ctx_w', 'ctx_b',
+                                   'out_w', 'out_b', 'value_w', 'value_b')]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/rl4rs_hip.h declares
@@ -124,6 +135,10 @@ SIGNATURES = {
     'rl4rs_policy_loss_grad': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, _P, _P, _P]),
     'rl4rs_policy_adam_step': (_I, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'rl4rs_rawpolicy_create': (_I, [C.POINTER(RawPolicyCfg), C.POINTER(RawPolicyWeights), _P, C.POINTER(_P)]),
+    'rl4rs_rawpolicy_destroy': (_I, [_P]),
+    'rl4rs_rawpolicy_act': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_rawpolicy_evaluate': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),

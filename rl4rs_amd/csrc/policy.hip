@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "gather_kernels.hpp"
 
 namespace rl4rs {
 
@@ -84,23 +85,13 @@ __device__ __forceinline__ float policy_row_forward(const PolDims& d, const floa
     return mx + logf(se);
 }
 
-// act / evaluate: one wave per sample.  SAMPLE: Gumbel-max draw from the masked categorical.
+// Outputs of one sample from its masked logits / value in s_out (shared by the FC policy and the raw-state policy):
+// entropy, optional logits copy, Gumbel-max draw (SAMPLE) or the given action, log-prob, value.
 template <bool SAMPLE>
-__global__ __launch_bounds__(256) void k_policy_forward(PolDims d, const float* __restrict__ prm, int N,
-                                                        const float* __restrict__ obs, const uint32_t* __restrict__ mask,
-                                                        uint32_t seed, uint32_t step, int32_t* __restrict__ actions,
-                                                        float* __restrict__ logp, float* __restrict__ value,
-                                                        float* __restrict__ entropy, float* __restrict__ logits_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = d.OD + d.HID + d.AE;
-    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
-    float* s_h = s_obs + d.OD;
-    float* s_out = s_h + d.HID;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
-    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+__device__ __forceinline__ void policy_row_outputs(const PolDims& d, const float* s_out, float lse, int n, int lane,
+                                                   uint32_t seed, uint32_t step, int32_t* __restrict__ actions,
+                                                   float* __restrict__ logp, float* __restrict__ value,
+                                                   float* __restrict__ entropy, float* __restrict__ logits_out) {
     float ent = 0.f, best = -3.4028235e38f;
     int best_a = 0x7fffffff;
     for (int a = lane; a < d.A; a += 64) {
@@ -133,6 +124,59 @@ __global__ __launch_bounds__(256) void k_policy_forward(PolDims d, const float* 
         if (value) value[n] = s_out[d.A];
         if (entropy) entropy[n] = ent;
     }
+}
+
+// act / evaluate: one wave per sample.  SAMPLE: Gumbel-max draw from the masked categorical.
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_policy_forward(PolDims d, const float* __restrict__ prm, int N,
+                                                        const float* __restrict__ obs, const uint32_t* __restrict__ mask,
+                                                        uint32_t seed, uint32_t step, int32_t* __restrict__ actions,
+                                                        float* __restrict__ logp, float* __restrict__ value,
+                                                        float* __restrict__ entropy, float* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = d.OD + d.HID + d.AE;
+    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
+    float* s_h = s_obs + d.OD;
+    float* s_out = s_h + d.HID;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
+    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+    policy_row_outputs<SAMPLE>(d, s_out, lse, n, lane, seed, step, actions, logp, value, entropy, logits_out);
+}
+
+// Raw-state policy head: [logits | value] rows come from a GEMM (context @ [out_w | value_w] + bias); this kernel adds the
+// action mask (rllib_mask_model.py:61-62 form), then the same outputs as k_policy_forward.  One wave per sample.
+template <bool SAMPLE>
+__global__ __launch_bounds__(256) void k_rawpolicy_head(PolDims d, int N, const float* __restrict__ ext, int64_t ext_ld,
+                                                        const uint32_t* __restrict__ mask, uint32_t seed, uint32_t step,
+                                                        int32_t* __restrict__ actions, float* __restrict__ logp,
+                                                        float* __restrict__ value, float* __restrict__ entropy,
+                                                        float* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* s_out = reinterpret_cast<float*>(smem) + (size_t)wave * d.AE;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
+    float mx = -3.4028235e38f;
+    for (int a = lane; a < d.AE; a += 64) {
+        float v = ext[(size_t)n * ext_ld + a];
+        if (a < d.A) {
+            bool ok = mrow ? ((mrow[a >> 5] >> (a & 31)) & 1u) : true;
+            if (!ok) v = v + (-3.4028235e38f);
+            mx = fmaxf(mx, v);
+        }
+        s_out[a] = v;
+    }
+    mx = wave_max(mx);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float se = 0.f;
+    for (int a = lane; a < d.A; a += 64) se += expf(s_out[a] - mx);
+    const float lse = mx + logf(wave_sum(se));
+    policy_row_outputs<SAMPLE>(d, s_out, lse, n, lane, seed, step, actions, logp, value, entropy, logits_out);
 }
 
 struct LossArgs {
@@ -496,6 +540,148 @@ int rl4rs_policy_adam_step(rl4rs_policy* p, const float* grad_dev, float lr, flo
     if (grad_clip > 0.f) hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(256), 0, st, grad_dev, p->n_params, p->sumsq);
     hipLaunchKernelGGL(k_adam, dim3((p->n_params + 255) / 256), dim3(256), 0, st, p->params, grad_dev, p->adam_m, p->adam_v,
                        p->n_params, lr_t, beta1, beta2, eps, p->sumsq, grad_clip);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// ---- raw-state policy encoder (rllib_rawstate_model.py:25-86, mask wrapper rllib_mask_model.py:67-115) ---------------
+}  // extern "C"
+
+struct rl4rs_rawpolicy {
+    rl4rs_rawpolicy_cfg c;
+    PolDims d;
+    int F;
+    float *cat_emb, *seq_emb, *dense_w1, *dense_b1, *dense_w2, *dense_b2, *ctx_w, *ctx_b, *head_w, *head_b;
+    float *feat, *dh, *ctx, *ext;
+    std::vector<void*> owned;
+};
+
+extern "C" {
+
+int rl4rs_rawpolicy_destroy(rl4rs_rawpolicy* p) {
+    if (!p) return RL4RS_OK;
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+    return RL4RS_OK;
+}
+
+int rl4rs_rawpolicy_create(const rl4rs_rawpolicy_cfg* c, const rl4rs_rawpolicy_weights* w, void* stream,
+                           rl4rs_rawpolicy** out) {
+    RL4RS_REQUIRE(c && w && out, "rawpolicy_create: null argument");
+    RL4RS_REQUIRE(c->emb_size > 0 && c->hidden_units > 0 && c->maxlen >= 1 && c->seq_num >= 1 && c->seq_num <= 4 &&
+                  c->category_feature_num >= 1 && c->category_hash_size > 0 && c->dense_feature_num > 0 &&
+                  c->action_size > 1 && c->max_rows > 0, "rawpolicy_create: bad sizes");
+    RL4RS_REQUIRE(w->cat_emb && w->seq_emb && w->dense_w1 && w->dense_b1 && w->dense_w2 && w->dense_b2 && w->ctx_w && w->ctx_b &&
+                  w->out_w && w->out_b && w->value_w && w->value_b, "rawpolicy_create: weights missing");
+    if (rl4rs_device_count() <= 0) {
+        set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
+        return RL4RS_EHIP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int E = c->emb_size, U = c->hidden_units, H = c->category_hash_size, S = c->seq_num, Dn = c->dense_feature_num;
+    const int A = c->action_size, AE = A + 1, CTX = 256;
+    rl4rs_rawpolicy* p = new rl4rs_rawpolicy();
+    p->c = *c;
+    p->d.OD = CTX; p->d.HID = 0; p->d.A = A; p->d.AE = AE; p->d.W = (A + 31) / 32;
+    p->F = S * E + U + E;                 // [sequence_feature | dense_feature | category_feature] (rllib_rawstate_model.py:52)
+    int rc;
+    std::vector<std::vector<float>> keep;
+    keep.reserve(16);
+    auto up = [&](float** dst, const float* src, size_t n) {
+        int r = dev_alloc(dst, n);
+        if (r) return r;
+        p->owned.push_back(*dst);
+        hipError_t e = hipMemcpyAsync(*dst, src, n * 4, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e)); return (int)RL4RS_EHIP; }
+        return (int)RL4RS_OK;
+    };
+    auto al = [&](float** dst, size_t n) {
+        int r = dev_alloc(dst, n);
+        if (r == RL4RS_OK) p->owned.push_back(*dst);
+        return r;
+    };
+#define RP_FAIL(expr) do { if ((rc = (expr)) != RL4RS_OK) { rl4rs_rawpolicy_destroy(p); return rc; } } while (0)
+#define RP_PK(dst, src, kk, nn) do { keep.push_back(pack_gemm_weight((src), (nn), (kk), (nn))); \
+        RP_FAIL(up(&p->dst, keep.back().data(), keep.back().size())); } while (0)
+    RP_FAIL(up(&p->cat_emb, w->cat_emb, (size_t)H * E));
+    RP_FAIL(up(&p->seq_emb, w->seq_emb, (size_t)H * E));
+    RP_PK(dense_w1, w->dense_w1, Dn, U);
+    RP_FAIL(up(&p->dense_b1, w->dense_b1, U));
+    RP_PK(dense_w2, w->dense_w2, U, U);
+    RP_FAIL(up(&p->dense_b2, w->dense_b2, U));
+    RP_PK(ctx_w, w->ctx_w, p->F, CTX);
+    RP_FAIL(up(&p->ctx_b, w->ctx_b, CTX));
+    {   // one head GEMM for [logits | value]
+        std::vector<float> hw((size_t)CTX * AE), hb(AE);
+        for (int k = 0; k < CTX; ++k) {
+            for (int a = 0; a < A; ++a) hw[(size_t)k * AE + a] = w->out_w[(size_t)k * A + a];
+            hw[(size_t)k * AE + A] = w->value_w[k];
+        }
+        for (int a = 0; a < A; ++a) hb[a] = w->out_b[a];
+        hb[A] = w->value_b[0];
+        keep.push_back(pack_gemm_weight(hw.data(), AE, CTX, AE));
+        RP_FAIL(up(&p->head_w, keep.back().data(), keep.back().size()));
+        keep.push_back(std::move(hb));
+        RP_FAIL(up(&p->head_b, keep.back().data(), keep.back().size()));
+    }
+    RP_FAIL(al(&p->feat, (size_t)c->max_rows * p->F));
+    RP_FAIL(al(&p->dh, (size_t)c->max_rows * U));
+    RP_FAIL(al(&p->ctx, (size_t)c->max_rows * CTX));
+    RP_FAIL(al(&p->ext, (size_t)c->max_rows * AE));
+#undef RP_PK
+#undef RP_FAIL
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error("rawpolicy_create: hipStreamSynchronize failed: %s", hipGetErrorString(e));
+        rl4rs_rawpolicy_destroy(p);
+        return RL4RS_EHIP;
+    }
+    *out = p;
+    return RL4RS_OK;
+}
+
+static int rawpolicy_forward(rl4rs_rawpolicy* p, int N, const int32_t* cat, const float* dense, const int32_t* const* seq,
+                             hipStream_t st) {
+    const int E = p->c.emb_size, U = p->c.hidden_units, H = p->c.category_hash_size, S = p->c.seq_num, Dn = p->c.dense_feature_num;
+    const int F = p->F, L = p->c.maxlen, Cn = p->c.category_feature_num;
+    const dim3 g4((N + 3) / 4), b256(256);
+    int rc;
+    for (int s = 0; s < S; ++s)          // sequence_input_concat (utils.py:57-77): mean over all maxlen positions
+        hipLaunchKernelGGL(k_emb_mean, g4, b256, 0, st, seq[s], N, L, H, E, p->seq_emb, p->feat, (int64_t)F, s * E);
+    hipLaunchKernelGGL(k_emb_mean, g4, b256, 0, st, cat, N, Cn, H, E, p->cat_emb, p->feat, (int64_t)F, S * E + U);
+    RL4RS_LAUNCH_CHECK();
+    if ((rc = launch_gemm_packed(dense, Dn, p->dense_w1, p->dense_b1, p->dh, U, N, U, Dn, 1, st))) return rc;
+    if ((rc = launch_gemm_packed(p->dh, U, p->dense_w2, p->dense_b2, p->feat + S * E, F, N, U, U, 1, st))) return rc;
+    if ((rc = launch_gemm_packed(p->feat, F, p->ctx_w, p->ctx_b, p->ctx, 256, N, 256, F, 1, st))) return rc;
+    return launch_gemm_packed(p->ctx, 256, p->head_w, p->head_b, p->ext, p->d.AE, N, p->d.AE, 256, 0, st);
+}
+
+int rl4rs_rawpolicy_act(rl4rs_rawpolicy* p, int32_t N, const int32_t* cat, const float* dense, const int32_t* const* seq,
+                        const uint32_t* mask_bits, uint32_t seed, uint32_t step, int32_t* actions, float* logp, float* value,
+                        float* entropy, float* logits, void* stream) {
+    RL4RS_REQUIRE(p && cat && dense && seq && actions && N > 0 && N <= p->c.max_rows,
+                  "rawpolicy_act: bad argument (N=%d, max_rows=%d)", N, p ? p->c.max_rows : -1);
+    for (int s = 0; s < p->c.seq_num; ++s) RL4RS_REQUIRE(seq[s], "rawpolicy_act: sequence input %d is NULL", s);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rawpolicy_forward(p, N, cat, dense, seq, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rawpolicy_head<true>, dim3((N + 3) / 4), dim3(256), (size_t)4 * p->d.AE * 4, st, p->d, N, p->ext,
+                       (int64_t)p->d.AE, mask_bits, seed, step, actions, logp, value, entropy, logits);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* p, int32_t N, const int32_t* cat, const float* dense, const int32_t* const* seq,
+                             const uint32_t* mask_bits, const int32_t* actions, float* logp, float* value, float* entropy,
+                             float* logits, void* stream) {
+    RL4RS_REQUIRE(p && cat && dense && seq && actions && N > 0 && N <= p->c.max_rows,
+                  "rawpolicy_evaluate: bad argument (N=%d, max_rows=%d)", N, p ? p->c.max_rows : -1);
+    for (int s = 0; s < p->c.seq_num; ++s) RL4RS_REQUIRE(seq[s], "rawpolicy_evaluate: sequence input %d is NULL", s);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rawpolicy_forward(p, N, cat, dense, seq, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rawpolicy_head<false>, dim3((N + 3) / 4), dim3(256), (size_t)4 * p->d.AE * 4, st, p->d, N, p->ext,
+                       (int64_t)p->d.AE, mask_bits, 0u, 0u, const_cast<int32_t*>(actions), logp, value, entropy, logits);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

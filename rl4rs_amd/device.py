@@ -468,6 +468,77 @@ class DeviceSimnet(object):
         return {}
 
 
+class DeviceRawPolicy(object):
+    """rl4rs_rawpolicy handle: the raw-state policy encoder (rllib_rawstate_model.py) with the action-mask rule,
+    forward only.  Inputs are the raw feature tensors an env with config['rawstate_as_obs'] exposes."""
+
+    def __init__(self, config, weights, max_rows, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.S, self.L, self.A = int(config['seq_num']), int(config['maxlen']), int(config['action_size'])
+        self.Cn, self.Dn = int(config['category_feature_num']), int(config['dense_feature_num'])
+        self.W = (self.A + 31) // 32
+        self.max_rows = int(max_rows)
+        cfg = _lib.RawPolicyCfg(self.L, int(config['emb_size']), int(config['hidden_units']), self.Dn, self.Cn,
+                                int(config['category_hash_size']), self.S, self.A, self.max_rows)
+        w = _lib.RawPolicyWeights()
+        keep = []
+        for name, _ in _lib.RawPolicyWeights._fields_:
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(arr)
+            setattr(w, name, arr.ctypes.data_as(_lib._FP))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_rawpolicy_create(C.byref(cfg), C.byref(w), _stream(), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_rawpolicy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _inputs(self, cat, dense, seqs, mask_bits):
+        N = cat.shape[0]
+        assert cat.dtype == torch.int32 and cat.shape == (N, self.Cn) and cat.is_contiguous()
+        assert dense.dtype == torch.float32 and dense.shape == (N, self.Dn) and dense.is_contiguous()
+        assert len(seqs) == self.S
+        for q in seqs:
+            assert q.dtype == torch.int32 and q.shape == (N, self.L) and q.is_contiguous()
+        if mask_bits is not None:
+            assert mask_bits.dtype == torch.int32 and mask_bits.shape == (N, self.W) and mask_bits.is_contiguous()
+        sp = (C.c_void_p * self.S)(*[_ptr(q) for q in seqs])
+        return N, sp
+
+    def _outs(self, N, want_logits):
+        f = lambda: torch.empty(N, dtype=torch.float32, device=self.device)
+        lg = torch.empty((N, self.A), dtype=torch.float32, device=self.device) if want_logits else None
+        return f(), f(), f(), lg
+
+    def act(self, cat, dense, seqs, mask_bits=None, seed=0, step=0, want_logits=False):
+        """-> actions [N] int32, logp, value, entropy (float32 [N]), masked logits [N, A] or None."""
+        N, sp = self._inputs(cat, dense, seqs, mask_bits)
+        a = torch.empty(N, dtype=torch.int32, device=self.device)
+        lp, v, ent, lg = self._outs(N, want_logits)
+        check(self.lib.rl4rs_rawpolicy_act(self.h, N, _ptr(cat), _ptr(dense), sp, _ptr(mask_bits), seed, step, _ptr(a),
+                                           _ptr(lp), _ptr(v), _ptr(ent), _ptr(lg), _stream()))
+        return a, lp, v, ent, lg
+
+    def evaluate(self, cat, dense, seqs, actions, mask_bits=None, want_logits=False):
+        N, sp = self._inputs(cat, dense, seqs, mask_bits)
+        actions = actions.to(torch.int32).contiguous()
+        lp, v, ent, lg = self._outs(N, want_logits)
+        check(self.lib.rl4rs_rawpolicy_evaluate(self.h, N, _ptr(cat), _ptr(dense), sp, _ptr(mask_bits), _ptr(actions),
+                                                _ptr(lp), _ptr(v), _ptr(ent), _ptr(lg), _stream()))
+        return lp, v, ent, lg
+
+
 def gemm_f32(a, w, bias=None, act=0):
     """C = act(a @ w + bias) through rl4rs_gemm_f32 (tests)."""
     lib = _lib.load()

@@ -408,6 +408,16 @@ class SlateRecEnv(RecSimBase):
         samples = rows.owner
         tensor_mode = samples._tensor_mode()
         B = self.batch_size
+        if self.config.get("rawstate_as_obs", False) and tensor_mode:
+            # zero-copy form of the raw-state observation (slate.py:250-262): device tensors of the whole batch, what
+            # DeviceRawPolicy.act takes
+            env = samples._live()
+            seq0, seq1 = env.snapshot(D.BUF_SEQ0), env.snapshot(D.BUF_SEQ1)
+            obs = {"category_feature": env.snapshot(D.BUF_CATEGORY), "dense_feature": env.snapshot(D.BUF_DENSE),
+                   "sequence_feature": [seq0] + [seq1] * (self.config['seq_num'] - 1)}
+            if masked:
+                obs["action_mask"] = state["action_mask"]
+            return obs
         if self.config.get("rawstate_as_obs", False):
             feat, _ = self.FeatureUtil.feature_extraction(rows)
             obs = [{"category_feature": feat[2][i], "dense_feature": feat[1][i], "sequence_feature": feat[0][i]}

@@ -172,3 +172,103 @@ def test_training_loop_runs_and_improves_masked_policy(tmp_path):
         # the masked policy only produces legal slates: rewards are not zeroed by the violation rule
         assert env.samples.get_violation().all()
         assert outs[-1]['episode_reward_mean'] > 0
+
+
+def test_rawstate_policy_forward_matches_oracle(tmp_path):
+    """rl4rs_rawpolicy_* (rllib_rawstate_model.py + mask wrapper) against the numpy fp64 restatement, then driven by the
+    raw features of a rawstate_as_obs env."""
+    import torch
+    from rl4rs_amd.device import DeviceRawPolicy
+    from rl4rs_amd.nets.rawpolicy import init_rawpolicy_weights
+    from oracle import policy as OP
+    cfg = {"maxlen": 64, "action_size": 284, "dense_feature_num": 432, "category_feature_num": 21,
+           "category_hash_size": 3000, "seq_num": 2, "emb_size": 128, "hidden_units": 128}
+    rs = np.random.RandomState(4)
+    N = 300
+    w = init_rawpolicy_weights(cfg, seed=2, emb_scale=0.5, head_std=1.0, bias_noise=0.2)
+    cat = rs.randint(0, 3000, size=(N, 21)).astype(np.int32)
+    dense = np.abs(rs.randn(N, 432) * 2).astype(np.float32)
+    seqs = [rs.randint(0, 284, size=(N, 64)).astype(np.int32) for _ in range(2)]
+    seqs[1][::2] = 0
+    _, mask, bits = _data(N, rs)
+    pol = DeviceRawPolicy(cfg, w, max_rows=N)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a, lp, v, ent, lg = pol.act(t(cat), t(dense), [t(s) for s in seqs], t(bits), seed=5, step=3, want_logits=True)
+    logits_ref, value_ref = OP.rawstate_forward(w, cat, dense, seqs, mask)
+    lsm = OP.log_softmax(logits_ref)
+    a_np = a.cpu().numpy()
+    assert mask[np.arange(N), a_np].all()                       # only allowed actions are drawn
+    ok = mask.astype(bool)
+    assert np.abs(lg.cpu().numpy()[ok] - logits_ref[ok]).max() < 2e-4
+    assert np.abs(v.cpu().numpy() - value_ref).max() < 2e-4
+    assert np.abs(lp.cpu().numpy() - lsm[np.arange(N), a_np]).max() < 2e-4
+    p = np.exp(lsm)
+    ent_ref = -(np.where(p > 0, p * lsm, 0.0)).sum(axis=1)
+    assert np.abs(ent.cpu().numpy() - ent_ref).max() < 2e-4
+    # evaluate() of the drawn actions reproduces act(); no mask = plain logits
+    lp2, v2, ent2, _ = pol.evaluate(t(cat), t(dense), [t(s) for s in seqs], a, t(bits))
+    assert torch.equal(lp, lp2) and torch.equal(v, v2) and torch.equal(ent, ent2)
+    _, _, _, lg0 = pol.evaluate(t(cat), t(dense), [t(s) for s in seqs], a, None, want_logits=True)
+    assert np.abs(lg0.cpu().numpy() - OP.rawstate_forward(w, cat, dense, seqs, None)[0]).max() < 2e-4
+    # sampling follows the masked categorical
+    rep = 20000
+    one = lambda x: t(np.repeat(x[:1], rep, axis=0))
+    pol2 = DeviceRawPolicy(cfg, w, max_rows=rep)
+    aa = pol2.act(one(cat), one(dense), [one(s) for s in seqs], one(bits), seed=11, step=0)[0].cpu().numpy()
+    freq = np.bincount(aa, minlength=284) / float(rep)
+    assert np.abs(freq - p[0]).max() < 0.02
+    with pytest.raises(Exception, match='max_rows'):
+        pol.act(one(cat), one(dense), [one(s) for s in seqs], one(bits))
+    pol.close()
+    pol2.close()
+
+
+def test_rawstate_policy_drives_rawstate_env(tmp_path):
+    """config['rawstate_as_obs'] + return_tensors: the env hands out device tensors of the raw features and the raw-state
+    policy acts on them; compared per step with the oracle forward on the oracle env's raw state."""
+    import os
+    import torch
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.device import DeviceRawPolicy
+    from rl4rs_amd.nets.rawpolicy import init_rawpolicy_weights
+    from rl4rs.env.slate import SlateRecEnv, SlateState
+    from oracle import policy as OP
+    B, T = 16, 9
+    d = str(tmp_path)
+    cat_path, log_path = os.path.join(d, 'item_info.csv'), os.path.join(d, 'log.csv')
+    cat_text = synth.make_catalog_text(seed=21)
+    synth.write_text(cat_path, cat_text)
+    records = synth.make_records(B, pages=1, seed=8, illegal_frac=0.0, hash_size=5000,
+                                 special_ids=synth.special_ids_from_text(cat_text))
+    synth.write_records(log_path, records)
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 5000, "seq_num": 2, "emb_size": 128,
+           "page_items": 9, "hidden_units": 128, "max_steps": T, "action_emb_size": 32,
+           "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": True, "cache_size": B, "model_seed": 3,
+           "support_rllib_mask": True, "rawstate_as_obs": True, "return_tensors": True}
+    env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
+    w = init_rawpolicy_weights(cfg, seed=1, emb_scale=0.5, head_std=1.0, bias_noise=0.1)
+    pol = DeviceRawPolicy(cfg, w, max_rows=B)
+    obs = env.reset(reset_file=True)
+    total = torch.zeros(B, dtype=torch.float64, device='cuda')
+    for t in range(T):
+        assert set(obs) == {'category_feature', 'dense_feature', 'sequence_feature', 'action_mask'}
+        mask = obs['action_mask']
+        mask_np = mask.cpu().numpy()
+        W = (284 + 31) // 32
+        bits = np.zeros((B, W * 32), dtype=np.int64)
+        bits[:, :284] = mask_np
+        bits = (bits.reshape(B, W, 32) << np.arange(32)).sum(axis=2).astype(np.uint32).view(np.int32)
+        a, lp, v, ent, lg = pol.act(obs['category_feature'], obs['dense_feature'], obs['sequence_feature'],
+                                    torch.from_numpy(bits).cuda(), seed=7, step=t, want_logits=True)
+        logits_ref, value_ref = OP.rawstate_forward(w, obs['category_feature'].cpu().numpy(), obs['dense_feature'].cpu().numpy(),
+                                                    [s.cpu().numpy() for s in obs['sequence_feature']], mask_np)
+        ok = mask_np.astype(bool)
+        assert np.abs(lg.cpu().numpy()[ok] - logits_ref[ok]).max() < 2e-4
+        assert np.abs(v.cpu().numpy() - value_ref).max() < 2e-4
+        assert mask_np[np.arange(B), a.cpu().numpy()].all()
+        obs, reward, done, info = env.step(a)
+        total += reward
+    assert bool(done[0]) if not torch.is_tensor(done) else bool(done.all())
+    assert float(total.abs().sum()) > 0
