@@ -45,6 +45,8 @@ def make_config(args, workdir, rank):
            "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": False, "cache_size": 2048,
            "model_seed": 7, "return_tensors": True, "scorer_precision": args.scorer,
            "algo": getattr(args, 'algo', 'dien')}
+    if getattr(args, 'conti', False):
+        cfg["support_conti_env"] = True       # configs[4]: continuous 32-d actions resolved by the masked K-NN
     return cfg, records
 
 
@@ -111,6 +113,8 @@ def main():
     ap.add_argument('--log-records', type=int, default=8193)
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conti', action='store_true',
+                    help="continuous-action env (support_conti_env): actions are 32-d embeddings resolved by the masked K-NN")
     ap.add_argument('--algo', choices=['dien', 'dnn', 'widedeep', 'lstm'], default='dien',
                     help="simulator family (config['algo']); the headline metric is quoted on dien")
     ap.add_argument('--scorer', choices=['auto', 'fp32', 'fp16x2'], default='auto',
@@ -227,7 +231,8 @@ def main():
                                    "%s simulator scorer, offline_action replay"
                                    % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T, cfg.get('algo', 'dien').upper() if is_dien else cfg['algo']),
                        "step": "one episode-batch = reset + %d env.step incl. reward forward" % T +
-                               ("" if not trainer else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()),
+                               ("" if not trainer else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()) +
+                               ("" if not args.conti else "; continuous actions -> masked K-NN over the catalogue"),
                        "parallelism": "independent env batches per GPU (no data-path collective)"},
             # dien: the AUGRU recurrence; the GEMM-only families (dnn / widedeep / lstm) have no dominant matrix kernel,
             # their line carries the HBM roofline of the feature-gather kernel
