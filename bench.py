@@ -24,7 +24,7 @@ if REPO not in sys.path:
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 # HBM bytes per AUGRU launch of the default workload, from the PMC passes (None until measured for a mode)
-TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 8.41e8}
+TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 7.34e8}
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
@@ -193,9 +193,9 @@ def main():
             if not seq and B == 4096 and T == 9 and not trainer:
                 # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
                 # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
-                # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 836 / 888 MB)
+                # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 721 / 863 MB)
                 roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
-                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01e_pmc.md fp16x2)"
+                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01f_pmc.md fp16x2)"
         kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples
