@@ -435,7 +435,10 @@ __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int 
 //   accumulator sets with all projections requested at the start of the epilogue, 64-row workgroups (MT = 2: halves
 //   the weight bytes per row but spills at 256 registers; +2 % on the reward-sized launch), spreading the projection
 //   loads over the items of slot C / the elements of the epilogue (2x SLOWER: every weight wait then sits behind an
-//   HBM-latency load).  Resident weights are the
+//   HBM-latency load), staging the next step's projections in 48 extra registers requested at the start of the
+//   epilogue (slot C drops from ~6K to ~3K cycles, but the 48 narrow loads of a wave take ~3.3K cycles of
+//   texture-address time to ISSUE and that lands in the exposed epilogue: net 4-6 % slower).  The projection loads take
+//   ~4.5K cycles to land - all CUs burst theirs at the same phase.  Resident weights are the
 //   lever that worked (-6 % at 14 of 48 items).  Next: a 64-row form that fits, or LDS-DMA staging of the ring.
 #ifdef RL4RS_H16_TRACE     // s_memtime marks of workgroup (0,0), steps 8..11: [wave][step][mark]
 #define RL4RS_TR(k) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t >= 8 && t < 12) \
