@@ -231,6 +231,12 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, vo
 int rl4rs_dien_destroy(rl4rs_dien* net);
 /* The mode the handle resolved to (RL4RS_SCORER_FP32 or RL4RS_SCORER_FP16X2). */
 int rl4rs_dien_scorer_mode(rl4rs_dien* net, int32_t* mode);
+/* Status bits since the last call (synchronises `stream`, then clears them).  RL4RS_DIEN_STATUS_FP16_RANGE: in
+ * FP16X2 mode a recurrent state left the fp16 range (|h| >= 6e4, or NaN) - possible only when the attention scores
+ * push the update gate outside [0, 1] until the state diverges; results of the affected forwards are invalid, use
+ * RL4RS_SCORER_FP32 for such a model. */
+enum { RL4RS_DIEN_STATUS_FP16_RANGE = 1 };
+int rl4rs_dien_status(rl4rs_dien* net, int32_t* flags, void* stream);
 
 /* Encode `n` id sequences of sequence input `s` into cache slots [slot_base, slot_base+n):
  * embedding lookup + first GRU over all maxlen steps (utils.py:119-120) and the input-side

@@ -111,6 +111,7 @@ SIGNATURES = {
     'rl4rs_dien_create': (_I, [C.POINTER(DienCfg), C.POINTER(DienWeights), _P, C.POINTER(_P)]),
     'rl4rs_dien_destroy': (_I, [_P]),
     'rl4rs_dien_scorer_mode': (_I, [_P, C.POINTER(_I32)]),
+    'rl4rs_dien_status': (_I, [_P, C.POINTER(_I32), _P]),
     'rl4rs_dien_encode': (_I, [_P, _I32, _P, _I32, _I32, _P]),
     'rl4rs_dien_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     'rl4rs_dien_head_prob': (_I, [_P, _I32, _P, _P, _P]),

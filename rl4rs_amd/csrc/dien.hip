@@ -170,6 +170,7 @@ struct RecurArgs {
     float* out; int64_t out_ld; int out_off; int out_seq_off;   // GRU: h1 cache rows ; AUGRU: allf
     int slot_base;
     unsigned long long* trace;   // -DRL4RS_H16_TRACE timing experiments only
+    int* range_flag;             // k_augru_h16: set to 1 when a state leaves the fp16 range (|h| >= 6e4 or NaN)
     int hard_gates;              // GRU mode: keras hard_sigmoid gates (simnet.hpp) instead of sigmoid
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
 };
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
 #pragma unroll
     for (int i = NRES; i < NRES + LA; ++i) wload(i, wh[i % RING], wl[i % RING]);
 
+    bool out_of_range = false;
 #pragma unroll 1
     for (int t = 0; t < L; ++t) {
         asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const float c = gate_tanh(acc_c[m][r]);
                 const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - c, c);     // u h + (1-u) c
+                out_of_range |= !(fabsf(hn) < 6.0e4f);      // fp16 planes cannot carry it (also catches NaN)
                 h_own[m][r] = hn;
                 const _Float16 vh = (_Float16)hn;
                 hp_hi[(m * 32 + crow(r, half)) * LDP + col] = vh;
@@ -640,6 +643,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
         for (int r = 0; r < 16; ++r)
             if (row0 + m * 32 + crow(r, half) < a.n_rows)
                 a.out[(int64_t)(row0 + m * 32 + crow(r, half)) * a.out_ld + a.out_off + sq * a.out_seq_off + col] = h_own[m][r];
+    if (out_of_range && a.range_flag) atomicOr(a.range_flag, 1);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -880,6 +884,7 @@ struct rl4rs_dien {
     float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
     float* augru_wc16[4];
     bool fp16x2;
+    int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
     float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
     float* augru_wc[4];
     // caches
@@ -1071,6 +1076,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = false;
     n->fp16x2 = want_fp16x2;
+    {
+        float* f = nullptr;
+        int rc0 = alloc_f(n, &f, 1);
+        if (rc0) return rc0;
+        n->range_flag = reinterpret_cast<int*>(f);
+        RL4RS_HIP_TRY(hipMemsetAsync(n->range_flag, 0, 4, (hipStream_t)stream));
+    }
     {
         int dev = 0, cus = 0;
         RL4RS_HIP_TRY(hipGetDevice(&dev));
@@ -1293,6 +1305,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         dim3 grid((R + 31) / 32, S), block(512);
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
+            a.range_flag = n->range_flag;
 #ifdef RL4RS_H16_TRACE
             static unsigned long long* trace_buf = nullptr;
             if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 8 * 4 * 8 * 8); (void)hipMemset(trace_buf, 0, 8 * 4 * 8 * 8); }
@@ -1377,6 +1390,17 @@ int rl4rs_dien_set_profiling(rl4rs_dien* n, int enable) {
 int rl4rs_dien_scorer_mode(rl4rs_dien* n, int32_t* mode) {
     RL4RS_REQUIRE(n && mode, "dien_scorer_mode: null argument");
     *mode = n->fp16x2 ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
+    return RL4RS_OK;
+}
+// Synchronises the stream, returns and clears the handle's status bits (include/rl4rs_hip.h RL4RS_DIEN_STATUS_*).
+int rl4rs_dien_status(rl4rs_dien* n, int32_t* flags, void* stream) {
+    RL4RS_REQUIRE(n && flags, "dien_status: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int v = 0;
+    RL4RS_HIP_TRY(hipMemcpyAsync(&v, n->range_flag, 4, hipMemcpyDeviceToHost, st));
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));
+    if (v) RL4RS_HIP_TRY(hipMemsetAsync(n->range_flag, 0, 4, st));
+    *flags = v ? RL4RS_DIEN_STATUS_FP16_RANGE : 0;
     return RL4RS_OK;
 }
 int rl4rs_dien_kernel_count(void) { return KID_COUNT; }

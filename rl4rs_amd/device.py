@@ -368,6 +368,15 @@ class DeviceDien(object):
         check(self.lib.rl4rs_dien_scorer_mode(self.h, C.byref(m)))
         return 'fp16x2' if m.value == 2 else 'fp32'
 
+    def check_status(self):
+        """Synchronising check of the handle's status bits: raises if the fp16x2 scorer left the fp16 range."""
+        f = C.c_int32()
+        check(self.lib.rl4rs_dien_status(self.h, C.byref(f), _stream()))
+        if f.value & 1:
+            raise _lib.Rl4rsHipError(
+                "fp16x2 scorer: a recurrent state left the fp16 range (|h| >= 6e4 or NaN); the affected forwards are "
+                "invalid - use config['scorer_precision'] = 'fp32' for this model")
+
     @property
     def augru_kernel(self):
         return AUGRU_KERNELS[SCORER_MODES[self.scorer_mode]]
@@ -456,6 +465,9 @@ class DeviceSimnet(object):
         prob = torch.empty(R, dtype=torch.float32, device=self.device)
         check(self.lib.rl4rs_simnet_head_prob(self.h, R, _ptr(obs), _ptr(prob), _stream()))
         return prob
+
+    def check_status(self):
+        pass
 
     # no-op profiling hooks so bench / facade code can treat every scorer alike
     def set_profiling(self, on):

@@ -482,4 +482,8 @@ class SlateRecEnv(RecSimBase):
             for i in range(B):
                 samples.info[i].update({'click_p': pr[i]})
         reward = env.reward(probs, p_last)
-        return reward if tensor_mode else reward.cpu().numpy().tolist()
+        if tensor_mode:
+            return reward          # zero-copy mode never synchronises; callers may poll model.device_net.check_status()
+        out = reward.cpu().numpy().tolist()
+        net.check_status()         # already synchronised by the copy: did the fp16x2 scorer stay in range?
+        return out

@@ -210,3 +210,38 @@ def test_scorer_mode_selection(monkeypatch, scorer_precision):
     net.close()
     with pytest.raises(Rl4rsHipError, match='fp16x2'):
         DeviceDien(dict(base, scorer_precision='fp16x2'), big, max_rows=8, max_slots=4)
+
+
+def test_fp16_range_status(scorer_precision):
+    """RL4RS_DIEN_STATUS_FP16_RANGE: attention scores far below 0 make (1 - a_t) u exceed 1, the AUGRU state then grows
+    geometrically; the fp16x2 kernel must report it (the fp32 kernel has nothing to report), and a sane model must not."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from rl4rs_amd._lib import Rl4rsHipError
+    R = 40
+    rs = np.random.RandomState(2)
+    seq, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+
+    def run(w):
+        net = DeviceDien(CFG, w, max_rows=R, max_slots=R)
+        for s in range(2):
+            net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+        slots = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+        net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, want_obs=True)
+        return net
+
+    net = run(init_dien_weights(CFG, seed=3, emb_scale=0.5))
+    net.check_status()                                  # sane model: silent in both modes
+    net.close()
+    bad = init_dien_weights(CFG, seed=3, emb_scale=0.5)
+    for i in range(2):
+        bad['att%d_b3' % i] = np.array([-40.0], dtype=np.float32)      # a_t ~ -40: u <- 41 u
+    net = run(bad)
+    if scorer_precision == 'fp16x2':
+        with pytest.raises(Rl4rsHipError, match='fp16 range'):
+            net.check_status()
+        net.check_status()                              # the flag is cleared by the read
+    else:
+        net.check_status()
+    net.close()
