@@ -102,6 +102,36 @@ def cpu_baseline(cfg, records, seq, sample_batch):
                       "(float32 %s scorer), %.1f s" % (T, sample_batch, algo.upper() if algo == 'dien' else algo, dt)}
 
 
+def fp32_leg(args, cfg, seq, rank, steps=3):
+    """The same workload with the exact-operand fp32 MFMA recurrence (scorer_precision='fp32'), reported next to the
+    default so that both arithmetic forms are on the line: value, ms per episode-batch, AUGRU roofline vs the fp32 peak."""
+    import torch
+    cfg32 = dict(cfg, scorer_precision='fp32')
+    env = build_env(cfg32, seq)
+    env.seed(1000 + rank)
+    env.sim._recData.store.preload(torch.device('cuda', torch.cuda.current_device()))
+    B, T = cfg['batch_size'], cfg['max_steps']
+    episode(env, T)
+    net = env.sim.model.device_net
+    net.set_profiling(True)
+    net.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        episode(env, T)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, launches = net.profile()[net.augru_kernel]
+    n_complete = T if not seq else cfg['page_items']
+    reward_calls = 1 if not seq else T // cfg['page_items']
+    rows = (T + 1) * B + reward_calls * (n_complete - 1) * B
+    flops = steps * rows * cfg['seq_num'] * cfg['maxlen'] * (2 * cfg['emb_size']) * (6 * cfg['emb_size']) * 2
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "dtype": "f32", "roofline": {"bound": "mfma", "kernel": net.augru_kernel, "achieved": tf,
+                                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -113,6 +143,8 @@ def main():
     ap.add_argument('--log-records', type=int, default=8193)
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-leg', action='store_true',
+                    help='skip the short extra run of the same workload with the exact-fp32 recurrence (N=1, default mode only)')
     ap.add_argument('--conti', action='store_true',
                     help="continuous-action env (support_conti_env): actions are 32-d embeddings resolved by the masked K-NN")
     ap.add_argument('--algo', choices=['dien', 'dnn', 'widedeep', 'lstm'], default='dien',
@@ -240,6 +272,8 @@ def main():
             "roofline_gather": gather,
             "kernels": kernels,
         }
+        if (world == 1 and is_dien and not trainer and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg):
+            out["exact_fp32_scorer"] = fp32_leg(args, cfg, seq, rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, records, seq, args.cpu_batch)
         print(json.dumps(out))
