@@ -59,6 +59,7 @@ __device__ __forceinline__ float policy_row_forward(const PolDims& d, const floa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < d.HID; j += 64) {
         float s = b1[j];
+#pragma unroll 8
         for (int k = 0; k < d.OD; ++k) s = fmaf(s_obs[k], W1[(size_t)k * d.HID + j], s);
         s_h[j] = tanhf(s);
     }
@@ -67,6 +68,7 @@ __device__ __forceinline__ float policy_row_forward(const PolDims& d, const floa
     float mx = -3.4028235e38f;
     for (int a = lane; a < d.AE; a += 64) {
         float s = b2[a];
+#pragma unroll 8
         for (int j = 0; j < d.HID; ++j) s = fmaf(s_h[j], W2[(size_t)j * d.AE + a], s);
         if (a < d.A) {
             // logits + max(log(mask), float32.min): 0 for allowed actions, -3.4028235e38 for masked ones
@@ -192,7 +194,7 @@ struct LossArgs {
 __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __restrict__ prm, int N,
                                                       const float* __restrict__ obs, const uint32_t* __restrict__ mask,
                                                       LossArgs L, float* __restrict__ H, float* __restrict__ dOut,
-                                                      float* __restrict__ dHpre, float4* __restrict__ terms) {
+                                                      float* __restrict__ dHpre, float4* __restrict__ terms, int stage_w2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per = d.OD + d.HID + 2 * d.AE;
@@ -200,6 +202,14 @@ __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __
     float* s_h = s_obs + d.OD;
     float* s_out = s_h + d.HID;
     float* s_d = s_out + d.AE;
+    // backward needs row j of W2 per lane j: staged once per workgroup (rows of an odd length map the 64 lanes onto 64
+    // different LDS banks; straight from memory that access is one cache line per lane per element)
+    float* s_w2 = stage_w2 ? reinterpret_cast<float*>(smem) + (size_t)4 * per : nullptr;
+    if (stage_w2) {
+        const float* W2g = prm + (size_t)d.OD * d.HID + d.HID;
+        for (int i = threadIdx.x; i < d.HID * d.AE; i += 256) s_w2[i] = W2g[i];
+        __syncthreads();
+    }
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
     const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
@@ -277,7 +287,8 @@ __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __
     const float* W2 = prm + (size_t)d.OD * d.HID + d.HID;
     for (int j = lane; j < d.HID; j += 64) {
         float s = 0.f;
-        const float* wr = W2 + (size_t)j * d.AE;
+        const float* wr = (s_w2 ? s_w2 : W2) + (size_t)j * d.AE;
+#pragma unroll 8
         for (int a = 0; a < d.AE; ++a) s = fmaf(s_d[a], wr[a], s);
         const float h = s_h[j];
         H[(size_t)n * d.HID + j] = h;
@@ -304,11 +315,19 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int n = n_lo; n < n_hi; n += 2) {
-        const int nn = n + half;
-        float a = (m_ok && nn < n_hi) ? A[(size_t)nn * lda + m] : 0.f;
-        float b = (j_ok && nn < n_hi) ? B[(size_t)nn * ldb + j] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    // 8 sample pairs per trip: the 16 loads are issued together, then the 8 MFMAs (same accumulation order as a plain
+    // loop; one load per MFMA made every step pay a full memory latency)
+    for (int n = n_lo; n < n_hi; n += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nn = n + 2 * u + half;
+            a[u] = (m_ok && nn < n_hi) ? A[(size_t)nn * lda + m] : 0.f;
+            b[u] = (j_ok && nn < n_hi) ? B[(size_t)nn * ldb + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (n + 2 * u < n_hi) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     float* out = part + (size_t)z * M * Nc;
     for (int r = 0; r < 16; ++r) {
@@ -324,7 +343,14 @@ __global__ void k_colsum(const float* __restrict__ X, int ld, int Nc, int Ns, in
     if (j >= Nc) return;
     const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
     float s = 0.f;
-    for (int n = n_lo; n < n_hi; ++n) s += X[(size_t)n * ld + j];
+    for (int n = n_lo; n < n_hi; n += 16) {       // 16 loads in flight, added in sample order
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (n + u < n_hi) ? X[(size_t)(n + u) * ld + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (n + u < n_hi) s += x[u];
+    }
     part[(size_t)z * Nc + j] = s;
 }
 
@@ -399,6 +425,7 @@ struct rl4rs_policy {
     float *H, *dOut, *dHpre, *part, *sumsq;
     float4* terms;
     int64_t adam_t;
+    bool train_attr;
     std::vector<void*> owned;
 };
 
@@ -423,6 +450,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->chunk = 512;
     p->nz = (max_rows + p->chunk - 1) / p->chunk;
     p->adam_t = 0;
+    p->train_attr = false;
     int rc;
     auto alloc = [&](float** dst, size_t n) {
         int r = dev_alloc(dst, n);
@@ -500,8 +528,15 @@ int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float
     L.algo = algo; L.vf_coeff = vf_coeff; L.ent_coeff = ent_coeff; L.clip = clip; L.vf_clip = vf_clip; L.kl_coeff = kl_coeff;
     L.scale = algo == 0 ? 1.0f : 1.0f / (float)N;
     L.actions = actions; L.adv = adv; L.ret = ret; L.old_logp = old_logp; L.old_value = old_value; L.old_logits = old_logits;
-    hipLaunchKernelGGL(k_policy_train, dim3((N + 3) / 4), dim3(256), fwd_smem(d, d.AE), st, d, p->params, N, obs, mask_bits, L,
-                       p->H, p->dOut, p->dHpre, p->terms);
+    const size_t w2_bytes = (size_t)d.HID * d.AE * 4;
+    const int stage_w2 = (fwd_smem(d, d.AE) + w2_bytes <= (size_t)150 * 1024) ? 1 : 0;
+    if (stage_w2 && !p->train_attr) {
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_train), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          150 * 1024));
+        p->train_attr = true;
+    }
+    hipLaunchKernelGGL(k_policy_train, dim3((N + 3) / 4), dim3(256), fwd_smem(d, d.AE) + (stage_w2 ? w2_bytes : 0), st, d, p->params,
+                       N, obs, mask_bits, L, p->H, p->dOut, p->dHpre, p->terms, stage_w2);
     RL4RS_LAUNCH_CHECK();
     const int nz = (N + p->chunk - 1) / p->chunk;
     float* gW1 = grad_dev;
