@@ -662,6 +662,7 @@ struct DinArgs {
     const float* proj[4]; int64_t pld;   // [slot*L, pld], AK at column 0
     const float* q;              // [R, E]
     const float* w1ac[4];        // [E, 64]   (W1a + W1c)
+    const float* qa; int64_t qa_stride;   // [n_seq][qa_stride] rows of 64: q @ (W1a + W1c), precomputed by a GEMM (or NULL)
     const float* w1d[4];         // packed [2][E/8][64][4]
     const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
     float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
@@ -712,7 +713,9 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
         for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {   // qa = q @ (W1a + W1c): lane = hidden unit
+        if (a.qa) {   // qa = q @ (W1a + W1c) comes from a GEMM over all rows (a 128-step serial loop per wave otherwise)
+            s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * ATT_H1 + lane];
+        } else {      // lane = hidden unit
             float s = 0.f;
 #pragma unroll 8
             for (int k = 0; k < E; ++k) s = fmaf(s_q[k], w1ac[k * ATT_H1 + lane], s);
@@ -879,6 +882,8 @@ struct rl4rs_dien {
     float* wproj[4];       // [E, PLD]  = [W1b - W1c | augru gate x-side | augru cand x-side]
     float* bproj[4];       // [PLD]
     float* w1ac[4];        // [E, 64]
+    float* w1ac_pk[4];     // the same, packed for k_gemm_pk
+    float* qa;             // [S, max_rows, 64]
     float* w1d[4];         // packed [2][E/8][64][4]
     float *att_w2[4], *att_b2[4], *att_w3[4], *att_b3[4];
     float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
@@ -1155,6 +1160,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
         keep.push_back(pack_gemm_weight(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_gemm_weight(wac.data(), ATT_H1, E, ATT_H1));
+        UP(w1ac_pk[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
         UP(w1d[s], keep.back().data(), keep.back().size());
@@ -1179,6 +1186,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     AL(allf, (size_t)c->max_rows * F);
     AL(dh, (size_t)c->max_rows * U);
     AL(q, (size_t)c->max_rows * E);
+    AL(qa, (size_t)S * c->max_rows * ATT_H1);
     AL(scores, (size_t)S * c->max_rows * L);
     AL(obs_tmp, (size_t)c->max_rows * OBS_DIM);
 #undef UP
@@ -1275,6 +1283,11 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         memset(&a, 0, sizeof(a));
         a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
         a.slots = slots; a.slots_stride = ngroups; a.pld = n->PLD; a.q = n->q;
+        a.qa = n->qa; a.qa_stride = (int64_t)n->c.max_rows * ATT_H1;
+        for (int s = 0; s < S; ++s) {
+            int rcq = launch_gemm_packed(n->q, E, n->w1ac_pk[s], nullptr, n->qa + (size_t)s * a.qa_stride, ATT_H1, R, ATT_H1, E, 0, st);
+            if (rcq) return rcq;
+        }
         for (int s = 0; s < S; ++s) {
             a.h1[s] = n->h1[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s];
             a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];
