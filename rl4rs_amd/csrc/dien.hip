@@ -673,13 +673,20 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = a.L, E = a.E, LDK = E + 4;
     const int sq = blockIdx.y;
-    float* s_w2 = reinterpret_cast<float*>(smem);        // [64][16]
-    float* s_misc = s_w2 + ATT_H1 * ATT_H2;              // b2[16] w3[16] b3[1] pad -> 48
+    // layer 2 runs on the matrix pipe: hid2^T [16 x steps] = W2^T [16 x 64 units] hid1^T, two hidden units per
+    // v_mfma_f32_32x32x2_f32.  The layer-1 accumulator layout IS a B operand of that MFMA (lane = step, register r of
+    // half-wave h = unit crow(r, h): the two half-waves supply k = 0 and k = 1), so only W2 needs arranging:
+    // s_w2pk[(m*16 + r)*64 + lane] = W2[m*32 + crow(r, half)][li] for li < 16, else 0 (the A operand, output unit = li).
+    float* s_w2 = reinterpret_cast<float*>(smem);        // [2*16][64]
+    float* s_misc = s_w2 + 2 * 16 * 64;                  // b2[16] w3[16] b3[1] pad -> 48
     float* s_wave = s_misc + 48;                         // per wave: q[E] + qa[64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     float* s_h1 = s_wave + (size_t)nw * (E + ATT_H1);    // STAGE: [L][LDK]
     const int half = lane >> 5, li = lane & 31;
-    for (int i = tid; i < ATT_H1 * ATT_H2; i += blockDim.x) s_w2[i] = a.w2[sq][i];
+    for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) {
+        const int ln = i & 63, mr = i >> 6, o = ln & 31;
+        s_w2[i] = o < ATT_H2 ? a.w2[sq][((mr >> 4) * 32 + crow(mr & 15, ln >> 5)) * ATT_H2 + o] : 0.f;
+    }
     if (tid < ATT_H2) { s_misc[tid] = a.b2[sq][tid]; s_misc[16 + tid] = a.w3[sq][tid]; }
     if (tid == 0) s_misc[32] = a.b3[sq][0];
     int g0, slot0 = 0;
@@ -773,9 +780,9 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
             const int t = n * 32 + li;
             const int tc = min(t, L - 1);
             const float* akp = a.proj[sq] + ((size_t)slot * L + tc) * a.pld;
-            float p[ATT_H2];
+            f32x16 acc2;
 #pragma unroll
-            for (int o = 0; o < ATT_H2; ++o) p[o] = 0.f;
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -787,20 +794,20 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                     for (int rr = 0; rr < 4; ++rr) {
                         const float accv = (n == 0) ? (m == 0 ? acc00[r4 * 4 + rr] : acc10[r4 * 4 + rr])
                                                     : (m == 0 ? acc01[r4 * 4 + rr] : acc11[r4 * 4 + rr]);
-                        float hv = gate_sigmoid(accv + s_qa[jr + rr] + akv[rr]);
-                        const float* w2r = s_w2 + (jr + rr) * ATT_H2;
-#pragma unroll
-                        for (int o = 0; o < ATT_H2; ++o) p[o] = fmaf(hv, w2r[o], p[o]);
+                        const float hv = gate_sigmoid(accv + s_qa[jr + rr] + akv[rr]);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(m * 16 + r4 * 4 + rr) * 64 + lane], hv, acc2, 0, 0, 0);
                     }
                 }
             }
+            // acc2 register r < 8 of this lane = hid2 pre-activation of output unit crow(r, half) at this lane's step
             float sc = 0.f;
 #pragma unroll
-            for (int o = 0; o < ATT_H2; ++o) {
-                float tot = p[o] + __shfl_xor(p[o], 32);
-                float h2 = gate_sigmoid(tot + s_misc[o]);
+            for (int r = 0; r < 8; ++r) {
+                const int o = crow(r, half);
+                const float h2 = gate_sigmoid(acc2[r] + s_misc[o]);
                 sc = fmaf(h2, s_misc[16 + o], sc);
             }
+            sc += __shfl_xor(sc, 32);
             sc += s_misc[32];
             if (half == 0 && t < L) a.scores[(size_t)sq * a.scores_stride + (size_t)row * L + t] = sc;
         }
@@ -1295,11 +1302,11 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
         if (group == 1) {
             const int nw = 4;
-            size_t smem = ((size_t)ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+            size_t smem = ((size_t)2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
             hipLaunchKernelGGL(k_din_scores<false>, dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
         } else {
             int nw = group % 4 == 0 ? 4 : (group % 3 == 0 ? 3 : (group % 2 == 0 ? 2 : (group < 4 ? group : 4)));
-            size_t smem = ((size_t)L * (E + 4) + ATT_H1 * ATT_H2 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
+            size_t smem = ((size_t)L * (E + 4) + 2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
             hipLaunchKernelGGL(k_din_scores<true>, dim3(ngroups, S), dim3(64 * nw), smem, st, a);
         }
         RL4RS_LAUNCH_CHECK();
