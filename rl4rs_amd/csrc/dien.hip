@@ -664,11 +664,12 @@ struct DinArgs {
     const float* w1ac[4];        // [E, 64]   (W1a + W1c)
     const float* qa; int64_t qa_stride;   // [n_seq][qa_stride] rows of 64: q @ (W1a + W1c), precomputed by a GEMM (or NULL)
     const float* w1d[4];         // packed [2][E/8][64][4]
+    const float* w1d16[4];       // H16: fp16 hi/lo planes [2][E/16][2][64][8 halfs] (pack_frag_h16)
     const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
     float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
 };
 
-template <bool STAGE>
+template <bool STAGE, bool H16>
 __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = a.L, E = a.E, LDK = E + 4;
@@ -737,6 +738,57 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
         f32x16 acc00, acc10, acc01, acc11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc10[r] = 0.f; acc01[r] = 0.f; acc11[r] = 0.f; }
+        if (H16) {
+            // fp16x2 layer 1 (scorer_mode FP16X2): same hi/lo operand split as k_augru_h16, 3 v_mfma_f32_32x32x16_f16 per
+            // product.  Lane (li, half) supplies k = kb*16 + half*8 + 0..7 of its step's (q * h1_t) row; q*h1 is bounded by
+            // the embedding table (range-checked at create), so the lo parts need no scaling.
+            const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1d16[sq]), 0, 2 * (E / 16) * 2048, 0x00020000);
+            const float* h0 = hsrc0 - half * 4 + half * 8;      // rows t0 / t1 at k = half*8
+            const float* h1p = hsrc1 - half * 4 + half * 8;
+            const float* qp = s_q + half * 8;
+            constexpr int KB16 = 8;
+            half8_t wa[2][2][2];            // [ring][m tile][plane]
+            float4 hr[2][2][2];             // [ring][step tile][lo/hi half of the 8 k]
+            auto ld = [&](int slot, int kb) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    wa[slot][m][0] = buf_load_h8(rs16, vl16, (m * KB16 + kb) * 2048);
+                    wa[slot][m][1] = buf_load_h8(rs16, vl16, (m * KB16 + kb) * 2048 + 1024);
+                }
+                hr[slot][0][0] = *reinterpret_cast<const float4*>(h0 + kb * 16);
+                hr[slot][0][1] = *reinterpret_cast<const float4*>(h0 + kb * 16 + 4);
+                hr[slot][1][0] = *reinterpret_cast<const float4*>(h1p + kb * 16);
+                hr[slot][1][1] = *reinterpret_cast<const float4*>(h1p + kb * 16 + 4);
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < KB16; ++kb) {
+                const int cb = kb & 1, nb = cb ^ 1;
+                if (kb + 1 < KB16) ld(nb, kb + 1);
+                const float4 qa4 = *reinterpret_cast<const float4*>(qp + kb * 16);
+                const float4 qb4 = *reinterpret_cast<const float4*>(qp + kb * 16 + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                half8_t bh[2], bl[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float pr[8] = {hr[cb][n][0].x * qa4.x, hr[cb][n][0].y * qa4.y, hr[cb][n][0].z * qa4.z, hr[cb][n][0].w * qa4.w,
+                                         hr[cb][n][1].x * qb4.x, hr[cb][n][1].y * qb4.y, hr[cb][n][1].z * qb4.z, hr[cb][n][1].w * qb4.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const _Float16 hi = (_Float16)pr[e];
+                        bh[n][e] = hi;
+                        bl[n][e] = (_Float16)(pr[e] - (float)hi);
+                    }
+                }
+#define RL4RS_DIN3(acc, m, n)                                                                         \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cb][m][0], bh[n], acc, 0, 0, 0);      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cb][m][1], bh[n], acc, 0, 0, 0);      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cb][m][0], bl[n], acc, 0, 0, 0);
+                RL4RS_DIN3(acc00, 0, 0) RL4RS_DIN3(acc10, 1, 0) RL4RS_DIN3(acc01, 0, 1) RL4RS_DIN3(acc11, 1, 1)
+#undef RL4RS_DIN3
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         // fully unrolled 2-deep ring over the E/8 k-blocks: weights through a buffer descriptor, (q*h1_t) operand
         // from LDS (STAGE) or straight from the cache (immediate offsets off two per-lane row pointers)
         float4 aw0[2], aw1[2], hv0[2], hv1[2], qv[2];
@@ -772,6 +824,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         // epilogue: lane holds, for step t (= N index), 16 of the 32 hidden units of each M tile
 #pragma unroll
@@ -892,10 +945,12 @@ struct rl4rs_dien {
     float* w1ac_pk[4];     // the same, packed for k_gemm_pk
     float* qa;             // [S, max_rows, 64]
     float* w1d[4];         // packed [2][E/8][64][4]
+    float* w1d16[4];       // fp16 hi/lo planes of the same fragments (fp16x2 mode)
     float *att_w2[4], *att_b2[4], *att_w3[4], *att_b3[4];
     float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
     float* augru_wc16[4];
     bool fp16x2;
+    bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
     float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
     float* augru_wc[4];
@@ -1088,6 +1143,21 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = false;
     n->fp16x2 = want_fp16x2;
+    n->din16 = false;
+    if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
+        float mx = 0.f;
+        bool fin = true;
+        for (size_t i = 0; i < (size_t)c->category_hash_size * c->emb_size; ++i) {
+            const float v = fabsf(w->seq_emb[i]);
+            fin = fin && v == v; mx = fmaxf(mx, v);
+        }
+        for (int s = 0; s < c->seq_num && w->att_w1[s]; ++s)
+            for (size_t i = (size_t)3 * c->emb_size * ATT_H1; i < (size_t)4 * c->emb_size * ATT_H1; ++i) {
+                const float v = fabsf(w->att_w1[s][i]);
+                fin = fin && v == v; mx = fmaxf(mx, v);
+            }
+        n->din16 = fin && mx < 6.0e4f && !(getenv("RL4RS_DIN16") && atoi(getenv("RL4RS_DIN16")) == 0);
+    }
     {
         float* f = nullptr;
         int rc0 = alloc_f(n, &f, 1);
@@ -1172,6 +1242,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
         UP(w1d[s], keep.back().data(), keep.back().size());
+        n->w1d16[s] = nullptr;
+        if (n->fp16x2 && n->din16) {
+            keep.push_back(pack_frag_h16(w1, ATT_H1, 3 * E, E, ATT_H1));
+            UP(w1d16[s], keep.back().data(), keep.back().size());
+        }
         UP(att_w2[s], w->att_w2[s], ATT_H1 * ATT_H2);
         UP(att_b2[s], w->att_b2[s], ATT_H2);
         UP(att_w3[s], w->att_w3[s], ATT_H2);
@@ -1216,7 +1291,9 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true>),
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
     RL4RS_HIP_TRY(hipStreamSynchronize(st));   // host staging (keep) may now be released
@@ -1291,23 +1368,26 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
         a.slots = slots; a.slots_stride = ngroups; a.pld = n->PLD; a.q = n->q;
         a.qa = n->qa; a.qa_stride = (int64_t)n->c.max_rows * ATT_H1;
+        const bool h16 = n->fp16x2 && n->din16;
         for (int s = 0; s < S; ++s) {
             int rcq = launch_gemm_packed(n->q, E, n->w1ac_pk[s], nullptr, n->qa + (size_t)s * a.qa_stride, ATT_H1, R, ATT_H1, E, 0, st);
             if (rcq) return rcq;
         }
         for (int s = 0; s < S; ++s) {
-            a.h1[s] = n->h1[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s];
+            a.h1[s] = n->h1[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s]; a.w1d16[s] = n->w1d16[s];
             a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];
         }
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
         if (group == 1) {
             const int nw = 4;
             size_t smem = ((size_t)2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
-            hipLaunchKernelGGL(k_din_scores<false>, dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
+            if (h16) hipLaunchKernelGGL((k_din_scores<false, true>), dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
+            else hipLaunchKernelGGL((k_din_scores<false, false>), dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
         } else {
             int nw = group % 4 == 0 ? 4 : (group % 3 == 0 ? 3 : (group % 2 == 0 ? 2 : (group < 4 ? group : 4)));
             size_t smem = ((size_t)L * (E + 4) + 2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
-            hipLaunchKernelGGL(k_din_scores<true>, dim3(ngroups, S), dim3(64 * nw), smem, st, a);
+            if (h16) hipLaunchKernelGGL((k_din_scores<true, true>), dim3(ngroups, S), dim3(64 * nw), smem, st, a);
+            else hipLaunchKernelGGL((k_din_scores<true, false>), dim3(ngroups, S), dim3(64 * nw), smem, st, a);
         }
         RL4RS_LAUNCH_CHECK();
     }
