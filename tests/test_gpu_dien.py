@@ -245,3 +245,12 @@ def test_fp16_range_status(scorer_precision):
     else:
         net.check_status()
     net.close()
+
+
+def test_fp16x2_recurrence_with_fp32_attention(monkeypatch, scorer_precision):
+    """fp16x2 AUGRU combined with the exact-fp32 DIN layer 1 (what the library falls back to when the sequence embedding
+    table or the q*k rows of att_w1 leave the fp16 range; forced here with RL4RS_DIN16=0)."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    monkeypatch.setenv('RL4RS_DIN16', '0')
+    test_dien_rowwise_matches_oracle(64)
