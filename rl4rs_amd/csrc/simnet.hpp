@@ -116,7 +116,6 @@ int rl4rs_simnet_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights* w
     const int Dn = c->dense_feature_num, K = c->class_num, L = c->maxlen;
     (void)L;
     rl4rs_simnet* n = new rl4rs_simnet();
-    memset(static_cast<void*>(&n->c), 0, sizeof(n->c));
     n->c = *c;
     n->cat_emb = n->seq_emb = n->fc_w = n->fc_b = n->obs_w = n->obs_b = nullptr;
     n->cat_tab = n->cat_wg = n->cat_wc = nullptr;
@@ -165,9 +164,14 @@ int rl4rs_simnet_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights* w
             SN_FAIL(sn_prepare_gru(n, n->seq_emb, w->seq_gru_kernel[s], w->seq_gru_recurrent[s], w->seq_gru_bias[s], &n->seq_tab[s],
                                    &n->seq_wg[s], &n->seq_wc[s], keep, st));
         }
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)((2 * 32 * (U + 4) + 32 * (64 + 1) + 32) * 4)));
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((2 * 32 * (U + 4) + 32 * (64 + 1) + 32) * 4));
+        if (ea != hipSuccess) {
+            set_error("simnet_create: hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
+            rl4rs_simnet_destroy(n);
+            return RL4RS_EHIP;
+        }
     }
     if (c->algo != RL4RS_SIMNET_DNN) {
         const int W = c->algo == RL4RS_SIMNET_WIDEDEEP ? E : U;
