@@ -261,7 +261,9 @@ int rl4rs_dien_head_prob(rl4rs_dien* net, int32_t R, const float* obs_dev, float
 
 /* Intermediate activations for parity tests; `which`: */
 enum {
-    RL4RS_DIEN_ALL_FEATURE = 0,   /* float32 [max_rows, 2*2E*seq_num/2 + U + (Cn+1)E] concat input of simulator_obs */
+    RL4RS_DIEN_ALL_FEATURE = 0,   /* float32 [max_rows, ld] concat input of simulator_obs; ld = n_bytes / (4 max_rows):
+                                     2E*seq_num + U + (Cn+1)E, or only the first 2E*seq_num + U + E columns when the
+                                     Flatten(category_emb) part lives in the head tables */
     RL4RS_DIEN_SCORES = 1,        /* float32 [seq_num, max_rows, maxlen] attention scores */
     RL4RS_DIEN_QUERY = 2,         /* float32 [max_rows, E] */
     RL4RS_DIEN_H1 = 3             /* float32 [seq_num, max_slots, maxlen, E] first-GRU states */

@@ -933,6 +933,7 @@ struct rl4rs_dien {
     rl4rs_dien_cfg c;
     int n_cu;
     int E, U, L, S, Cn, Dn, H, K, F, PLD, NH2;
+    int Fld;               // row stride of allf: F, or only the Kh columns that exist in the table form of the head
     // weights (device)
     float *cat_emb, *seq_emb, *dense_w1, *dense_b1, *dense_w2, *dense_b2, *obs_w, *obs_b, *out_w, *out_b;
     float* ptab;           // [Cn, H, 256] head tables of the flattened category embeddings (NULL = GEMM form)
@@ -1265,7 +1266,10 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         AL(h1[s], (size_t)c->max_slots * L * E);
         AL(proj[s], (size_t)c->max_slots * L * PLD);
     }
-    AL(allf, (size_t)c->max_rows * F);
+    // table form: the Flatten(category_emb) columns are never materialised, so the rows are only Kh wide (contiguous
+    // 3 KB rows for the head GEMM instead of 3 KB out of every 13.8 KB)
+    n->Fld = n->ptab ? Kh : F;
+    AL(allf, (size_t)c->max_rows * n->Fld);
     AL(dh, (size_t)c->max_rows * U);
     AL(q, (size_t)c->max_rows * E);
     AL(qa, (size_t)S * c->max_rows * ATT_H1);
@@ -1345,7 +1349,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     RL4RS_REQUIRE(R > 0 && R <= n->c.max_rows, "dien_forward: R=%d exceeds max_rows=%d", R, n->c.max_rows);
     RL4RS_REQUIRE(group >= 1 && R % group == 0, "dien_forward: R=%d is not a multiple of group=%d", R, group);
     hipStream_t st = (hipStream_t)stream;
-    const int E = n->E, U = n->U, L = n->L, S = n->S, Cn = n->Cn, F = n->F, NH2 = n->NH2;
+    const int E = n->E, U = n->U, L = n->L, S = n->S, Cn = n->Cn, F = n->Fld, NH2 = n->NH2;
     const int off_d = S * NH2, off_c = off_d + U;
     const int ngroups = R / group;
     int rc;
@@ -1445,7 +1449,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             hipLaunchKernelGGL(k_head_finish, dim3((R + 3) / 4), dim3(256), 0, st, obs_out, R, cat, Cn, n->H, n->ptab, n->obs_b);
             RL4RS_LAUNCH_CHECK();
         } else {
-            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, F, 1, st))) return rc;
+            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, n->F, 1, st))) return rc;
         }
     }
     if (prob) {
@@ -1471,7 +1475,7 @@ int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
     int64_t b = 0;
     void* ptr = nullptr;
     switch (which) {
-        case RL4RS_DIEN_ALL_FEATURE: ptr = n->allf; b = (int64_t)n->c.max_rows * n->F * 4; break;
+        case RL4RS_DIEN_ALL_FEATURE: ptr = n->allf; b = (int64_t)n->c.max_rows * n->Fld * 4; break;
         case RL4RS_DIEN_SCORES: ptr = n->scores; b = (int64_t)n->S * n->c.max_rows * n->L * 4; break;
         case RL4RS_DIEN_QUERY: ptr = n->q; b = (int64_t)n->c.max_rows * n->E * 4; break;
         case RL4RS_DIEN_H1: ptr = n->h1[0]; b = (int64_t)n->c.max_slots * n->L * n->E * 4; break;

@@ -332,7 +332,7 @@ class DeviceDien(object):
         n = C.c_int64()
         check(self.lib.rl4rs_dien_buffer(self.h, which, C.byref(p), C.byref(n)))
         if which == DIEN_ALL_FEATURE:
-            shape = (self.max_rows, self.F)
+            shape = (self.max_rows, n.value // (4 * self.max_rows))      # F, or the Kh columns of the table form
         elif which == DIEN_SCORES:
             shape = (self.S, self.max_rows, self.L)
         elif which == DIEN_QUERY:
