@@ -120,6 +120,7 @@ class SlateState(RecState):
         self._env = env
         self._ctx['owner'] = self
         env.load_batch(cols['exposed'], cols['feedback'], cols['history'], cols['user_dense'], cols['user_cat'])
+        self._feedback = cols['feedback']          # logged click labels [B, log_steps] (simulator training, rl4rs_amd/simtrain.py)
         env.reset()
         self._seq1_version = 0
         self._batch_version = self._ctx.get('batch_version', 0) + 1

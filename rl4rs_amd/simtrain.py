@@ -1,0 +1,73 @@
+"""Supervised training of the simulator from the logs, on the device (dnn family).
+
+The reference builds its supervised set in ``script/data_preprocess.py:91-131``: one sample per (page record, slot j) with
+``category = user_cat(10) + [sequence_id] + exposed_items(9) + [item_j]``, ``dense = user_dense(32) + item_feature(9 x 40)
++ item_feature_j`` and ``label = user_feedback[j]`` - exactly the complete-state rows the env scores at the reward step
+(``SlateState.get_complete_states``, slate.py:117-131) when the logged slate is replayed.  So a training batch is: sample
+records (``RecDataBase``), replay ``offline_action`` through the device state machine, take the complete-state rows and the
+logged feedback.  The model, loss and optimiser are those of ``script/supervised_train.py:37-42`` with
+``model_type='dnn'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
+"""
+import numpy as np
+import torch
+
+from . import device as D
+from .nets import simnets
+
+
+class SimulatorTrainer(object):
+    def __init__(self, sim, weights=None, minibatch=256, seed=0, lr=1e-3, dropout_rate=0.2):
+        """sim: a ``SlateRecEnv`` (its config names the log / catalogue files and the model sizes)."""
+        cfg = sim.config
+        if cfg.get('algo', 'dien') != 'dnn':
+            raise NotImplementedError("device-side simulator training exists for config['algo'] = 'dnn' only "
+                                      "(got %r)" % (cfg.get('algo', 'dien'),))
+        self.sim = sim
+        self.minibatch, self.seed, self.lr, self.dropout_rate = int(minibatch), int(seed), lr, dropout_rate
+        if weights is None:
+            weights = sim.model.weights
+        self.trainer = D.DeviceSimTrainer(cfg, weights, max_batch=self.minibatch)
+        self.P = int(cfg.get('page_items', 9))
+
+    def dataset_from_logs(self):
+        """One cache window of the log -> (dense [B*P, Dn] f32, cat [B*P, Cn] i32, labels [B*P] i32) on the device."""
+        data = self.sim._recData
+        data.reset()
+        samples = data.sample(self.sim.batch_size)
+        env = samples._live()
+        assert not samples.is_seq, "simulator training replays one page per record (SlateState)"
+        for _ in range(self.P):
+            env.act_discrete(env.offline_action())
+        env.build_complete()
+        dense = env.snapshot(D.BUF_C_DENSE)
+        cat = env.snapshot(D.BUF_C_CATEGORY)
+        labels = samples._feedback[:, :self.P].reshape(-1).to(torch.int32).contiguous()
+        return dense, cat, labels
+
+    def fit(self, windows=1, epochs=1):
+        """``epochs`` shuffled passes of minibatch SGD (Adam) over each of ``windows`` cache windows; returns the losses."""
+        losses = []
+        rs = np.random.RandomState(self.seed)
+        for _ in range(windows):
+            dense, cat, labels = self.dataset_from_logs()
+            n = dense.shape[0]
+            for _ in range(epochs):
+                perm = torch.from_numpy(rs.permutation(n)).to(dense.device)
+                d, c, y = dense[perm], cat[perm], labels[perm]
+                for lo in range(0, n - self.minibatch + 1, self.minibatch):
+                    hi = lo + self.minibatch
+                    losses.append(self.trainer.step(d[lo:hi], c[lo:hi], y[lo:hi], lr=self.lr, dropout_rate=self.dropout_rate,
+                                                    seed=self.seed))
+        return [float(x.item()) for x in losses]
+
+    def export_weights(self):
+        """Trained parameters as numpy arrays (``rl4rs_amd.nets.simnets.simnet_spec`` names) - what ``model_file`` takes."""
+        return dict((k, v.cpu().numpy()) for k, v in self.trainer.weights().items())
+
+    def install(self):
+        """Put the trained weights into the simulator the env scores with."""
+        self.sim.model.weights = simnets.OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32))
+                                                     for k, v in self.export_weights().items())
+        if self.sim.model.device_net is not None:
+            self.sim.model.device_net.close()
+            self.sim.model.device_net = None

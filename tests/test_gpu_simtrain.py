@@ -1,0 +1,144 @@
+"""Supervised training of the 'dnn' simulator on the device (rl4rs_simtrain_*) against torch float64 autograd of the
+numpy-restated model (oracle/simnets.py): gradients with and without dropout, the Adam update, and a short run that must
+fit a learnable labelling.  Gradient tolerance: 2e-4 of the largest gradient entry (fp32 kernels vs fp64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"maxlen": 64, "class_num": 2, "dense_feature_num": 432, "category_feature_num": 21, "category_hash_size": 3000,
+       "seq_num": 2, "emb_size": 128, "hidden_units": 128}
+
+
+def _batch(N, rs):
+    dense = np.abs(rs.randn(N, 432)).astype(np.float32)
+    cat = rs.randint(0, 3000, size=(N, 21)).astype(np.int32)
+    labels = rs.randint(0, 2, size=N).astype(np.int32)
+    return dense, cat, labels
+
+
+@pytest.mark.parametrize('rate', [0.0, 0.2])
+@pytest.mark.parametrize('N', [256, 700])
+def test_gradients_match_autograd(rate, N):
+    import torch
+    from rl4rs_amd.nets.simnets import init_simnet_weights
+    from rl4rs_amd.device import DeviceSimTrainer
+    from oracle.simnets import dnn_loss_and_grad
+    rs = np.random.RandomState(N + int(rate * 10))
+    w = init_simnet_weights(CFG, 'dnn', seed=3, emb_scale=0.5, bias_noise=0.2)
+    dense, cat, labels = _batch(N, rs)
+    tr = DeviceSimTrainer(CFG, w, max_batch=N)
+    t = lambda a: torch.from_numpy(a).cuda()
+    loss = tr.grad(t(dense), t(cat), t(labels), dropout_rate=rate, seed=5, step=2)
+    g = dict((k, v.cpu().numpy()) for k, v in tr.gradients().items())
+    m1 = m2 = None
+    if rate > 0:
+        # the counter RNG is a pure function of (seed, step, row, column): a second call redraws the same masks
+        loss2 = tr.grad(t(dense), t(cat), t(labels), dropout_rate=rate, seed=5, step=2)
+        assert torch.equal(loss, loss2)
+        m1, m2 = [m.cpu().numpy().astype(np.float64) for m in tr.masks(N)]
+        assert not np.array_equal(m1, m2)
+        keep = np.mean(m1)
+        assert abs(keep - (1 - rate)) < 0.02
+    loss_ref, g_ref = dnn_loss_and_grad(w, dense, cat, labels, m1, m2, rate)
+    assert abs(float(loss.item()) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    for k in g_ref:
+        scale = np.abs(g_ref[k]).max()
+        assert np.abs(g[k] - g_ref[k]).max() < 2e-4 * max(scale, 1e-8), (k, np.abs(g[k] - g_ref[k]).max(), scale)
+    tr.close()
+
+
+def test_adam_step_and_training_fits(tmp_path):
+    import torch
+    from rl4rs_amd.nets.simnets import init_simnet_weights
+    from rl4rs_amd.device import DeviceSimTrainer, DeviceSimnet
+    rs = np.random.RandomState(0)
+    w = init_simnet_weights(CFG, 'dnn', seed=1, emb_scale=0.05)
+    N = 256
+    dense, cat, _ = _batch(N, rs)
+    labels = (dense[:, :8].sum(axis=1) > np.median(dense[:, :8].sum(axis=1))).astype(np.int32)     # learnable rule
+    tr = DeviceSimTrainer(CFG, w, max_batch=N)
+    t = lambda a: torch.from_numpy(a).cuda()
+    # first step: keras Adam with m = v = 0 moves every touched weight by lr * g / (|g| + eps * sqrt(1-b2)) ~ lr * sign(g)
+    before = dict((k, v.clone()) for k, v in tr.weights().items())
+    tr.grad(t(dense), t(cat), t(labels), dropout_rate=0.0)
+    g = tr.gradients()
+    tr.iteration = 0
+    tr.step(t(dense), t(cat), t(labels), lr=1e-3, dropout_rate=0.0)
+    after = tr.weights()
+    for k in ('out_w', 'fc_w', 'dense_w1'):
+        gk = g[k]
+        lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+        expect = before[k] - lr_t * (0.1 * gk) / (torch.sqrt(0.001 * gk * gk) + 1e-7)
+        assert torch.allclose(after[k], expect, rtol=0, atol=2e-6), k
+    untouched = np.setdiff1d(np.arange(3000), np.unique(cat))
+    assert torch.equal(after['cat_emb'][untouched], before['cat_emb'][untouched])      # zero gradient rows do not move
+    losses = []
+    for it in range(200):
+        losses.append(float(tr.step(t(dense), t(cat), t(labels), lr=1e-3, dropout_rate=0.2, seed=9).item()))
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    # the trained weights drop into the inference scorer
+    trained = dict((k, v.cpu().numpy()) for k, v in tr.weights().items())
+    net = DeviceSimnet(CFG, trained, max_rows=N, max_slots=1, algo='dnn')
+    slots = torch.zeros((2, N), dtype=torch.int32).cuda()
+    _, prob = net.forward(N, 1, t(dense), t(cat), slots, want_obs=False, want_prob=True)
+    acc = ((prob.cpu().numpy() > 0.5).astype(np.int32) == labels).mean()
+    assert acc > 0.8, acc
+    net.close()
+    tr.close()
+
+
+def test_training_set_from_logs_and_fit(tmp_path):
+    """SimulatorTrainer: the device-built training set equals the reference's construction (data_preprocess.py:91-131:
+    category = user_cat + [sequence_id] + exposed + [item_j], dense = user_dense + item vectors of the page + item_j,
+    label = user_feedback[j]); a short fit lowers the loss and the trained weights drop into the env."""
+    import os
+    import torch
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.data import CatalogTables
+    from rl4rs_amd.simtrain import SimulatorTrainer
+    from rl4rs.env.slate import SlateRecEnv, SlateState
+    B = 64
+    d = str(tmp_path)
+    cat_path, log_path = os.path.join(d, 'item_info.csv'), os.path.join(d, 'log.csv')
+    cat_text = synth.make_catalog_text(seed=21)
+    synth.write_text(cat_path, cat_text)
+    records = synth.make_records(B, pages=1, seed=8, illegal_frac=0.0, hash_size=5000,
+                                 special_ids=synth.special_ids_from_text(cat_text))
+    synth.write_records(log_path, records)
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 5000, "seq_num": 2, "emb_size": 128,
+           "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32,
+           "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": True, "cache_size": B, "model_seed": 3,
+           "algo": "dnn", "return_tensors": True}
+    sim = SlateRecEnv(cfg, state_cls=SlateState)
+    tr = SimulatorTrainer(sim, minibatch=64, seed=1)
+    dense, cat, labels = tr.dataset_from_logs()
+    assert dense.shape == (B * 9, 432) and cat.shape == (B * 9, 21) and labels.shape == (B * 9,)
+    tab = CatalogTables(cat_path, 284, 32)
+    dn, cn, ln = dense.cpu().numpy(), cat.cpu().numpy(), labels.cpu().numpy()
+    for b in (0, 17, B - 1):
+        f = records[b].split('@')
+        exposed = [int(x) for x in f[3].split(',')][:9]
+        feedback = [int(x) for x in f[4].split(',')][:9]
+        portrait = [float(x) for x in f[6].split(',')]
+        for j in (0, 4, 8):
+            row = b * 9 + j
+            exp_cat = [int(x) for x in portrait[:10]] + [1] + exposed + [exposed[j]]
+            assert list(cn[row]) == exp_cat
+            exp_dense = np.concatenate([np.asarray(portrait[10:], dtype=np.float32)] + [tab.item_vec[i] for i in exposed] +
+                                       [tab.item_vec[exposed[j]]])
+            assert np.array_equal(dn[row], exp_dense)
+            assert ln[row] == feedback[j]
+    losses = tr.fit(windows=1, epochs=12)
+    assert len(losses) == 12 * (B * 9 // 64)
+    assert np.mean(losses[-9:]) < 0.8 * np.mean(losses[:9]), (np.mean(losses[:9]), np.mean(losses[-9:]))
+    tr.install()
+    env = rl4rs_amd.make('SlateRecEnv-v0', recsim=sim)
+    env.reset(reset_file=True)
+    total = 0.0
+    for _ in range(9):
+        obs, reward, done, info = env.step(env.offline_action)
+        total += float(reward.sum())
+    assert np.isfinite(total) and total > 0
