@@ -417,13 +417,15 @@ int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* pol, int32_t N, const int32_t* cat
                              const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
                              float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev, void* stream);
 
-/* Supervised training of the 'dnn' simulator (rl4rs/nets/dnn.py) on the device: what script/supervised_train.py:37-42 does
- * with model.compile(loss='binary_crossentropy', optimizer='adam') + model.fit - forward in training mode (Dropout after
- * each dense-tower layer, utils.py:48-54), keras binary_crossentropy of the softmax output against the one-hot label,
- * backward, Adam.  cfg->algo must be RL4RS_SIMNET_DNN.  Parameters, gradients and Adam state are flat float32 buffers:
- *   [ cat_emb | dense_w1 | dense_b1 | dense_w2 | dense_b2 | fc_w | fc_b | obs_w | obs_b | out_w | out_b ]
- * dense_dev [N, dense_feature_num] f32, cat_dev [N, category_feature_num] i32, labels_dev [N] i32 in [0, class_num);
- * the dropout masks are a pure function of (seed, step, row, column). */
+/* Supervised training of the 'dnn' / 'widedeep' simulators (rl4rs/nets/dnn.py, widedeep.py) on the device: what
+ * script/supervised_train.py:37-42 does with model.compile(loss='binary_crossentropy', optimizer='adam') + model.fit -
+ * forward in training mode (Dropout after each dense-tower layer, utils.py:48-54), keras binary_crossentropy of the
+ * softmax output against the one-hot label, backward, Adam.  cfg->algo = RL4RS_SIMNET_DNN or RL4RS_SIMNET_WIDEDEEP.
+ * Parameters, gradients and Adam state are flat float32 buffers (arrays a family does not have are skipped):
+ *   [ cat_emb | seq_emb (widedeep) | dense_w1 | dense_b1 | dense_w2 | dense_b2 | fc_w | fc_b | obs_w, obs_b (dnn) | out_w | out_b ]
+ * dense_dev [N, dense_feature_num] f32, cat_dev [N, category_feature_num] i32, seq_dev: seq_num pointers of int32
+ * [N, maxlen] (widedeep; may be NULL for dnn), labels_dev [N] i32 in [0, class_num); the dropout masks are a pure
+ * function of (seed, step, row, column). */
 typedef struct rl4rs_simtrain rl4rs_simtrain;
 int rl4rs_simtrain_create(const rl4rs_simnet_cfg* cfg, const rl4rs_simnet_weights* w, int32_t max_batch, void* stream,
                           rl4rs_simtrain** out);
@@ -434,12 +436,12 @@ int rl4rs_simtrain_params(rl4rs_simtrain* tr, float** params_dev, float** grad_d
 int rl4rs_simtrain_masks(rl4rs_simtrain* tr, uint8_t** mask1_dev, uint8_t** mask2_dev);
 /* forward + loss + backward into the gradient buffer; loss_dev[0] = mean loss (may be NULL) */
 int rl4rs_simtrain_grad(rl4rs_simtrain* tr, int32_t N, const float* dense_dev, const int32_t* cat_dev,
-                        const int32_t* labels_dev, float dropout_rate, uint32_t seed, uint32_t step, float* loss_dev,
-                        void* stream);
+                        const int32_t* const* seq_dev, const int32_t* labels_dev, float dropout_rate, uint32_t seed,
+                        uint32_t step, float* loss_dev, void* stream);
 /* rl4rs_simtrain_grad + one Adam update (keras defaults: lr 1e-3, beta 0.9 / 0.999, epsilon 1e-7) */
 int rl4rs_simtrain_step(rl4rs_simtrain* tr, int32_t N, const float* dense_dev, const int32_t* cat_dev,
-                        const int32_t* labels_dev, float lr, float beta1, float beta2, float eps, float dropout_rate,
-                        uint32_t seed, uint32_t step, float* loss_dev, void* stream);
+                        const int32_t* const* seq_dev, const int32_t* labels_dev, float lr, float beta1, float beta2,
+                        float eps, float dropout_rate, uint32_t seed, uint32_t step, float* loss_dev, void* stream);
 
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */

@@ -95,14 +95,13 @@ class OracleSimnet(object):
         return self.reward_probs(seq, dense, cat)[:, 1]
 
 
-def dnn_loss_and_grad(weights, dense, cat, labels, mask1=None, mask2=None, rate=0.0, class_num=2):
-    """Training-mode forward + keras binary_crossentropy + gradients of the dnn model by torch float64 autograd - the
-    checker for the hand-written HIP backward (rl4rs/nets/dnn.py:31-37 + model.compile(loss='binary_crossentropy'),
-    dnn.py:44; Dropout(0.2) after each dense-tower layer, utils.py:51,53).  mask1 / mask2: the keep masks [N, U] the device
-    drew (None = no dropout).  -> mean loss, dict of gradients."""
+def loss_and_grad(algo, weights, dense, cat, labels, seqs=None, mask1=None, mask2=None, rate=0.0, class_num=2):
+    """Training-mode forward + keras binary_crossentropy + gradients of the dnn / widedeep model by torch float64 autograd -
+    the checker for the hand-written HIP backward (rl4rs/nets/dnn.py:31-37, widedeep.py:31-38 +
+    model.compile(loss='binary_crossentropy'); Dropout(0.2) after each dense-tower layer, utils.py:51,53).
+    mask1 / mask2: the keep masks [N, U] the device drew (None = no dropout).  -> mean loss, dict of gradients."""
     import torch
-    w = dict((k, torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True)) for k, v in weights.items()
-             if k in ('cat_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'obs_w', 'obs_b', 'out_w', 'out_b'))
+    w = dict((k, torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True)) for k, v in weights.items())
     elu = torch.nn.functional.elu
     x = torch.tensor(np.asarray(dense, dtype=np.float64))
     ids = torch.tensor(np.asarray(cat, dtype=np.int64))
@@ -112,12 +111,16 @@ def dnn_loss_and_grad(weights, dense, cat, labels, mask1=None, mask2=None, rate=
     h = elu(h @ w['dense_w2'] + w['dense_b2'])
     if mask2 is not None:
         h = h * torch.tensor(np.asarray(mask2, dtype=np.float64)) / (1.0 - rate)
-    feat = torch.cat([w['cat_emb'][ids].mean(dim=1), h], dim=1)
-    a = elu(feat @ w['fc_w'] + w['fc_b'])
-    obs = elu(a @ w['obs_w'] + w['obs_b'])
+    if algo == 'dnn':
+        feat = torch.cat([w['cat_emb'][ids].mean(dim=1), h], dim=1)
+        a = elu(feat @ w['fc_w'] + w['fc_b'])
+        obs = elu(a @ w['obs_w'] + w['obs_b'])
+    else:
+        pooled = torch.cat([w['seq_emb'][torch.tensor(np.asarray(q, dtype=np.int64))].mean(dim=1) for q in seqs], dim=1)
+        obs = torch.cat([elu(pooled @ w['fc_w'] + w['fc_b']), h, w['cat_emb'][ids].reshape(ids.shape[0], -1)], dim=1)
     p = torch.softmax(obs @ w['out_w'] + w['out_b'], dim=1)
     y = torch.nn.functional.one_hot(torch.tensor(np.asarray(labels, dtype=np.int64)), class_num).double()
     pc = torch.clamp(p, 1e-7, 1.0 - 1e-7)
     loss = (-(y * torch.log(pc) + (1.0 - y) * torch.log(1.0 - pc)).mean(dim=1)).mean()
     loss.backward()
-    return float(loss.item()), dict((k, v.grad.numpy()) for k, v in w.items())
+    return float(loss.item()), dict((k, v.grad.numpy()) for k, v in w.items() if v.grad is not None)

@@ -480,27 +480,34 @@ class DeviceSimnet(object):
         return {}
 
 
-SIMTRAIN_ORDER = ('cat_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'obs_w', 'obs_b', 'out_w', 'out_b')
+SIMTRAIN_ORDER = {
+    'dnn': ('cat_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'obs_w', 'obs_b', 'out_w', 'out_b'),
+    'widedeep': ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'out_w', 'out_b'),
+}
 
 
 class DeviceSimTrainer(object):
-    """rl4rs_simtrain handle: supervised training of the 'dnn' simulator on the device (script/supervised_train.py with
-    model_type='dnn'): forward with dropout, keras binary_crossentropy, backward, Adam."""
+    """rl4rs_simtrain handle: supervised training of the 'dnn' / 'widedeep' simulators on the device
+    (script/supervised_train.py): forward with dropout, keras binary_crossentropy, backward, Adam."""
 
-    def __init__(self, config, weights, max_batch=256, device=None):
+    def __init__(self, config, weights, max_batch=256, algo=None, device=None):
         _lib.require_device()
         self.lib = _lib.load()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.config = dict(config)
+        self.algo = str(algo if algo is not None else config.get('algo', 'dnn')).lower()
+        if self.algo not in SIMTRAIN_ORDER:
+            raise NotImplementedError("device-side simulator training exists for %s (got %r)" % (sorted(SIMTRAIN_ORDER), self.algo))
         self.Cn, self.Dn = int(config['category_feature_num']), int(config['dense_feature_num'])
+        self.S, self.L = int(config['seq_num']), int(config['maxlen'])
         self.max_batch = int(max_batch)
-        cfg = _lib.SimnetCfg(SIMNET_ALGOS['dnn'], int(config['maxlen']), int(config['emb_size']), int(config['hidden_units']),
-                             self.Dn, self.Cn, int(config['category_hash_size']), int(config['seq_num']),
+        cfg = _lib.SimnetCfg(SIMNET_ALGOS[self.algo], self.L, int(config['emb_size']), int(config['hidden_units']),
+                             self.Dn, self.Cn, int(config['category_hash_size']), self.S,
                              int(config['class_num']), self.max_batch, 1)
         w = _lib.SimnetWeights()
         keep = []
         self.shapes = []
-        for name in SIMTRAIN_ORDER:
+        for name in SIMTRAIN_ORDER[self.algo]:
             arr = np.ascontiguousarray(weights[name], dtype=np.float32)
             keep.append(arr)
             self.shapes.append((name, arr.shape))
@@ -556,27 +563,33 @@ class DeviceSimTrainer(object):
             out.append(t)
         return out
 
-    def _batch(self, dense, cat, labels):
+    def _batch(self, dense, cat, labels, seqs):
         N = dense.shape[0]
         assert dense.dtype == torch.float32 and dense.shape == (N, self.Dn) and dense.is_contiguous()
         assert cat.dtype == torch.int32 and cat.shape == (N, self.Cn) and cat.is_contiguous()
         labels = labels.to(torch.int32).contiguous()
         assert labels.shape == (N,)
-        return N, labels
+        sp = None
+        if self.algo == 'widedeep':
+            assert seqs is not None and len(seqs) == self.S, "widedeep needs the seq_num sequence inputs"
+            for q in seqs:
+                assert q.dtype == torch.int32 and q.shape == (N, self.L) and q.is_contiguous()
+            sp = (C.c_void_p * self.S)(*[_ptr(q) for q in seqs])
+        return N, labels, sp
 
-    def grad(self, dense, cat, labels, dropout_rate=0.2, seed=0, step=0):
+    def grad(self, dense, cat, labels, seqs=None, dropout_rate=0.2, seed=0, step=0):
         """Forward + loss + backward; returns the mean loss (device scalar tensor)."""
-        N, labels = self._batch(dense, cat, labels)
+        N, labels, sp = self._batch(dense, cat, labels, seqs)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        check(self.lib.rl4rs_simtrain_grad(self.h, N, _ptr(dense), _ptr(cat), _ptr(labels), dropout_rate, seed, step, _ptr(loss),
-                                           _stream()))
+        check(self.lib.rl4rs_simtrain_grad(self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), dropout_rate, seed, step,
+                                           _ptr(loss), _stream()))
         return loss
 
-    def step(self, dense, cat, labels, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, dropout_rate=0.2, seed=0):
-        N, labels = self._batch(dense, cat, labels)
+    def step(self, dense, cat, labels, seqs=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, dropout_rate=0.2, seed=0):
+        N, labels, sp = self._batch(dense, cat, labels, seqs)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        check(self.lib.rl4rs_simtrain_step(self.h, N, _ptr(dense), _ptr(cat), _ptr(labels), lr, beta1, beta2, eps, dropout_rate,
-                                           seed, self.iteration, _ptr(loss), _stream()))
+        check(self.lib.rl4rs_simtrain_step(self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), lr, beta1, beta2, eps,
+                                           dropout_rate, seed, self.iteration, _ptr(loss), _stream()))
         self.iteration += 1
         return loss
 

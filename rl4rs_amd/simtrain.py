@@ -1,4 +1,4 @@
-"""Supervised training of the simulator from the logs, on the device (dnn family).
+"""Supervised training of the simulator from the logs, on the device (dnn and widedeep families).
 
 The reference builds its supervised set in ``script/data_preprocess.py:91-131``: one sample per (page record, slot j) with
 ``category = user_cat(10) + [sequence_id] + exposed_items(9) + [item_j]``, ``dense = user_dense(32) + item_feature(9 x 40)
@@ -6,7 +6,7 @@ The reference builds its supervised set in ``script/data_preprocess.py:91-131``:
 (``SlateState.get_complete_states``, slate.py:117-131) when the logged slate is replayed.  So a training batch is: sample
 records (``RecDataBase``), replay ``offline_action`` through the device state machine, take the complete-state rows and the
 logged feedback.  The model, loss and optimiser are those of ``script/supervised_train.py:37-42`` with
-``model_type='dnn'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
+``model_type='dnn'`` / ``'widedeep'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
 """
 import numpy as np
 import torch
@@ -19,9 +19,10 @@ class SimulatorTrainer(object):
     def __init__(self, sim, weights=None, minibatch=256, seed=0, lr=1e-3, dropout_rate=0.2):
         """sim: a ``SlateRecEnv`` (its config names the log / catalogue files and the model sizes)."""
         cfg = sim.config
-        if cfg.get('algo', 'dien') != 'dnn':
-            raise NotImplementedError("device-side simulator training exists for config['algo'] = 'dnn' only "
-                                      "(got %r)" % (cfg.get('algo', 'dien'),))
+        if cfg.get('algo', 'dien') not in D.SIMTRAIN_ORDER:
+            raise NotImplementedError("device-side simulator training exists for config['algo'] in %s (got %r)"
+                                      % (sorted(D.SIMTRAIN_ORDER), cfg.get('algo', 'dien')))
+        self.algo = cfg['algo']
         self.sim = sim
         self.minibatch, self.seed, self.lr, self.dropout_rate = int(minibatch), int(seed), lr, dropout_rate
         if weights is None:
@@ -30,7 +31,9 @@ class SimulatorTrainer(object):
         self.P = int(cfg.get('page_items', 9))
 
     def dataset_from_logs(self):
-        """One cache window of the log -> (dense [B*P, Dn] f32, cat [B*P, Cn] i32, labels [B*P] i32) on the device."""
+        """One cache window of the log -> (dense [B*P, Dn] f32, cat [B*P, Cn] i32, labels [B*P] i32, seqs) on the device;
+        seqs = the seq_num sequence inputs [B*P, maxlen] i32 (user history, then the constant [0] sequence of page 1,
+        data_preprocess.py:103-105)."""
         data = self.sim._recData
         data.reset()
         samples = data.sample(self.sim.batch_size)
@@ -42,22 +45,25 @@ class SimulatorTrainer(object):
         dense = env.snapshot(D.BUF_C_DENSE)
         cat = env.snapshot(D.BUF_C_CATEGORY)
         labels = samples._feedback[:, :self.P].reshape(-1).to(torch.int32).contiguous()
-        return dense, cat, labels
+        hist = env.snapshot(D.BUF_SEQ0).repeat_interleave(self.P, dim=0).contiguous()
+        seqs = [hist] + [torch.zeros_like(hist) for _ in range(int(self.sim.config['seq_num']) - 1)]
+        return dense, cat, labels, seqs
 
     def fit(self, windows=1, epochs=1):
         """``epochs`` shuffled passes of minibatch SGD (Adam) over each of ``windows`` cache windows; returns the losses."""
         losses = []
         rs = np.random.RandomState(self.seed)
         for _ in range(windows):
-            dense, cat, labels = self.dataset_from_logs()
+            dense, cat, labels, seqs = self.dataset_from_logs()
             n = dense.shape[0]
             for _ in range(epochs):
                 perm = torch.from_numpy(rs.permutation(n)).to(dense.device)
                 d, c, y = dense[perm], cat[perm], labels[perm]
+                q = [x[perm] for x in seqs] if self.algo == 'widedeep' else None
                 for lo in range(0, n - self.minibatch + 1, self.minibatch):
                     hi = lo + self.minibatch
-                    losses.append(self.trainer.step(d[lo:hi], c[lo:hi], y[lo:hi], lr=self.lr, dropout_rate=self.dropout_rate,
-                                                    seed=self.seed))
+                    losses.append(self.trainer.step(d[lo:hi], c[lo:hi], y[lo:hi], None if q is None else [x[lo:hi] for x in q],
+                                                    lr=self.lr, dropout_rate=self.dropout_rate, seed=self.seed))
         return [float(x.item()) for x in losses]
 
     def export_weights(self):

@@ -1,4 +1,4 @@
-"""Supervised training of the 'dnn' simulator on the device (rl4rs_simtrain_*) against torch float64 autograd of the
+"""Supervised training of the 'dnn' / 'widedeep' simulators on the device (rl4rs_simtrain_*) against torch float64 autograd of the
 numpy-restated model (oracle/simnets.py): gradients with and without dropout, the Adam update, and a short run that must
 fit a learnable labelling.  Gradient tolerance: 2e-4 of the largest gradient entry (fp32 kernels vs fp64)."""
 import numpy as np
@@ -17,31 +17,36 @@ def _batch(N, rs):
     return dense, cat, labels
 
 
+@pytest.mark.parametrize('algo', ['dnn', 'widedeep'])
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 @pytest.mark.parametrize('N', [256, 700])
-def test_gradients_match_autograd(rate, N):
+def test_gradients_match_autograd(algo, rate, N):
     import torch
     from rl4rs_amd.nets.simnets import init_simnet_weights
     from rl4rs_amd.device import DeviceSimTrainer
-    from oracle.simnets import dnn_loss_and_grad
+    from oracle.simnets import loss_and_grad
     rs = np.random.RandomState(N + int(rate * 10))
-    w = init_simnet_weights(CFG, 'dnn', seed=3, emb_scale=0.5, bias_noise=0.2)
+    w = init_simnet_weights(CFG, algo, seed=3, emb_scale=0.5, bias_noise=0.2)
     dense, cat, labels = _batch(N, rs)
-    tr = DeviceSimTrainer(CFG, w, max_batch=N)
+    seqs = [rs.randint(0, 284, size=(N, 64)).astype(np.int32) for _ in range(2)]
+    seqs[1][::2] = 0
+    tr = DeviceSimTrainer(CFG, w, max_batch=N, algo=algo)
     t = lambda a: torch.from_numpy(a).cuda()
-    loss = tr.grad(t(dense), t(cat), t(labels), dropout_rate=rate, seed=5, step=2)
+    dseqs = [t(q) for q in seqs] if algo == 'widedeep' else None
+    loss = tr.grad(t(dense), t(cat), t(labels), dseqs, dropout_rate=rate, seed=5, step=2)
     g = dict((k, v.cpu().numpy()) for k, v in tr.gradients().items())
     m1 = m2 = None
     if rate > 0:
         # the counter RNG is a pure function of (seed, step, row, column): a second call redraws the same masks
-        loss2 = tr.grad(t(dense), t(cat), t(labels), dropout_rate=rate, seed=5, step=2)
+        loss2 = tr.grad(t(dense), t(cat), t(labels), dseqs, dropout_rate=rate, seed=5, step=2)
         assert torch.equal(loss, loss2)
         m1, m2 = [m.cpu().numpy().astype(np.float64) for m in tr.masks(N)]
         assert not np.array_equal(m1, m2)
         keep = np.mean(m1)
         assert abs(keep - (1 - rate)) < 0.02
-    loss_ref, g_ref = dnn_loss_and_grad(w, dense, cat, labels, m1, m2, rate)
+    loss_ref, g_ref = loss_and_grad(algo, w, dense, cat, labels, seqs, m1, m2, rate)
     assert abs(float(loss.item()) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    assert set(g) == set(g_ref)
     for k in g_ref:
         scale = np.abs(g_ref[k]).max()
         assert np.abs(g[k] - g_ref[k]).max() < 2e-4 * max(scale, 1e-8), (k, np.abs(g[k] - g_ref[k]).max(), scale)
@@ -88,7 +93,8 @@ def test_adam_step_and_training_fits(tmp_path):
     tr.close()
 
 
-def test_training_set_from_logs_and_fit(tmp_path):
+@pytest.mark.parametrize('algo', ['dnn', 'widedeep'])
+def test_training_set_from_logs_and_fit(tmp_path, algo):
     """SimulatorTrainer: the device-built training set equals the reference's construction (data_preprocess.py:91-131:
     category = user_cat + [sequence_id] + exposed + [item_j], dense = user_dense + item vectors of the page + item_j,
     label = user_feedback[j]); a short fit lowers the loss and the trained weights drop into the env."""
@@ -111,10 +117,11 @@ def test_training_set_from_logs_and_fit(tmp_path):
            "category_feature_num": 21, "category_hash_size": 5000, "seq_num": 2, "emb_size": 128,
            "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32,
            "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": True, "cache_size": B, "model_seed": 3,
-           "algo": "dnn", "return_tensors": True}
+           "algo": algo, "return_tensors": True}
     sim = SlateRecEnv(cfg, state_cls=SlateState)
     tr = SimulatorTrainer(sim, minibatch=64, seed=1)
-    dense, cat, labels = tr.dataset_from_logs()
+    dense, cat, labels, seqs = tr.dataset_from_logs()
+    assert len(seqs) == 2 and seqs[0].shape == (B * 9, 64) and int(seqs[1].abs().sum()) == 0
     assert dense.shape == (B * 9, 432) and cat.shape == (B * 9, 21) and labels.shape == (B * 9,)
     tab = CatalogTables(cat_path, 284, 32)
     dn, cn, ln = dense.cpu().numpy(), cat.cpu().numpy(), labels.cpu().numpy()
