@@ -417,14 +417,16 @@ int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* pol, int32_t N, const int32_t* cat
                              const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
                              float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev, void* stream);
 
-/* Supervised training of the 'dnn' / 'widedeep' simulators (rl4rs/nets/dnn.py, widedeep.py) on the device: what
+/* Supervised training of the 'dnn' / 'widedeep' / 'lstm' simulators (rl4rs/nets/dnn.py, widedeep.py, lstm.py) on the device: what
  * script/supervised_train.py:37-42 does with model.compile(loss='binary_crossentropy', optimizer='adam') + model.fit -
  * forward in training mode (Dropout after each dense-tower layer, utils.py:48-54), keras binary_crossentropy of the
- * softmax output against the one-hot label, backward, Adam.  cfg->algo = RL4RS_SIMNET_DNN or RL4RS_SIMNET_WIDEDEEP.
+ * softmax output against the one-hot label, backward (BPTT through the keras GRUs of the lstm family), Adam.
+ * cfg->algo = RL4RS_SIMNET_DNN, RL4RS_SIMNET_WIDEDEEP or RL4RS_SIMNET_LSTM.
  * Parameters, gradients and Adam state are flat float32 buffers (arrays a family does not have are skipped):
- *   [ cat_emb | seq_emb (widedeep) | dense_w1 | dense_b1 | dense_w2 | dense_b2 | fc_w | fc_b | obs_w, obs_b (dnn) | out_w | out_b ]
+ *   [ cat_emb | seq_emb | dense_w1 | dense_b1 | dense_w2 | dense_b2 | fc_w | fc_b | obs_w | obs_b | out_w | out_b |
+ *     lstm: cat_gru kernel, recurrent, bias | seq0_gru kernel, recurrent, bias | seq1_gru ... ]
  * dense_dev [N, dense_feature_num] f32, cat_dev [N, category_feature_num] i32, seq_dev: seq_num pointers of int32
- * [N, maxlen] (widedeep; may be NULL for dnn), labels_dev [N] i32 in [0, class_num); the dropout masks are a pure
+ * [N, maxlen] (widedeep, lstm; may be NULL for dnn), labels_dev [N] i32 in [0, class_num); the dropout masks are a pure
  * function of (seed, step, row, column). */
 typedef struct rl4rs_simtrain rl4rs_simtrain;
 int rl4rs_simtrain_create(const rl4rs_simnet_cfg* cfg, const rl4rs_simnet_weights* w, int32_t max_batch, void* stream,

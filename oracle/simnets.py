@@ -96,7 +96,7 @@ class OracleSimnet(object):
 
 
 def loss_and_grad(algo, weights, dense, cat, labels, seqs=None, mask1=None, mask2=None, rate=0.0, class_num=2):
-    """Training-mode forward + keras binary_crossentropy + gradients of the dnn / widedeep model by torch float64 autograd -
+    """Training-mode forward + keras binary_crossentropy + gradients of the dnn / widedeep / lstm model by torch float64 autograd -
     the checker for the hand-written HIP backward (rl4rs/nets/dnn.py:31-37, widedeep.py:31-38 +
     model.compile(loss='binary_crossentropy'); Dropout(0.2) after each dense-tower layer, utils.py:51,53).
     mask1 / mask2: the keep masks [N, U] the device drew (None = no dropout).  -> mean loss, dict of gradients."""
@@ -111,10 +111,29 @@ def loss_and_grad(algo, weights, dense, cat, labels, seqs=None, mask1=None, mask
     h = elu(h @ w['dense_w2'] + w['dense_b2'])
     if mask2 is not None:
         h = h * torch.tensor(np.asarray(mask2, dtype=np.float64)) / (1.0 - rate)
+    def gru_last(X, i):      # keras GRU (see keras_gru_last above) in torch
+        k, r, b = w[i + '_kernel'], w[i + '_recurrent'], w[i + '_bias']
+        U = r.shape[0]
+        hs = lambda v: torch.clamp(0.2 * v + 0.5, 0.0, 1.0)
+        hst = torch.zeros((X.shape[0], U), dtype=torch.float64)
+        for t in range(X.shape[1]):
+            xp = X[:, t] @ k + b
+            hz = hst @ r[:, :2 * U]
+            z = hs(xp[:, :U] + hz[:, :U])
+            rr = hs(xp[:, U:2 * U] + hz[:, U:])
+            hh = torch.tanh(xp[:, 2 * U:] + (rr * hst) @ r[:, 2 * U:])
+            hst = z * hst + (1.0 - z) * hh
+        return hst
+
     if algo == 'dnn':
         feat = torch.cat([w['cat_emb'][ids].mean(dim=1), h], dim=1)
         a = elu(feat @ w['fc_w'] + w['fc_b'])
         obs = elu(a @ w['obs_w'] + w['obs_b'])
+    elif algo == 'lstm':
+        finals = [gru_last(w['seq_emb'][torch.tensor(np.asarray(q, dtype=np.int64))], 'seq%d_gru' % i) for i, q in enumerate(seqs)]
+        cg = gru_last(w['cat_emb'][ids], 'cat_gru')
+        feat = torch.cat(finals + [h, cg, w['cat_emb'][ids].reshape(ids.shape[0], -1)], dim=1)
+        obs = elu(feat @ w['obs_w'] + w['obs_b'])
     else:
         pooled = torch.cat([w['seq_emb'][torch.tensor(np.asarray(q, dtype=np.int64))].mean(dim=1) for q in seqs], dim=1)
         obs = torch.cat([elu(pooled @ w['fc_w'] + w['fc_b']), h, w['cat_emb'][ids].reshape(ids.shape[0], -1)], dim=1)

@@ -1,7 +1,7 @@
-// Supervised training of the 'dnn' and 'widedeep' simulator families on the device: one optimiser step = forward (training mode:
+// Supervised training of the 'dnn', 'widedeep' and 'lstm' simulator families on the device: one optimiser step = forward (training mode:
 // Dropout(0.2) after each dense-tower layer, utils.py:48-54) + keras binary_crossentropy on the softmax output against
 // the one-hot label + backward + Adam - what `model.compile(loss='binary_crossentropy', optimizer='adam')` /
-// `model.fit` do in script/supervised_train.py:37-42 for rl4rs/nets/dnn.py and rl4rs/nets/widedeep.py.  Included at the end of policy.hip: it uses
+// `model.fit` do in script/supervised_train.py:37-42 for rl4rs/nets/dnn.py, widedeep.py and lstm.py.  Included at the end of policy.hip: it uses
 // that translation unit's sample-axis gradient reductions (k_gemm_tn / k_colsum / k_reduce_chunks) and Adam kernel.
 // Everything is fp32 on the fp32 MFMA GEMMs; batches are small (256 in the reference), so this path is launch-bound.
 //
@@ -62,11 +62,11 @@ __global__ void k_bce_softmax(const float* __restrict__ logits, const int32_t* _
     for (int k = 0; k < K; ++k) dlogits[(size_t)n * K + k] = p[k] * (dp[k] - dot) / (float)N;
 }
 
-__global__ void k_transpose(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+__global__ void k_transpose(const float* __restrict__ w, int64_t ldw, int rows, int cols, float* __restrict__ wt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int r = i / cols, c = i - r * cols;
-    wt[(size_t)c * rows + r] = w[i];
+    wt[(size_t)c * rows + r] = w[(size_t)r * ldw + c];
 }
 
 // gradient of the mean-pooled embedding: g_table[ids[row, j]] += d_feat[row] / len   (float atomics)
@@ -94,6 +94,80 @@ __global__ __launch_bounds__(256) void k_emb_flatten_bwd(const int32_t* __restri
     }
 }
 
+// ---- keras GRU (hard_sigmoid gates, reset_after = False: z, r = hs(x W + h U + b); hh = tanh(x Wh + (r*h) Uh + bh);
+//      h = z h + (1-z) hh), training mode ---------------------------------------------------------------------------
+// All per-sequence arrays are [N, len, W] row-major; a step works on the slice t (row stride len*W).
+__device__ __forceinline__ float hard_sig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float hard_sig_grad(float x) { return (x > -2.5f && x < 2.5f) ? 0.2f : 0.f; }
+
+// z, r = hs(x-side + h_prev U_zr);  keeps the pre-activations (for hs') and r * h_prev (operand of the candidate GEMM)
+__global__ void k_gru_gates(const float* __restrict__ a1, const float* __restrict__ g, const float* __restrict__ hprev,
+                            int64_t ldh, float* __restrict__ azr, float* __restrict__ z, float* __restrict__ r,
+                            float* __restrict__ rh, int N, int U, int len, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * U) return;
+    const int n = i / U, c = i - n * U;
+    const size_t s3 = ((size_t)n * len + t) * 3 * U, s2 = ((size_t)n * len + t) * 2 * U, s1 = ((size_t)n * len + t) * U;
+    const float az = a1[s3 + c] + g[(size_t)n * 2 * U + c];
+    const float ar = a1[s3 + U + c] + g[(size_t)n * 2 * U + U + c];
+    const float hp = hprev[(size_t)n * ldh + c];
+    const float rr = hard_sig(ar);
+    azr[s2 + c] = az; azr[s2 + U + c] = ar;
+    z[s1 + c] = hard_sig(az); r[s1 + c] = rr;
+    rh[s1 + c] = rr * hp;
+}
+
+// hh = tanh(x-side + (r*h_prev) U_h);  h = z h_prev + (1 - z) hh
+__global__ void k_gru_update(const float* __restrict__ a1, const float* __restrict__ gh, const float* __restrict__ hprev,
+                             int64_t ldh, const float* __restrict__ z, float* __restrict__ hh, float* __restrict__ h,
+                             int N, int U, int len, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * U) return;
+    const int n = i / U, c = i - n * U;
+    const size_t s3 = ((size_t)n * len + t) * 3 * U, s1 = ((size_t)n * len + t) * U;
+    const float c_ = tanhf(a1[s3 + 2 * U + c] + gh[(size_t)n * U + c]);
+    const float zz = z[s1 + c];
+    hh[s1 + c] = c_;
+    h[s1 + c] = zz * hprev[(size_t)n * ldh + c] + (1.0f - zz) * c_;
+}
+
+// BPTT step, part 1: dh = dh_a + dh_b (+ upstream at the last step);  da_h = dh (1 - z) (1 - hh^2)
+__global__ void k_gru_bwd_pre(const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* __restrict__ up,
+                              int64_t ld_up, float* __restrict__ dh, const float* __restrict__ z, const float* __restrict__ hh,
+                              float* __restrict__ dA, int N, int U, int len, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * U) return;
+    const int n = i / U, c = i - n * U;
+    const size_t s3 = ((size_t)n * len + t) * 3 * U, s1 = ((size_t)n * len + t) * U;
+    float d = (dh_a ? dh_a[i] : 0.f) + (dh_b ? dh_b[i] : 0.f) + (up ? up[(size_t)n * ld_up + c] : 0.f);
+    dh[i] = d;
+    const float c_ = hh[s1 + c];
+    dA[s3 + 2 * U + c] = d * (1.0f - z[s1 + c]) * (1.0f - c_ * c_);
+}
+
+// part 2 (after d_rh = da_h U_h^T): da_z, da_r and the direct terms of dh_{t-1}
+__global__ void k_gru_bwd_mid(const float* __restrict__ dh, const float* __restrict__ d_rh, const float* __restrict__ hprev,
+                              int64_t ldh, const float* __restrict__ z, const float* __restrict__ r, const float* __restrict__ hh,
+                              const float* __restrict__ azr, float* __restrict__ dA, float* __restrict__ dh_part, int N, int U,
+                              int len, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * U) return;
+    const int n = i / U, c = i - n * U;
+    const size_t s3 = ((size_t)n * len + t) * 3 * U, s2 = ((size_t)n * len + t) * 2 * U, s1 = ((size_t)n * len + t) * U;
+    const float d = dh[i], hp = hprev[(size_t)n * ldh + c], q = d_rh[i];
+    dA[s3 + c] = d * (hp - hh[s1 + c]) * hard_sig_grad(azr[s2 + c]);
+    dA[s3 + U + c] = q * hp * hard_sig_grad(azr[s2 + U + c]);
+    dh_part[i] = d * z[s1 + c] + q * r[s1 + c];
+}
+
+// Hprev[n, t] = H[n, t-1] (0 at t = 0), as a contiguous [N*len, U] operand of the weight-gradient reductions
+__global__ void k_shift_prev(const float* __restrict__ h, float* __restrict__ hprev, int N, int U, int len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * len * U) return;
+    const int c = i % U, t = (i / U) % len;
+    hprev[i] = t == 0 ? 0.f : h[i - U];
+}
+
 __global__ void k_mean(const float* __restrict__ x, int n, float* __restrict__ out) {
     __shared__ float sm[256];
     float s = 0.f;
@@ -109,7 +183,16 @@ __global__ void k_mean(const float* __restrict__ x, int n, float* __restrict__ o
 
 }  // namespace rl4rs
 
-enum { SP_CAT_EMB = 0, SP_SEQ_EMB, SP_DW1, SP_DB1, SP_DW2, SP_DB2, SP_FC_W, SP_FC_B, SP_OBS_W, SP_OBS_B, SP_OUT_W, SP_OUT_B, SP_COUNT };
+enum { SP_CAT_EMB = 0, SP_SEQ_EMB, SP_DW1, SP_DB1, SP_DW2, SP_DB2, SP_FC_W, SP_FC_B, SP_OBS_W, SP_OBS_B, SP_OUT_W, SP_OUT_B,
+       SP_GRU0,                    // lstm: 3 arrays (kernel, recurrent, bias) per GRU: the category GRU, then one per sequence
+       SP_COUNT = SP_GRU0 + 3 * 5 };
+
+// one keras GRU of the lstm family in training mode: everything the BPTT needs is kept from the forward
+struct GruSave {
+    float *X, *A1, *H, *Z, *R, *HH, *RH, *AZR;     // [N, len, E | 3U | U | U | U | U | U | 2U]
+    int len, emb, pk;                              // sequence length, SP_* index of its embedding table, of its kernel
+    const int32_t* ids;
+};
 
 struct rl4rs_simtrain {
     rl4rs_simnet_cfg c;
@@ -121,8 +204,102 @@ struct rl4rs_simtrain {
     float *d_logits, *d_obs, *d_a, *d_feat, *d_h1, *d_h2, *wt, *part, *loss_rows, *lr_dummy;
     uint8_t *mask1, *mask2;
     int64_t adam_t;
+    // lstm: saved forwards of the 1 + seq_num GRUs and BPTT scratch
+    GruSave gru[5];
+    float *g_dA, *g_dX, *g_hprev, *g_G, *g_Gh, *g_dh, *g_dhp, *g_dhg, *g_drh, *g_zero, *g_uzrT, *g_uhT, *g_tmpw;
     std::vector<void*> owned;
 };
+
+namespace {
+
+// sample-axis reductions / transposed-weight GEMM over an explicit number of samples
+void st_tn(rl4rs_simtrain* t, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
+    const int nz = (Ns + t->chunk - 1) / t->chunk;
+    const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
+    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, t->chunk, nz == 1 ? dst : t->part);
+    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, t->part, M * Nc, nz, dst);
+}
+void st_cs(rl4rs_simtrain* t, hipStream_t st, const float* X, int ld, int Nc, int Ns, float* dst) {
+    const int nz = (Ns + t->chunk - 1) / t->chunk;
+    hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, Ns, t->chunk, nz == 1 ? dst : t->part);
+    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, t->part, Nc, nz, dst);
+}
+int st_back(rl4rs_simtrain* t, hipStream_t st, const float* dY, int ldy, int Nout, const float* W, int ldw, int Kin, float* dX, int ldx,
+            int Ns) {      // dX [Ns, Kin] = dY [Ns, Nout] W^T,  W [Kin, Nout] with leading dimension ldw
+    hipLaunchKernelGGL(k_transpose, dim3((Kin * Nout + 255) / 256), dim3(256), 0, st, W, (int64_t)ldw, Kin, Nout, t->wt);
+    return launch_gemm_f32(dY, ldy, t->wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
+}
+
+// keras GRU forward over `len` steps for N rows, keeping gates and states (utils.py:34,91: layers.GRU(units=U))
+int gru_forward(rl4rs_simtrain* t, int N, GruSave& g, hipStream_t st) {
+    const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = g.len;
+    const float* K = t->params + t->off[g.pk];
+    const float* Rw = t->params + t->off[g.pk + 1];
+    const float* b = t->params + t->off[g.pk + 2];
+    int rc;
+    hipLaunchKernelGGL(k_emb_flatten, dim3((N + 3) / 4), dim3(256), 0, st, g.ids, N, len, H, E, t->params + t->off[g.emb], g.X,
+                       (int64_t)len * E, 0);
+    if ((rc = launch_gemm_f32(g.X, E, K, 3 * U, b, g.A1, 3 * U, N * len, 3 * U, E, 0, st))) return rc;
+    const dim3 ew((N * U + 255) / 256), b256(256);
+    for (int ts = 0; ts < len; ++ts) {
+        const float* hprev = ts == 0 ? t->g_zero : g.H + (size_t)(ts - 1) * U;
+        const int64_t ldh = ts == 0 ? U : (int64_t)len * U;
+        if ((rc = launch_gemm_f32(hprev, ldh, Rw, 3 * U, nullptr, t->g_G, 2 * U, N, 2 * U, U, 0, st))) return rc;
+        hipLaunchKernelGGL(k_gru_gates, ew, b256, 0, st, g.A1, t->g_G, hprev, ldh, g.AZR, g.Z, g.R, g.RH, N, U, len, ts);
+        if ((rc = launch_gemm_f32(g.RH + (size_t)ts * U, (int64_t)len * U, Rw + 2 * U, 3 * U, nullptr, t->g_Gh, U, N, U, U, 0, st))) return rc;
+        hipLaunchKernelGGL(k_gru_update, ew, b256, 0, st, g.A1, t->g_Gh, hprev, ldh, g.Z, g.HH, g.H, N, U, len, ts);
+    }
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// BPTT of one GRU from the gradient of its final state (`up`, row stride ld_up); accumulates into the embedding gradient
+int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t ld_up, hipStream_t st) {
+    const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = g.len;
+    const float* K = t->params + t->off[g.pk];
+    const float* Rw = t->params + t->off[g.pk + 1];
+    float* gK = t->grad + t->off[g.pk];
+    float* gR = t->grad + t->off[g.pk + 1];
+    float* gb = t->grad + t->off[g.pk + 2];
+    int rc;
+    const dim3 ew((N * U + 255) / 256), b256(256);
+    hipLaunchKernelGGL(k_transpose, dim3((U * 2 * U + 255) / 256), b256, 0, st, Rw, (int64_t)3 * U, U, 2 * U, t->g_uzrT);        // [2U, U]
+    hipLaunchKernelGGL(k_transpose, dim3((U * U + 255) / 256), b256, 0, st, Rw + 2 * U, (int64_t)3 * U, U, U, t->g_uhT);        // [U, U]
+    const float* dh_a = nullptr;
+    const float* dh_b = nullptr;
+    for (int ts = len - 1; ts >= 0; --ts) {
+        const float* hprev = ts == 0 ? t->g_zero : g.H + (size_t)(ts - 1) * U;
+        const int64_t ldh = ts == 0 ? U : (int64_t)len * U;
+        hipLaunchKernelGGL(k_gru_bwd_pre, ew, b256, 0, st, dh_a, dh_b, ts == len - 1 ? up : (const float*)nullptr, ld_up, t->g_dh, g.Z, g.HH,
+                           t->g_dA, N, U, len, ts);
+        if ((rc = launch_gemm_f32(t->g_dA + (size_t)ts * 3 * U + 2 * U, (int64_t)len * 3 * U, t->g_uhT, U, nullptr, t->g_drh, U, N, U, U, 0, st)))
+            return rc;
+        hipLaunchKernelGGL(k_gru_bwd_mid, ew, b256, 0, st, t->g_dh, t->g_drh, hprev, ldh, g.Z, g.R, g.HH, g.AZR, t->g_dA, t->g_dhp, N, U,
+                           len, ts);
+        if (ts > 0) {
+            if ((rc = launch_gemm_f32(t->g_dA + (size_t)ts * 3 * U, (int64_t)len * 3 * U, t->g_uzrT, U, nullptr, t->g_dhg, U, N, U, 2 * U, 0, st)))
+                return rc;
+        }
+        dh_a = t->g_dhp;
+        dh_b = t->g_dhg;
+    }
+    // parameter gradients over all (row, step) samples
+    const int Ns = N * len;
+    hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, t->g_hprev, N, U, len);
+    st_tn(t, st, g.X, E, E, t->g_dA, 3 * U, 3 * U, Ns, gK);
+    st_cs(t, st, t->g_dA, 3 * U, 3 * U, Ns, gb);
+    st_tn(t, st, t->g_hprev, U, U, t->g_dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
+    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, t->g_tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
+    st_tn(t, st, g.RH, U, U, t->g_dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
+    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR + 2 * U, (size_t)3 * U * 4, t->g_tmpw, (size_t)U * 4, (size_t)U * 4, U, hipMemcpyDeviceToDevice, st));
+    if ((rc = st_back(t, st, t->g_dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
+    hipLaunchKernelGGL(k_emb_flatten_bwd, dim3((N + 3) / 4), b256, 0, st, g.ids, N, len, H, E, t->g_dX, (int64_t)len * E,
+                       t->grad + t->off[g.emb]);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -136,14 +313,23 @@ int rl4rs_simtrain_destroy(rl4rs_simtrain* t) {
 int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights* w, int32_t max_batch, void* stream,
                           rl4rs_simtrain** out) {
     RL4RS_REQUIRE(c && w && out && max_batch > 0, "simtrain_create: bad argument");
-    RL4RS_REQUIRE(c->algo == RL4RS_SIMNET_DNN || c->algo == RL4RS_SIMNET_WIDEDEEP,
-                  "simtrain: the dnn (1) and widedeep (2) families can be trained on the device (got algo %d)", c->algo);
+    RL4RS_REQUIRE(c->algo >= RL4RS_SIMNET_DNN && c->algo <= RL4RS_SIMNET_LSTM,
+                  "simtrain: algo must be 1 (dnn), 2 (widedeep) or 3 (lstm), got %d", c->algo);
     RL4RS_REQUIRE(c->emb_size > 0 && c->hidden_units > 0 && c->dense_feature_num > 0 && c->category_feature_num > 0 &&
                   c->category_hash_size > 0 && c->class_num >= 2 && c->class_num <= 8 && c->seq_num >= 1 && c->seq_num <= 4 &&
                   c->maxlen >= 1, "simtrain: bad sizes");
-    const bool wd = c->algo == RL4RS_SIMNET_WIDEDEEP;
-    RL4RS_REQUIRE(w->cat_emb && w->dense_w1 && w->dense_b1 && w->dense_w2 && w->dense_b2 && w->fc_w && w->fc_b && w->out_w &&
-                  w->out_b && (wd ? w->seq_emb != nullptr : (w->obs_w && w->obs_b)), "simtrain_create: weights missing");
+    const bool wd = c->algo == RL4RS_SIMNET_WIDEDEEP, ls = c->algo == RL4RS_SIMNET_LSTM;
+    RL4RS_REQUIRE(w->cat_emb && w->dense_w1 && w->dense_b1 && w->dense_w2 && w->dense_b2 && w->out_w && w->out_b,
+                  "simtrain_create: weights missing");
+    RL4RS_REQUIRE(ls || (w->fc_w && w->fc_b), "simtrain_create: fc weights missing");
+    RL4RS_REQUIRE(wd || (w->obs_w && w->obs_b), "simtrain_create: obs weights missing");
+    RL4RS_REQUIRE(!(wd || ls) || w->seq_emb, "simtrain_create: seq_emb missing");
+    if (ls) {
+        RL4RS_REQUIRE(w->cat_gru_kernel && w->cat_gru_recurrent && w->cat_gru_bias, "simtrain_create: category GRU weights missing");
+        for (int s2 = 0; s2 < c->seq_num; ++s2)
+            RL4RS_REQUIRE(w->seq_gru_kernel[s2] && w->seq_gru_recurrent[s2] && w->seq_gru_bias[s2],
+                          "simtrain_create: GRU weights of sequence input %d missing", s2);
+    }
     if (rl4rs_device_count() <= 0) {
         set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
         return RL4RS_EHIP;
@@ -158,11 +344,20 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
     t->nz = (max_batch + t->chunk - 1) / t->chunk;
     t->adam_t = 0;
     t->OD = wd ? (int)(256 + U + Cn * E) : 256;
-    t->FCK = wd ? (int)(S * E) : (int)(E + U);
-    const int64_t sizes[SP_COUNT] = {H * E, wd ? H * E : 0, Dn * U, U, U * U, U, (int64_t)t->FCK * 256, 256, wd ? 0 : 256 * 256,
-                                     wd ? 0 : 256, (int64_t)t->OD * K, K};
+    // FCK = width of the concat that feeds the first dense layer above the branches (fc for dnn / widedeep, obs for lstm)
+    t->FCK = wd ? (int)(S * E) : (ls ? (int)(S * U + 2 * U + Cn * E) : (int)(E + U));
+    int64_t sizes[SP_COUNT] = {H * E, (wd || ls) ? H * E : 0, Dn * U, U, U * U, U, ls ? 0 : (int64_t)t->FCK * 256, ls ? 0 : 256,
+                               wd ? 0 : (ls ? (int64_t)t->FCK * 256 : 256 * 256), wd ? 0 : 256, (int64_t)t->OD * K, K};
     const float* src[SP_COUNT] = {w->cat_emb, w->seq_emb, w->dense_w1, w->dense_b1, w->dense_w2, w->dense_b2, w->fc_w, w->fc_b,
                                   w->obs_w, w->obs_b, w->out_w, w->out_b};
+    for (int i = SP_GRU0; i < SP_COUNT; ++i) { sizes[i] = 0; src[i] = nullptr; }
+    const int n_gru = ls ? 1 + (int)S : 0;
+    for (int g = 0; g < n_gru; ++g) {
+        sizes[SP_GRU0 + 3 * g] = E * 3 * U; sizes[SP_GRU0 + 3 * g + 1] = U * 3 * U; sizes[SP_GRU0 + 3 * g + 2] = 3 * U;
+        src[SP_GRU0 + 3 * g] = g == 0 ? w->cat_gru_kernel : w->seq_gru_kernel[g - 1];
+        src[SP_GRU0 + 3 * g + 1] = g == 0 ? w->cat_gru_recurrent : w->seq_gru_recurrent[g - 1];
+        src[SP_GRU0 + 3 * g + 2] = g == 0 ? w->cat_gru_bias : w->seq_gru_bias[g - 1];
+    }
     int64_t o = 0;
     for (int i = 0; i < SP_COUNT; ++i) { t->off[i] = o; t->size[i] = sizes[i]; o += sizes[i]; }
     t->n_params = o;
@@ -201,8 +396,30 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
     if ((int64_t)t->FCK * 256 > wmax) wmax = (int64_t)t->FCK * 256;
     if (256 * 256 > wmax) wmax = 256 * 256;
     if ((int64_t)t->OD * K > wmax) wmax = (int64_t)t->OD * K;
+    if (E * 3 * U > wmax) wmax = E * 3 * U;
+    if (U * 3 * U > wmax) wmax = U * 3 * U;
+    const int64_t maxlen_any = ls ? (c->maxlen > Cn ? c->maxlen : Cn) : 1;
+    const int nz_all = (int)((B * maxlen_any + t->chunk - 1) / t->chunk);       // the GRU gradients reduce over N * len samples
     ST_FAIL(al(&t->wt, wmax));
-    ST_FAIL(al(&t->part, (size_t)t->nz * wmax));
+    ST_FAIL(al(&t->part, (size_t)(nz_all > t->nz ? nz_all : t->nz) * wmax));
+    for (int g = 0; g < 5; ++g) memset(&t->gru[g], 0, sizeof(GruSave));
+    if (ls) {
+        for (int g = 0; g < n_gru; ++g) {
+            GruSave& q = t->gru[g];
+            q.len = g == 0 ? (int)Cn : c->maxlen;
+            q.emb = g == 0 ? SP_CAT_EMB : SP_SEQ_EMB;
+            q.pk = SP_GRU0 + 3 * g;
+            const size_t n = B * q.len;
+            ST_FAIL(al(&q.X, n * E)); ST_FAIL(al(&q.A1, n * 3 * U)); ST_FAIL(al(&q.H, n * U)); ST_FAIL(al(&q.Z, n * U));
+            ST_FAIL(al(&q.R, n * U)); ST_FAIL(al(&q.HH, n * U)); ST_FAIL(al(&q.RH, n * U)); ST_FAIL(al(&q.AZR, n * 2 * U));
+        }
+        const size_t nm = B * maxlen_any;
+        ST_FAIL(al(&t->g_dA, nm * 3 * U)); ST_FAIL(al(&t->g_dX, nm * E)); ST_FAIL(al(&t->g_hprev, nm * U));
+        ST_FAIL(al(&t->g_G, B * 2 * U)); ST_FAIL(al(&t->g_Gh, B * U)); ST_FAIL(al(&t->g_dh, B * U)); ST_FAIL(al(&t->g_dhp, B * U));
+        ST_FAIL(al(&t->g_dhg, B * U)); ST_FAIL(al(&t->g_drh, B * U)); ST_FAIL(al(&t->g_zero, B * U));
+        ST_FAIL(al(&t->g_uzrT, 2 * U * U)); ST_FAIL(al(&t->g_uhT, U * U)); ST_FAIL(al(&t->g_tmpw, U * 2 * U));
+        ST_HIP(hipMemsetAsync(t->g_zero, 0, B * U * 4, st));
+    }
     ST_FAIL(al(&t->loss_rows, B));
     ST_FAIL(al(&t->lr_dummy, 4));
     {
@@ -242,9 +459,9 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
     RL4RS_REQUIRE(t && dense && cat && labels && N > 0 && N <= t->max_batch, "simtrain_grad: bad argument (N=%d, max_batch=%d)", N,
                   t ? t->max_batch : -1);
     RL4RS_REQUIRE(dropout_rate >= 0.f && dropout_rate < 1.f, "simtrain_grad: dropout_rate must be in [0, 1)");
-    const bool wd = t->c.algo == RL4RS_SIMNET_WIDEDEEP;
-    if (wd) {
-        RL4RS_REQUIRE(seq, "simtrain_grad: widedeep needs the sequence inputs");
+    const bool wd = t->c.algo == RL4RS_SIMNET_WIDEDEEP, ls = t->c.algo == RL4RS_SIMNET_LSTM;
+    if (wd || ls) {
+        RL4RS_REQUIRE(seq, "simtrain_grad: widedeep / lstm need the sequence inputs");
         for (int s = 0; s < t->c.seq_num; ++s) RL4RS_REQUIRE(seq[s], "simtrain_grad: sequence input %d is NULL", s);
     }
     hipStream_t st = (hipStream_t)stream;
@@ -258,9 +475,9 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
     auto ew = [](int n) { return dim3((n + 255) / 256); };
     const dim3 g4((N + 3) / 4), b256(256);
     // where the (dropped-out) dense-tower output lives, and its gradient
-    float* tower_out = wd ? t->obs + 256 : t->feat + E;
+    float* tower_out = wd ? t->obs + 256 : (ls ? t->feat + S * U : t->feat + E);
     const int tower_ld = wd ? OD : FCK;
-    float* d_tower = wd ? t->d_obs + 256 : t->d_feat + E;
+    float* d_tower = wd ? t->d_obs + 256 : (ls ? t->d_feat + S * U : t->d_feat + E);
     // ---- forward
     if ((rc = launch_gemm_f32(dense, Dn, P + o[SP_DW1], U, P + o[SP_DB1], t->h1, U, N, U, Dn, 1, st))) return rc;
     RL4RS_HIP_TRY(hipMemcpyAsync(t->h1d, t->h1, (size_t)N * U * 4, hipMemcpyDeviceToDevice, st));
@@ -274,6 +491,18 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
             hipLaunchKernelGGL(k_emb_mean, g4, b256, 0, st, seq[s], N, L, H, E, P + o[SP_SEQ_EMB], t->feat, (int64_t)FCK, s * E);
         if ((rc = launch_gemm_f32(t->feat, FCK, P + o[SP_FC_W], 256, P + o[SP_FC_B], t->obs, OD, N, 256, FCK, 1, st))) return rc;
         hipLaunchKernelGGL(k_emb_flatten, g4, b256, 0, st, cat, N, Cn, H, E, P + o[SP_CAT_EMB], t->obs, (int64_t)OD, 256 + U);
+    } else if (ls) {
+        // [GRU finals of the sequences | tower | GRU final of the category embeddings | Flatten(category emb)] -> obs (lstm.py:31-36)
+        for (int g = 0; g <= S; ++g) {
+            t->gru[g].ids = g == 0 ? cat : seq[g - 1];
+            if ((rc = gru_forward(t, N, t->gru[g], st))) return rc;
+            const int off = g == 0 ? S * U + U : (g - 1) * U;
+            const GruSave& q = t->gru[g];
+            RL4RS_HIP_TRY(hipMemcpy2DAsync(t->feat + off, (size_t)FCK * 4, q.H + (size_t)(q.len - 1) * U, (size_t)q.len * U * 4, (size_t)U * 4,
+                                           N, hipMemcpyDeviceToDevice, st));
+        }
+        hipLaunchKernelGGL(k_emb_flatten, g4, b256, 0, st, cat, N, Cn, H, E, P + o[SP_CAT_EMB], t->feat, (int64_t)FCK, S * U + 2 * U);
+        if ((rc = launch_gemm_f32(t->feat, FCK, P + o[SP_OBS_W], 256, P + o[SP_OBS_B], t->obs, 256, N, 256, FCK, 1, st))) return rc;
     } else {
         hipLaunchKernelGGL(k_emb_mean, g4, b256, 0, st, cat, N, Cn, H, E, P + o[SP_CAT_EMB], t->feat, (int64_t)FCK, 0);
         if ((rc = launch_gemm_f32(t->feat, FCK, P + o[SP_FC_W], 256, P + o[SP_FC_B], t->a1, 256, N, 256, FCK, 1, st))) return rc;
@@ -295,7 +524,7 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), b256, 0, st, t->part, Nc, nz, dst);
     };
     auto back = [&](const float* dY, int ldy, int Nout, const float* W, int Kin, float* dX, int ldx) -> int {   // dX = dY W^T
-        hipLaunchKernelGGL(k_transpose, ew(Kin * Nout), b256, 0, st, W, Kin, Nout, t->wt);
+        hipLaunchKernelGGL(k_transpose, ew(Kin * Nout), b256, 0, st, W, (int64_t)Nout, Kin, Nout, t->wt);
         return launch_gemm_f32(dY, ldy, t->wt, Kin, nullptr, dX, ldx, N, Kin, Nout, 0, st);
     };
     RL4RS_HIP_TRY(hipMemsetAsync(G + o[SP_CAT_EMB], 0, (size_t)H * E * 4, st));
@@ -312,6 +541,17 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         for (int s = 0; s < S; ++s)
             hipLaunchKernelGGL(k_emb_mean_bwd, g4, b256, 0, st, seq[s], N, L, H, E, t->d_feat + s * E, (int64_t)FCK, G + o[SP_SEQ_EMB]);
         hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, cat, N, Cn, H, E, t->d_obs + 256 + U, (int64_t)OD, G + o[SP_CAT_EMB]);
+    } else if (ls) {
+        hipLaunchKernelGGL(k_elu_bwd, ew(N * 256), b256, 0, st, t->d_obs, (int64_t)256, t->obs, (int64_t)256, (const uint8_t*)nullptr, 0.f, N * 256, 256);
+        tn(t->feat, FCK, FCK, t->d_obs, 256, 256, G + o[SP_OBS_W]);
+        cs(t->d_obs, 256, 256, G + o[SP_OBS_B]);
+        if ((rc = back(t->d_obs, 256, 256, P + o[SP_OBS_W], FCK, t->d_feat, FCK))) return rc;
+        RL4RS_HIP_TRY(hipMemsetAsync(G + o[SP_SEQ_EMB], 0, (size_t)H * E * 4, st));
+        hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, cat, N, Cn, H, E, t->d_feat + S * U + 2 * U, (int64_t)FCK, G + o[SP_CAT_EMB]);
+        for (int g = 0; g <= S; ++g) {
+            const int off = g == 0 ? S * U + U : (g - 1) * U;
+            if ((rc = gru_backward(t, N, t->gru[g], t->d_feat + off, (int64_t)FCK, st))) return rc;
+        }
     } else {
         hipLaunchKernelGGL(k_elu_bwd, ew(N * 256), b256, 0, st, t->d_obs, (int64_t)256, t->obs, (int64_t)256, (const uint8_t*)nullptr, 0.f, N * 256, 256);
         tn(t->a1, 256, 256, t->d_obs, 256, 256, G + o[SP_OBS_W]);

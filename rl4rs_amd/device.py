@@ -483,11 +483,22 @@ class DeviceSimnet(object):
 SIMTRAIN_ORDER = {
     'dnn': ('cat_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'obs_w', 'obs_b', 'out_w', 'out_b'),
     'widedeep': ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'fc_w', 'fc_b', 'out_w', 'out_b'),
+    # lstm: + the keras GRUs (category GRU, then one per sequence input; the names carry the sequence index)
+    'lstm': ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'obs_w', 'obs_b', 'out_w', 'out_b',
+             'cat_gru_kernel', 'cat_gru_recurrent', 'cat_gru_bias'),
 }
 
 
+def _simtrain_names(algo, seq_num):
+    names = list(SIMTRAIN_ORDER[algo])
+    if algo == 'lstm':
+        for i in range(seq_num):
+            names += ['seq%d_gru_kernel' % i, 'seq%d_gru_recurrent' % i, 'seq%d_gru_bias' % i]
+    return names
+
+
 class DeviceSimTrainer(object):
-    """rl4rs_simtrain handle: supervised training of the 'dnn' / 'widedeep' simulators on the device
+    """rl4rs_simtrain handle: supervised training of the 'dnn' / 'widedeep' / 'lstm' simulators on the device
     (script/supervised_train.py): forward with dropout, keras binary_crossentropy, backward, Adam."""
 
     def __init__(self, config, weights, max_batch=256, algo=None, device=None):
@@ -507,11 +518,15 @@ class DeviceSimTrainer(object):
         w = _lib.SimnetWeights()
         keep = []
         self.shapes = []
-        for name in SIMTRAIN_ORDER[self.algo]:
+        for name in _simtrain_names(self.algo, self.S):
             arr = np.ascontiguousarray(weights[name], dtype=np.float32)
             keep.append(arr)
             self.shapes.append((name, arr.shape))
-            setattr(w, name, arr.ctypes.data_as(_lib._FP))
+            ptr = arr.ctypes.data_as(_lib._FP)
+            if name.startswith('seq') and '_gru_' in name:
+                getattr(w, 'seq_gru_' + name.split('_gru_')[1])[int(name[3:name.index('_')])] = ptr
+            else:
+                setattr(w, name, ptr)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.rl4rs_simtrain_create(C.byref(cfg), C.byref(w), self.max_batch, _stream(), C.byref(h)))
@@ -570,8 +585,8 @@ class DeviceSimTrainer(object):
         labels = labels.to(torch.int32).contiguous()
         assert labels.shape == (N,)
         sp = None
-        if self.algo == 'widedeep':
-            assert seqs is not None and len(seqs) == self.S, "widedeep needs the seq_num sequence inputs"
+        if self.algo in ('widedeep', 'lstm'):
+            assert seqs is not None and len(seqs) == self.S, "widedeep / lstm need the seq_num sequence inputs"
             for q in seqs:
                 assert q.dtype == torch.int32 and q.shape == (N, self.L) and q.is_contiguous()
             sp = (C.c_void_p * self.S)(*[_ptr(q) for q in seqs])

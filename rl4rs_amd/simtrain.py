@@ -1,4 +1,4 @@
-"""Supervised training of the simulator from the logs, on the device (dnn and widedeep families).
+"""Supervised training of the simulator from the logs, on the device (the dnn, widedeep and lstm families).
 
 The reference builds its supervised set in ``script/data_preprocess.py:91-131``: one sample per (page record, slot j) with
 ``category = user_cat(10) + [sequence_id] + exposed_items(9) + [item_j]``, ``dense = user_dense(32) + item_feature(9 x 40)
@@ -6,7 +6,7 @@ The reference builds its supervised set in ``script/data_preprocess.py:91-131``:
 (``SlateState.get_complete_states``, slate.py:117-131) when the logged slate is replayed.  So a training batch is: sample
 records (``RecDataBase``), replay ``offline_action`` through the device state machine, take the complete-state rows and the
 logged feedback.  The model, loss and optimiser are those of ``script/supervised_train.py:37-42`` with
-``model_type='dnn'`` / ``'widedeep'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
+``model_type='dnn'`` / ``'widedeep'`` / ``'lstm'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
 """
 import numpy as np
 import torch
@@ -59,7 +59,7 @@ class SimulatorTrainer(object):
             for _ in range(epochs):
                 perm = torch.from_numpy(rs.permutation(n)).to(dense.device)
                 d, c, y = dense[perm], cat[perm], labels[perm]
-                q = [x[perm] for x in seqs] if self.algo == 'widedeep' else None
+                q = [x[perm] for x in seqs] if self.algo != 'dnn' else None
                 for lo in range(0, n - self.minibatch + 1, self.minibatch):
                     hi = lo + self.minibatch
                     losses.append(self.trainer.step(d[lo:hi], c[lo:hi], y[lo:hi], None if q is None else [x[lo:hi] for x in q],

@@ -17,7 +17,7 @@ def _batch(N, rs):
     return dense, cat, labels
 
 
-@pytest.mark.parametrize('algo', ['dnn', 'widedeep'])
+@pytest.mark.parametrize('algo', ['dnn', 'widedeep', 'lstm'])
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 @pytest.mark.parametrize('N', [256, 700])
 def test_gradients_match_autograd(algo, rate, N):
@@ -32,7 +32,7 @@ def test_gradients_match_autograd(algo, rate, N):
     seqs[1][::2] = 0
     tr = DeviceSimTrainer(CFG, w, max_batch=N, algo=algo)
     t = lambda a: torch.from_numpy(a).cuda()
-    dseqs = [t(q) for q in seqs] if algo == 'widedeep' else None
+    dseqs = [t(q) for q in seqs] if algo != 'dnn' else None
     loss = tr.grad(t(dense), t(cat), t(labels), dseqs, dropout_rate=rate, seed=5, step=2)
     g = dict((k, v.cpu().numpy()) for k, v in tr.gradients().items())
     m1 = m2 = None
@@ -93,7 +93,7 @@ def test_adam_step_and_training_fits(tmp_path):
     tr.close()
 
 
-@pytest.mark.parametrize('algo', ['dnn', 'widedeep'])
+@pytest.mark.parametrize('algo', ['dnn', 'widedeep', 'lstm'])
 def test_training_set_from_logs_and_fit(tmp_path, algo):
     """SimulatorTrainer: the device-built training set equals the reference's construction (data_preprocess.py:91-131:
     category = user_cat + [sequence_id] + exposed + [item_j], dense = user_dense + item vectors of the page + item_j,
