@@ -445,6 +445,28 @@ int rl4rs_simtrain_step(rl4rs_simtrain* tr, int32_t N, const float* dense_dev, c
                         const int32_t* const* seq_dev, const int32_t* labels_dev, float lr, float beta1, float beta2,
                         float eps, float dropout_rate, uint32_t seed, uint32_t step, float* loss_dev, void* stream);
 
+/* Supervised training of the DIEN simulator (rl4rs/nets/dien.py; script/supervised_train.py with model_type='dien') on the
+ * device: training-mode forward (Dropout after each dense-tower layer), keras binary_crossentropy, backward through the
+ * head, the category self-attention, the dense tower and, per sequence input, the DIN attention MLP, the AUGRU and the
+ * first GRU (explicit BPTT), Adam.  Weights / sizes as for rl4rs_dien_create (max_rows, max_slots, scorer_mode unused).
+ * Flat parameter / gradient layout:
+ *   [ cat_emb | seq_emb | dense_w1 | dense_b1 | dense_w2 | dense_b2 | obs_w | obs_b | out_w | out_b |
+ *     per sequence input: gru_gate_w, gru_gate_b, gru_cand_w, gru_cand_b, att_w1, att_b1, att_w2, att_b2, att_w3, att_b3,
+ *                         augru_gate_w, augru_gate_b, augru_cand_w, augru_cand_b ]
+ * Arguments of grad / step as for rl4rs_simtrain_grad / rl4rs_simtrain_step (seq_dev is required). */
+typedef struct rl4rs_dientrain rl4rs_dientrain;
+int rl4rs_dientrain_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, int32_t max_batch, void* stream,
+                           rl4rs_dientrain** out);
+int rl4rs_dientrain_destroy(rl4rs_dientrain* tr);
+int rl4rs_dientrain_params(rl4rs_dientrain* tr, float** params_dev, float** grad_dev, int64_t* count);
+int rl4rs_dientrain_masks(rl4rs_dientrain* tr, uint8_t** mask1_dev, uint8_t** mask2_dev);
+int rl4rs_dientrain_grad(rl4rs_dientrain* tr, int32_t N, const float* dense_dev, const int32_t* cat_dev,
+                         const int32_t* const* seq_dev, const int32_t* labels_dev, float dropout_rate, uint32_t seed,
+                         uint32_t step, float* loss_dev, void* stream);
+int rl4rs_dientrain_step(rl4rs_dientrain* tr, int32_t N, const float* dense_dev, const int32_t* cat_dev,
+                         const int32_t* const* seq_dev, const int32_t* labels_dev, float lr, float beta1, float beta2,
+                         float eps, float dropout_rate, uint32_t seed, uint32_t step, float* loss_dev, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

@@ -128,3 +128,67 @@ class OracleDien(object):
     def prob(self, seq, dense, cat):
         """res[:,1] as float32, the dtype keras would hand back (slate.py:298)."""
         return self.reward_probs(seq, dense, cat)[:, 1].astype(np.float32)
+
+
+def loss_and_grad(weights, config, seq, dense, cat, labels, mask1=None, mask2=None, rate=0.0):
+    """Training-mode DIEN forward + keras binary_crossentropy + gradients by torch float64 autograd: the checker for the
+    hand-written HIP backward (rl4rs_dientrain_*).  Same restatement as OracleDien above (PARITY UNPINNED, see the module
+    header) with Dropout(rate) after each dense-tower layer (utils.py:51,53) applied through the keep masks the device drew.
+    seq [N, S, L] ids.  -> mean loss, dict of gradients."""
+    import torch
+    w = dict((k, torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True)) for k, v in weights.items())
+    S, K = config['seq_num'], config['class_num']
+    elu = torch.nn.functional.elu
+    sig = torch.sigmoid
+    ids = torch.tensor(np.asarray(cat, dtype=np.int64))
+    sq = torch.tensor(np.asarray(seq, dtype=np.int64))
+    x = torch.tensor(np.asarray(dense, dtype=np.float64))
+    N = ids.shape[0]
+    Ec = w['cat_emb'][ids]
+    att = torch.softmax(Ec @ Ec.transpose(1, 2), dim=-1) @ Ec
+    c = torch.cat([att.mean(dim=1), Ec.reshape(N, -1)], dim=1)
+    h = elu(x @ w['dense_w1'] + w['dense_b1'])
+    if mask1 is not None:
+        h = h * torch.tensor(np.asarray(mask1, dtype=np.float64)) / (1.0 - rate)
+    h = elu(h @ w['dense_w2'] + w['dense_b2'])
+    if mask2 is not None:
+        h = h * torch.tensor(np.asarray(mask2, dtype=np.float64)) / (1.0 - rate)
+    q = w['seq_emb'][ids[:, -10:]].mean(dim=1)
+
+    def cell(xt, hs, Wg, bg, Wc, bc, a=None):
+        n = Wc.shape[1]
+        g = sig(torch.cat([xt, hs], dim=1) @ Wg + bg)
+        r, u = g[:, :n], g[:, n:]
+        cc = torch.tanh(torch.cat([xt, r * hs], dim=1) @ Wc + bc)
+        if a is not None:
+            u = (1.0 - a) * u
+        return u * hs + (1.0 - u) * cc
+
+    finals = []
+    for i in range(S):
+        X = w['seq_emb'][sq[:, i, :]]
+        L, E = X.shape[1], X.shape[2]
+        hs = torch.zeros((N, E), dtype=torch.float64)
+        keys = []
+        for t in range(L):
+            hs = cell(X[:, t], hs, w['gru%d_gate_w' % i], w['gru%d_gate_b' % i], w['gru%d_cand_w' % i], w['gru%d_cand_b' % i])
+            keys.append(hs)
+        Kk = torch.stack(keys, dim=1)
+        qq = q[:, None, :].expand_as(Kk)
+        a = torch.cat([qq, Kk, qq - Kk, qq * Kk], dim=-1)
+        s1 = sig(a @ w['att%d_w1' % i] + w['att%d_b1' % i])
+        s2 = sig(s1 @ w['att%d_w2' % i] + w['att%d_b2' % i])
+        score = (s2 @ w['att%d_w3' % i] + w['att%d_b3' % i])[..., 0]
+        h2 = torch.zeros((N, 2 * E), dtype=torch.float64)
+        for t in range(L):
+            h2 = cell(Kk[:, t], h2, w['augru%d_gate_w' % i], w['augru%d_gate_b' % i], w['augru%d_cand_w' % i],
+                      w['augru%d_cand_b' % i], score[:, t:t + 1])
+        finals.append(h2)
+    allf = torch.cat(finals + [h, c], dim=1)
+    obs = elu(allf @ w['obs_w'] + w['obs_b'])
+    p = torch.softmax(obs @ w['out_w'] + w['out_b'], dim=1)
+    y = torch.nn.functional.one_hot(torch.tensor(np.asarray(labels, dtype=np.int64)), K).double()
+    pc = torch.clamp(p, 1e-7, 1.0 - 1e-7)
+    loss = (-(y * torch.log(pc) + (1.0 - y) * torch.log(1.0 - pc)).mean(dim=1)).mean()
+    loss.backward()
+    return float(loss.item()), dict((k, v.grad.numpy()) for k, v in w.items() if v.grad is not None)

@@ -750,3 +750,4 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
 }  // extern "C"
 
 #include "simtrain.hpp"
+#include "dientrain.hpp"

@@ -213,21 +213,22 @@ struct rl4rs_simtrain {
 namespace {
 
 // sample-axis reductions / transposed-weight GEMM over an explicit number of samples
-void st_tn(rl4rs_simtrain* t, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
-    const int nz = (Ns + t->chunk - 1) / t->chunk;
+struct TrainCtx { int chunk; float* part; float* wt; };
+void st_tn(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
+    const int nz = (Ns + x.chunk - 1) / x.chunk;
     const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
-    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, t->chunk, nz == 1 ? dst : t->part);
-    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, t->part, M * Nc, nz, dst);
+    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, x.chunk, nz == 1 ? dst : x.part);
+    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, x.part, M * Nc, nz, dst);
 }
-void st_cs(rl4rs_simtrain* t, hipStream_t st, const float* X, int ld, int Nc, int Ns, float* dst) {
-    const int nz = (Ns + t->chunk - 1) / t->chunk;
-    hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, Ns, t->chunk, nz == 1 ? dst : t->part);
-    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, t->part, Nc, nz, dst);
+void st_cs(const TrainCtx& x, hipStream_t st, const float* X, int ld, int Nc, int Ns, float* dst) {
+    const int nz = (Ns + x.chunk - 1) / x.chunk;
+    hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, Ns, x.chunk, nz == 1 ? dst : x.part);
+    if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, x.part, Nc, nz, dst);
 }
-int st_back(rl4rs_simtrain* t, hipStream_t st, const float* dY, int ldy, int Nout, const float* W, int ldw, int Kin, float* dX, int ldx,
+int st_back(const TrainCtx& x, hipStream_t st, const float* dY, int ldy, int Nout, const float* W, int ldw, int Kin, float* dX, int ldx,
             int Ns) {      // dX [Ns, Kin] = dY [Ns, Nout] W^T,  W [Kin, Nout] with leading dimension ldw
-    hipLaunchKernelGGL(k_transpose, dim3((Kin * Nout + 255) / 256), dim3(256), 0, st, W, (int64_t)ldw, Kin, Nout, t->wt);
-    return launch_gemm_f32(dY, ldy, t->wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
+    hipLaunchKernelGGL(k_transpose, dim3((Kin * Nout + 255) / 256), dim3(256), 0, st, W, (int64_t)ldw, Kin, Nout, x.wt);
+    return launch_gemm_f32(dY, ldy, x.wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
 }
 
 // keras GRU forward over `len` steps for N rows, keeping gates and states (utils.py:34,91: layers.GRU(units=U))
@@ -286,13 +287,14 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     // parameter gradients over all (row, step) samples
     const int Ns = N * len;
     hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, t->g_hprev, N, U, len);
-    st_tn(t, st, g.X, E, E, t->g_dA, 3 * U, 3 * U, Ns, gK);
-    st_cs(t, st, t->g_dA, 3 * U, 3 * U, Ns, gb);
-    st_tn(t, st, t->g_hprev, U, U, t->g_dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
+    const TrainCtx cx = {t->chunk, t->part, t->wt};
+    st_tn(cx, st, g.X, E, E, t->g_dA, 3 * U, 3 * U, Ns, gK);
+    st_cs(cx, st, t->g_dA, 3 * U, 3 * U, Ns, gb);
+    st_tn(cx, st, t->g_hprev, U, U, t->g_dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
     RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, t->g_tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
-    st_tn(t, st, g.RH, U, U, t->g_dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
+    st_tn(cx, st, g.RH, U, U, t->g_dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
     RL4RS_HIP_TRY(hipMemcpy2DAsync(gR + 2 * U, (size_t)3 * U * 4, t->g_tmpw, (size_t)U * 4, (size_t)U * 4, U, hipMemcpyDeviceToDevice, st));
-    if ((rc = st_back(t, st, t->g_dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
+    if ((rc = st_back(cx, st, t->g_dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
     hipLaunchKernelGGL(k_emb_flatten_bwd, dim3((N + 3) / 4), b256, 0, st, g.ids, N, len, H, E, t->g_dX, (int64_t)len * E,
                        t->grad + t->off[g.emb]);
     RL4RS_LAUNCH_CHECK();

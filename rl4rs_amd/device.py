@@ -532,10 +532,12 @@ class DeviceSimTrainer(object):
             check(self.lib.rl4rs_simtrain_create(C.byref(cfg), C.byref(w), self.max_batch, _stream(), C.byref(h)))
         self.h = h
         self.iteration = 0
+        self._fn = dict(destroy=self.lib.rl4rs_simtrain_destroy, params=self.lib.rl4rs_simtrain_params,
+                        masks=self.lib.rl4rs_simtrain_masks, grad=self.lib.rl4rs_simtrain_grad, step=self.lib.rl4rs_simtrain_step)
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
-            self.lib.rl4rs_simtrain_destroy(self.h)
+            self._fn['destroy'](self.h)
             self.h = None
 
     def __del__(self):
@@ -546,7 +548,7 @@ class DeviceSimTrainer(object):
 
     def _flat(self, which):
         p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
-        check(self.lib.rl4rs_simtrain_params(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        check(self._fn['params'](self.h, C.byref(p), C.byref(g), C.byref(n)))
         out = torch.empty(n.value, dtype=torch.float32, device=self.device)
         check(self.lib.rl4rs_copy_d2d(_ptr(out), p if which == 'params' else g, n.value * 4, _stream()))
         return out
@@ -569,7 +571,7 @@ class DeviceSimTrainer(object):
     def masks(self, N):
         """The dropout keep-masks [N, hidden_units] (uint8) of the last grad / step call."""
         m1, m2 = C.c_void_p(), C.c_void_p()
-        check(self.lib.rl4rs_simtrain_masks(self.h, C.byref(m1), C.byref(m2)))
+        check(self._fn['masks'](self.h, C.byref(m1), C.byref(m2)))
         U = int(self.config['hidden_units'])
         out = []
         for m in (m1, m2):
@@ -585,8 +587,8 @@ class DeviceSimTrainer(object):
         labels = labels.to(torch.int32).contiguous()
         assert labels.shape == (N,)
         sp = None
-        if self.algo in ('widedeep', 'lstm'):
-            assert seqs is not None and len(seqs) == self.S, "widedeep / lstm need the seq_num sequence inputs"
+        if self.algo != 'dnn':
+            assert seqs is not None and len(seqs) == self.S, "every family but dnn needs the seq_num sequence inputs"
             for q in seqs:
                 assert q.dtype == torch.int32 and q.shape == (N, self.L) and q.is_contiguous()
             sp = (C.c_void_p * self.S)(*[_ptr(q) for q in seqs])
@@ -596,17 +598,60 @@ class DeviceSimTrainer(object):
         """Forward + loss + backward; returns the mean loss (device scalar tensor)."""
         N, labels, sp = self._batch(dense, cat, labels, seqs)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        check(self.lib.rl4rs_simtrain_grad(self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), dropout_rate, seed, step,
+        check(self._fn['grad'](self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), dropout_rate, seed, step,
                                            _ptr(loss), _stream()))
         return loss
 
     def step(self, dense, cat, labels, seqs=None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, dropout_rate=0.2, seed=0):
         N, labels, sp = self._batch(dense, cat, labels, seqs)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        check(self.lib.rl4rs_simtrain_step(self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), lr, beta1, beta2, eps,
+        check(self._fn['step'](self.h, N, _ptr(dense), _ptr(cat), sp, _ptr(labels), lr, beta1, beta2, eps,
                                            dropout_rate, seed, self.iteration, _ptr(loss), _stream()))
         self.iteration += 1
         return loss
+
+
+DIENTRAIN_BASE = ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'obs_w', 'obs_b', 'out_w', 'out_b')
+DIENTRAIN_SEQ = ('gru%d_gate_w', 'gru%d_gate_b', 'gru%d_cand_w', 'gru%d_cand_b', 'att%d_w1', 'att%d_b1', 'att%d_w2', 'att%d_b2',
+                 'att%d_w3', 'att%d_b3', 'augru%d_gate_w', 'augru%d_gate_b', 'augru%d_cand_w', 'augru%d_cand_b')
+
+
+class DeviceDienTrainer(DeviceSimTrainer):
+    """rl4rs_dientrain handle: supervised training of the DIEN simulator on the device (same interface as DeviceSimTrainer)."""
+
+    def __init__(self, config, weights, max_batch=256, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.config = dict(config)
+        self.algo = 'dien'
+        self.Cn, self.Dn = int(config['category_feature_num']), int(config['dense_feature_num'])
+        self.S, self.L = int(config['seq_num']), int(config['maxlen'])
+        self.max_batch = int(max_batch)
+        cfg = _lib.DienCfg(self.L, int(config['emb_size']), int(config['hidden_units']), self.Dn, self.Cn,
+                           int(config['category_hash_size']), self.S, int(config['class_num']), self.max_batch, 1, 0)
+        w = _lib.DienWeights()
+        keep = []
+        self.shapes = []
+        names = list(DIENTRAIN_BASE) + [n % i for i in range(self.S) for n in DIENTRAIN_SEQ]
+        for name in names:
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(arr)
+            self.shapes.append((name, arr.shape))
+            ptr = arr.ctypes.data_as(_lib._FP)
+            if name in DIENTRAIN_BASE:
+                setattr(w, name, ptr)
+            else:                                   # 'gru0_gate_w' -> field gru_gate_w[0]
+                head, tail = name.split('_', 1)
+                idx = int(''.join(ch for ch in head if ch.isdigit()))
+                getattr(w, ''.join(ch for ch in head if not ch.isdigit()) + '_' + tail)[idx] = ptr
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_dientrain_create(C.byref(cfg), C.byref(w), self.max_batch, _stream(), C.byref(h)))
+        self.h = h
+        self.iteration = 0
+        self._fn = dict(destroy=self.lib.rl4rs_dientrain_destroy, params=self.lib.rl4rs_dientrain_params,
+                        masks=self.lib.rl4rs_dientrain_masks, grad=self.lib.rl4rs_dientrain_grad, step=self.lib.rl4rs_dientrain_step)
 
 
 class DeviceRawPolicy(object):

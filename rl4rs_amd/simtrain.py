@@ -1,4 +1,4 @@
-"""Supervised training of the simulator from the logs, on the device (the dnn, widedeep and lstm families).
+"""Supervised training of the simulator from the logs, on the device (all four simulator families - dien, dnn, widedeep, lstm).
 
 The reference builds its supervised set in ``script/data_preprocess.py:91-131``: one sample per (page record, slot j) with
 ``category = user_cat(10) + [sequence_id] + exposed_items(9) + [item_j]``, ``dense = user_dense(32) + item_feature(9 x 40)
@@ -6,28 +6,31 @@ The reference builds its supervised set in ``script/data_preprocess.py:91-131``:
 (``SlateState.get_complete_states``, slate.py:117-131) when the logged slate is replayed.  So a training batch is: sample
 records (``RecDataBase``), replay ``offline_action`` through the device state machine, take the complete-state rows and the
 logged feedback.  The model, loss and optimiser are those of ``script/supervised_train.py:37-42`` with
-``model_type='dnn'`` / ``'widedeep'`` / ``'lstm'`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*``).
+any ``model_type`` (``DeviceSimTrainer`` / ``rl4rs_simtrain_*`` for dnn / widedeep / lstm, ``DeviceDienTrainer`` /
+``rl4rs_dientrain_*`` for dien).
 """
 import numpy as np
 import torch
 
 from . import device as D
-from .nets import simnets
+from collections import OrderedDict
 
 
 class SimulatorTrainer(object):
     def __init__(self, sim, weights=None, minibatch=256, seed=0, lr=1e-3, dropout_rate=0.2):
         """sim: a ``SlateRecEnv`` (its config names the log / catalogue files and the model sizes)."""
         cfg = sim.config
-        if cfg.get('algo', 'dien') not in D.SIMTRAIN_ORDER:
-            raise NotImplementedError("device-side simulator training exists for config['algo'] in %s (got %r)"
-                                      % (sorted(D.SIMTRAIN_ORDER), cfg.get('algo', 'dien')))
-        self.algo = cfg['algo']
+        self.algo = cfg.get('algo', 'dien')
+        if self.algo != 'dien' and self.algo not in D.SIMTRAIN_ORDER:
+            raise NotImplementedError("config['algo'] must be dien, dnn, widedeep or lstm (got %r)" % (self.algo,))
         self.sim = sim
         self.minibatch, self.seed, self.lr, self.dropout_rate = int(minibatch), int(seed), lr, dropout_rate
         if weights is None:
             weights = sim.model.weights
-        self.trainer = D.DeviceSimTrainer(cfg, weights, max_batch=self.minibatch)
+        if self.algo == 'dien':
+            self.trainer = D.DeviceDienTrainer(cfg, weights, max_batch=self.minibatch)
+        else:
+            self.trainer = D.DeviceSimTrainer(cfg, weights, max_batch=self.minibatch)
         self.P = int(cfg.get('page_items', 9))
 
     def dataset_from_logs(self):
@@ -72,7 +75,7 @@ class SimulatorTrainer(object):
 
     def install(self):
         """Put the trained weights into the simulator the env scores with."""
-        self.sim.model.weights = simnets.OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32))
+        self.sim.model.weights = OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32))
                                                      for k, v in self.export_weights().items())
         if self.sim.model.device_net is not None:
             self.sim.model.device_net.close()

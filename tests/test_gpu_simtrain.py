@@ -1,4 +1,4 @@
-"""Supervised training of the 'dnn' / 'widedeep' simulators on the device (rl4rs_simtrain_*) against torch float64 autograd of the
+"""Supervised training of the simulator families on the device (rl4rs_simtrain_* for dnn / widedeep / lstm, rl4rs_dientrain_* for dien) against torch float64 autograd of the
 numpy-restated model (oracle/simnets.py): gradients with and without dropout, the Adam update, and a short run that must
 fit a learnable labelling.  Gradient tolerance: 2e-4 of the largest gradient entry (fp32 kernels vs fp64)."""
 import numpy as np
@@ -93,7 +93,7 @@ def test_adam_step_and_training_fits(tmp_path):
     tr.close()
 
 
-@pytest.mark.parametrize('algo', ['dnn', 'widedeep', 'lstm'])
+@pytest.mark.parametrize('algo', ['dnn', 'widedeep', 'lstm', 'dien'])
 def test_training_set_from_logs_and_fit(tmp_path, algo):
     """SimulatorTrainer: the device-built training set equals the reference's construction (data_preprocess.py:91-131:
     category = user_cat + [sequence_id] + exposed + [item_j], dense = user_dense + item vectors of the page + item_j,
@@ -149,3 +149,41 @@ def test_training_set_from_logs_and_fit(tmp_path, algo):
         obs, reward, done, info = env.step(env.offline_action)
         total += float(reward.sum())
     assert np.isfinite(total) and total > 0
+
+
+DIEN_CFG = {"maxlen": 64, "class_num": 2, "dense_feature_num": 432, "category_feature_num": 21, "category_hash_size": 3000,
+            "seq_num": 2, "emb_size": 128, "hidden_units": 128}
+
+
+@pytest.mark.parametrize('rate', [0.0, 0.2])
+def test_dien_gradients_match_autograd(rate):
+    """rl4rs_dientrain_grad: every parameter gradient of the DIEN training step (head, category self-attention, dense tower
+    with dropout, attention MLP, AUGRU and first-GRU BPTT, both embedding tables) against torch float64 autograd."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDienTrainer
+    from oracle.dien import loss_and_grad
+    rs = np.random.RandomState(7)
+    N = 40
+    w = init_dien_weights(DIEN_CFG, seed=3, emb_scale=0.5, bias_noise=0.2)
+    dense, cat, labels = _batch(N, rs)
+    cat[:, 10:] = rs.randint(0, 284, size=(N, 11))
+    seq = rs.randint(0, 284, size=(N, 2, 64)).astype(np.int32)
+    seq[: N // 3, 0, :20] = 0
+    seq[::2, 1, :] = 0
+    tr = DeviceDienTrainer(DIEN_CFG, w, max_batch=N)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dseqs = [t(seq[:, i]) for i in range(2)]
+    loss = tr.grad(t(dense), t(cat), t(labels), dseqs, dropout_rate=rate, seed=5, step=2)
+    g = dict((k, v.cpu().numpy()) for k, v in tr.gradients().items())
+    m1 = m2 = None
+    if rate > 0:
+        m1, m2 = [m.cpu().numpy().astype(np.float64) for m in tr.masks(N)]
+    loss_ref, g_ref = loss_and_grad(w, DIEN_CFG, seq, dense, cat, labels, m1, m2, rate)
+    assert abs(float(loss.item()) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    assert set(g) == set(g_ref)
+    for k in sorted(g_ref):
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(g[k] - g_ref[k]).max()
+        assert err < 5e-4 * max(scale, 1e-8) + 1e-9, (k, err, scale)
+    tr.close()
