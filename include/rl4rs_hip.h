@@ -417,6 +417,29 @@ int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* pol, int32_t N, const int32_t* cat
                              const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
                              float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev, void* stream);
 
+/* Trainable raw-state policy: the model of rl4rs_rawpolicy with RLlib's A2C / PPO losses (rl4rs_policy_loss_grad semantics),
+ * backward through both heads, the context layer, the dense tower and the mean-pooled embeddings, Adam.  Flat parameter /
+ * gradient layout: [ cat_emb | seq_emb | dense_w1 | dense_b1 | dense_w2 | dense_b2 | ctx_w | ctx_b |
+ *                    head_w 256 x (A+1) = [out_w | value_w] | head_b (A+1) ].  act / evaluate as rl4rs_rawpolicy_*. */
+typedef struct rl4rs_rawtrain rl4rs_rawtrain;
+int rl4rs_rawtrain_create(const rl4rs_rawpolicy_cfg* cfg, const rl4rs_rawpolicy_weights* w, void* stream, rl4rs_rawtrain** out);
+int rl4rs_rawtrain_destroy(rl4rs_rawtrain* pol);
+int rl4rs_rawtrain_params(rl4rs_rawtrain* pol, float** params_dev, float** grad_dev, int64_t* count);
+int rl4rs_rawtrain_act(rl4rs_rawtrain* pol, int32_t N, const int32_t* cat_dev, const float* dense_dev,
+                       const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, uint32_t seed, uint32_t step,
+                       int32_t* actions_dev, float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev,
+                       void* stream);
+int rl4rs_rawtrain_evaluate(rl4rs_rawtrain* pol, int32_t N, const int32_t* cat_dev, const float* dense_dev,
+                            const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
+                            float* logp_dev, float* value_dev, float* entropy_dev, float* logits_dev, void* stream);
+int rl4rs_rawtrain_loss_grad(rl4rs_rawtrain* pol, int32_t algo, int32_t N, const int32_t* cat_dev, const float* dense_dev,
+                             const int32_t* const* seq_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
+                             const float* adv_dev, const float* ret_dev, const float* old_logp_dev,
+                             const float* old_value_dev, const float* old_logits_dev, float vf_coeff, float ent_coeff,
+                             float clip, float vf_clip, float kl_coeff, float* stats_dev, void* stream);
+int rl4rs_rawtrain_adam_step(rl4rs_rawtrain* pol, float lr, float beta1, float beta2, float eps, float grad_clip,
+                             void* stream);
+
 /* Supervised training of the 'dnn' / 'widedeep' / 'lstm' simulators (rl4rs/nets/dnn.py, widedeep.py, lstm.py) on the device: what
  * script/supervised_train.py:37-42 does with model.compile(loss='binary_crossentropy', optimizer='adam') + model.fit -
  * forward in training mode (Dropout after each dense-tower layer, utils.py:48-54), keras binary_crossentropy of the

@@ -116,3 +116,49 @@ def rawstate_forward(weights, cat, dense, seqs, mask=None):
         with np.errstate(divide='ignore'):
             logits = logits + np.maximum(np.log(np.asarray(mask, dtype=np.float64)), F32_MIN)
     return logits, (ctx @ w['value_w'] + w['value_b'])[:, 0]
+
+
+def rawstate_loss_and_grad(algo, weights, cat, dense, seqs, mask, actions, adv, ret, old_logp=None, old_value=None,
+                           old_logits=None, vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2):
+    """float64 autograd of RLlib's A2C (algo 0) / PPO (algo 1) loss on the raw-state policy (rawstate_forward above) -> dict of
+    gradients (with head_w = [out_w | value_w], head_b = [out_b | value_b]), stats[4] sums."""
+    import torch
+    t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float64)
+    w = dict((k, t(v).clone().requires_grad_(True)) for k, v in weights.items())
+    elu = torch.nn.functional.elu
+    seq_feat = [w['seq_emb'][torch.as_tensor(np.asarray(s), dtype=torch.int64)].mean(dim=1) for s in seqs]
+    d = elu(elu(t(dense) @ w['dense_w1'] + w['dense_b1']) @ w['dense_w2'] + w['dense_b2'])
+    c = w['cat_emb'][torch.as_tensor(np.asarray(cat), dtype=torch.int64)].mean(dim=1)
+    ctx = elu(torch.cat(seq_feat + [d, c], dim=1) @ w['ctx_w'] + w['ctx_b'])
+    logits = ctx @ w['out_w'] + w['out_b']
+    v = (ctx @ w['value_w'] + w['value_b'])[:, 0]
+    if mask is not None:
+        logits = logits + torch.clamp(torch.log(t(mask)), min=F32_MIN)
+    lsm = torch.log_softmax(logits, dim=1)
+    pr = torch.exp(lsm)
+    ent = -(torch.where(pr > 0, pr * lsm, torch.zeros_like(pr))).sum(1)
+    a = torch.as_tensor(np.asarray(actions), dtype=torch.int64)
+    lp = lsm.gather(1, a[:, None])[:, 0]
+    adv_t, ret_t = t(adv), t(ret)
+    if algo == 0:
+        pi = -(lp * adv_t)
+        vf = 0.5 * (v - ret_t) ** 2
+        kl = torch.zeros_like(lp)
+        total = pi.sum() + vf_coeff * vf.sum() - ent_coeff * ent.sum()
+    else:
+        ratio = torch.exp(lp - t(old_logp))
+        pi = -torch.minimum(adv_t * ratio, adv_t * torch.clamp(ratio, 1 - clip, 1 + clip))
+        pv = t(old_value)
+        l1 = (v - ret_t) ** 2
+        vc = pv + torch.clamp(v - pv, -vf_clip, vf_clip)
+        vf = torch.maximum(l1, (vc - ret_t) ** 2)
+        olsm = torch.log_softmax(t(old_logits), dim=1)
+        q = torch.exp(olsm)
+        kl = torch.where(q > 0, q * (olsm - lsm), torch.zeros_like(q)).sum(1)
+        total = (pi + kl_coeff * kl + vf_coeff * vf - ent_coeff * ent).mean()
+    total.backward()
+    g = dict((k, x.grad.numpy()) for k, x in w.items())
+    g['head_w'] = np.concatenate([g.pop('out_w'), g.pop('value_w')], axis=1)
+    g['head_b'] = np.concatenate([g.pop('out_b'), g.pop('value_b')])
+    stats = np.array([pi.sum().item(), vf.sum().item(), ent.sum().item(), kl.sum().item()])
+    return g, stats

@@ -154,6 +154,14 @@ SIGNATURES = {
     'rl4rs_rawpolicy_destroy': (_I, [_P]),
     'rl4rs_rawpolicy_act': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     'rl4rs_rawpolicy_evaluate': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_rawtrain_create': (_I, [C.POINTER(RawPolicyCfg), C.POINTER(RawPolicyWeights), _P, C.POINTER(_P)]),
+    'rl4rs_rawtrain_destroy': (_I, [_P]),
+    'rl4rs_rawtrain_params': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    'rl4rs_rawtrain_act': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_rawtrain_evaluate': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_rawtrain_loss_grad': (_I, [_P, _I32, _I32, _P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, _P, _P]),
+    'rl4rs_rawtrain_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),

@@ -188,32 +188,11 @@ struct LossArgs {
     const float* old_logp; const float* old_value; const float* old_logits;   // PPO
 };
 
-// Training forward + per-sample backward down to the pre-activation of the hidden layer.
-// Writes H [N,HID], dOut [N,AE] (d loss / d [logits | value]), dHpre [N,HID] and per-sample loss terms
-// terms[n] = {pi_loss, vf_loss, entropy, kl}.
-__global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __restrict__ prm, int N,
-                                                      const float* __restrict__ obs, const uint32_t* __restrict__ mask,
-                                                      LossArgs L, float* __restrict__ H, float* __restrict__ dOut,
-                                                      float* __restrict__ dHpre, float4* __restrict__ terms, int stage_w2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = d.OD + d.HID + 2 * d.AE;
-    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
-    float* s_h = s_obs + d.OD;
-    float* s_out = s_h + d.HID;
-    float* s_d = s_out + d.AE;
-    // backward needs row j of W2 per lane j: staged once per workgroup (rows of an odd length map the 64 lanes onto 64
-    // different LDS banks; straight from memory that access is one cache line per lane per element)
-    float* s_w2 = stage_w2 ? reinterpret_cast<float*>(smem) + (size_t)4 * per : nullptr;
-    if (stage_w2) {
-        const float* W2g = prm + (size_t)d.OD * d.HID + d.HID;
-        for (int i = threadIdx.x; i < d.HID * d.AE; i += 256) s_w2[i] = W2g[i];
-        __syncthreads();
-    }
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
-    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+// A2C / PPO loss of one sample from its masked logits / value in s_out and their log-sum-exp: writes d loss / d [logits |
+// value] into s_d (LDS) and dOut (global, may be NULL), returns {pi_loss, vf_loss, entropy, kl}.  Shared by the FC mask policy
+// and the raw-state policy.
+__device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossArgs& L, const float* s_out, float lse, int n, int lane,
+                                                  float* s_d, float* __restrict__ dOut) {
     const int act = L.actions[n];
     const float adv = L.adv[n], ret = L.ret[n];
     const float v = s_out[d.A];
@@ -280,8 +259,38 @@ __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __
             g = g_v;
         }
         s_d[a] = g;
-        dOut[(size_t)n * d.AE + a] = g;
+        if (dOut) dOut[(size_t)n * d.AE + a] = g;
     }
+    return make_float4(pi_loss, vf_loss, ent, kl);
+}
+
+// Training forward + per-sample backward down to the pre-activation of the hidden layer.
+// Writes H [N,HID], dOut [N,AE] (d loss / d [logits | value]), dHpre [N,HID] and per-sample loss terms
+// terms[n] = {pi_loss, vf_loss, entropy, kl}.
+__global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __restrict__ prm, int N,
+                                                      const float* __restrict__ obs, const uint32_t* __restrict__ mask,
+                                                      LossArgs L, float* __restrict__ H, float* __restrict__ dOut,
+                                                      float* __restrict__ dHpre, float4* __restrict__ terms, int stage_w2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = d.OD + d.HID + 2 * d.AE;
+    float* s_obs = reinterpret_cast<float*>(smem) + (size_t)wave * per;
+    float* s_h = s_obs + d.OD;
+    float* s_out = s_h + d.HID;
+    float* s_d = s_out + d.AE;
+    // backward needs row j of W2 per lane j: staged once per workgroup (rows of an odd length map the 64 lanes onto 64
+    // different LDS banks; straight from memory that access is one cache line per lane per element)
+    float* s_w2 = stage_w2 ? reinterpret_cast<float*>(smem) + (size_t)4 * per : nullptr;
+    if (stage_w2) {
+        const float* W2g = prm + (size_t)d.OD * d.HID + d.HID;
+        for (int i = threadIdx.x; i < d.HID * d.AE; i += 256) s_w2[i] = W2g[i];
+        __syncthreads();
+    }
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const uint32_t* mrow = mask ? mask + (size_t)n * d.W : nullptr;
+    const float lse = policy_row_forward(d, prm, obs + (size_t)n * d.OD, mrow, s_obs, s_h, s_out, lane);
+    const float4 tm = policy_row_loss(d, L, s_out, lse, n, lane, s_d, dOut);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const float* W2 = prm + (size_t)d.OD * d.HID + d.HID;
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __
         H[(size_t)n * d.HID + j] = h;
         dHpre[(size_t)n * d.HID + j] = s * (1.f - h * h);
     }
-    if (lane == 0) terms[n] = make_float4(pi_loss, vf_loss, ent, kl);
+    if (lane == 0) terms[n] = tm;
 }
 
 // C_part[z][M][Nc] = sum over samples n in chunk z of A[n][m] * B[n][j]   ("A^T B" over the sample axis).
@@ -751,3 +760,4 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
 
 #include "simtrain.hpp"
 #include "dientrain.hpp"
+#include "rawtrain.hpp"

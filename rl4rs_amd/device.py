@@ -725,6 +725,96 @@ class DeviceRawPolicy(object):
         return lp, v, ent, lg
 
 
+class DeviceRawTrainer(DeviceRawPolicy):
+    """rl4rs_rawtrain handle: the raw-state policy with A2C / PPO loss, backward and Adam on the device."""
+    A2C, PPO = 0, 1
+    ORDER = ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'ctx_w', 'ctx_b', 'head_w', 'head_b')
+
+    def __init__(self, config, weights, max_rows, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.S, self.L, self.A = int(config['seq_num']), int(config['maxlen']), int(config['action_size'])
+        self.Cn, self.Dn = int(config['category_feature_num']), int(config['dense_feature_num'])
+        self.W = (self.A + 31) // 32
+        self.max_rows = int(max_rows)
+        E, U = int(config['emb_size']), int(config['hidden_units'])
+        H = int(config['category_hash_size'])
+        cfg = _lib.RawPolicyCfg(self.L, E, U, self.Dn, self.Cn, H, self.S, self.A, self.max_rows)
+        w = _lib.RawPolicyWeights()
+        keep = []
+        for name, _ in _lib.RawPolicyWeights._fields_:
+            arr = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(arr)
+            setattr(w, name, arr.ctypes.data_as(_lib._FP))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_rawtrain_create(C.byref(cfg), C.byref(w), _stream(), C.byref(h)))
+        self.h = h
+        self.shapes = [('cat_emb', (H, E)), ('seq_emb', (H, E)), ('dense_w1', (self.Dn, U)), ('dense_b1', (U,)), ('dense_w2', (U, U)),
+                       ('dense_b2', (U,)), ('ctx_w', (self.S * E + U + E, 256)), ('ctx_b', (256,)), ('head_w', (256, self.A + 1)),
+                       ('head_b', (self.A + 1,))]
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_rawtrain_destroy(self.h)
+            self.h = None
+
+    def _flat(self, which):
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_rawtrain_params(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p if which == 'params' else g, n.value * 4, _stream()))
+        return out
+
+    def _split(self, flat):
+        out, o = {}, 0
+        for name, shape in self.shapes:
+            k = int(np.prod(shape))
+            out[name] = flat[o:o + k].reshape(shape)
+            o += k
+        return out
+
+    def weights(self):
+        """head_w = [out_w | value_w], head_b = [out_b | value_b]."""
+        return self._split(self._flat('params'))
+
+    def gradients(self):
+        return self._split(self._flat('grad'))
+
+    def act(self, cat, dense, seqs, mask_bits=None, seed=0, step=0, want_logits=False):
+        N, sp = self._inputs(cat, dense, seqs, mask_bits)
+        a = torch.empty(N, dtype=torch.int32, device=self.device)
+        lp, v, ent, lg = self._outs(N, want_logits)
+        check(self.lib.rl4rs_rawtrain_act(self.h, N, _ptr(cat), _ptr(dense), sp, _ptr(mask_bits), seed, step, _ptr(a), _ptr(lp),
+                                          _ptr(v), _ptr(ent), _ptr(lg), _stream()))
+        return a, lp, v, ent, lg
+
+    def evaluate(self, cat, dense, seqs, actions, mask_bits=None, want_logits=False):
+        N, sp = self._inputs(cat, dense, seqs, mask_bits)
+        actions = actions.to(torch.int32).contiguous()
+        lp, v, ent, lg = self._outs(N, want_logits)
+        check(self.lib.rl4rs_rawtrain_evaluate(self.h, N, _ptr(cat), _ptr(dense), sp, _ptr(mask_bits), _ptr(actions), _ptr(lp),
+                                               _ptr(v), _ptr(ent), _ptr(lg), _stream()))
+        return lp, v, ent, lg
+
+    def loss_grad(self, algo, cat, dense, seqs, actions, adv, ret, mask_bits=None, old_logp=None, old_value=None, old_logits=None,
+                  vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2):
+        """-> stats [pi_loss, vf_loss, entropy, kl] sums (device tensor); the gradient stays in the handle (gradients())."""
+        N, sp = self._inputs(cat, dense, seqs, mask_bits)
+        f = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        actions = actions.to(torch.int32).contiguous()
+        adv, ret, old_logp, old_value, old_logits = f(adv), f(ret), f(old_logp), f(old_value), f(old_logits)
+        stats = torch.empty(4, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_rawtrain_loss_grad(self.h, algo, N, _ptr(cat), _ptr(dense), sp, _ptr(mask_bits), _ptr(actions), _ptr(adv),
+                                                _ptr(ret), _ptr(old_logp), _ptr(old_value), _ptr(old_logits), vf_coeff, ent_coeff,
+                                                clip, vf_clip, kl_coeff, _ptr(stats), _stream()))
+        return stats
+
+    def adam_step(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_clip=0.0):
+        check(self.lib.rl4rs_rawtrain_adam_step(self.h, lr, beta1, beta2, eps, grad_clip, _stream()))
+
+
 def gemm_f32(a, w, bias=None, act=0):
     """C = act(a @ w + bias) through rl4rs_gemm_f32 (tests)."""
     lib = _lib.load()
