@@ -69,6 +69,23 @@ class SimulatorTrainer(object):
                                                     lr=self.lr, dropout_rate=self.dropout_rate, seed=self.seed))
         return [float(x.item()) for x in losses]
 
+    def fit_tfrecord(self, filenames, steps, seed=None):
+        """``model.fit(featureutil.read_tfrecord(files), steps_per_epoch=steps)`` of script/supervised_train.py:34-42: `steps`
+        Adam steps on shuffled batches of the reference's TFRecord training set (rl4rs_amd/utils/tfrecord.py reads it)."""
+        from .utils.datautil import FeatureUtil
+        fu = FeatureUtil(dict(self.sim.config, batch_size=self.minibatch))
+        it = fu.read_tfrecord(filenames, is_pred=False, seed=self.seed if seed is None else seed)
+        dev = self.trainer.device
+        losses = []
+        for _ in range(steps):
+            (seq, dense, cat, _), target = next(it)
+            seqs = None if self.algo == 'dnn' else [torch.from_numpy(np.ascontiguousarray(seq[:, s])).to(dev)
+                                                    for s in range(seq.shape[1])]
+            losses.append(self.trainer.step(torch.from_numpy(dense).to(dev), torch.from_numpy(cat).to(dev),
+                                            torch.from_numpy(target.argmax(axis=1).astype(np.int32)).to(dev), seqs, lr=self.lr,
+                                            dropout_rate=self.dropout_rate, seed=self.seed))
+        return [float(x.item()) for x in losses]
+
     def export_weights(self):
         """Trained parameters as numpy arrays (``rl4rs_amd.nets.simnets.simnet_spec`` names) - what ``model_file`` takes."""
         return dict((k, v.cpu().numpy()) for k, v in self.trainer.weights().items())

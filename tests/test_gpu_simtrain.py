@@ -187,3 +187,35 @@ def test_dien_gradients_match_autograd(rate):
         err = np.abs(g[k] - g_ref[k]).max()
         assert err < 5e-4 * max(scale, 1e-8) + 1e-9, (k, err, scale)
     tr.close()
+
+
+def test_fit_from_tfrecord(tmp_path):
+    """The reference's training-set format end to end: samples -> FeatureUtil.to_tfrecord -> SimulatorTrainer.fit_tfrecord."""
+    import os
+    from rl4rs_amd import synth
+    from rl4rs_amd.simtrain import SimulatorTrainer
+    from rl4rs_amd.utils.datautil import FeatureUtil
+    from rl4rs.env.slate import SlateRecEnv, SlateState
+    B = 32
+    d = str(tmp_path)
+    cat_path, log_path = os.path.join(d, 'item_info.csv'), os.path.join(d, 'log.csv')
+    cat_text = synth.make_catalog_text(seed=21)
+    synth.write_text(cat_path, cat_text)
+    synth.write_records(log_path, synth.make_records(B, pages=1, seed=8, illegal_frac=0.0, hash_size=5000,
+                                                     special_ids=synth.special_ids_from_text(cat_text)))
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 5000, "seq_num": 2, "emb_size": 128,
+           "page_items": 9, "hidden_units": 128, "max_steps": 9, "action_emb_size": 32,
+           "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": True, "cache_size": B, "model_seed": 3,
+           "algo": "widedeep", "return_tensors": True}
+    sim = SlateRecEnv(cfg, state_cls=SlateState)
+    tr = SimulatorTrainer(sim, minibatch=32, seed=2)
+    # the device-built training set of one window, written in the reference's TFRecord layout
+    dense, cat, labels, seqs = [x.cpu().numpy() if hasattr(x, 'cpu') else [y.cpu().numpy() for y in x] for x in tr.dataset_from_logs()]
+    data = [[0, [seqs[0][i].tolist(), seqs[1][i].tolist()], dense[i].tolist(), cat[i].tolist(), [0] * 9, int(labels[i])]
+            for i in range(len(labels))]
+    path = os.path.join(d, 'train.tfrecord')
+    FeatureUtil(cfg).to_tfrecord(data, path)
+    losses = tr.fit_tfrecord(path, steps=60)
+    assert len(losses) == 60 and np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 0.9 * np.mean(losses[:10]), (np.mean(losses[:10]), np.mean(losses[-10:]))
