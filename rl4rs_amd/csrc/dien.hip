@@ -30,6 +30,9 @@ constexpr int ATT_H1 = 64, ATT_H2 = 16, OBS_DIM = 256;
 #define RL4RS_AUGRU_U 2
 #endif
 constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-ring slot
+#ifndef RL4RS_H16_NLDS
+#define RL4RS_H16_NLDS 5         // further weight items of a step kept in the LDS the planes leave free (16 KB per item)
+#endif
 #ifndef RL4RS_H16_NRES
 #define RL4RS_H16_NRES 14        // weight items of a step kept resident in registers (k_augru_h16)
 #endif
@@ -427,7 +430,9 @@ __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int 
 //   INTO the accumulators (MFMA C-in), so they cost no registers; they are requested at points that are followed by a
 //   long stretch without weight waits (the in-order vmcnt makes every later weight wait also wait for them: ~5K
 //   cycles when they were issued inside slot R).  The weight fragments stream through a RING-deep register ring, LA =
-//   RING-1 items ahead, across slots and steps; the first NRES items of a step stay resident in registers.
+//   RING-1 items ahead, across slots and steps; the first NRES items of a step stay resident in registers and the
+//   next NLDS items in the LDS the operand planes leave free (each wave keeps and re-reads only its own fragments,
+//   ds_read_b128 one item ahead: 10 of 34 streamed items leave the L1 / texture-address path, measured -1.5 %).
 //   What bounds it (s_memtime marks of one workgroup, tools/h16_trace.py; PMC: matrix pipe ~41 % busy): the L1 /
 //   texture-address path.  8 waves x 2 KB of weight fragments per item at 64 B/clk = 256 cycles against 192 cycles
 //   of MFMA, plus ~3.3K cycles per step for the 384 dword-per-lane projection loads; the two waves of a SIMD
@@ -485,6 +490,9 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     }
     const int aoff = li * LDP + half * 8;
     const int xcol4 = (a.xoff + col) * 4;
+    // items NRES .. NRES+NLDS-1 of this wave, hi and lo planes: [item][plane][lane][8 halfs] at 1 KB per (item, plane)
+    constexpr int NLDS = RL4RS_H16_NLDS;
+    char* lds_w = reinterpret_cast<char*>(s_xoff + MR) + (size_t)wave * NLDS * 2048;
     __syncthreads();
 
     // weight item i of a step: gate i / KB, k-block i % KB (i is a compile-time constant after unrolling).
@@ -527,7 +535,19 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
         load_x(acc_c[m], m, 0, 2);
     }
 #pragma unroll
-    for (int i = NRES; i < NRES + LA; ++i) wload(i, wh[i % RING], wl[i % RING]);
+    for (int i = 0; i < NLDS; ++i) {
+        half8_t hi, lo;
+        wload(NRES + i, hi, lo);
+        *reinterpret_cast<half8_t*>(lds_w + i * 2048 + vl16) = hi;
+        *reinterpret_cast<half8_t*>(lds_w + i * 2048 + 1024 + vl16) = lo;
+    }
+#pragma unroll
+    for (int i = NRES + NLDS; i < NRES + NLDS + LA; ++i) wload(i % NI, wh[i % RING], wl[i % RING]);
+    // (the LDS-resident items are read back by the owning wave only: no barrier needed, the compiler orders the accesses)
+    if (NLDS > 0) {
+        wh[NRES % RING] = *reinterpret_cast<const half8_t*>(lds_w + vl16);
+        wl[NRES % RING] = *reinterpret_cast<const half8_t*>(lds_w + 1024 + vl16);
+    }
 
     bool out_of_range = false;
 #pragma unroll 1
@@ -555,7 +575,11 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
                 }
             }
             // streamed items run LA ahead in the ring (the resident ones are skipped)
-            if ((i + LA) % NI >= NRES) wload((i + LA) % NI, wh[(i + LA) % RING], wl[(i + LA) % RING]);
+            if ((i + LA) % NI >= NRES + NLDS) wload((i + LA) % NI, wh[(i + LA) % RING], wl[(i + LA) % RING]);
+            if ((i + 1) % NI >= NRES && (i + 1) % NI < NRES + NLDS) {       // next item lives in LDS: read it one item ahead
+                wh[(i + 1) % RING] = *reinterpret_cast<const half8_t*>(lds_w + ((i + 1) % NI - NRES) * 2048 + vl16);
+                wl[(i + 1) % RING] = *reinterpret_cast<const half8_t*>(lds_w + ((i + 1) % NI - NRES) * 2048 + 1024 + vl16);
+            }
             if (i == 2 * KB && t + 1 < L) {
                 // next step's r-gate projection goes into the (retired) r accumulators
 #pragma unroll
@@ -926,7 +950,7 @@ struct EvPair { int id; hipEvent_t a, b; };
 }  // namespace
 
 static size_t augru_h16_smem(int mt, int nh2, int L) {
-    return (size_t)4 * mt * 32 * (nh2 + 8) * 2 + (size_t)(mt * 32 * (L + 1) + mt * 32) * 4;
+    return (size_t)4 * mt * 32 * (nh2 + 8) * 2 + (size_t)(mt * 32 * (L + 1) + mt * 32) * 4 + (size_t)8 * RL4RS_H16_NLDS * 2048;
 }
 
 struct rl4rs_dien {
