@@ -104,6 +104,11 @@ int rl4rs_parse_records(const char* text, int64_t len, int32_t max_records, int3
                         int32_t* history_host, float* user_dense_host, int32_t* user_cat_host,
                         int32_t* exposed_len_host, int32_t* n_parsed);
 
+/* HOST-side CRC-32C (Castagnoli) of a byte range, continuing the running checksum `crc` (0 starts one): the
+ * checksum of the TFRecord framing (tf.io behind FeatureUtil.to_tfrecord / read_tfrecord, datautil.py:71-230)
+ * and of the tensor-bundle checkpoints tf.train.Saver writes (base.py:129,151; supervised_train.py:44-46). */
+uint32_t rl4rs_crc32c(const void* data, int64_t len, uint32_t crc);
+
 /* RecState.__init__ (base.py:27-31) + SlateState.__init__ (slate.py:15-19): zero prev_actions, masks
  * to all-ones, cur_steps = 0, feature rows = the un-acted state. */
 int rl4rs_env_reset(rl4rs_env* env, void* stream);

@@ -134,3 +134,40 @@ extern "C" int rl4rs_parse_records(const char* text, int64_t len, int32_t max_re
     *n_parsed = rec;
     return RL4RS_OK;
 }
+
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8: the checksum of the TFRecord framing
+// (rl4rs/utils/datautil.py:71-230 reads / writes TFRecords through tf.io) and of TF tensor-bundle checkpoints
+// (tf.train.Saver, rl4rs/env/base.py:129,151).  `crc` continues a running checksum (0 starts one).
+namespace {
+struct Crc32cTables {
+    uint32_t t[8][256];
+    Crc32cTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = t[0][t[k - 1][i] & 0xFF] ^ (t[k - 1][i] >> 8);
+    }
+};
+}  // namespace
+
+extern "C" uint32_t rl4rs_crc32c(const void* data, int64_t len, uint32_t crc) {
+    static const Crc32cTables T;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = ~crc;
+    while (len >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T.t[7][lo & 0xFF] ^ T.t[6][(lo >> 8) & 0xFF] ^ T.t[5][(lo >> 16) & 0xFF] ^ T.t[4][lo >> 24] ^
+            T.t[3][hi & 0xFF] ^ T.t[2][(hi >> 8) & 0xFF] ^ T.t[1][(hi >> 16) & 0xFF] ^ T.t[0][hi >> 24];
+        p += 8;
+        len -= 8;
+    }
+    while (len-- > 0) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}

@@ -90,6 +90,16 @@ class SimulatorTrainer(object):
         """Trained parameters as numpy arrays (``rl4rs_amd.nets.simnets.simnet_spec`` names) - what ``model_file`` takes."""
         return dict((k, v.cpu().numpy()) for k, v in self.trainer.weights().items())
 
+    def save(self, model_file):
+        """``saver.save(sess, model_file)`` (supervised_train.py:44-46): an ``.npz`` of this package's weight names, or -
+        any other path - a TF checkpoint prefix under the reference's graph variable names (``utils.tfckpt``)."""
+        w = self.export_weights()
+        if str(model_file).endswith('.npz'):
+            np.savez(model_file, **w)
+        else:
+            from .utils import tfckpt
+            tfckpt.save_simulator_weights(model_file, w, self.sim.config, self.algo)
+
     def install(self):
         """Put the trained weights into the simulator the env scores with."""
         self.sim.model.weights = OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32))

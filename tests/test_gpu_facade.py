@@ -283,3 +283,34 @@ def test_offline_dataset_generation_matches_oracle_replay(tmp_path, seq, T):
         assert term[:, j + 1].tolist() == [float(x) for x in done]
     assert act[:, T].tolist() == [0] * B
     assert rew[:, T].sum() > 0
+
+
+@pytest.mark.parametrize('algo', ['dien', 'lstm'])
+def test_model_file_may_be_a_tf_checkpoint_prefix(tmp_path, algo):
+    """base.py:148-151: ``model_file`` is a ``tf.train.Saver`` prefix in the reference.  The same weights handed over as a
+    checkpoint (read without TensorFlow, ``utils.tfckpt``) or as an .npz must give bit-identical episodes; a trainer's
+    ``save(prefix)`` is what ``reload_model(prefix)`` takes (supervised_train.py:44-46)."""
+    from rl4rs_amd.utils import tfckpt
+    from rl4rs_amd.nets import simnets
+    B = 64
+    cfg, records, w = _setup(tmp_path, False, B, 9, algo=algo)
+    if algo != 'dien':
+        w = simnets.init_simnet_weights(cfg, algo, seed=5, emb_scale=0.5, bias_noise=0.2)
+        np.savez(os.path.join(str(tmp_path), 'sim.npz'), **w)
+        cfg['model_file'] = os.path.join(str(tmp_path), 'sim.npz')
+    prefix = os.path.join(str(tmp_path), 'simulator_a_' + algo)
+    tfckpt.save_simulator_weights(prefix, w, cfg, algo)
+    runs = []
+    for model_file in (cfg['model_file'], prefix):
+        env = _make(dict(cfg, model_file=model_file), False)
+        obs = [np.asarray(env.reset(reset_file=True))]
+        rewards = []
+        for t in range(9):
+            o, r, done, _ = env.step(env.offline_action)
+            obs.append(np.asarray(o))
+            rewards.append(np.asarray(r))
+        runs.append((np.stack(obs), np.stack(rewards)))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert np.abs(runs[0][1]).sum() > 0
+    with pytest.raises(FileNotFoundError):
+        _make(dict(cfg, model_file=os.path.join(str(tmp_path), 'no_such_checkpoint')), False)
