@@ -35,12 +35,22 @@ def _make_table():
 _TABLE = _make_table()
 
 
-def crc32c(data):
+def _crc32c_py(data):
     c = 0xFFFFFFFF
     tab = _TABLE
     for b in data:
         c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like; records go through the native ``rl4rs_crc32c`` (a training set is ~GBs of records)."""
+    if len(data) < 64:
+        return _crc32c_py(data)
+    import ctypes
+    from .. import _lib
+    data = bytes(data)
+    return int(_lib.load().rl4rs_crc32c(ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p), len(data), 0))
 
 
 def masked_crc(data):

@@ -25,7 +25,7 @@ def test_crc32c_known_answers_and_streaming():
     assert tfckpt.crc32c(b'\xff' * 32) == 0x62A8AB43
     assert tfckpt.crc32c(bytes(range(32))) == 0x46DD794E
     blob = np.random.RandomState(0).randint(0, 256, 100003).astype(np.uint8).tobytes()
-    assert tfckpt.crc32c(blob) == tfrecord.crc32c(blob)                 # native slicing-by-8 == bytewise table
+    assert tfckpt.crc32c(blob) == tfrecord._crc32c_py(blob) == tfrecord.crc32c(blob)    # slicing-by-8 == bytewise table
     for cut in (0, 1, 7, 8, 9, 4096, len(blob)):
         assert tfckpt.crc32c(blob[cut:], tfckpt.crc32c(blob[:cut])) == tfckpt.crc32c(blob)
     assert tfckpt.crc32c(np.frombuffer(blob, np.uint8)) == tfckpt.crc32c(blob)
