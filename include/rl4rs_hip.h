@@ -495,8 +495,58 @@ int rl4rs_dientrain_step(rl4rs_dientrain* tr, int32_t N, const float* dense_dev,
                          const int32_t* const* seq_dev, const int32_t* labels_dev, float lr, float beta1, float beta2,
                          float eps, float dropout_rate, uint32_t seed, uint32_t step, float* loss_dev, void* stream);
 
+/* Offline-RL learner networks and losses: what script/batchrl_trainer.py:34-90 trains with d3rlpy (DiscreteBC, DiscreteBCQ,
+ * DiscreteCQL) on the logged-policy dataset, BASELINE configs[4].  A qnet is one encoder + d3rlpy's Linear head:
+ *   mask_size = page_items + 1 > 0: CustomVectorEncoder of rl4rs/nets/cql/encoder.py:9-67 (with_q=True):
+ *       relu(fc1(x)) | Embedding(action_size, emb_size)(x[-mask_size:]) -> fc2 -> [action_size], entries whose mask is 0 set to 0
+ *       (mask = location_mask[cur_step % 9 // 3], previous actions and - once one was chosen - special items removed), then
+ *       head Linear(action_size, action_size);
+ *   mask_size = 0: d3rlpy VectorEncoder relu(fc1) -> relu(fc2) [hidden2], head Linear(hidden2, action_size).
+ * Flat float32 parameter / gradient layout, matrices stored [in, out]:
+ *   [ fc1_w obs_dim x hidden1 | fc1_b | emb action_size x emb_size (custom only) | fc2_w | fc2_b | head_w | head_b ]
+ * params_host, location_mask [n_layers, action_size] and is_special [action_size] are HOST pointers (the masks may be NULL for
+ * the plain encoder).  forward keeps the activations in the handle; backward must follow the forward of the SAME rows and
+ * writes the gradient of sum(out * dout_dev).  adam_step is torch.optim.Adam.  status: bit 0 = an id in an observation tail
+ * or an action was out of range (torch would raise IndexError), bit 1 = mask layer out of range. */
+typedef struct rl4rs_qnet rl4rs_qnet;
+typedef struct rl4rs_qnet_cfg {
+    int32_t obs_dim;
+    int32_t action_size;
+    int32_t mask_size;
+    int32_t emb_size;
+    int32_t hidden1;
+    int32_t hidden2;
+    int32_t n_layers;
+    int32_t max_rows;
+} rl4rs_qnet_cfg;
+int rl4rs_qnet_create(const rl4rs_qnet_cfg* cfg, const float* params_host, const uint8_t* location_mask,
+                      const uint8_t* is_special, void* stream, rl4rs_qnet** out);
+int rl4rs_qnet_destroy(rl4rs_qnet* net);
+int rl4rs_qnet_params(rl4rs_qnet* net, float** params_dev, float** grad_dev, int64_t* count);
+int rl4rs_qnet_copy_params(rl4rs_qnet* dst, const rl4rs_qnet* src, void* stream);
+int rl4rs_qnet_status(rl4rs_qnet* net, int32_t* flags, void* stream);
+int rl4rs_qnet_forward(rl4rs_qnet* net, int32_t N, const float* obs_dev, float* out_dev, void* stream);
+int rl4rs_qnet_backward(rl4rs_qnet* net, int32_t N, const float* obs_dev, const float* dout_dev, void* stream);
+int rl4rs_qnet_adam_step(rl4rs_qnet* net, float lr, float beta1, float beta2, float eps, void* stream);
+/* Greedy action per row [N]: argmax q (first maximum), or - with imitator logits - the DiscreteBCQ rule
+ * argmax (q - min q) * [log pi - max log pi > log(action_flexibility)]. */
+int rl4rs_q_best_action(int32_t N, int32_t A, const float* q_dev, const float* imitator_logits_dev,
+                        float action_flexibility, int32_t* actions_dev, void* stream);
+/* DiscreteImitator.compute_error: loss2_dev = {mean nll_loss(log_softmax(logits), a), mean_n sum_k logits^2}; dlogits_dev =
+ * gradient of nll + beta * mean(logits^2).  rows_scratch_dev: [N, 2] float32. */
+int rl4rs_qloss_imitation(rl4rs_qnet* net, int32_t N, const float* logits_dev, const int32_t* actions_dev, float beta,
+                          float* dlogits_dev, float* rows_scratch_dev, float* loss2_dev, void* stream);
+/* DoubleDQN temporal-difference loss (+ DiscreteCQL's conservative term when cql_alpha > 0): the next action is chosen
+ * from q_next_dev by rl4rs_q_best_action's rule (imitator_next_logits_dev NULL = argmax), evaluated on q_next_target_dev;
+ * loss2_dev = {mean huber(r + gamma * Q_targ(s')[a*] * (1 - terminal) - Q(s)[a]), mean(logsumexp Q(s) - Q(s)[a])};
+ * dq_dev = gradient of td + cql_alpha * conservative wrt q_t_dev.  best_next_action_dev (optional) receives a*. */
+int rl4rs_qloss_dqn(rl4rs_qnet* net, int32_t N, const float* q_t_dev, const int32_t* actions_dev, const float* rewards_dev,
+                    const float* terminals_dev, const float* q_next_dev, const float* q_next_target_dev,
+                    const float* imitator_next_logits_dev, float action_flexibility, float gamma, float cql_alpha,
+                    float* dq_dev, float* rows_scratch_dev, float* loss2_dev, int32_t* best_next_action_dev, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
- * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh. */
+ * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh, 4 ReLU. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,
                    const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
                    int act, void* stream);

@@ -63,6 +63,11 @@ class SimnetWeights(C.Structure):
     ]
 
 
+class QNetCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('obs_dim', 'action_size', 'mask_size', 'emb_size', 'hidden1', 'hidden2', 'n_layers',
+                                         'max_rows')]
+
+
 class RawPolicyCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num', 'category_hash_size',
@@ -164,6 +169,17 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_float, _P, _P]),
     'rl4rs_rawtrain_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
+    'rl4rs_qnet_create': (_I, [_P, _FP, _P, _P, _P, _P]),
+    'rl4rs_qnet_destroy': (_I, [_P]),
+    'rl4rs_qnet_params': (_I, [_P, _P, _P, _P]),
+    'rl4rs_qnet_copy_params': (_I, [_P, _P, _P]),
+    'rl4rs_qnet_status': (_I, [_P, C.POINTER(_I32), _P]),
+    'rl4rs_qnet_forward': (_I, [_P, _I32, _P, _P, _P]),
+    'rl4rs_qnet_backward': (_I, [_P, _I32, _P, _P, _P]),
+    'rl4rs_qnet_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'rl4rs_q_best_action': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P]),
+    'rl4rs_qloss_imitation': (_I, [_P, _I32, _P, _P, C.c_float, _P, _P, _P, _P]),
+    'rl4rs_qloss_dqn': (_I, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
 }

@@ -19,13 +19,14 @@ namespace rl4rs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_RELU = 4 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case ACT_ELU: return x > 0.f ? x : expm1f(x);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
         case ACT_TANH: return tanhf(x);
+        case ACT_RELU: return fmaxf(x, 0.f);
         default: return x;
     }
 }

@@ -761,3 +761,4 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
 #include "simtrain.hpp"
 #include "dientrain.hpp"
 #include "rawtrain.hpp"
+#include "qlearn.hpp"

@@ -954,3 +954,154 @@ class DevicePolicy(object):
 
     def adam_step(self, grad, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_clip=0.0):
         check(self.lib.rl4rs_policy_adam_step(self.h, _ptr(grad), lr, beta1, beta2, eps, grad_clip, _stream()))
+
+
+class DeviceQNet(object):
+    """rl4rs_qnet handle: one offline-RL network (the reference's ``CustomVectorEncoder`` of rl4rs/nets/cql/encoder.py:9-67,
+    or d3rlpy's plain ``VectorEncoder``, + d3rlpy's Linear head) with forward, backward and torch-style Adam on the device.
+    ``params``: dict of float32 arrays stored [in, out]: fc1_w, fc1_b, (emb,) fc2_w, fc2_b, head_w, head_b."""
+
+    def __init__(self, obs_dim, action_size, params, mask_size=0, emb_size=32, hidden1=256, hidden2=256, location_mask=None,
+                 special_items=None, max_rows=256, device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.D, self.A, self.M, self.ES = int(obs_dim), int(action_size), int(mask_size), int(emb_size)
+        self.H1, self.H2 = int(hidden1), int(hidden2)
+        self.custom = self.M > 0
+        self.max_rows = int(max_rows)
+        f2 = self.H1 + self.M * self.ES if self.custom else self.H1
+        n2 = self.A if self.custom else self.H2
+        self.shapes = [('fc1_w', (self.D, self.H1)), ('fc1_b', (self.H1,))]
+        if self.custom:
+            self.shapes.append(('emb', (self.A, self.ES)))
+        self.shapes += [('fc2_w', (f2, n2)), ('fc2_b', (n2,)), ('head_w', (n2, self.A)), ('head_b', (self.A,))]
+        flat = []
+        for name, shape in self.shapes:
+            arr = np.ascontiguousarray(params[name], dtype=np.float32)
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError('qnet parameter %r has shape %r, expected %r' % (name, tuple(arr.shape), tuple(shape)))
+            flat.append(arr.reshape(-1))
+        flat = np.ascontiguousarray(np.concatenate(flat))
+        loc = sp = None
+        n_layers = 0
+        if self.custom:
+            loc = np.ascontiguousarray(np.asarray(location_mask) >= 0.5, dtype=np.uint8)
+            if loc.ndim != 2 or loc.shape[1] != self.A:
+                raise ValueError('location_mask must be [n_layers, action_size]')
+            n_layers = loc.shape[0]
+            sp = np.zeros(self.A, dtype=np.uint8)
+            sp[np.asarray(list(special_items), dtype=np.int64)] = 1
+        cfg = _lib.QNetCfg(self.D, self.A, self.M, self.ES, self.H1, 0 if self.custom else self.H2, n_layers, self.max_rows)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_qnet_create(C.byref(cfg), flat.ctypes.data_as(_lib._FP),
+                                             loc.ctypes.data_as(C.c_void_p) if loc is not None else None,
+                                             sp.ctypes.data_as(C.c_void_p) if sp is not None else None, _stream(), C.byref(h)))
+        self.h = h
+        self.n_params = int(flat.size)
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_qnet_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _buffers(self):
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_qnet_params(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        return p, g, n.value
+
+    def _flat(self, which):
+        p, g, n = self._buffers()
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p if which == 'params' else g, n * 4, _stream()))
+        return out
+
+    def _split(self, flat):
+        out, o = {}, 0
+        for name, shape in self.shapes:
+            k = int(np.prod(shape))
+            out[name] = flat[o:o + k].reshape(shape)
+            o += k
+        return out
+
+    def weights(self):
+        return self._split(self._flat('params'))
+
+    def gradients(self):
+        return self._split(self._flat('grad'))
+
+    def flat_gradient(self):
+        return self._flat('grad')
+
+    def set_flat_gradient(self, flat):
+        _, g, n = self._buffers()
+        assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
+        check(self.lib.rl4rs_copy_d2d(g, _ptr(flat), n * 4, _stream()))
+
+    def copy_from(self, other):
+        check(self.lib.rl4rs_qnet_copy_params(self.h, other.h, _stream()))
+
+    def check_status(self):
+        flags = C.c_int32(0)
+        check(self.lib.rl4rs_qnet_status(self.h, C.byref(flags), _stream()))
+        if flags.value & 1:
+            raise IndexError('offline-RL batch: an item id in an observation tail or an action is outside [0, action_size)')
+        if flags.value & 2:
+            raise IndexError('offline-RL batch: cur_step %% 9 // 3 selects a location_mask row that does not exist')
+
+    def _obs(self, obs):
+        obs = _dev_tensor(obs, torch.float32, self.device)
+        if obs.dim() != 2 or obs.shape[1] != self.D or not 0 < obs.shape[0] <= self.max_rows:
+            raise ValueError('obs must be [N <= %d, %d] (got %r)' % (self.max_rows, self.D, tuple(obs.shape)))
+        return obs
+
+    def forward(self, obs):
+        """out [N, action_size]: Q values / imitator logits.  Keeps the activations for ``backward``."""
+        obs = self._obs(obs)
+        out = torch.empty((obs.shape[0], self.A), dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_qnet_forward(self.h, obs.shape[0], _ptr(obs), _ptr(out), _stream()))
+        return out
+
+    def backward(self, obs, dout):
+        """Gradient of sum(out * dout) into the handle (after ``forward`` of the same rows)."""
+        obs = self._obs(obs)
+        dout = _dev_tensor(dout, torch.float32, self.device)
+        assert tuple(dout.shape) == (obs.shape[0], self.A)
+        check(self.lib.rl4rs_qnet_backward(self.h, obs.shape[0], _ptr(obs), _ptr(dout), _stream()))
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        check(self.lib.rl4rs_qnet_adam_step(self.h, lr, beta1, beta2, eps, _stream()))
+
+    def imitation_loss(self, logits, actions, beta):
+        """(loss2 = [mean nll, mean_n sum_k logits^2], dlogits) of ``nll + beta * mean(logits^2)``."""
+        N = logits.shape[0]
+        actions = _dev_tensor(actions, torch.int32, self.device)
+        d = torch.empty_like(logits)
+        rows = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        loss2 = torch.empty(2, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_qloss_imitation(self.h, N, _ptr(logits), _ptr(actions), beta, _ptr(d), _ptr(rows), _ptr(loss2), _stream()))
+        return loss2, d
+
+    def dqn_loss(self, q_t, actions, rewards, terminals, q_next, q_next_target, imitator_next=None, action_flexibility=0.3,
+                 gamma=0.99, cql_alpha=0.0):
+        """(loss2 = [mean huber TD, mean conservative], dq, best next action)."""
+        N = q_t.shape[0]
+        actions = _dev_tensor(actions, torch.int32, self.device)
+        rewards = _dev_tensor(rewards, torch.float32, self.device)
+        terminals = _dev_tensor(terminals, torch.float32, self.device)
+        dq = torch.empty_like(q_t)
+        rows = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        loss2 = torch.empty(2, dtype=torch.float32, device=self.device)
+        best = torch.empty(N, dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_qloss_dqn(self.h, N, _ptr(q_t), _ptr(actions), _ptr(rewards), _ptr(terminals), _ptr(q_next),
+                                       _ptr(q_next_target), _ptr(imitator_next), action_flexibility, gamma, cql_alpha, _ptr(dq),
+                                       _ptr(rows), _ptr(loss2), _ptr(best), _stream()))
+        return loss2, dq, best
+
+    def best_action(self, q, imitator_logits=None, action_flexibility=0.3):
+        out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_q_best_action(q.shape[0], self.A, _ptr(q), _ptr(imitator_logits), action_flexibility, _ptr(out), _stream()))
+        return out
