@@ -35,13 +35,32 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
     return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
+// Wave-wide reductions, result in every lane.  DPP row operations (quad_perm, row_half_mirror, row_mirror) reduce each row of
+// 16 lanes in 4 steps of a few cycles, the four row results meet through v_readlane: ~10x less latency than the six dependent
+// ds_bpermute steps of a __shfl_xor butterfly, which dominated the per-row loss code (8 reductions per sample).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f32<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f32<0x141>(v));     // row_half_mirror
+    v = fmaxf(v, dpp_f32<0x140>(v));     // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Shared forward of one sample by one wave.  s_obs[OD], s_h[HID], s_out[AE] are this wave's LDS slots.
@@ -195,19 +214,50 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
                                                   float* s_d, float* __restrict__ dOut) {
     const int act = L.actions[n];
     const float adv = L.adv[n], ret = L.ret[n];
+    const float old_lp = L.algo == 1 ? L.old_logp[n] : 0.f, old_v = L.algo == 1 ? L.old_value[n] : 0.f;
     const float v = s_out[d.A];
     const float lp_a = s_out[act] - lse;
+    // PPO: this lane's old logits (columns lane, lane + 64, ...) are fetched ONCE, all loads in flight together; the four
+    // passes below then run from registers (columns past 64 * OLR fall back to memory)
+    constexpr int OLR = 8;
+    float olr[OLR];
+#pragma unroll
+    for (int c = 0; c < OLR; ++c) olr[c] = 0.f;
+    if (L.algo == 1) {                      // clamped addresses: unconditional loads issue together
+#pragma unroll
+        for (int c = 0; c < OLR; ++c) olr[c] = L.old_logits[(size_t)n * d.A + min(lane + 64 * c, d.A - 1)];
+    }
     // entropy and (PPO) KL(old || new) need full sums first
     float ent = 0.f, kl = 0.f, old_lse = 0.f;
     if (L.algo == 1) {
         float om = -3.4028235e38f;
-        for (int a = lane; a < d.A; a += 64) om = fmaxf(om, L.old_logits[(size_t)n * d.A + a]);
+#pragma unroll
+        for (int c = 0; c < OLR; ++c)
+            if (lane + 64 * c < d.A) om = fmaxf(om, olr[c]);
+        for (int a = lane + 64 * OLR; a < d.A; a += 64) om = fmaxf(om, L.old_logits[(size_t)n * d.A + a]);
         om = wave_max(om);
         float os = 0.f;
-        for (int a = lane; a < d.A; a += 64) os += expf(L.old_logits[(size_t)n * d.A + a] - om);
+#pragma unroll
+        for (int c = 0; c < OLR; ++c)
+            if (lane + 64 * c < d.A) os += expf(olr[c] - om);
+        for (int a = lane + 64 * OLR; a < d.A; a += 64) os += expf(L.old_logits[(size_t)n * d.A + a] - om);
         old_lse = om + logf(wave_sum(os));
     }
-    for (int a = lane; a < d.A; a += 64) {
+#pragma unroll
+    for (int c = 0; c < OLR; ++c) {
+        const int a = lane + 64 * c;
+        if (a < d.A) {
+            const float lp = s_out[a] - lse;
+            const float p = expf(lp);
+            if (p > 0.f) ent -= p * lp;
+            if (L.algo == 1) {
+                const float olp = olr[c] - old_lse;
+                const float q = expf(olp);
+                if (q > 0.f) kl += q * (olp - lp);
+            }
+        }
+    }
+    for (int a = lane + 64 * OLR; a < d.A; a += 64) {
         const float lp = s_out[a] - lse;
         const float p = expf(lp);
         if (p > 0.f) ent -= p * lp;
@@ -227,12 +277,12 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
         g_lp = -adv;
         g_v = L.vf_coeff * (v - ret);
     } else {
-        const float ratio = expf(lp_a - L.old_logp[n]);
+        const float ratio = expf(lp_a - old_lp);
         const float clipped = fminf(fmaxf(ratio, 1.f - L.clip), 1.f + L.clip);
         const float s1 = adv * ratio, s2 = adv * clipped;
         pi_loss = -fminf(s1, s2);
         g_lp = (s1 <= s2) ? -adv * ratio : 0.f;        // the clipped branch has zero gradient
-        const float pv = L.old_value[n];
+        const float pv = old_v;
         const float l1 = (v - ret) * (v - ret);
         const float vc = pv + fminf(fmaxf(v - pv, -L.vf_clip), L.vf_clip);
         const float l2 = (vc - ret) * (vc - ret);
@@ -243,7 +293,7 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
     g_lp *= L.scale;
     g_v *= L.scale;
     const float ce = L.ent_coeff * L.scale, ck = (L.algo == 1) ? L.kl_coeff * L.scale : 0.f;
-    for (int a = lane; a < d.AE; a += 64) {
+    for (int a = lane, c = 0; a < d.AE; a += 64, ++c) {
         float g;
         if (a < d.A) {
             const float lp = s_out[a] - lse;
@@ -252,8 +302,13 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
             g = g_lp * ((a == act ? 1.f : 0.f) - p);
             if (p > 0.f) g += ce * p * (lp + ent);
             if (L.algo == 1) {
-                const float q = expf(L.old_logits[(size_t)n * d.A + a] - old_lse);
-                g += ck * (p - q);
+                float ol;
+                switch (c) {            // register file is not indexable: select the lane's c-th old logit
+                    case 0: ol = olr[0]; break; case 1: ol = olr[1]; break; case 2: ol = olr[2]; break; case 3: ol = olr[3]; break;
+                    case 4: ol = olr[4]; break; case 5: ol = olr[5]; break; case 6: ol = olr[6]; break; case 7: ol = olr[7]; break;
+                    default: ol = L.old_logits[(size_t)n * d.A + a];
+                }
+                g += ck * (p - expf(ol - old_lse));
             }
         } else {
             g = g_v;
@@ -423,6 +478,327 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     p[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// One PPO SGD pass (all minibatches: forward, loss, backward, gradient reductions, Adam) as ONE persistent kernel.
+// The per-minibatch path above is a chain of 7 small dependent kernels (144 x 7 per pass at RLlib's 256-sample
+// minibatches) and is bound by that serial depth.  Here MB / 32 workgroups of 8 waves stay resident for the whole pass and
+// meet at two grid barriers per minibatch:
+//   phase A  workgroup g owns samples [32g, 32g+32) of the minibatch: obs tile -> LDS, hidden = tanh(obs W1 + b1) and
+//            out = h W2e + b2e on 32x32x2 fp32 MFMA tiles (layer 1 split over K across waves, partials summed in a fixed
+//            order), the A2C/PPO row loss (policy_row_loss, one wave per row), dH = dOut W2e^T (k-permuted so that both
+//            operands read 4 consecutive k per lane), dHpre = dH (1 - h^2); H, dOut, dHpre go to a [MB, .] scratch
+//   barrier
+//   phase B  45 wave-sized tasks over all waves: the 32x32 tiles of dW1 = obs^T dHpre and dW2e = H^T dOut (sample-axis
+//            MFMA reductions as in k_gemm_tn) and the bias column sums, each followed by the Adam update of exactly the
+//            parameters it produced (no separate gradient / Adam kernels, no clip: the caller falls back to the
+//            per-minibatch path when grad_clip > 0)
+//   barrier
+// Grid barrier: monotonically increasing arrival counter, agent-scope release / acquire fences on both sides (the
+// XCDs' L2s are not coherent with each other without them).  Parameters are mutated in-kernel: no const / __restrict__.
+struct PassArgs {
+    PolDims d;
+    int N, MB, rows;
+    float *prm, *am, *av;
+    const float* obs;
+    const uint32_t* mask;
+    LossArgs L;
+    float *H, *dOut, *dHpre;
+    float4* terms;
+    float* grad;
+    unsigned* bar;
+    float lr, b1, b2, eps;
+    long long t0;
+    unsigned long long* trace;
+};
+
+#ifdef RL4RS_PASS_TRACE     // s_memtime marks of workgroup 0 / wave 0 in minibatch 10 (timing experiments)
+#define RL4RS_PT(k) do { if (a.trace && blockIdx.x == 0 && tid == 0 && mb == 10) a.trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RL4RS_PT(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen) {
+    __syncthreads();            // every wave's stores have been acknowledged by L2 (s_waitcnt vmcnt(0) before s_barrier)
+    gen += 1;
+    if (threadIdx.x == 0) {
+        // release: write this XCD's dirty L2 lines back; acquire: drop stale L2 lines and this CU's L1 (cache-wide operations,
+        // one thread per workgroup is enough)
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * nwg;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void adam_elem(float* p, float* m, float* v, float g, float lr_t, float b1, float b2, float eps) {
+    const float mi = b1 * *m + (1.f - b1) * g;
+    const float vi = b2 * *v + (1.f - b2) * g * g;
+    *m = mi;
+    *v = vi;
+    *p -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PolDims d = a.d;
+    const int OD = d.OD, HID = d.HID, AE = d.AE, MB = a.MB;
+    const int SO = OD | 1, SH = HID | 1, SA = AE | 1;               // odd row strides: conflict-free column walks
+    float* s_obs = reinterpret_cast<float*>(smem);                   // [32][SO]
+    float* s_h = s_obs + 32 * SO;                                    // [32][SH]
+    float* s_out = s_h + 32 * SH;                                    // [32][SA]  (scratch for the dH partials afterwards)
+    float* s_d = s_out + 32 * SA;                                    // [32][SA]  (scratch for the layer-1 partials before)
+    float* s_old = s_d + 32 * SA;                                    // [32][A]   old logits of the tile's rows
+    float* s_sc = s_old + 32 * d.A;                                  // [5][32]   action (as int), adv, ret, old logp, old value
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    float* W1 = a.prm;
+    float* b1p = W1 + (size_t)OD * HID;
+    float* W2 = b1p + HID;
+    float* b2p = W2 + (size_t)HID * AE;
+    const int NT1 = HID / 32, NT2 = (AE + 31) / 32, parts = 8 / NT1;
+    const int R = a.rows;                    // samples of this workgroup (8, 16 or 32): rows R..31 of every MFMA tile are idle
+    const int r0 = blockIdx.x * R;
+    const int nmb = a.N / MB;
+    unsigned gen = 0;
+    for (int mb = 0; mb < nmb; ++mb) {
+        const size_t lo = (size_t)mb * MB;
+        // ------------------------------------------------------------------ phase A
+        RL4RS_PT(0);
+        for (int i0 = tid; i0 < R * OD; i0 += 512 * 16) {               // 16 loads in flight per thread and trip
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = a.obs[(lo + r0) * OD + min(i0 + 512 * u, R * OD - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = i0 + 512 * u;
+                if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = x[u];
+            }
+        }
+        // the row-loss inputs do not depend on the parameters: staged here, in one round trip with the observations
+        for (int i0 = tid; i0 < R * d.A; i0 += 512 * 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = a.L.old_logits[(lo + r0) * d.A + min(i0 + 512 * u, R * d.A - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (i0 + 512 * u < R * d.A) s_old[i0 + 512 * u] = x[u];
+        }
+        if (tid < R) {
+            reinterpret_cast<int32_t*>(s_sc)[tid] = a.L.actions[lo + r0 + tid];
+            s_sc[32 + tid] = a.L.adv[lo + r0 + tid];
+            s_sc[64 + tid] = a.L.ret[lo + r0 + tid];
+            s_sc[96 + tid] = a.L.old_logp[lo + r0 + tid];
+            s_sc[128 + tid] = a.L.old_value[lo + r0 + tid];
+        }
+        __syncthreads();
+        RL4RS_PT(1);
+        {   // layer 1, split over K: wave -> (tile t, part q)
+            const int t = wave % NT1, q = wave / NT1, kper = OD / parts;
+            f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int k = q * kper; k < (q + 1) * kper; k += 32) {
+                float bv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bv[u] = W1[(size_t)(k + 2 * u + half) * HID + t * 32 + li];      // kper % 32 == 0
+                __builtin_amdgcn_sched_barrier(0);      // all loads of the trip in flight before the first MFMA
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_obs[li * SO + k + 2 * u + half], bv[u], acc, 0, 0, 0);
+            }
+            float* part = s_d + (size_t)(t * parts + q) * 1024;
+            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+        }
+        __syncthreads();
+        for (int i = tid; i < R * HID; i += 512) {
+            const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
+            float s = b1p[j];
+            for (int q = 0; q < parts; ++q) s += s_d[(size_t)(t * parts + q) * 1024 + r * 32 + c];
+            const float h = tanhf(s);
+            s_h[r * SH + j] = h;
+            a.H[(size_t)(r0 + r) * HID + j] = h;
+        }
+        __syncthreads();
+        RL4RS_PT(2);
+        for (int t = wave; t < NT2; t += 8) {   // layer 2 (+ action mask)
+            const int col = t * 32 + li;
+            const bool c_ok = col < AE;
+            const int colc = c_ok ? col : AE - 1;          // clamped: the loads stay unconditional and issue together
+            f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int k = 0; k < HID; k += 32) {
+                float bv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) bv[u] = W2[(size_t)(k + 2 * u + half) * AE + colc];              // HID % 32 == 0
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_h[li * SH + k + 2 * u + half], bv[u], acc, 0, 0, 0);
+            }
+            {
+                const float bias = b2p[colc];
+                uint32_t mw[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mw[r] = a.mask ? a.mask[(lo + r0 + min((r & 3) + 8 * (r >> 2) + 4 * half, R - 1)) * d.W + (colc >> 5)] : 0xffffffffu;
+                if (c_ok)
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v = acc[r] + bias;
+                        if (col < d.A && !((mw[r] >> (col & 31)) & 1u)) v = v + (-3.4028235e38f);
+                        if (row < R) s_out[row * SA + col] = v;
+                    }
+            }
+        }
+        __syncthreads();
+        RL4RS_PT(3);
+        {   // row losses: wave w takes rows 4w .. 4w+3
+            LossArgs L = a.L;                      // inputs from the LDS copies, indexed by the row within the tile
+            L.actions = reinterpret_cast<const int32_t*>(s_sc); L.adv = s_sc + 32; L.ret = s_sc + 64; L.old_logp = s_sc + 96;
+            L.old_value = s_sc + 128; L.old_logits = s_old;
+            for (int row = wave; row < R; row += 8) {
+                const float* so = s_out + row * SA;
+                float mx = -3.4028235e38f;
+                for (int c = lane; c < d.A; c += 64) mx = fmaxf(mx, so[c]);
+                mx = wave_max(mx);
+                float se = 0.f;
+                for (int c = lane; c < d.A; c += 64) se += expf(so[c] - mx);
+                const float lse = mx + logf(wave_sum(se));
+                const float4 tm = policy_row_loss(d, L, so, lse, row, lane, s_d + row * SA, a.dOut + (size_t)r0 * AE);
+                if (lane == 0) a.terms[r0 + row] = tm;
+                if (row == 0) RL4RS_PT(11);
+            }
+        }
+        __syncthreads();
+        RL4RS_PT(4);
+        {   // dH = dOut W2e^T, split over K in blocks of 8: wave -> (tile t, part q); lane half h reads k0 + 4h .. 4h+3
+            const int t = wave % NT1, q = wave / NT1;
+            const int nblk = (AE + 7) / 8, bper = (nblk + parts - 1) / parts;
+            f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* wrow = W2 + (size_t)(t * 32 + li) * AE;
+            const float* drow = s_d + li * SA;
+            const int blk_hi = min((q + 1) * bper, nblk);
+            for (int blk = q * bper; blk < blk_hi; blk += 4) {           // 16 loads in flight per trip
+                float wv[16], dv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = (blk + (u >> 2)) * 8 + 4 * half + (u & 3);
+                    const bool ok = (blk + (u >> 2)) < blk_hi && k < AE;
+                    const int kc = k < AE ? k : AE - 1;
+                    wv[u] = wrow[kc];
+                    dv[u] = ok ? drow[kc] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], wv[u], acc, 0, 0, 0);
+            }
+            float* part = s_out + (size_t)(t * parts + q) * 1024;
+            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+        }
+        __syncthreads();
+        for (int i = tid; i < R * HID; i += 512) {
+            const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
+            float s = 0.f;
+            for (int q = 0; q < parts; ++q) s += s_out[(size_t)(t * parts + q) * 1024 + r * 32 + c];
+            const float h = s_h[r * SH + j];
+            a.dHpre[(size_t)(r0 + r) * HID + j] = s * (1.f - h * h);
+        }
+        RL4RS_PT(5);
+        grid_barrier(a.bar, gridDim.x, gen);
+        RL4RS_PT(6);
+        // ------------------------------------------------------------------ phase B
+        {
+            const double tt = (double)(a.t0 + mb + 1);
+            const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, tt)) / (1.0 - pow((double)a.b1, tt)));
+            RL4RS_PT(10);
+            const int n_t1 = (OD / 32) * NT1, n_t2 = NT1 * NT2, total = n_t1 + n_t2 + NT1 + NT2;
+            const float* obs_mb = a.obs + lo * OD;
+            for (int task = blockIdx.x * 8 + wave; task < total; task += gridDim.x * 8) {
+                if (task < n_t1 + n_t2) {
+                    // 32x32 tile of A^T B over the MB samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut
+                    const bool first = task < n_t1;
+                    const int tl = first ? task : task - n_t1;
+                    const int tn_n = first ? NT1 : NT2;
+                    const int tm = tl / tn_n, tn = tl - tm * tn_n;
+                    const float* A = first ? obs_mb : a.H;
+                    const float* B = first ? a.dHpre : a.dOut;
+                    const int lda = first ? OD : HID, ldb = first ? HID : AE, Nc = first ? HID : AE;
+                    const int m = tm * 32 + li, j = tn * 32 + li;
+                    const bool j_ok = j < Nc;
+                    const int jc = j_ok ? j : Nc - 1;
+                    f32x16 acc;
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    for (int n = 0; n < MB; n += 32) {
+                        float av[16], bv[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int nn = n + 2 * u + half;
+                            av[u] = A[(size_t)nn * lda + m];
+                            bv[u] = B[(size_t)nn * ldb + jc];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+                    }
+                    RL4RS_PT(9);
+                    if (j_ok) {
+                        const size_t base = first ? 0 : (size_t)OD * HID + HID;
+                        // loads of all 16 elements first: the three arrays may alias as far as the compiler knows, so an
+                        // element-by-element update is 16 dependent memory round trips
+                        float pp[16], mm[16], vv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const size_t idx = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
+                            pp[r] = a.prm[idx]; mm[r] = a.am[idx]; vv[r] = a.av[idx];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const size_t idx = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
+                            const float g = acc[r];
+                            const float mi = a.b1 * mm[r] + (1.f - a.b1) * g;
+                            const float vi = a.b2 * vv[r] + (1.f - a.b2) * g * g;
+                            a.grad[idx] = g;
+                            a.am[idx] = mi;
+                            a.av[idx] = vi;
+                            a.prm[idx] = pp[r] - lr_t * mi / (sqrtf(vi) + a.eps);
+                        }
+                    }
+                } else {
+                    // bias column sums: lanes = 32 columns x 2 sample parities
+                    const int tl = task - n_t1 - n_t2;
+                    const bool first = tl < NT1;
+                    const int tn = first ? tl : tl - NT1;
+                    const float* X = first ? a.dHpre : a.dOut;
+                    const int ld = first ? HID : AE, Nc = ld;
+                    const int j = tn * 32 + li;
+                    float s = 0.f;
+                    const int jc = j < Nc ? j : Nc - 1;
+                    for (int n = half; n < MB; n += 32) {               // 16 loads in flight per trip (MB % 32 == 0)
+                        float x[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) x[u] = X[(size_t)(n + 2 * u) * ld + jc];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) s += x[u];
+                    }
+                    s += __shfl_xor(s, 32);
+                    if (j < Nc && half == 0) {
+                        const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
+                        a.grad[idx] = s;
+                        adam_elem(a.prm + idx, a.am + idx, a.av + idx, s, lr_t, a.b1, a.b2, a.eps);
+                    }
+                }
+            }
+        }
+        RL4RS_PT(7);
+        grid_barrier(a.bar, gridDim.x, gen);
+        RL4RS_PT(8);
+    }
+}
+
 }  // namespace rl4rs
 
 using namespace rl4rs;
@@ -433,8 +809,9 @@ struct rl4rs_policy {
     float *params, *adam_m, *adam_v;
     float *H, *dOut, *dHpre, *part, *sumsq;
     float4* terms;
+    unsigned* bar;
     int64_t adam_t;
-    bool train_attr;
+    bool train_attr, pass_attr;
     std::vector<void*> owned;
 };
 
@@ -460,6 +837,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->nz = (max_rows + p->chunk - 1) / p->chunk;
     p->adam_t = 0;
     p->train_attr = false;
+    p->pass_attr = false;
     int rc;
     auto alloc = [&](float** dst, size_t n) {
         int r = dev_alloc(dst, n);
@@ -475,6 +853,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     size_t part_n = (size_t)p->nz * ((size_t)obs_dim * hidden > (size_t)hidden * p->d.AE ? (size_t)obs_dim * hidden : (size_t)hidden * p->d.AE);
     if ((rc = alloc(&p->part, part_n))) return rc;
     if ((rc = alloc(&p->sumsq, 4))) return rc;
+    { float* b4; if ((rc = alloc(&b4, 4))) return rc; p->bar = reinterpret_cast<unsigned*>(b4); }
     float* t4;
     if ((rc = alloc(&t4, (size_t)max_rows * 4))) return rc;
     p->terms = reinterpret_cast<float4*>(t4);
@@ -744,6 +1123,61 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
     RL4RS_REQUIRE(minibatch > 0 && N >= minibatch && minibatch <= p->max_rows,
                   "policy_ppo_epoch: bad sizes (N=%d, minibatch=%d, max_rows=%d)", N, minibatch, p->max_rows);
     const PolDims& d = p->d;
+    // fused persistent pass (k_ppo_pass) when the shapes fit its tiling and no global-norm clip is asked for
+    const int NT1 = d.HID / 32;
+    const size_t pass_smem = (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5) * 4;
+    // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
+    // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
+    static const int rows_env = getenv("RL4RS_PPO_ROWS") ? atoi(getenv("RL4RS_PPO_ROWS")) : 8;
+    const int pass_rows = (rows_env == 32 || rows_env == 16) ? rows_env : 8;
+    static const bool no_fused = getenv("RL4RS_PPO_FUSED") && atoi(getenv("RL4RS_PPO_FUSED")) == 0;     // A/B measurements
+    const bool fused = !no_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
+                       d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 32 == 0 && minibatch % 32 == 0 && minibatch / pass_rows <= 128 &&
+                       (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && pass_smem <= (size_t)160 * 1024;
+    if (fused) {
+        hipStream_t st = (hipStream_t)stream;
+        if (!p->pass_attr) {
+            RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024));
+            p->pass_attr = true;
+        }
+        PassArgs a;
+        a.d = d; a.N = N; a.MB = minibatch;
+        a.rows = pass_rows;
+        a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v;
+        a.obs = obs; a.mask = mask_bits;
+        a.L.algo = 1; a.L.vf_coeff = vf_coeff; a.L.ent_coeff = ent_coeff; a.L.clip = clip; a.L.vf_clip = vf_clip; a.L.kl_coeff = kl_coeff;
+        a.L.scale = 1.0f / (float)minibatch;
+        a.L.actions = actions; a.L.adv = adv; a.L.ret = ret; a.L.old_logp = old_logp; a.L.old_value = old_value; a.L.old_logits = old_logits;
+        a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms; a.grad = grad_dev; a.bar = p->bar;
+        a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.t0 = p->adam_t;
+        a.trace = nullptr;
+#ifdef RL4RS_PASS_TRACE
+        static unsigned long long* trace_buf = nullptr;
+        if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 16 * 8);
+        a.trace = trace_buf;
+#endif
+        RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
+        hipLaunchKernelGGL(k_ppo_pass, dim3(minibatch / pass_rows), dim3(512), pass_smem, st, a);
+        RL4RS_LAUNCH_CHECK();
+        p->adam_t += N / minibatch;
+#ifdef RL4RS_PASS_TRACE
+        {
+            unsigned long long h[16];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
+            static const char* nm[] = {"stage", "layer1", "layer2", "loss", "dH", "barrier1", "phaseB", "barrier2"};
+            for (int k = 0; k < 8; ++k) fprintf(stderr, "  %-14s %8.2f us\n", nm[k], (double)(h[k + 1] - h[k]) / 2400.0);   // core clocks at ~2.4 GHz
+            fprintf(stderr, "  lr_t %.2f  tile-loop %.2f  adam %.2f | first loss row %.2f\n", (double)(h[10] - h[6]) / 2400.0,
+                    (double)(h[9] - h[10]) / 2400.0, (double)(h[7] - h[9]) / 2400.0, (double)(h[11] - h[3]) / 2400.0);
+        }
+#endif
+        if (stats_dev) {
+            hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms, minibatch, stats_dev);
+            RL4RS_LAUNCH_CHECK();
+        }
+        return RL4RS_OK;
+    }
     for (int lo = 0; lo + minibatch <= N; lo += minibatch) {
         const bool last = lo + 2 * minibatch > N;
         int rc = rl4rs_policy_loss_grad(p, 1, minibatch, obs + (size_t)lo * d.OD, mask_bits ? mask_bits + (size_t)lo * d.W : nullptr,

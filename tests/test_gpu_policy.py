@@ -113,7 +113,10 @@ def test_loss_gradients_match_autograd(algo):
 
 
 def test_ppo_epoch_equals_minibatch_sequence():
-    """rl4rs_policy_ppo_epoch == loss_grad + adam_step per minibatch, bit for bit (trailing rows dropped)."""
+    """rl4rs_policy_ppo_epoch (one persistent kernel for the whole pass, k_ppo_pass) == loss_grad + adam_step per minibatch
+    (trailing rows dropped).  The fused pass sums its MFMA tiles in another order than the per-minibatch kernels, so the
+    comparison is numerical: Adam turns a gradient into ~lr * sign-like steps, hence entries whose gradient is at rounding
+    level may differ by up to lr per step; everything else must agree to 2e-5."""
     import torch
     from rl4rs_amd.device import DevicePolicy
     from rl4rs_amd.nets.policy import init_policy_params
@@ -140,8 +143,14 @@ def test_ppo_epoch_equals_minibatch_sequence():
                                  old_value=ov[lo:hi], old_logits=ol[lo:hi], **kw)
         p1.adam_step(g, lr=1e-3)
     stats2 = p2.ppo_epoch(o, a, adv, ret, b, olp, ov, ol, minibatch=MB, lr=1e-3, **kw)
-    assert torch.equal(p1.params(), p2.params())
-    assert torch.equal(stats1, stats2)
+    w1, w2 = p1.params().cpu().numpy().astype(np.float64), p2.params().cpu().numpy().astype(np.float64)
+    diff = np.abs(w1 - w2)
+    steps = N // MB
+    assert (diff < 2e-5).mean() > 0.999, (diff < 2e-5).mean()
+    assert diff.max() <= 2 * steps * 1e-3, diff.max()
+    moved = np.abs(w1 - flat.astype(np.float64))
+    assert np.median(diff[moved > 1e-4]) < 1e-6
+    assert np.allclose(stats1.cpu().numpy(), stats2.cpu().numpy(), rtol=2e-3, atol=1e-4), (stats1, stats2)
     assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
 
 
