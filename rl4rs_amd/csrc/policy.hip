@@ -500,6 +500,7 @@ struct PassArgs {
     PolDims d;
     int N, MB, rows;
     float *prm, *am, *av;
+    float* w2t;              // [AE, HID] transposed copy of W2e, kept current by the Adam updates (coalesced dH operand)
     const float* obs;
     const uint32_t* mask;
     LossArgs L;
@@ -518,16 +519,22 @@ struct PassArgs {
 #define RL4RS_PT(k) do { } while (0)
 #endif
 
+// Grid barrier (all workgroups resident): monotonically increasing arrival counter.  Producer side: every wave drains its
+// stores, lane 0 writes the XCD's dirty L2 lines back (agent release), and - the compiler may drop the wait that belongs to the
+// release when it believes nothing is outstanding - an explicit s_waitcnt before the RELAXED arrival, so the counter cannot
+// overtake the write-back.  Consumer side: relaxed polling, ONE agent acquire (invalidates this CU's L1), workgroup barrier,
+// then plain loads.
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen) {
-    __syncthreads();            // every wave's stores have been acknowledged by L2 (s_waitcnt vmcnt(0) before s_barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     gen += 1;
     if (threadIdx.x == 0) {
-        // release: write this XCD's dirty L2 lines back; acquire: drop stale L2 lines and this CU's L1 (cache-wide operations,
-        // one thread per workgroup is enough)
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -551,6 +558,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     float* s_d = s_out + 32 * SA;                                    // [32][SA]  (scratch for the layer-1 partials before)
     float* s_old = s_d + 32 * SA;                                    // [32][A]   old logits of the tile's rows
     float* s_sc = s_old + 32 * d.A;                                  // [5][32]   action (as int), adv, ret, old logp, old value
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_sc + 5 * 32);   // [32][W]   action-mask words of the tile's rows
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
     float* W1 = a.prm;
     float* b1p = W1 + (size_t)OD * HID;
@@ -561,6 +569,11 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     const int r0 = blockIdx.x * R;
     const int nmb = a.N / MB;
     unsigned gen = 0;
+    for (int i = blockIdx.x * 512 + tid; i < HID * AE; i += gridDim.x * 512) {
+        const int j = i / AE, c = i - j * AE;
+        a.w2t[(size_t)c * HID + j] = W2[i];
+    }
+    grid_barrier(a.bar, gridDim.x, gen);
     for (int mb = 0; mb < nmb; ++mb) {
         const size_t lo = (size_t)mb * MB;
         // ------------------------------------------------------------------ phase A
@@ -586,6 +599,8 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             for (int u = 0; u < 16; ++u)
                 if (i0 + 512 * u < R * d.A) s_old[i0 + 512 * u] = x[u];
         }
+        if (a.mask)
+            for (int i = tid; i < R * d.W; i += 512) s_mask[i] = a.mask[(lo + r0) * d.W + i];
         if (tid < R) {
             reinterpret_cast<int32_t*>(s_sc)[tid] = a.L.actions[lo + r0 + tid];
             s_sc[32 + tid] = a.L.adv[lo + r0 + tid];
@@ -599,13 +614,13 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             const int t = wave % NT1, q = wave / NT1, kper = OD / parts;
             f32x16 acc;
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int k = q * kper; k < (q + 1) * kper; k += 32) {
-                float bv[16];
+            for (int k = q * kper; k < (q + 1) * kper; k += 64) {       // one memory round trip per 64 k (kper % 64 == 0)
+                float bv[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) bv[u] = W1[(size_t)(k + 2 * u + half) * HID + t * 32 + li];      // kper % 32 == 0
+                for (int u = 0; u < 32; ++u) bv[u] = W1[(size_t)(k + 2 * u + half) * HID + t * 32 + li];
                 __builtin_amdgcn_sched_barrier(0);      // all loads of the trip in flight before the first MFMA
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 32; ++u)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_obs[li * SO + k + 2 * u + half], bv[u], acc, 0, 0, 0);
             }
             float* part = s_d + (size_t)(t * parts + q) * 1024;
@@ -622,33 +637,32 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         }
         __syncthreads();
         RL4RS_PT(2);
-        for (int t = wave; t < NT2; t += 8) {   // layer 2 (+ action mask)
+        for (int t = wave; t < NT2; t += 8) {   // layer 2 (+ action mask): one memory round trip per tile and 64 k
             const int col = t * 32 + li;
             const bool c_ok = col < AE;
             const int colc = c_ok ? col : AE - 1;          // clamped: the loads stay unconditional and issue together
             f32x16 acc;
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int k = 0; k < HID; k += 32) {
-                float bv[16];
+            for (int k = 0; k < HID; k += 64) {            // HID % 64 == 0
+                float bv[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) bv[u] = W2[(size_t)(k + 2 * u + half) * AE + colc];              // HID % 32 == 0
+                for (int u = 0; u < 32; ++u) bv[u] = W2[(size_t)(k + 2 * u + half) * AE + colc];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 32; ++u)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_h[li * SH + k + 2 * u + half], bv[u], acc, 0, 0, 0);
             }
             {
                 const float bias = b2p[colc];
-                uint32_t mw[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    mw[r] = a.mask ? a.mask[(lo + r0 + min((r & 3) + 8 * (r >> 2) + 4 * half, R - 1)) * d.W + (colc >> 5)] : 0xffffffffu;
                 if (c_ok)
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v = acc[r] + bias;
-                        if (col < d.A && !((mw[r] >> (col & 31)) & 1u)) v = v + (-3.4028235e38f);
-                        if (row < R) s_out[row * SA + col] = v;
+                        if (row < R) {
+                            float v = acc[r] + bias;
+                            const uint32_t mw = a.mask ? s_mask[row * d.W + (colc >> 5)] : 0xffffffffu;
+                            if (col < d.A && !((mw >> (col & 31)) & 1u)) v = v + (-3.4028235e38f);
+                            s_out[row * SA + col] = v;
+                        }
                     }
             }
         }
@@ -673,32 +687,30 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         }
         __syncthreads();
         RL4RS_PT(4);
-        {   // dH = dOut W2e^T, split over K in blocks of 8: wave -> (tile t, part q); lane half h reads k0 + 4h .. 4h+3
+        {   // dH = dOut W2e^T, split over K: wave -> (tile t, part q); the B operand comes from the transposed copy (coalesced)
             const int t = wave % NT1, q = wave / NT1;
-            const int nblk = (AE + 7) / 8, bper = (nblk + parts - 1) / parts;
+            const int kper = ((AE + parts - 1) / parts + 1) & ~1;      // even number of k per part
             f32x16 acc;
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* wrow = W2 + (size_t)(t * 32 + li) * AE;
             const float* drow = s_d + li * SA;
-            const int blk_hi = min((q + 1) * bper, nblk);
-            for (int blk = q * bper; blk < blk_hi; blk += 4) {           // 16 loads in flight per trip
-                float wv[16], dv[16];
+            const int k_hi = min((q + 1) * kper, AE);
+            for (int k = q * kper; k < k_hi; k += 72) {                 // 36 loads in flight per trip (one trip for AE <= 288)
+                float wv[36];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int k = (blk + (u >> 2)) * 8 + 4 * half + (u & 3);
-                    const bool ok = (blk + (u >> 2)) < blk_hi && k < AE;
-                    const int kc = k < AE ? k : AE - 1;
-                    wv[u] = wrow[kc];
-                    dv[u] = ok ? drow[kc] : 0.f;
-                }
+                for (int u = 0; u < 36; ++u) wv[u] = a.w2t[(size_t)min(k + 2 * u + half, AE - 1) * HID + t * 32 + li];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], wv[u], acc, 0, 0, 0);
+                for (int u = 0; u < 36; ++u) {
+                    const int kk = k + 2 * u + half;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk < k_hi ? drow[min(kk, AE - 1)] : 0.f, wv[u], acc, 0, 0, 0);
+                }
             }
+            RL4RS_PT(12);
             float* part = s_out + (size_t)(t * parts + q) * 1024;
             for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
         }
         __syncthreads();
+        RL4RS_PT(13);
         for (int i = tid; i < R * HID; i += 512) {
             const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
             float s = 0.f;
@@ -710,28 +722,46 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         grid_barrier(a.bar, gridDim.x, gen);
         RL4RS_PT(6);
         // ------------------------------------------------------------------ phase B
+        // One task = one 32x32 gradient tile (or 32 bias columns) + the Adam update of its parameters, done by a GROUP of 4
+        // waves of one workgroup: each wave reduces a quarter of the minibatch's samples (MB / 4, two trips of 16 sample
+        // pairs), the four partials meet in LDS and are summed in a fixed order, then each wave updates a quarter of the
+        // tile's parameters.
         {
             const double tt = (double)(a.t0 + mb + 1);
             const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, tt)) / (1.0 - pow((double)a.b1, tt)));
             RL4RS_PT(10);
             const int n_t1 = (OD / 32) * NT1, n_t2 = NT1 * NT2, total = n_t1 + n_t2 + NT1 + NT2;
             const float* obs_mb = a.obs + lo * OD;
-            for (int task = blockIdx.x * 8 + wave; task < total; task += gridDim.x * 8) {
-                if (task < n_t1 + n_t2) {
-                    // 32x32 tile of A^T B over the MB samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut
-                    const bool first = task < n_t1;
+            const int grp = wave >> 2, q = wave & 3, spq = MB / 4;        // group of the wave, its sample quarter
+            float* s_part = s_obs + (size_t)grp * 4 * 1024;               // [4 quarters][32 x 32] per group (s_obs is free here)
+            for (int t0 = 0; t0 < total; t0 += gridDim.x * 2) {           // uniform trip count: the barriers below are workgroup-wide
+                const int task = t0 + blockIdx.x * 2 + grp;
+                const bool live = task < total;
+                const bool is_tile = task < n_t1 + n_t2;
+                const bool first = is_tile ? task < n_t1 : (task - n_t1 - n_t2) < NT1;
+                int tm = 0, tn = 0;
+                if (is_tile) {
                     const int tl = first ? task : task - n_t1;
                     const int tn_n = first ? NT1 : NT2;
-                    const int tm = tl / tn_n, tn = tl - tm * tn_n;
+                    tm = tl / tn_n;
+                    tn = tl - tm * tn_n;
+                } else {
+                    const int tl = task - n_t1 - n_t2;
+                    tn = first ? tl : tl - NT1;
+                }
+                const int Nc = first ? HID : AE;
+                const int j = tn * 32 + li;
+                const bool j_ok = j < Nc;
+                const int jc = j_ok ? j : Nc - 1;
+                if (live && is_tile) {
+                    // quarter of A^T B over the samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut
                     const float* A = first ? obs_mb : a.H;
                     const float* B = first ? a.dHpre : a.dOut;
-                    const int lda = first ? OD : HID, ldb = first ? HID : AE, Nc = first ? HID : AE;
-                    const int m = tm * 32 + li, j = tn * 32 + li;
-                    const bool j_ok = j < Nc;
-                    const int jc = j_ok ? j : Nc - 1;
+                    const int lda = first ? OD : HID, ldb = Nc;
+                    const int m = tm * 32 + li;
                     f32x16 acc;
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    for (int n = 0; n < MB; n += 32) {
+                    for (int n = q * spq; n < (q + 1) * spq; n += 32) {
                         float av[16], bv[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
@@ -743,54 +773,61 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
 #pragma unroll
                         for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
                     }
-                    RL4RS_PT(9);
-                    if (j_ok) {
-                        const size_t base = first ? 0 : (size_t)OD * HID + HID;
-                        // loads of all 16 elements first: the three arrays may alias as far as the compiler knows, so an
-                        // element-by-element update is 16 dependent memory round trips
-                        float pp[16], mm[16], vv[16];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const size_t idx = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
-                            pp[r] = a.prm[idx]; mm[r] = a.am[idx]; vv[r] = a.av[idx];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const size_t idx = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
-                            const float g = acc[r];
-                            const float mi = a.b1 * mm[r] + (1.f - a.b1) * g;
-                            const float vi = a.b2 * vv[r] + (1.f - a.b2) * g * g;
-                            a.grad[idx] = g;
-                            a.am[idx] = mi;
-                            a.av[idx] = vi;
-                            a.prm[idx] = pp[r] - lr_t * mi / (sqrtf(vi) + a.eps);
-                        }
-                    }
-                } else {
-                    // bias column sums: lanes = 32 columns x 2 sample parities
-                    const int tl = task - n_t1 - n_t2;
-                    const bool first = tl < NT1;
-                    const int tn = first ? tl : tl - NT1;
+                    for (int r = 0; r < 16; ++r) s_part[q * 1024 + r * 64 + lane] = acc[r];
+                } else if (live) {
+                    // quarter of the bias column sums: lanes = 32 columns x 2 sample parities
                     const float* X = first ? a.dHpre : a.dOut;
-                    const int ld = first ? HID : AE, Nc = ld;
-                    const int j = tn * 32 + li;
-                    float s = 0.f;
-                    const int jc = j < Nc ? j : Nc - 1;
-                    for (int n = half; n < MB; n += 32) {               // 16 loads in flight per trip (MB % 32 == 0)
+                    float sum = 0.f;
+                    for (int n = q * spq + half; n < (q + 1) * spq; n += 32) {
                         float x[16];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) x[u] = X[(size_t)(n + 2 * u) * ld + jc];
+                        for (int u = 0; u < 16; ++u) x[u] = X[(size_t)(n + 2 * u) * Nc + jc];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) s += x[u];
+                        for (int u = 0; u < 16; ++u) sum += x[u];
                     }
-                    s += __shfl_xor(s, 32);
-                    if (j < Nc && half == 0) {
-                        const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
-                        a.grad[idx] = s;
-                        adam_elem(a.prm + idx, a.am + idx, a.av + idx, s, lr_t, a.b1, a.b2, a.eps);
-                    }
+                    s_part[q * 1024 + lane] = sum;
                 }
+                RL4RS_PT(9);
+                __syncthreads();
+                if (live && is_tile) {
+                    // wave q owns accumulator registers 4q .. 4q+3 of the tile
+                    if (j_ok) {
+                        const size_t base = first ? 0 : (size_t)OD * HID + HID;
+                        size_t idx[4];
+                        float g[4], pp[4], mm[4], vv[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int r = 4 * q + c;
+                            idx[c] = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
+                            pp[c] = a.prm[idx[c]]; mm[c] = a.am[idx[c]]; vv[c] = a.av[idx[c]];
+                            g[c] = ((s_part[r * 64 + lane] + s_part[1024 + r * 64 + lane]) + s_part[2048 + r * 64 + lane]) +
+                                   s_part[3072 + r * 64 + lane];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float mi = a.b1 * mm[c] + (1.f - a.b1) * g[c];
+                            const float vi = a.b2 * vv[c] + (1.f - a.b2) * g[c] * g[c];
+                            a.grad[idx[c]] = g[c];
+                            a.am[idx[c]] = mi;
+                            a.av[idx[c]] = vi;
+                            const float pn = pp[c] - lr_t * mi / (sqrtf(vi) + a.eps);
+                            a.prm[idx[c]] = pn;
+                            if (!first) {
+                                const int r = 4 * q + c;
+                                a.w2t[(size_t)j * HID + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = pn;
+                            }
+                        }
+                    }
+                } else if (live && q == 0 && half == 0 && j_ok) {
+                    float sum = 0.f;
+                    for (int qq = 0; qq < 4; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
+                    const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
+                    a.grad[idx] = sum;
+                    adam_elem(a.prm + idx, a.am + idx, a.av + idx, sum, lr_t, a.b1, a.b2, a.eps);
+                }
+                __syncthreads();                                          // s_part is rewritten by the next trip
             }
         }
         RL4RS_PT(7);
@@ -807,7 +844,7 @@ struct rl4rs_policy {
     PolDims d;
     int max_rows, n_params, nz, chunk;
     float *params, *adam_m, *adam_v;
-    float *H, *dOut, *dHpre, *part, *sumsq;
+    float *H, *dOut, *dHpre, *part, *sumsq, *w2t;
     float4* terms;
     unsigned* bar;
     int64_t adam_t;
@@ -853,6 +890,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     size_t part_n = (size_t)p->nz * ((size_t)obs_dim * hidden > (size_t)hidden * p->d.AE ? (size_t)obs_dim * hidden : (size_t)hidden * p->d.AE);
     if ((rc = alloc(&p->part, part_n))) return rc;
     if ((rc = alloc(&p->sumsq, 4))) return rc;
+    if ((rc = alloc(&p->w2t, (size_t)hidden * p->d.AE))) return rc;
     { float* b4; if ((rc = alloc(&b4, 4))) return rc; p->bar = reinterpret_cast<unsigned*>(b4); }
     float* t4;
     if ((rc = alloc(&t4, (size_t)max_rows * 4))) return rc;
@@ -1125,14 +1163,14 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
     const PolDims& d = p->d;
     // fused persistent pass (k_ppo_pass) when the shapes fit its tiling and no global-norm clip is asked for
     const int NT1 = d.HID / 32;
-    const size_t pass_smem = (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5) * 4;
+    const size_t pass_smem = (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5 + d.W) * 4;
     // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
     // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
     static const int rows_env = getenv("RL4RS_PPO_ROWS") ? atoi(getenv("RL4RS_PPO_ROWS")) : 8;
     const int pass_rows = (rows_env == 32 || rows_env == 16) ? rows_env : 8;
     static const bool no_fused = getenv("RL4RS_PPO_FUSED") && atoi(getenv("RL4RS_PPO_FUSED")) == 0;     // A/B measurements
     const bool fused = !no_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
-                       d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 32 == 0 && minibatch % 32 == 0 && minibatch / pass_rows <= 128 &&
+                       d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0 && d.HID % 64 == 0 && minibatch % 128 == 0 && minibatch / pass_rows <= 128 && (size_t)32 * (d.OD | 1) >= 8192 &&
                        (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && pass_smem <= (size_t)160 * 1024;
     if (fused) {
         hipStream_t st = (hipStream_t)stream;
@@ -1144,7 +1182,7 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
         PassArgs a;
         a.d = d; a.N = N; a.MB = minibatch;
         a.rows = pass_rows;
-        a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v;
+        a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v; a.w2t = p->w2t;
         a.obs = obs; a.mask = mask_bits;
         a.L.algo = 1; a.L.vf_coeff = vf_coeff; a.L.ent_coeff = ent_coeff; a.L.clip = clip; a.L.vf_clip = vf_clip; a.L.kl_coeff = kl_coeff;
         a.L.scale = 1.0f / (float)minibatch;
@@ -1168,6 +1206,8 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
             (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
             static const char* nm[] = {"stage", "layer1", "layer2", "loss", "dH", "barrier1", "phaseB", "barrier2"};
             for (int k = 0; k < 8; ++k) fprintf(stderr, "  %-14s %8.2f us\n", nm[k], (double)(h[k + 1] - h[k]) / 2400.0);   // core clocks at ~2.4 GHz
+            fprintf(stderr, "  dH: mfma %.2f  partial+sync %.2f  combine %.2f\n", (double)(h[12] - h[4]) / 2400.0, (double)(h[13] - h[12]) / 2400.0,
+                    (double)(h[5] - h[13]) / 2400.0);
             fprintf(stderr, "  lr_t %.2f  tile-loop %.2f  adam %.2f | first loss row %.2f\n", (double)(h[10] - h[6]) / 2400.0,
                     (double)(h[9] - h[10]) / 2400.0, (double)(h[7] - h[9]) / 2400.0, (double)(h[11] - h[3]) / 2400.0);
         }

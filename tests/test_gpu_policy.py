@@ -154,6 +154,43 @@ def test_ppo_epoch_equals_minibatch_sequence():
     assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
 
 
+def test_ppo_pass_is_deterministic_over_many_minibatches():
+    """The persistent pass hands activations and parameters between workgroups through two grid barriers per minibatch
+    (cross-XCD L2 write-back / L1 invalidate).  A stale read would be timing dependent, so: two handles, identical state,
+    160 minibatches with other work queued in between - parameters, Adam moments' effect and statistics must be bit-identical,
+    and must also equal a third run made while another stream keeps the chip busy."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    rs = np.random.RandomState(3)
+    N, MB = 160 * 256, 256
+    obs, mask, bits = _data(N, rs)
+    flat = init_policy_params(seed=4)
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    o, b = t(obs), torch.from_numpy(bits).cuda()
+    ref = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+    a, lp, v, ent, lg = ref.act(o, mask_bits=b, seed=5, step=0, want_logits=True)
+    adv, ret = t(rs.randn(N)), t(rs.randn(N) * 20 + 50)
+    outs = []
+    for run in range(3):
+        pol = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+        side = torch.cuda.Stream()
+        if run == 2:                                          # uneven load: a second stream hammers HBM during the pass
+            big = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+            with torch.cuda.stream(side):
+                for _ in range(40):
+                    big.mul_(1.0001)
+        stats = None
+        for _ in range(2):                                     # two consecutive passes (Adam step counter carries over)
+            stats = pol.ppo_epoch(o, a, adv, ret, b, lp, v, lg, minibatch=MB, lr=3e-4)
+        torch.cuda.synchronize()
+        outs.append((pol.params().clone(), stats.clone()))
+    for k in (1, 2):
+        assert torch.equal(outs[0][0], outs[k][0]), 'run %d: parameters differ' % k
+        assert torch.equal(outs[0][1], outs[k][1])
+    assert torch.isfinite(outs[0][0]).all() and not torch.equal(outs[0][0].cpu(), torch.from_numpy(flat))
+
+
 def test_training_loop_runs_and_improves_masked_policy(tmp_path):
     """A2C / PPO iterations over the GPU env: runs, stays finite, never plays a masked action."""
     import torch
