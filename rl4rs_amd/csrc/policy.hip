@@ -533,7 +533,14 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsign
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        // bounded wait (~seconds): if the workgroups are not all resident (a tool that serialises workgroups, a shared GPU)
+        // the pass gives up instead of hanging the device - bar[1] is raised and rl4rs_policy_ppo_epoch reports it
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
+               __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -836,6 +843,181 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// act / evaluate / loss+backward of whole batches on MFMA tiles: the phase-A body of k_ppo_pass as an ordinary kernel, one
+// workgroup of 8 waves per 8 samples (the per-row output / loss code is instruction bound, so one row per wave; the 32-row
+// MFMA tiles stay mostly idle, which is free).  Against the one-wave-per-sample kernels above (every wave streams all
+// 137 KB of weights through L2 and multiplies with scalar FMAs) the weights are read once per 8 samples and the products
+// run on the matrix pipe.  MODE 0 = act (Gumbel-max sample), 1 = evaluate given actions, 2 = training forward + loss +
+// backward to dHpre (needs w2t, the transposed W2e).
+struct TileArgs {
+    PolDims d;
+    int N;
+    const float* prm;
+    const float* w2t;
+    const float* obs;
+    const uint32_t* mask;
+    LossArgs L;
+    uint32_t seed, step;
+    int32_t* actions;
+    float *logp, *value, *entropy, *logits_out;
+    float *H, *dOut, *dHpre;
+    float4* terms;
+};
+
+__global__ void k_w2_transpose(const float* __restrict__ W2, int HID, int AE, float* __restrict__ w2t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HID * AE) return;
+    const int j = i / AE, c = i - j * AE;
+    w2t[(size_t)c * HID + j] = W2[i];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_policy_tile(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PolDims d = a.d;
+    const int OD = d.OD, HID = d.HID, AE = d.AE;
+    constexpr int R = 8;
+    const int SO = OD | 1, SH = HID | 1, SA = AE | 1;
+    float* s_obs = reinterpret_cast<float*>(smem);                   // [R][SO]   (MFMA rows >= R read row R - 1)
+    float* s_h = s_obs + R * SO;                                     // [R][SH]
+    float* s_out = s_h + R * SH;                                     // [R][SA]
+    float* s_d = s_out + R * SA;                                     // [R][SA]   (MODE 2)
+    float* s_scr = s_d + (MODE == 2 ? R * SA : 0);                   // [8][1024] split-K partials
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_scr + 8 * 1024);   // [R][W]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int lr = li < R ? li : R - 1;                              // the LDS row this lane feeds into the A operand
+    const float* W1 = a.prm;
+    const float* b1p = W1 + (size_t)OD * HID;
+    const float* W2 = b1p + HID;
+    const float* b2p = W2 + (size_t)HID * AE;
+    const int NT1 = HID / 32, NT2 = (AE + 31) / 32, parts = 8 / NT1;
+    const int r0 = blockIdx.x * R;
+    const int nrow = min(R, a.N - r0);                               // live rows of this workgroup
+    // stage observations (rows past N repeat the last live row) and mask words
+    for (int i0 = tid; i0 < R * OD; i0 += 512 * 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = min(i0 + 512 * u, R * OD - 1);
+            x[u] = a.obs[(size_t)(r0 + min(i / OD, nrow - 1)) * OD + i % OD];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + 512 * u;
+            if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = x[u];
+        }
+    }
+    if (a.mask)
+        for (int i = tid; i < R * d.W; i += 512) s_mask[i] = a.mask[(size_t)(r0 + min(i / d.W, nrow - 1)) * d.W + i % d.W];
+    __syncthreads();
+    {   // layer 1, split over K: wave -> (tile t, part q)
+        const int t = wave % NT1, q = wave / NT1, kper = OD / parts;
+        f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = q * kper; k < (q + 1) * kper; k += 64) {
+            float bv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) bv[u] = W1[(size_t)(k + 2 * u + half) * HID + t * 32 + li];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_obs[lr * SO + k + 2 * u + half], bv[u], acc, 0, 0, 0);
+        }
+        float* part = s_scr + (size_t)(t * parts + q) * 1024;
+        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < R * HID; i += 512) {
+        const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
+        float sum = b1p[j];
+        for (int q = 0; q < parts; ++q) sum += s_scr[(size_t)(t * parts + q) * 1024 + r * 32 + c];
+        const float h = tanhf(sum);
+        s_h[r * SH + j] = h;
+        if (MODE == 2 && r < nrow) a.H[(size_t)(r0 + r) * HID + j] = h;
+    }
+    __syncthreads();
+    for (int t = wave; t < NT2; t += 8) {   // layer 2 (+ action mask)
+        const int col = t * 32 + li;
+        const bool c_ok = col < AE;
+        const int colc = c_ok ? col : AE - 1;
+        f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = 0; k < HID; k += 64) {
+            float bv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) bv[u] = W2[(size_t)(k + 2 * u + half) * AE + colc];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_h[lr * SH + k + 2 * u + half], bv[u], acc, 0, 0, 0);
+        }
+        const float bias = b2p[colc];
+        if (c_ok)
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < R) {
+                    float v = acc[r] + bias;
+                    const uint32_t mw = a.mask ? s_mask[row * d.W + (colc >> 5)] : 0xffffffffu;
+                    if (col < d.A && !((mw >> (col & 31)) & 1u)) v = v + (-3.4028235e38f);
+                    s_out[row * SA + col] = v;
+                }
+            }
+    }
+    __syncthreads();
+    {   // one row per wave: log-sum-exp, then outputs (act / evaluate) or loss (train)
+        const int row = wave;
+        const float* so = s_out + row * SA;
+        float mx = -3.4028235e38f;
+        for (int c = lane; c < d.A; c += 64) mx = fmaxf(mx, so[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < d.A; c += 64) se += expf(so[c] - mx);
+        const float lse = mx + logf(wave_sum(se));
+        if (MODE != 2) {
+            if (row < nrow)
+                policy_row_outputs<MODE == 0>(d, so, lse, r0 + row, lane, a.seed, a.step, a.actions, a.logp, a.value, a.entropy, a.logits_out);
+            return;
+        }
+        if (row < nrow) {
+            const float4 tm = policy_row_loss(d, a.L, so, lse, r0 + row, lane, s_d + row * SA, a.dOut);
+            if (lane == 0) a.terms[r0 + row] = tm;
+        } else {
+            for (int c = lane; c < AE; c += 64) s_d[row * SA + c] = 0.f;
+        }
+    }
+    __syncthreads();
+    {   // dH = dOut W2e^T, split over K; B operand from the transposed copy (coalesced)
+        const int t = wave % NT1, q = wave / NT1;
+        const int kper = ((AE + parts - 1) / parts + 1) & ~1;
+        f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* drow = s_d + lr * SA;
+        const int k_hi = min((q + 1) * kper, AE);
+        for (int k = q * kper; k < k_hi; k += 72) {
+            float wv[36];
+#pragma unroll
+            for (int u = 0; u < 36; ++u) wv[u] = a.w2t[(size_t)min(k + 2 * u + half, AE - 1) * HID + t * 32 + li];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 36; ++u) {
+                const int kk = k + 2 * u + half;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk < k_hi ? drow[min(kk, AE - 1)] : 0.f, wv[u], acc, 0, 0, 0);
+            }
+        }
+        float* part = s_scr + (size_t)(t * parts + q) * 1024;
+        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < nrow * HID; i += 512) {
+        const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
+        float sum = 0.f;
+        for (int q = 0; q < parts; ++q) sum += s_scr[(size_t)(t * parts + q) * 1024 + r * 32 + c];
+        const float h = s_h[r * SH + j];
+        a.dHpre[(size_t)(r0 + r) * HID + j] = sum * (1.f - h * h);
+    }
+}
+
 }  // namespace rl4rs
 
 using namespace rl4rs;
@@ -848,7 +1030,7 @@ struct rl4rs_policy {
     float4* terms;
     unsigned* bar;
     int64_t adam_t;
-    bool train_attr, pass_attr;
+    bool train_attr, pass_attr, pass_launched, tile_attr[3];
     std::vector<void*> owned;
 };
 
@@ -875,6 +1057,8 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->adam_t = 0;
     p->train_attr = false;
     p->pass_attr = false;
+    p->pass_launched = false;
+    p->tile_attr[0] = p->tile_attr[1] = p->tile_attr[2] = false;
     int rc;
     auto alloc = [&](float** dst, size_t n) {
         int r = dev_alloc(dst, n);
@@ -920,10 +1104,47 @@ int rl4rs_policy_params(rl4rs_policy* p, float** params_dev, int32_t* count) {
 
 static size_t fwd_smem(const PolDims& d, int extra) { return (size_t)4 * (d.OD + d.HID + d.AE + extra) * 4; }
 
+}  // extern "C"
+
+namespace {
+
+// does k_policy_tile's tiling fit this policy?  (RL4RS_POLICY_TILE=0 keeps the one-wave-per-sample kernels: A/B measurements)
+bool tile_fits(const PolDims& d) {
+    static const bool off = getenv("RL4RS_POLICY_TILE") && atoi(getenv("RL4RS_POLICY_TILE")) == 0;
+    const int NT1 = d.HID / 32;
+    return !off && d.HID % 64 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) && d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0;
+}
+size_t tile_smem(const PolDims& d, int mode) {
+    return (size_t)(8 * ((d.OD | 1) + (d.HID | 1) + (mode == 2 ? 2 : 1) * (d.AE | 1) + d.W) + 8 * 1024) * 4;
+}
+template <int MODE>
+int launch_policy_tile(rl4rs_policy* p, const TileArgs& a, hipStream_t st) {
+    const size_t smem = tile_smem(p->d, MODE);
+    if (!p->tile_attr[MODE]) {
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_tile<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)smem));
+        p->tile_attr[MODE] = true;
+    }
+    hipLaunchKernelGGL(k_policy_tile<MODE>, dim3((a.N + 7) / 8), dim3(512), smem, st, a);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int rl4rs_policy_act(rl4rs_policy* p, int32_t N, const float* obs, const uint32_t* mask_bits, uint32_t seed,
                      uint32_t step, int32_t* actions, float* logp, float* value, float* entropy, float* logits,
                      void* stream) {
     RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_act: bad argument");
+    if (tile_fits(p->d)) {
+        TileArgs a;
+        memset(&a, 0, sizeof(a));
+        a.d = p->d; a.N = N; a.prm = p->params; a.obs = obs; a.mask = mask_bits; a.seed = seed; a.step = step;
+        a.actions = actions; a.logp = logp; a.value = value; a.entropy = entropy; a.logits_out = logits;
+        return launch_policy_tile<0>(p, a, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(k_policy_forward<true>, dim3((N + 3) / 4), dim3(256), fwd_smem(p->d, 0), (hipStream_t)stream, p->d,
                        p->params, N, obs, mask_bits, seed, step, actions, logp, value, entropy, logits);
     RL4RS_LAUNCH_CHECK();
@@ -934,6 +1155,13 @@ int rl4rs_policy_evaluate(rl4rs_policy* p, int32_t N, const float* obs, const ui
                           const int32_t* actions, float* logp, float* value, float* entropy, float* logits,
                           void* stream) {
     RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_evaluate: bad argument");
+    if (tile_fits(p->d)) {
+        TileArgs a;
+        memset(&a, 0, sizeof(a));
+        a.d = p->d; a.N = N; a.prm = p->params; a.obs = obs; a.mask = mask_bits;
+        a.actions = const_cast<int32_t*>(actions); a.logp = logp; a.value = value; a.entropy = entropy; a.logits_out = logits;
+        return launch_policy_tile<1>(p, a, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(k_policy_forward<false>, dim3((N + 3) / 4), dim3(256), fwd_smem(p->d, 0), (hipStream_t)stream, p->d,
                        p->params, N, obs, mask_bits, 0u, 0u, const_cast<int32_t*>(actions), logp, value, entropy, logits);
     RL4RS_LAUNCH_CHECK();
@@ -956,13 +1184,25 @@ int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float
     L.actions = actions; L.adv = adv; L.ret = ret; L.old_logp = old_logp; L.old_value = old_value; L.old_logits = old_logits;
     const size_t w2_bytes = (size_t)d.HID * d.AE * 4;
     const int stage_w2 = (fwd_smem(d, d.AE) + w2_bytes <= (size_t)150 * 1024) ? 1 : 0;
-    if (stage_w2 && !p->train_attr) {
+    const bool tiled = tile_fits(d);
+    if (tiled) {
+        hipLaunchKernelGGL(k_w2_transpose, dim3((d.HID * d.AE + 255) / 256), dim3(256), 0, st, p->params + (size_t)d.OD * d.HID + d.HID,
+                           d.HID, d.AE, p->w2t);
+        TileArgs a;
+        memset(&a, 0, sizeof(a));
+        a.d = d; a.N = N; a.prm = p->params; a.w2t = p->w2t; a.obs = obs; a.mask = mask_bits; a.L = L;
+        a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms;
+        int rc = launch_policy_tile<2>(p, a, st);
+        if (rc) return rc;
+    }
+    if (!tiled && stage_w2 && !p->train_attr) {
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_train), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           150 * 1024));
         p->train_attr = true;
     }
-    hipLaunchKernelGGL(k_policy_train, dim3((N + 3) / 4), dim3(256), fwd_smem(d, d.AE) + (stage_w2 ? w2_bytes : 0), st, d, p->params,
-                       N, obs, mask_bits, L, p->H, p->dOut, p->dHpre, p->terms, stage_w2);
+    if (!tiled)
+        hipLaunchKernelGGL(k_policy_train, dim3((N + 3) / 4), dim3(256), fwd_smem(d, d.AE) + (stage_w2 ? w2_bytes : 0), st, d, p->params,
+                           N, obs, mask_bits, L, p->H, p->dOut, p->dHpre, p->terms, stage_w2);
     RL4RS_LAUNCH_CHECK();
     const int nz = (N + p->chunk - 1) / p->chunk;
     float* gW1 = grad_dev;
@@ -1195,7 +1435,18 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
         if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 16 * 8);
         a.trace = trace_buf;
 #endif
-        RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
+        if (p->pass_launched) {        // outcome of the previous pass (it has long finished: this is the next iteration)
+            unsigned flags[2] = {0u, 0u};
+            RL4RS_HIP_TRY(hipMemcpyAsync(flags, p->bar, 8, hipMemcpyDeviceToHost, st));
+            RL4RS_HIP_TRY(hipStreamSynchronize(st));
+            if (flags[1]) {
+                set_error("policy_ppo_epoch: the persistent pass timed out at a grid barrier (workgroups not co-resident); "
+                          "its parameters are invalid - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels");
+                return RL4RS_EHIP;
+            }
+        }
+        p->pass_launched = true;
+        RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 8, st));
         hipLaunchKernelGGL(k_ppo_pass, dim3(minibatch / pass_rows), dim3(512), pass_smem, st, a);
         RL4RS_LAUNCH_CHECK();
         p->adam_t += N / minibatch;
