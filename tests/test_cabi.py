@@ -75,3 +75,14 @@ def test_library_missing_is_an_error(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/librl4rs_hip.so')
     with pytest.raises(_lib.Rl4rsHipError):
         _lib.load()
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/rl4rs_hip.h must compile as C99 on its own (no C++, no torch types)."""
+    import subprocess
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "rl4rs_hip.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-I', inc, str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
