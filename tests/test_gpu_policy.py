@@ -25,7 +25,7 @@ def test_forward_masking_and_sampling():
     from rl4rs_amd.nets.policy import init_policy_params
     from oracle import policy as OP
     rs = np.random.RandomState(0)
-    N = 1000
+    N = 1003                                                 # not a multiple of the 8-row tiles of k_policy_tile
     obs, mask, bits = _data(N, rs)
     flat = init_policy_params(seed=3) + (rs.randn(34973) * 0.05).astype(np.float32)
     pol = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
