@@ -539,7 +539,8 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsign
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
                __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21))     // ~1 us per poll: gives up after a few seconds __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1u << 21))     // ~1 us per poll: gives up after a few seconds
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
