@@ -227,7 +227,7 @@ def main():
                 # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
                 # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 721 / 863 MB)
                 roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
-                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01f_pmc.md fp16x2)"
+                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01f_pmc.md / r01g_pmc.md fp16x2)"
         kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples

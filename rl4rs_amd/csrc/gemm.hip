@@ -50,87 +50,66 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
     // staging map: thread -> (row, 4-float chunk); 128 rows x 8 chunks = 1024 chunks, 4 per thread.
-    // All global loads of a k-tile (4 A chunks + 16 B values per thread) are UNCONDITIONAL - addresses clamped into the
-    // matrix, out-of-range values zeroed by a select afterwards - and are requested one tile ahead: a predicated load is a
-    // branch, and the compiler then waits for every load before it issues the next (the kernel ran at memory latency x 20).
-    const bool fast_a = vec_ok && (K & 3) == 0;
+    // (Measured and reverted: unconditional clamped loads with the B operand prefetched one k-tile ahead in 16 registers -
+    // the loads then issue in batches, but the create-time 100000 x 128 x 384 products ran 8 % SLOWER (144 vs 134 us) and
+    // the training steps that use this kernel did not move; the scorer's GEMMs go through k_gemm_pk.)
     float4 stage[4];
     auto load_tile = [&](int kt) {
-        if (fast_a) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int c = tid + p * 256;
-                const int r = c >> 3, kq = (c & 7) << 2;
-                const int gr = m0 + r, gk = kt * GBK + kq;
-                const float4 v = *reinterpret_cast<const float4*>(A + (size_t)min(gr, M - 1) * lda + min(gk, K - 4));
-                stage[p] = (gr < M && gk < K) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < 4; ++p) {
+            int c = tid + p * 256;
+            int r = c >> 3, kq = (c & 7) << 2;
+            int gr = m0 + r, gk = kt * GBK + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < M) {
+                const float* src = A + (size_t)gr * lda + gk;
+                if (vec_ok && gk + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (gk + 0 < K) v.x = src[0];
+                    if (gk + 1 < K) v.y = src[1];
+                    if (gk + 2 < K) v.z = src[2];
+                    if (gk + 3 < K) v.w = src[3];
+                }
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int c = tid + p * 256;
-                const int r = c >> 3, kq = (c & 7) << 2;
-                const int gr = m0 + r, gk = kt * GBK + kq;
-                const float* src = A + (size_t)min(gr, M - 1) * lda;
-                float4 v;
-                v.x = src[min(gk + 0, K - 1)]; v.y = src[min(gk + 1, K - 1)]; v.z = src[min(gk + 2, K - 1)]; v.w = src[min(gk + 3, K - 1)];
-                const bool ok = gr < M;
-                stage[p] = make_float4(ok && gk + 0 < K ? v.x : 0.f, ok && gk + 1 < K ? v.y : 0.f, ok && gk + 2 < K ? v.z : 0.f,
-                                       ok && gk + 3 < K ? v.w : 0.f);
-            }
+            stage[p] = v;
         }
     };
     auto store_tile = [&](int buf) {
-#pragma unroll
         for (int p = 0; p < 4; ++p) {
             int c = tid + p * 256;
             int r = c >> 3, kq = (c & 7) << 2;
             *reinterpret_cast<float4*>(&As[buf][r][kq]) = stage[p];
         }
     };
-    // this lane's B values of one k-tile: b[kb * 4 + i] = W[kt * 32 + kb * 8 + half * 4 + i][col]
-    const int colc = col_ok ? col : N - 1;
-    auto load_b = [&](int kt, float (&b)[16]) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int gk = kt * GBK + (u >> 2) * 8 + half * 4 + (u & 3);
-            const float v = W[(size_t)min(gk, K - 1) * ldw + colc];
-            b[u] = (col_ok && gk < K) ? v : 0.f;
-        }
-    };
 
     const int nkt = (K + GBK - 1) / GBK;
-    float bcur[16], bnext[16];
     load_tile(0);
-    load_b(0, bcur);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) {
-            load_tile(kt + 1);
-            load_b(kt + 1, bnext);
-        }
+        if (kt + 1 < nkt) load_tile(kt + 1);
         const int arow = wm * 64 + li;
 #pragma unroll
         for (int kb = 0; kb < GBK / 8; ++kb) {
             const int kk = kb * 8 + half * 4;
             float4 a0 = *reinterpret_cast<const float4*>(&As[cur][arow][kk]);
             float4 a1 = *reinterpret_cast<const float4*>(&As[cur][arow + 32][kk]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bcur[kb * 4 + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bcur[kb * 4 + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bcur[kb * 4 + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bcur[kb * 4 + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bcur[kb * 4 + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bcur[kb * 4 + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bcur[kb * 4 + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bcur[kb * 4 + 3], acc1, 0, 0, 0);
-        }
-        if (kt + 1 < nkt) {
-            store_tile(cur ^ 1);
+            const int gk = kt * GBK + kk;
+            float b[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) bcur[u] = bnext[u];
+            for (int i = 0; i < 4; ++i)
+                b[i] = (col_ok && gk + i < K) ? W[(size_t)(gk + i) * ldw + col] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[3], acc1, 0, 0, 0);
         }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
         __syncthreads();
     }
     // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
