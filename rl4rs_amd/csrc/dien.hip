@@ -671,6 +671,135 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// First-layer GRU with the same fp16x2 operand splitting (scorer_mode fp16x2): NH = E = 128, 4 waves, 32 rows per
+// workgroup, wave w owns hidden columns [32w, 32w+32) of r, u, c and h.  At this size nothing has to stream: the gate
+// weights of a wave (2 gates x 8 k-blocks x hi/lo planes = 128 registers) stay in registers for the whole kernel, its
+// candidate weights (16 KB) in LDS, and the input projections come from the per-item table as MFMA C-in (requested a
+// slot or more ahead).  Per step 24 items x 3 v_mfma_f32_32x32x16_f16 = 2.3K cycles of matrix pipe against 12.3K for the
+// exact-fp32 form (k_recur<128, false>), with the same schedule of epilogues: reset gate in the shadow of slot U,
+// update gate in the shadow of slot C, candidate + blend exposed.  h stays in (-1, 1): no range flag needed.
+__global__ __launch_bounds__(256) void k_gru_h16(RecurArgs a) {
+    constexpr int NH = 128, NW = 4, KB = NH / 16, LDP = NH + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* hp_hi = reinterpret_cast<_Float16*>(smem);     // [32][LDP] each
+    _Float16* hp_lo = hp_hi + 32 * LDP;
+    _Float16* rp_hi = hp_lo + 32 * LDP;
+    _Float16* rp_lo = rp_hi + 32 * LDP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, li = lane & 31;
+    const int row0 = blockIdx.x * 32;
+    const int L = a.L, LDT = L + 1;
+    const int col = wave * 32 + li;
+    const int xld4 = (int)a.xld * 4;
+    int32_t* s_ids = reinterpret_cast<int32_t*>(rp_lo + 32 * LDP);                  // [32][LDT]
+    char* lds_wc = smem + ((4 * 32 * LDP * 2 + 32 * LDT * 4 + 15) & ~15) + wave * KB * 2048;     // this wave's [kb][plane][lane][8]
+    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[0]), 0, 2 * NW * KB * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[0]), 0, NW * KB * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[0]), 0, (int)a.xbytes, 0x00020000);
+    const int vl16 = lane * 16;
+
+    for (int i = tid; i < 2 * 32 * LDP; i += 256) hp_hi[i] = (_Float16)0.f;          // hi and lo planes of h
+    for (int i = tid; i < 32 * L; i += 256) {
+        const int r = i / L, t = i - r * L;
+        s_ids[r * LDT + t] = a.ids[(size_t)min(row0 + r, a.n_rows - 1) * L + t];
+    }
+    half8_t wr_h[KB], wr_l[KB], wu_h[KB], wu_l[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        wr_h[kb] = buf_load_h8(rs_wg, vl16, (wave * KB + kb) * 2048);
+        wr_l[kb] = buf_load_h8(rs_wg, vl16, (wave * KB + kb) * 2048 + 1024);
+        wu_h[kb] = buf_load_h8(rs_wg, vl16, ((NW + wave) * KB + kb) * 2048);
+        wu_l[kb] = buf_load_h8(rs_wg, vl16, ((NW + wave) * KB + kb) * 2048 + 1024);
+        *reinterpret_cast<half8_t*>(lds_wc + kb * 2048 + vl16) = buf_load_h8(rs_wc, vl16, (wave * KB + kb) * 2048);
+        *reinterpret_cast<half8_t*>(lds_wc + kb * 2048 + 1024 + vl16) = buf_load_h8(rs_wc, vl16, (wave * KB + kb) * 2048 + 1024);
+    }
+    __syncthreads();
+
+    const int xcol4 = (a.xoff + col) * 4;
+    auto load_x = [&](f32x16& dst, int t, int block) {       // table row of each of the lane's 16 rows -> accumulator (C-in)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dst[r] = buf_load1(rs_x, s_ids[crow(r, half) * LDT + t] * xld4 + xcol4, block * NH * 4);
+    };
+    f32x16 acc_r, acc_u, acc_c, h_own;
+    float ug[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
+    load_x(acc_r, 0, 0);
+    load_x(acc_u, 0, 1);
+    load_x(acc_c, 0, 2);
+    const int aoff = li * LDP + half * 8;
+
+#pragma unroll 1
+    for (int t = 0; t < L; ++t) {
+        // ---- slot R: acc_r += h Wr
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8_t ah = *reinterpret_cast<const half8_t*>(hp_hi + aoff + kb * 16);
+            const half8_t al = *reinterpret_cast<const half8_t*>(hp_lo + aoff + kb * 16);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wr_h[kb], acc_r, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wr_l[kb], acc_r, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wr_h[kb], acc_r, 0, 0, 0);
+        }
+        // ---- slot U: acc_u += h Wu   ||   reset gate: item kb retires accumulator registers 2kb, 2kb + 1
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8_t ah = *reinterpret_cast<const half8_t*>(hp_hi + aoff + kb * 16);
+            const half8_t al = *reinterpret_cast<const half8_t*>(hp_lo + aoff + kb * 16);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wu_h[kb], acc_u, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wu_l[kb], acc_u, 0, 0, 0);
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wu_h[kb], acc_u, 0, 0, 0);
+#pragma unroll
+            for (int r = 2 * kb; r < 2 * kb + 2; ++r) {
+                const float v = gate_sigmoid(acc_r[r]) * h_own[r];
+                const _Float16 vh = (_Float16)v;
+                rp_hi[crow(r, half) * LDP + col] = vh;
+                rp_lo[crow(r, half) * LDP + col] = (_Float16)(v - (float)vh);
+            }
+        }
+        if (t + 1 < L) load_x(acc_r, t + 1, 0);              // next step's r projection into the retired accumulators
+        __syncthreads();
+        // ---- slot C: acc_c += (r*h) Wc (LDS, one item ahead)   ||   update gate
+        half8_t wc_h[2], wc_l[2];
+        wc_h[0] = *reinterpret_cast<const half8_t*>(lds_wc + vl16);
+        wc_l[0] = *reinterpret_cast<const half8_t*>(lds_wc + 1024 + vl16);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int cb = kb & 1, nb = cb ^ 1;
+            if (kb + 1 < KB) {
+                wc_h[nb] = *reinterpret_cast<const half8_t*>(lds_wc + (kb + 1) * 2048 + vl16);
+                wc_l[nb] = *reinterpret_cast<const half8_t*>(lds_wc + (kb + 1) * 2048 + 1024 + vl16);
+            }
+            const half8_t ah = *reinterpret_cast<const half8_t*>(rp_hi + aoff + kb * 16);
+            const half8_t al = *reinterpret_cast<const half8_t*>(rp_lo + aoff + kb * 16);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wc_h[cb], acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wc_l[cb], acc_c, 0, 0, 0);
+            acc_c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wc_h[cb], acc_c, 0, 0, 0);
+            ug[2 * kb] = gate_sigmoid(acc_u[2 * kb]);
+            ug[2 * kb + 1] = gate_sigmoid(acc_u[2 * kb + 1]);
+        }
+        if (t + 1 < L) load_x(acc_u, t + 1, 1);
+        // ---- exposed: candidate, blend, new state planes, h1 cache row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float c = gate_tanh(acc_c[r]);
+            const float hn = __builtin_fmaf(ug[r], h_own[r] - c, c);     // u h + (1-u) c
+            h_own[r] = hn;
+            const _Float16 vh = (_Float16)hn;
+            hp_hi[crow(r, half) * LDP + col] = vh;
+            hp_lo[crow(r, half) * LDP + col] = (_Float16)(hn - (float)vh);
+            if (row0 + crow(r, half) < a.n_rows) {
+                const int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
+                a.out[orow * a.out_ld + a.out_off + col] = hn;
+            }
+        }
+        if (t + 1 < L) load_x(acc_c, t + 1, 2);
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // DIN attention scores (deepctr LocalActivationUnit, att_hidden_units=(64,16), sigmoid, raw scores).
 //   hid1^T [64 units x L steps] = W1d^T (q*h1_t) + qa + AK_t    as 2x2 32x32 MFMA tiles per row
 //   hid2 = sigmoid(hid1 W2 + b2), score = hid2 w3 + b3           in registers (+ one half-wave swap)
@@ -974,6 +1103,9 @@ struct rl4rs_dien {
     float *att_w2[4], *att_b2[4], *att_w3[4], *att_b3[4];
     float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
     float* augru_wc16[4];
+    float* gru_wg16[4];    // first GRU, fp16 hi/lo planes (k_gru_h16)
+    float* gru_wc16[4];
+    bool gru16, gru16_attr;
     bool fp16x2;
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
@@ -1169,6 +1301,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->profiling = false;
     n->fp16x2 = want_fp16x2;
     n->din16 = false;
+    n->gru16 = false;
+    n->gru16_attr = false;
     if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
         float mx = 0.f;
         bool fin = true;
@@ -1182,6 +1316,20 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 fin = fin && v == v; mx = fmaxf(mx, v);
             }
         n->din16 = fin && mx < 6.0e4f && !(getenv("RL4RS_DIN16") && atoi(getenv("RL4RS_DIN16")) == 0);
+        // the first GRU in the same split form: E = 128 only, h-side weights inside fp16 range
+        float gmx = 0.f;
+        bool gfin = true;
+        for (int s = 0; s < c->seq_num && w->gru_gate_w[s] && w->gru_cand_w[s]; ++s) {
+            for (size_t i = 0; i < (size_t)2 * c->emb_size * 2 * c->emb_size; ++i) {
+                const float v = fabsf(w->gru_gate_w[s][i]);
+                gfin = gfin && v == v; gmx = fmaxf(gmx, v);
+            }
+            for (size_t i = 0; i < (size_t)2 * c->emb_size * c->emb_size; ++i) {
+                const float v = fabsf(w->gru_cand_w[s][i]);
+                gfin = gfin && v == v; gmx = fmaxf(gmx, v);
+            }
+        }
+        n->gru16 = c->emb_size == 128 && gfin && gmx < 6.0e4f && !(getenv("RL4RS_GRU16") && atoi(getenv("RL4RS_GRU16")) == 0);
     }
     {
         float* f = nullptr;
@@ -1246,6 +1394,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         UP(gru_wg[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w->gru_cand_w[s], E, E, E, E));
         UP(gru_wc[s], keep.back().data(), keep.back().size());
+        n->gru_wg16[s] = n->gru_wc16[s] = nullptr;
+        if (n->gru16) {
+            keep.push_back(pack_frag_h16(w->gru_gate_w[s], 2 * E, E, E, 2 * E));
+            UP(gru_wg16[s], keep.back().data(), keep.back().size());
+            keep.push_back(pack_frag_h16(w->gru_cand_w[s], E, E, E, E));
+            UP(gru_wc16[s], keep.back().data(), keep.back().size());
+        }
         // ---- projections of h1: [W1b - W1c | augru gate x-side | augru cand x-side], bias [b1 | bg | bc]
         std::vector<float> wp((size_t)E * PLD), bp(PLD), wac((size_t)E * ATT_H1);
         const float* w1 = w->att_w1[s];    // rows: q [0,E) | k [E,2E) | q-k [2E,3E) | q*k [3E,4E)
@@ -1354,8 +1509,19 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
         a.ids = ids; a.slots = nullptr; a.slots_stride = 0;
         a.wg[0] = n->gru_wg[s]; a.wc[0] = n->gru_wc[s]; a.att = nullptr; a.att_stride = 0;
         a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.out_seq_off = 0; a.slot_base = slot_base;
-        size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
-        hipLaunchKernelGGL((k_recur<128, false, GRU_U>), dim3((cnt + 31) / 32, 1), dim3(256), smem, st, a);
+        if (n->gru16) {
+            a.wg[0] = n->gru_wg16[s]; a.wc[0] = n->gru_wc16[s];
+            const size_t smem16 = (((size_t)4 * 32 * (128 + 8) * 2 + (size_t)32 * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * 8 * 2048;
+            if (!n->gru16_attr) {
+                RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_h16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)smem16));
+                n->gru16_attr = true;
+            }
+            hipLaunchKernelGGL(k_gru_h16, dim3((cnt + 31) / 32, 1), dim3(256), smem16, st, a);
+        } else {
+            size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
+            hipLaunchKernelGGL((k_recur<128, false, GRU_U>), dim3((cnt + 31) / 32, 1), dim3(256), smem, st, a);
+        }
         RL4RS_LAUNCH_CHECK();
     }
     {
