@@ -155,7 +155,9 @@ int rl4rs_env_reward_split(rl4rs_env* env, const float* probs_dev, const float* 
 int rl4rs_env_violation(rl4rs_env* env, int32_t* out_dev, void* stream);
 
 /* state['action_mask'] = action_mask & location_mask[layer(post-increment cur_steps)] & special_mask
- * (slate.py:92-97, seqslate.py:15-17).  out_dev [B, action_size]; dtype: 0=uint8 1=int32 2=int64 3=float32 */
+ * (slate.py:92-97, seqslate.py:15-17).  out_dev [B, action_size]; dtype: 0=uint8 1=int32 2=int64 3=float32;
+ * dtype 4: packed, out_dev [B, (action_size + 31) / 32] uint32 words, bit k & 31 of word k >> 5 = action k (the mask_bits
+ * layout of rl4rs_policy_*) */
 int rl4rs_env_obs_mask(rl4rs_env* env, void* out_dev, int dtype, void* stream);
 
 /* offline_action (slate.py:149-162): ids_dev [B] int32, and/or emb_dev [B, E] float64 (conti mode). */

@@ -399,6 +399,14 @@ __global__ void k_obs_mask(EnvDev e, int layer, void* out, int dtype) {
     }
 }
 
+// packed form of the same mask: one uint32 word per 32 actions (what the policy kernels take as mask_bits)
+__global__ void k_obs_mask_bits(EnvDev e, int layer, uint32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e.B * e.W) return;
+    const int w = i % e.W;
+    out[i] = e.amask[i] & e.smask[i] & e.loc_bits[layer * e.W + w];
+}
+
 __global__ void k_offline_action(EnvDev e, int cur, int32_t* ids, double* emb) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= e.B) return;
@@ -749,10 +757,16 @@ int rl4rs_env_violation(rl4rs_env* e, int32_t* out, void* stream) {
 }
 
 int rl4rs_env_obs_mask(rl4rs_env* e, void* out, int dtype, void* stream) {
-    RL4RS_REQUIRE(e && out && dtype >= 0 && dtype <= 3, "obs_mask: bad argument");
+    RL4RS_REQUIRE(e && out && dtype >= 0 && dtype <= 4, "obs_mask: bad argument");
     const EnvDev& d = e->d;
     int layer = d.is_seq ? (e->cur_steps % d.P) / 3 : e->cur_steps / 3;   // POST-increment (slate.py:93)
     RL4RS_REQUIRE(layer < 4, "location layer %d out of range (cur_steps=%d)", layer, e->cur_steps);
+    if (dtype == 4) {
+        hipLaunchKernelGGL(k_obs_mask_bits, dim3((unsigned)((d.B * d.W + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->d, layer,
+                           reinterpret_cast<uint32_t*>(out));
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     size_t total = (size_t)d.B * d.A;
     hipLaunchKernelGGL(k_obs_mask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->d,
                        layer, out, dtype);

@@ -178,6 +178,12 @@ class DeviceEnv(object):
         check(self.lib.rl4rs_env_obs_mask(self.h, _ptr(out), _MASK_DTYPES[dtype], _stream()))
         return out
 
+    def obs_mask_bits(self):
+        """The same mask packed 32 actions per int32 word, [B, (A + 31) // 32] - the ``mask_bits`` the policy kernels take."""
+        out = torch.empty((self.B, (self.A + 31) // 32), dtype=torch.int32, device=self.device)
+        check(self.lib.rl4rs_env_obs_mask(self.h, _ptr(out), 4, _stream()))
+        return out
+
     def offline_action(self, conti=False):
         ids = torch.empty(self.B, dtype=torch.int32, device=self.device)
         emb = torch.empty((self.B, self.E), dtype=torch.float64, device=self.device) if conti else None

@@ -127,14 +127,7 @@ class Trainer(object):
 
     def _mask_bits(self):
         """Packed obs-side action mask (action_mask & location_mask[layer] & special_mask, slate.py:92-97)."""
-        env = self.env.samples._live()
-        m = env.obs_mask(torch.uint8).to(torch.int32)                      # [B, A] in {0,1}
-        W = self.policy.W
-        pad = W * 32 - self.A
-        if pad:
-            m = torch.nn.functional.pad(m, (0, pad))
-        w = (m.view(self.B, W, 32) << torch.arange(32, device=m.device, dtype=torch.int32)).sum(dim=2, dtype=torch.int64)
-        return (w & 0xffffffff).to(torch.int32).contiguous()
+        return self.env.samples._live().obs_mask_bits()          # packed on the device: no dense [B, A] round trip
 
     def rollout(self):
         B, T = self.B, self.T

@@ -220,6 +220,36 @@ def test_training_loop_runs_and_improves_masked_policy(tmp_path):
         assert outs[-1]['episode_reward_mean'] > 0
 
 
+def test_packed_obs_mask_equals_dense_mask(tmp_path):
+    """rl4rs_env_obs_mask dtype 4 (packed words, what the trainer hands to the policy) == the dense mask packed on the host,
+    along a whole episode."""
+    import os
+    import torch
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    d = str(tmp_path)
+    text = synth.make_catalog_text(seed=4)
+    synth.write_text(os.path.join(d, 'c.csv'), text)
+    recs = synth.make_records(70, seed=2, hash_size=2000, special_ids=synth.special_ids_from_text(text))
+    synth.write_records(os.path.join(d, 'log.csv'), recs)
+    cfg = {"maxlen": 64, "batch_size": 64, "action_size": 284, "class_num": 2, "dense_feature_num": 432, "category_feature_num": 21,
+           "category_hash_size": 2000, "seq_num": 2, "emb_size": 128, "page_items": 9, "hidden_units": 128, "max_steps": 9,
+           "action_emb_size": 32, "sample_file": os.path.join(d, 'log.csv'), "iteminfo_file": os.path.join(d, 'c.csv'),
+           "is_eval": True, "cache_size": 64, "return_tensors": True}
+    env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
+    env.reset()
+    for t in range(9):
+        live = env.samples._live()
+        dense = live.obs_mask(torch.uint8).cpu().numpy().astype(np.uint32)
+        want = np.zeros((64, 9), np.uint32)
+        for k in range(284):
+            want[:, k >> 5] |= dense[:, k] << np.uint32(k & 31)
+        got = live.obs_mask_bits().cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), t
+        env.step(env.offline_action)
+
+
 def test_rawstate_policy_forward_matches_oracle(tmp_path):
     """rl4rs_rawpolicy_* (rllib_rawstate_model.py + mask wrapper) against the numpy fp64 restatement, then driven by the
     raw features of a rawstate_as_obs env."""
