@@ -178,9 +178,12 @@ class DeviceEnv(object):
         check(self.lib.rl4rs_env_obs_mask(self.h, _ptr(out), _MASK_DTYPES[dtype], _stream()))
         return out
 
-    def obs_mask_bits(self):
-        """The same mask packed 32 actions per int32 word, [B, (A + 31) // 32] - the ``mask_bits`` the policy kernels take."""
-        out = torch.empty((self.B, (self.A + 31) // 32), dtype=torch.int32, device=self.device)
+    def obs_mask_bits(self, out=None):
+        """The same mask packed 32 actions per int32 word, [B, (A + 31) // 32] - the ``mask_bits`` the policy kernels take
+        (``out``: a contiguous int32 [B, W] tensor to fill, e.g. a slice of a rollout buffer)."""
+        if out is None:
+            out = torch.empty((self.B, (self.A + 31) // 32), dtype=torch.int32, device=self.device)
+        assert out.dtype == torch.int32 and tuple(out.shape) == (self.B, (self.A + 31) // 32) and out.is_contiguous()
         check(self.lib.rl4rs_env_obs_mask(self.h, _ptr(out), 4, _stream()))
         return out
 
@@ -902,15 +905,23 @@ class DevicePolicy(object):
         assert mask_bits.dtype == torch.int32 and mask_bits.shape == (N, self.W) and mask_bits.is_contiguous()
         return mask_bits
 
-    def act(self, obs, mask_bits=None, seed=0, step=0, want_logits=False):
+    def act(self, obs, mask_bits=None, seed=0, step=0, want_logits=False, out=None):
+        """Sample actions.  ``out`` = (actions i32 [N], logp f32 [N], value f32 [N], logits f32 [N, A] or None): contiguous
+        tensors to fill in place (slices of a rollout buffer) instead of fresh ones."""
         N = obs.shape[0]
         assert obs.dtype == torch.float32 and obs.shape == (N, self.obs_dim) and obs.is_contiguous()
         m = self._mask(mask_bits, N)
-        a = torch.empty(N, dtype=torch.int32, device=self.device)
-        lp = torch.empty(N, dtype=torch.float32, device=self.device)
-        v = torch.empty(N, dtype=torch.float32, device=self.device)
+        if out is not None:
+            a, lp, v, lg = out
+            assert a.dtype == torch.int32 and lp.dtype == torch.float32 and v.dtype == torch.float32
+            assert a.shape == (N,) and lp.shape == (N,) and v.shape == (N,) and a.is_contiguous() and lp.is_contiguous() and v.is_contiguous()
+            assert lg is None or (lg.dtype == torch.float32 and tuple(lg.shape) == (N, self.action_size) and lg.is_contiguous())
+        else:
+            a = torch.empty(N, dtype=torch.int32, device=self.device)
+            lp = torch.empty(N, dtype=torch.float32, device=self.device)
+            v = torch.empty(N, dtype=torch.float32, device=self.device)
+            lg = torch.empty((N, self.action_size), dtype=torch.float32, device=self.device) if want_logits else None
         ent = torch.empty(N, dtype=torch.float32, device=self.device)
-        lg = torch.empty((N, self.action_size), dtype=torch.float32, device=self.device) if want_logits else None
         check(self.lib.rl4rs_policy_act(self.h, N, _ptr(obs), _ptr(m), seed & 0xffffffff, step & 0xffffffff, _ptr(a),
                                         _ptr(lp), _ptr(v), _ptr(ent), _ptr(lg), _stream()))
         return a, lp, v, ent, lg

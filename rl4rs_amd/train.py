@@ -136,16 +136,12 @@ class Trainer(object):
         for t in range(T):
             obs_t = obs['obs'] if isinstance(obs, dict) else obs
             sl = slice(t * B, (t + 1) * B)
-            mask = self._mask_bits()
-            a, lp, v, ent, lg = self.policy.act(obs_t.contiguous(), mask, seed=self.seed, step=self.iteration * T + t,
-                                                want_logits=self.algo == D.DevicePolicy.PPO)
+            # mask, sampled actions, log-probs, values (and PPO's logits) are written straight into the rollout buffers
+            mask = self.env.samples._live().obs_mask_bits(out=b['mask'][sl])
             b['obs'][sl] = obs_t
-            b['mask'][sl] = mask
-            b['act'][sl] = a
-            b['logp'][sl] = lp
-            b['val'][sl] = v
-            if lg is not None:
-                b['logits'][sl] = lg
+            ppo = self.algo == D.DevicePolicy.PPO
+            a = self.policy.act(b['obs'][sl], mask, seed=self.seed, step=self.iteration * T + t, want_logits=ppo,
+                                out=(b['act'][sl], b['logp'][sl], b['val'][sl], b['logits'][sl] if ppo else None))[0]
             obs, reward, done, info = self.env.step(a)
             b['rew'][sl] = reward
         # gamma = 1, lambda = 1: advantage = (sum of future rewards) - V
