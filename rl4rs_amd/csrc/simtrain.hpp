@@ -164,7 +164,7 @@ __global__ void k_gru_bwd_mid(const float* __restrict__ dh, const float* __restr
 __global__ void k_shift_prev(const float* __restrict__ h, float* __restrict__ hprev, int N, int U, int len) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * len * U) return;
-    const int c = i % U, t = (i / U) % len;
+    const int t = (i / U) % len;
     hprev[i] = t == 0 ? 0.f : h[i - U];
 }
 
