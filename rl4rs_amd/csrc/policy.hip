@@ -28,11 +28,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-// counter-based uniform in (0,1): a pure function of (seed, step, row, action)
+// counter-based uniform STRICTLY inside (0,1): a pure function of (seed, step, row, action).  23 random bits + 0.5 is exactly
+// representable in fp32, so the largest value is 1 - 2^-24; with 24 bits the top value rounded to 1.0f, and the Gumbel draw
+// logit - log(-log(u)) became +inf - which let a MASKED action (logit -3.4e38) win about once per 2^24 draws
+// (tests/test_gpu_policy.py::test_wider_hidden_layer_takes_the_same_paths caught it).
 __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t row, uint32_t a) {
     uint32_t h = mix32(seed ^ mix32(step * 0x9E3779B9U + 0x85EBCA6BU) ^ mix32(row * 0xC2B2AE35U + a * 0x27D4EB2FU + 1U));
     h = mix32(h + a);
-    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 // Wave-wide reductions, result in every lane.  DPP row operations (quad_perm, row_half_mirror, row_mirror) reduce each row of

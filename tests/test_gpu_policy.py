@@ -220,6 +220,56 @@ def test_training_loop_runs_and_improves_masked_policy(tmp_path):
         assert outs[-1]['episode_reward_mean'] > 0
 
 
+def test_wider_hidden_layer_takes_the_same_paths():
+    """hidden = 128 (4 hidden tiles, 2-way K split, 81 gradient tasks > 64 wave groups): sampling, both losses and the
+    persistent PPO pass against the float64 oracle / the per-minibatch sequence."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    from oracle import policy as OP
+    HID, A = 128, 284
+    rs = np.random.RandomState(21)
+    N, MB = 1027, 256
+    obs, mask, bits = _data(N, rs)
+    n_par = 256 * HID + HID + HID * (A + 1) + A + 1
+    flat = init_policy_params(hidden=HID, seed=6) + (rs.randn(n_par) * 0.05).astype(np.float32)
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    o, b = t(obs), torch.from_numpy(bits).cuda()
+    pol = DevicePolicy(256, HID, A, max_rows=N, params=flat)
+    assert pol.n_params == n_par
+    a, lp, v, ent, lg = pol.act(o, b, seed=3, step=1, want_logits=True)
+    logits, value = OP.forward(flat, obs, mask, hid=HID)
+    ok = mask > 0
+    assert np.abs(lg.cpu().numpy()[ok] - logits[ok]).max() < 2e-5
+    assert np.abs(v.cpu().numpy() - value).max() < 2e-5
+    a_np = a.cpu().numpy()
+    assert mask[np.arange(N), a_np].all()
+    lsm = OP.log_softmax(logits)
+    assert np.abs(lp.cpu().numpy() - lsm[np.arange(N), a_np]).max() < 3e-5
+    adv, ret = rs.randn(N) * 3, rs.randn(N) * 50 + 100
+    old_logp = lsm[np.arange(N), a_np]
+    kw = dict(vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=30.0, kl_coeff=0.2)
+    ol = np.maximum(logits, -3.4e38).astype(np.float32)
+    for algo in (0, 1):
+        g, stats = pol.loss_grad(algo, o, a, t(adv), t(ret), mask_bits=b, old_logp=t(old_logp), old_value=t(value), old_logits=t(ol), **kw)
+        g_ref, s_ref = OP.loss_and_grad(algo, flat, obs, mask, a_np, adv, ret, old_logp, value, logits, hid=HID, **kw)
+        assert np.abs(g.cpu().numpy() - g_ref).max() < 2e-4 * np.abs(g_ref).max(), algo
+        assert np.allclose(stats.cpu().numpy(), s_ref, rtol=2e-4, atol=1e-3)
+    # persistent pass == minibatch sequence (numerically: see test_ppo_epoch_equals_minibatch_sequence)
+    p1 = DevicePolicy(256, HID, A, max_rows=N, params=flat)
+    p2 = DevicePolicy(256, HID, A, max_rows=N, params=flat)
+    kw2 = dict(vf_coeff=0.5, ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2)
+    for lo in range(0, N - MB + 1, MB):
+        hi = lo + MB
+        g, _ = p1.loss_grad(1, o[lo:hi], a[lo:hi], t(adv)[lo:hi], t(ret)[lo:hi], mask_bits=b[lo:hi], old_logp=t(old_logp)[lo:hi],
+                            old_value=t(value)[lo:hi], old_logits=t(ol)[lo:hi], **kw2)
+        p1.adam_step(g, lr=1e-3)
+    p2.ppo_epoch(o, a, t(adv), t(ret), b, t(old_logp), t(value), t(ol), minibatch=MB, lr=1e-3, **kw2)
+    w1, w2 = p1.params().cpu().numpy().astype(np.float64), p2.params().cpu().numpy().astype(np.float64)
+    diff = np.abs(w1 - w2)
+    assert (diff < 2e-5).mean() > 0.999 and diff.max() <= 2 * (N // MB) * 1e-3, ((diff < 2e-5).mean(), diff.max())
+
+
 def test_packed_obs_mask_equals_dense_mask(tmp_path):
     """rl4rs_env_obs_mask dtype 4 (packed words, what the trainer hands to the policy) == the dense mask packed on the host,
     along a whole episode."""
