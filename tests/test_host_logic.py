@@ -175,3 +175,23 @@ def test_native_record_parser_matches_python_parser():
     t = time.time(); RecordColumns(big, 64); tp = time.time() - t
     t = time.time(); parse_records_native(big, 64); tn = time.time() - t
     assert tn < tp
+
+
+def test_fileutil_lookup_helpers(tmp_path):
+    """rl4rs/utils/fileutil.py:7-24: glob under each directory of a pathsep-separated search path; newest by ctime, '' if none."""
+    import os
+    import time
+    from rl4rs.utils.fileutil import find_match_files, find_newest_files
+    a, b = tmp_path / 'a', tmp_path / 'b'
+    a.mkdir()
+    b.mkdir()
+    (a / 'train.tfrecord-0').write_text('x')
+    time.sleep(0.02)
+    (b / 'train.tfrecord-1').write_text('y')
+    (b / 'other.txt').write_text('z')
+    path = os.pathsep.join([str(a), str(b)])
+    found = sorted(os.path.basename(p) for p in find_match_files('train.tfrecord*', path))
+    assert found == ['train.tfrecord-0', 'train.tfrecord-1']
+    assert os.path.basename(find_newest_files('train.tfrecord*', path)) == 'train.tfrecord-1'
+    assert find_newest_files('nothing*', path) == ''
+    assert list(find_match_files('*.txt', str(a))) == []
