@@ -55,3 +55,57 @@ def test_single_process_is_a_noop():
     assert D.max_over_ranks(3.5) == 3.5
     g = torch.ones(4)
     assert D.allreduce_mean_(g) is g
+
+
+class _StubNet(object):
+    """Stands in for a DeviceQNet: a flat gradient buffer and a plain SGD 'adam_step' so the update is checkable on CPU."""
+
+    def __init__(self, grad):
+        import torch
+        self.g = grad.clone()
+        self.p = torch.zeros_like(grad)
+        self.steps = 0
+
+    def flat_gradient(self):
+        return self.g.clone()
+
+    def set_flat_gradient(self, g):
+        self.g = g.clone()
+
+    def adam_step(self, lr):
+        self.p -= lr * self.g
+        self.steps += 1
+
+
+def _learner_worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from rl4rs_amd import dist as D
+    from rl4rs_amd.offline_rl import _Learner
+    D.init('gloo')
+    learner = _Learner.__new__(_Learner)           # the data-parallel update rule only: no device network is built
+    learner.lr = 0.5
+    net = _StubNet(torch.arange(6, dtype=torch.float32) * (rank + 1))
+    learner._apply(net)
+    D.barrier()
+    out.put((rank, net.g.tolist(), net.p.tolist(), net.steps))
+
+
+def test_offline_learner_update_is_data_parallel():
+    """offline_rl._Learner._apply: each rank's flat gradient is mean-all-reduced before the optimiser step (SURVEY 8e:
+    'BCQ/offline: data-parallel minibatches, gradient all-reduce only'), so every rank applies the same update."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mean = [1.5 * k for k in range(6)]                                   # ranks hold k and 2k
+    for _, g, p, steps in res:
+        assert g == mean and p == [-0.5 * x for x in mean] and steps == 1
