@@ -386,14 +386,37 @@ int rl4rs_policy_loss_grad(rl4rs_policy* pol, int32_t algo, int32_t N, const flo
 int rl4rs_policy_adam_step(rl4rs_policy* pol, const float* grad_dev, float lr, float beta1, float beta2,
                            float eps, float grad_clip, void* stream);
 /* One PPO SGD pass over N already shuffled samples in minibatches of `minibatch` consecutive rows (loss + backward
- * + Adam per minibatch; the trailing N % minibatch rows are dropped; stats of the last minibatch).  Identical
- * arithmetic to rl4rs_policy_loss_grad(algo 1) + rl4rs_policy_adam_step per minibatch, one host call. */
+ * + Adam per minibatch; the trailing N % minibatch rows are dropped).  Identical arithmetic to
+ * rl4rs_policy_loss_grad(algo 1) + rl4rs_policy_adam_step per minibatch, one host call (one persistent kernel when the
+ * shapes fit and its grid can be co-resident on this device, checked against the runtime's occupancy answer).
+ * stats_dev (optional) float[8]: [0..3] = sums of {policy loss, value loss, entropy, kl} over the LAST minibatch,
+ * [4..7] = the same sums over every sample of the pass (RLlib reports the pass-mean KL and feeds it to its adaptive
+ * kl_coeff rule: script/modelfree_train.py:189 kl_coeff, :216 kl_target). */
 int rl4rs_policy_ppo_epoch(rl4rs_policy* pol, int32_t N, int32_t minibatch, const float* obs_dev,
                            const uint32_t* mask_bits_dev, const int32_t* actions_dev, const float* adv_dev,
                            const float* ret_dev, const float* old_logp_dev, const float* old_value_dev,
                            const float* old_logits_dev, float vf_coeff, float ent_coeff, float clip, float vf_clip,
                            float kl_coeff, float lr, float beta1, float beta2, float eps, float grad_clip,
                            float* grad_dev, float* stats_dev, void* stream);
+/* Data-parallel form of the pass (gradient all-reduce only): the PPO gradient of minibatch `mb_index`
+ * (rows [mb_index*minibatch, (mb_index+1)*minibatch) of the N shuffled samples) into grad_dev WITHOUT updating the
+ * parameters.  Each rank calls it on its own shard, mean-all-reduces grad_dev and applies rl4rs_policy_adam_step.
+ * stats_dev (optional) float[4] = sums over the minibatch. */
+int rl4rs_policy_ppo_minibatch_grad(rl4rs_policy* pol, int32_t N, int32_t minibatch, int32_t mb_index,
+                                    const float* obs_dev, const uint32_t* mask_bits_dev, const int32_t* actions_dev,
+                                    const float* adv_dev, const float* ret_dev, const float* old_logp_dev,
+                                    const float* old_value_dev, const float* old_logits_dev, float vf_coeff,
+                                    float ent_coeff, float clip, float vf_clip, float kl_coeff, float* grad_dev,
+                                    float* stats_dev, void* stream);
+/* Status bits since the last call (synchronises `stream`, then clears them).  RL4RS_POLICY_STATUS_PASS_TIMEOUT: a grid
+ * barrier of a persistent PPO pass timed out (workgroups not co-resident: another process holds compute units); the pass
+ * stopped at the last completed minibatch and is incomplete. */
+enum { RL4RS_POLICY_STATUS_PASS_TIMEOUT = 1 };
+int rl4rs_policy_status(rl4rs_policy* pol, int32_t* flags, void* stream);
+/* Adam state of the handle (first / second moments, device pointers owned by the handle; same layout as the
+ * parameters) and its step counter: a data-parallel trainer broadcasts rank 0's at start, a checkpoint saves them. */
+int rl4rs_policy_adam_state(rl4rs_policy* pol, float** m_dev, float** v_dev, int64_t* step);
+int rl4rs_policy_set_adam_step(rl4rs_policy* pol, int64_t step);
 
 /* Raw-state policy encoder: rl4rs/nets/rllib/rllib_rawstate_model.py:25-86 (and its action-mask wrapper,
  * rllib_mask_model.py:67-115) for envs with config['rawstate_as_obs'] (rl4rs/env/slate.py:250-262):

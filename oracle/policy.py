@@ -162,3 +162,49 @@ def rawstate_loss_and_grad(algo, weights, cat, dense, seqs, mask, actions, adv, 
     g['head_b'] = np.concatenate([g.pop('out_b'), g.pop('value_b')])
     stats = np.array([pi.sum().item(), vf.sum().item(), ent.sum().item(), kl.sum().item()])
     return g, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PPO train calls restated in float64 (what rl4rs_amd.train.Trainer must track): RLlib 1.5.1's minibatch SGD over one
+# shuffled train batch (script/modelfree_train.py:179-216: sgd_minibatch_size 256, num_sgd_iter 1, lr 1e-4, kl_coeff 0.2,
+# kl_target 0.01), tf.train.AdamOptimizer, and KLCoeffMixin.update_kl.  PARITY UNPINNED like the rest of this module
+# (ray is absent); the update rule below is RLlib's published one.
+def adam_update(flat, m, v, t, grad, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One tf.train.AdamOptimizer step in float64 -> (flat, m, v, t)."""
+    t = t + 1
+    m = beta1 * m + (1.0 - beta1) * grad
+    v = beta2 * v + (1.0 - beta2) * grad * grad
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    return flat - lr_t * m / (np.sqrt(v) + eps), m, v, t
+
+
+def update_kl_coeff(kl_coeff, sampled_kl, kl_target):
+    """ray/rllib/agents/ppo/ppo_tf_policy.py KLCoeffMixin.update_kl (1.5.1)."""
+    if sampled_kl > 2.0 * kl_target:
+        kl_coeff *= 1.5
+    elif sampled_kl < 0.5 * kl_target:
+        kl_coeff *= 0.5
+    return kl_coeff
+
+
+def ppo_train_call(state, batch, minibatch, lr, kl_coeff, kl_target, mask_fn, od=256, hid=64, A=284, vf_coeff=0.5, clip=0.3,
+                   vf_clip=500.0):
+    """One PPO train call on an already shuffled batch.  state = (flat, m, v, t) float64; batch = dict of numpy arrays
+    obs, act, mask (dense [N, A] 0/1 or None via mask_fn), adv, ret, logp, val, logits.  Minibatches are consecutive rows,
+    the trailing N % minibatch rows are dropped.  -> (state, stats) with stats = dict(kl_mean, kl_coeff (updated),
+    last = [pi, vf, ent, kl] MEANS of the last minibatch)."""
+    flat, m, v, t = state
+    N = batch['obs'].shape[0]
+    kl_sum, count, last = 0.0, 0, None
+    for lo in range(0, N - minibatch + 1, minibatch):
+        hi = lo + minibatch
+        mask = mask_fn(batch['mask'][lo:hi]) if batch.get('mask') is not None else None
+        g, s = loss_and_grad(1, flat, batch['obs'][lo:hi], mask, batch['act'][lo:hi], batch['adv'][lo:hi], batch['ret'][lo:hi],
+                             old_logp=batch['logp'][lo:hi], old_value=batch['val'][lo:hi], old_logits=batch['logits'][lo:hi],
+                             vf_coeff=vf_coeff, ent_coeff=0.0, clip=clip, vf_clip=vf_clip, kl_coeff=kl_coeff, od=od, hid=hid, A=A)
+        flat, m, v, t = adam_update(flat, m, v, t, g, lr)
+        kl_sum += s[3]
+        count += minibatch
+        last = s / minibatch
+    kl_mean = kl_sum / max(count, 1)
+    return (flat, m, v, t), dict(kl_mean=kl_mean, kl_coeff=update_kl_coeff(kl_coeff, kl_mean, kl_target), last=last)

@@ -169,6 +169,10 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_float, _P, _P]),
     'rl4rs_rawtrain_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
+    'rl4rs_policy_ppo_minibatch_grad': (_I, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 5 + [_P, _P, _P]),
+    'rl4rs_policy_status': (_I, [_P, _P, _P]),
+    'rl4rs_policy_adam_state': (_I, [_P, _P, _P, _P]),
+    'rl4rs_policy_set_adam_step': (_I, [_P, C.c_int64]),
     'rl4rs_qnet_create': (_I, [_P, _FP, _P, _P, _P, _P]),
     'rl4rs_qnet_destroy': (_I, [_P]),
     'rl4rs_qnet_params': (_I, [_P, _P, _P, _P]),

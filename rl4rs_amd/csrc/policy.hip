@@ -450,6 +450,11 @@ __global__ __launch_bounds__(256) void k_reduce_terms(const float4* __restrict__
     if (threadIdx.x == 0) { stats[0] = sm[0].x; stats[1] = sm[0].y; stats[2] = sm[0].z; stats[3] = sm[0].w; }
 }
 
+// acc[0..3] += x[0..3] (per-minibatch loss sums accumulated over a pass, fixed order)
+__global__ void k_axpy4(const float* __restrict__ x, float* __restrict__ acc) {
+    if (threadIdx.x < 4) acc[threadIdx.x] += x[threadIdx.x];
+}
+
 // sum of squares of a flat buffer -> out[0] (single block, fixed order)
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int count, float* __restrict__ out) {
     __shared__ float sm[256];
@@ -513,6 +518,8 @@ struct PassArgs {
     unsigned* bar;
     float lr, b1, b2, eps;
     long long t0;
+    int mb_begin, mb_end;    // minibatches [mb_begin, mb_end) of the pass
+    int apply;               // 1: Adam inside phase B (single GPU); 0: gradient only (the caller all-reduces it, then rl4rs_policy_adam_step)
     unsigned long long* trace;
 };
 
@@ -527,7 +534,10 @@ struct PassArgs {
 // release when it believes nothing is outstanding - an explicit s_waitcnt before the RELAXED arrival, so the counter cannot
 // overtake the write-back.  Consumer side: relaxed polling, ONE agent acquire (invalidates this CU's L1), workgroup barrier,
 // then plain loads.
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen) {
+// Returns false once any workgroup has given up (bar[1] != 0): the caller then stops touching the parameters, so a pass whose
+// workgroups were not co-resident leaves them at the last consistent minibatch instead of running racy updates.
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen) {
+    __shared__ unsigned s_dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
@@ -545,9 +555,11 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg, unsign
             if (++spins > (1u << 21))     // ~1 us per poll: gives up after a few seconds
                 __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        s_dead = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    return s_dead == 0u;
 }
 
 __device__ __forceinline__ void adam_elem(float* p, float* m, float* v, float g, float lr_t, float b1, float b2, float eps) {
@@ -578,14 +590,13 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     const int NT1 = HID / 32, NT2 = (AE + 31) / 32, parts = 8 / NT1;
     const int R = a.rows;                    // samples of this workgroup (8, 16 or 32): rows R..31 of every MFMA tile are idle
     const int r0 = blockIdx.x * R;
-    const int nmb = a.N / MB;
     unsigned gen = 0;
     for (int i = blockIdx.x * 512 + tid; i < HID * AE; i += gridDim.x * 512) {
         const int j = i / AE, c = i - j * AE;
         a.w2t[(size_t)c * HID + j] = W2[i];
     }
-    grid_barrier(a.bar, gridDim.x, gen);
-    for (int mb = 0; mb < nmb; ++mb) {
+    if (!grid_barrier(a.bar, gridDim.x, gen)) return;
+    for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
         const size_t lo = (size_t)mb * MB;
         // ------------------------------------------------------------------ phase A
         RL4RS_PT(0);
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 for (int c = lane; c < d.A; c += 64) se += expf(so[c] - mx);
                 const float lse = mx + logf(wave_sum(se));
                 const float4 tm = policy_row_loss(d, L, so, lse, row, lane, s_d + row * SA, a.dOut + (size_t)r0 * AE);
-                if (lane == 0) a.terms[r0 + row] = tm;
+                if (lane == 0) a.terms[lo + r0 + row] = tm;       // per-sample loss terms of the whole pass (KL mean -> kl_coeff rule)
                 if (row == 0) RL4RS_PT(11);
             }
         }
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             a.dHpre[(size_t)(r0 + r) * HID + j] = s * (1.f - h * h);
         }
         RL4RS_PT(5);
-        grid_barrier(a.bar, gridDim.x, gen);
+        if (!grid_barrier(a.bar, gridDim.x, gen)) return;
         RL4RS_PT(6);
         // ------------------------------------------------------------------ phase B
         // One task = one 32x32 gradient tile (or 32 bias columns) + the Adam update of its parameters, done by a GROUP of 4
@@ -821,6 +832,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                             const float mi = a.b1 * mm[c] + (1.f - a.b1) * g[c];
                             const float vi = a.b2 * vv[c] + (1.f - a.b2) * g[c] * g[c];
                             a.grad[idx[c]] = g[c];
+                            if (!a.apply) continue;
                             a.am[idx[c]] = mi;
                             a.av[idx[c]] = vi;
                             const float pn = pp[c] - lr_t * mi / (sqrtf(vi) + a.eps);
@@ -836,13 +848,13 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                     for (int qq = 0; qq < 4; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
                     const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
                     a.grad[idx] = sum;
-                    adam_elem(a.prm + idx, a.am + idx, a.av + idx, sum, lr_t, a.b1, a.b2, a.eps);
+                    if (a.apply) adam_elem(a.prm + idx, a.am + idx, a.av + idx, sum, lr_t, a.b1, a.b2, a.eps);
                 }
                 __syncthreads();                                          // s_part is rewritten by the next trip
             }
         }
         RL4RS_PT(7);
-        grid_barrier(a.bar, gridDim.x, gen);
+        if (!grid_barrier(a.bar, gridDim.x, gen)) return;
         RL4RS_PT(8);
     }
 }
@@ -1035,6 +1047,7 @@ struct rl4rs_policy {
     unsigned* bar;
     int64_t adam_t;
     bool train_attr, pass_attr, pass_launched, tile_attr[3];
+    int pass_resident_wgs;     // workgroups of k_ppo_pass the device can hold at once (-1 = not queried yet)
     std::vector<void*> owned;
 };
 
@@ -1062,6 +1075,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->train_attr = false;
     p->pass_attr = false;
     p->pass_launched = false;
+    p->pass_resident_wgs = -1;
     p->tile_attr[0] = p->tile_attr[1] = p->tile_attr[2] = false;
     int rc;
     auto alloc = [&](float** dst, size_t n) {
@@ -1087,6 +1101,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     RL4RS_HIP_TRY(hipMemcpyAsync(p->params, params_host, (size_t)p->n_params * 4, hipMemcpyHostToDevice, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_m, 0, (size_t)p->n_params * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_v, 0, (size_t)p->n_params * 4, st));
+    RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 16, st));
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     *out = p;
     return RL4RS_OK;
@@ -1103,6 +1118,20 @@ int rl4rs_policy_params(rl4rs_policy* p, float** params_dev, int32_t* count) {
     RL4RS_REQUIRE(p && params_dev, "policy_params: null argument");
     *params_dev = p->params;
     if (count) *count = p->n_params;
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_adam_state(rl4rs_policy* p, float** m_dev, float** v_dev, int64_t* step) {
+    RL4RS_REQUIRE(p, "policy_adam_state: null handle");
+    if (m_dev) *m_dev = p->adam_m;
+    if (v_dev) *v_dev = p->adam_v;
+    if (step) *step = p->adam_t;
+    return RL4RS_OK;
+}
+
+int rl4rs_policy_set_adam_step(rl4rs_policy* p, int64_t step) {
+    RL4RS_REQUIRE(p && step >= 0, "policy_set_adam_step: bad argument");
+    p->adam_t = step;
     return RL4RS_OK;
 }
 
@@ -1395,6 +1424,106 @@ int rl4rs_rawpolicy_evaluate(rl4rs_rawpolicy* p, int32_t N, const int32_t* cat, 
 // over N already shuffled samples: loss + backward + Adam per minibatch of `minibatch` consecutive rows, the trailing
 // N % minibatch rows are dropped.  Same arithmetic as calling rl4rs_policy_loss_grad + rl4rs_policy_adam_step per
 // minibatch; exists so that a single-GPU trainer pays one host call per pass instead of two per minibatch.
+}  // extern "C"
+
+namespace {
+
+struct PpoCall {
+    int32_t N, minibatch;
+    const float* obs; const uint32_t* mask_bits; const int32_t* actions; const float* adv; const float* ret;
+    const float* old_logp; const float* old_value; const float* old_logits;
+    float vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, lr, beta1, beta2, eps;
+};
+
+size_t pass_smem_bytes(const PolDims& d) { return (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5 + d.W) * 4; }
+
+int pass_rows_per_wg() {
+    // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
+    // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
+    static const int rows_env = getenv("RL4RS_PPO_ROWS") ? atoi(getenv("RL4RS_PPO_ROWS")) : 8;
+    return (rows_env == 32 || rows_env == 16) ? rows_env : 8;
+}
+
+// Does the persistent pass fit this policy / minibatch, and can its whole grid be resident at once?  The software grid barrier
+// needs every workgroup on a compute unit at the same time: checked against the occupancy the runtime reports for this kernel
+// and launch shape x the device's CU count (a partitioned or otherwise smaller device falls back to the per-minibatch kernels).
+bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
+    const PolDims& d = p->d;
+    const int NT1 = d.HID / 32;
+    const size_t smem = pass_smem_bytes(d);
+    static const bool no_fused = getenv("RL4RS_PPO_FUSED") && atoi(getenv("RL4RS_PPO_FUSED")) == 0;     // A/B measurements
+    const int rows = pass_rows_per_wg();
+    const bool shape_ok = !no_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
+                          d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0 && d.HID % 64 == 0 && minibatch % 128 == 0 && minibatch / rows <= 128 &&
+                          (size_t)32 * (d.OD | 1) >= 8192 && (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && smem <= (size_t)160 * 1024;
+    if (!shape_ok) return false;
+    if (!p->pass_attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return false;
+        p->pass_attr = true;
+    }
+    if (p->pass_resident_wgs < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ppo_pass, 512, smem) != hipSuccess)
+            p->pass_resident_wgs = 0;
+        else
+            p->pass_resident_wgs = per_cu * cus;
+        static const char* cap = getenv("RL4RS_PPO_RESIDENT_WGS");       // tests: pretend a smaller device
+        if (cap) p->pass_resident_wgs = atoi(cap);
+    }
+    return minibatch / rows <= p->pass_resident_wgs;
+}
+
+// minibatches [mb_begin, mb_end) through k_ppo_pass; apply = 0 leaves the parameters alone (gradient of ONE minibatch only)
+int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end, int apply, float* grad_dev, hipStream_t st) {
+    const PolDims& d = p->d;
+    PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d = d; a.N = c.N; a.MB = c.minibatch;
+    a.rows = pass_rows_per_wg();
+    a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v; a.w2t = p->w2t;
+    a.obs = c.obs; a.mask = c.mask_bits;
+    a.L.algo = 1; a.L.vf_coeff = c.vf_coeff; a.L.ent_coeff = c.ent_coeff; a.L.clip = c.clip; a.L.vf_clip = c.vf_clip; a.L.kl_coeff = c.kl_coeff;
+    a.L.scale = 1.0f / (float)c.minibatch;
+    a.L.actions = c.actions; a.L.adv = c.adv; a.L.ret = c.ret; a.L.old_logp = c.old_logp; a.L.old_value = c.old_value; a.L.old_logits = c.old_logits;
+    a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms; a.grad = grad_dev; a.bar = p->bar;
+    a.lr = c.lr; a.b1 = c.beta1; a.b2 = c.beta2; a.eps = c.eps; a.t0 = p->adam_t;
+    a.mb_begin = mb_begin; a.mb_end = mb_end; a.apply = apply;
+    a.trace = nullptr;
+#ifdef RL4RS_PASS_TRACE
+    static unsigned long long* trace_buf = nullptr;
+    if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 16 * 8);
+    a.trace = trace_buf;
+#endif
+    // bar[0] = arrival counter (reset per launch), bar[1] = sticky "a grid barrier timed out" flag (rl4rs_policy_status)
+    RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
+    hipLaunchKernelGGL(k_ppo_pass, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
+    RL4RS_LAUNCH_CHECK();
+    p->pass_launched = true;
+#ifdef RL4RS_PASS_TRACE
+    {
+        unsigned long long h[16];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* nm[] = {"stage", "layer1", "layer2", "loss", "dH", "barrier1", "phaseB", "barrier2"};
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "  %-14s %8.2f us\n", nm[k], (double)(h[k + 1] - h[k]) / 2400.0);   // core clocks at ~2.4 GHz
+        fprintf(stderr, "  dH: mfma %.2f  partial+sync %.2f  combine %.2f\n", (double)(h[12] - h[4]) / 2400.0, (double)(h[13] - h[12]) / 2400.0,
+                (double)(h[5] - h[13]) / 2400.0);
+        fprintf(stderr, "  lr_t %.2f  tile-loop %.2f  adam %.2f | first loss row %.2f\n", (double)(h[10] - h[6]) / 2400.0,
+                (double)(h[9] - h[10]) / 2400.0, (double)(h[7] - h[9]) / 2400.0, (double)(h[11] - h[3]) / 2400.0);
+    }
+#endif
+    return RL4RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// stats_dev (optional): 8 floats - [0..3] sums of {pi_loss, vf_loss, entropy, kl} over the LAST minibatch, [4..7] the same sums
+// over every sample of the pass (RLlib's PPO reports the KL averaged over the minibatches of the pass and feeds it to the
+// adaptive kl_coeff rule, script/modelfree_train.py:189,216).
 int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const float* obs, const uint32_t* mask_bits,
                            const int32_t* actions, const float* adv, const float* ret, const float* old_logp,
                            const float* old_value, const float* old_logits, float vf_coeff, float ent_coeff, float clip,
@@ -1402,85 +1531,89 @@ int rl4rs_policy_ppo_epoch(rl4rs_policy* p, int32_t N, int32_t minibatch, const 
                            float* grad_dev, float* stats_dev, void* stream) {
     RL4RS_REQUIRE(p && obs && actions && adv && ret && old_logp && old_value && old_logits && grad_dev,
                   "policy_ppo_epoch: null argument");
-    RL4RS_REQUIRE(minibatch > 0 && N >= minibatch && minibatch <= p->max_rows,
+    RL4RS_REQUIRE(minibatch > 0 && N >= minibatch && minibatch <= p->max_rows && N <= p->max_rows,
                   "policy_ppo_epoch: bad sizes (N=%d, minibatch=%d, max_rows=%d)", N, minibatch, p->max_rows);
     const PolDims& d = p->d;
-    // fused persistent pass (k_ppo_pass) when the shapes fit its tiling and no global-norm clip is asked for
-    const int NT1 = d.HID / 32;
-    const size_t pass_smem = (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5 + d.W) * 4;
-    // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
-    // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
-    static const int rows_env = getenv("RL4RS_PPO_ROWS") ? atoi(getenv("RL4RS_PPO_ROWS")) : 8;
-    const int pass_rows = (rows_env == 32 || rows_env == 16) ? rows_env : 8;
-    static const bool no_fused = getenv("RL4RS_PPO_FUSED") && atoi(getenv("RL4RS_PPO_FUSED")) == 0;     // A/B measurements
-    const bool fused = !no_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
-                       d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0 && d.HID % 64 == 0 && minibatch % 128 == 0 && minibatch / pass_rows <= 128 && (size_t)32 * (d.OD | 1) >= 8192 &&
-                       (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && pass_smem <= (size_t)160 * 1024;
-    if (fused) {
-        hipStream_t st = (hipStream_t)stream;
-        if (!p->pass_attr) {
-            RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              160 * 1024));
-            p->pass_attr = true;
-        }
-        PassArgs a;
-        a.d = d; a.N = N; a.MB = minibatch;
-        a.rows = pass_rows;
-        a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v; a.w2t = p->w2t;
-        a.obs = obs; a.mask = mask_bits;
-        a.L.algo = 1; a.L.vf_coeff = vf_coeff; a.L.ent_coeff = ent_coeff; a.L.clip = clip; a.L.vf_clip = vf_clip; a.L.kl_coeff = kl_coeff;
-        a.L.scale = 1.0f / (float)minibatch;
-        a.L.actions = actions; a.L.adv = adv; a.L.ret = ret; a.L.old_logp = old_logp; a.L.old_value = old_value; a.L.old_logits = old_logits;
-        a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms; a.grad = grad_dev; a.bar = p->bar;
-        a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.t0 = p->adam_t;
-        a.trace = nullptr;
-#ifdef RL4RS_PASS_TRACE
-        static unsigned long long* trace_buf = nullptr;
-        if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 16 * 8);
-        a.trace = trace_buf;
-#endif
-        if (p->pass_launched) {        // outcome of the previous pass (it has long finished: this is the next iteration)
-            unsigned flags[2] = {0u, 0u};
-            RL4RS_HIP_TRY(hipMemcpyAsync(flags, p->bar, 8, hipMemcpyDeviceToHost, st));
-            RL4RS_HIP_TRY(hipStreamSynchronize(st));
-            if (flags[1]) {
-                set_error("policy_ppo_epoch: the persistent pass timed out at a grid barrier (workgroups not co-resident); "
-                          "its parameters are invalid - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels");
-                return RL4RS_EHIP;
-            }
-        }
-        p->pass_launched = true;
-        RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 8, st));
-        hipLaunchKernelGGL(k_ppo_pass, dim3(minibatch / pass_rows), dim3(512), pass_smem, st, a);
-        RL4RS_LAUNCH_CHECK();
-        p->adam_t += N / minibatch;
-#ifdef RL4RS_PASS_TRACE
-        {
-            unsigned long long h[16];
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost);
-            static const char* nm[] = {"stage", "layer1", "layer2", "loss", "dH", "barrier1", "phaseB", "barrier2"};
-            for (int k = 0; k < 8; ++k) fprintf(stderr, "  %-14s %8.2f us\n", nm[k], (double)(h[k + 1] - h[k]) / 2400.0);   // core clocks at ~2.4 GHz
-            fprintf(stderr, "  dH: mfma %.2f  partial+sync %.2f  combine %.2f\n", (double)(h[12] - h[4]) / 2400.0, (double)(h[13] - h[12]) / 2400.0,
-                    (double)(h[5] - h[13]) / 2400.0);
-            fprintf(stderr, "  lr_t %.2f  tile-loop %.2f  adam %.2f | first loss row %.2f\n", (double)(h[10] - h[6]) / 2400.0,
-                    (double)(h[9] - h[10]) / 2400.0, (double)(h[7] - h[9]) / 2400.0, (double)(h[11] - h[3]) / 2400.0);
-        }
-#endif
+    hipStream_t st = (hipStream_t)stream;
+    const int nmb = N / minibatch;
+    // fused persistent pass (k_ppo_pass) when the shapes fit its tiling, its grid can be co-resident, and no global-norm clip is asked for
+    if (pass_fits(p, minibatch, grad_clip)) {
+        PpoCall c = {N, minibatch, obs, mask_bits, actions, adv, ret, old_logp, old_value, old_logits,
+                     vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, lr, beta1, beta2, eps};
+        int rc = launch_ppo_pass(p, c, 0, nmb, 1, grad_dev, st);
+        if (rc) return rc;
+        p->adam_t += nmb;
         if (stats_dev) {
-            hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms, minibatch, stats_dev);
+            hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms + (size_t)(nmb - 1) * minibatch, minibatch, stats_dev);
+            hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms, nmb * minibatch, stats_dev + 4);
             RL4RS_LAUNCH_CHECK();
         }
         return RL4RS_OK;
     }
+    if (stats_dev) RL4RS_HIP_TRY(hipMemsetAsync(stats_dev + 4, 0, 16, st));
     for (int lo = 0; lo + minibatch <= N; lo += minibatch) {
-        const bool last = lo + 2 * minibatch > N;
         int rc = rl4rs_policy_loss_grad(p, 1, minibatch, obs + (size_t)lo * d.OD, mask_bits ? mask_bits + (size_t)lo * d.W : nullptr,
                                         actions + lo, adv + lo, ret + lo, old_logp + lo, old_value + lo,
                                         old_logits + (size_t)lo * d.A, vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, grad_dev,
-                                        last ? stats_dev : nullptr, stream);
+                                        stats_dev, stream);
         if (rc) return rc;
+        if (stats_dev) {
+            hipLaunchKernelGGL(k_axpy4, dim3(1), dim3(64), 0, st, stats_dev, stats_dev + 4);
+            RL4RS_LAUNCH_CHECK();
+        }
         if ((rc = rl4rs_policy_adam_step(p, grad_dev, lr, beta1, beta2, eps, grad_clip, stream))) return rc;
+    }
+    return RL4RS_OK;
+}
+
+// Gradient of ONE minibatch (rows [mb_index * minibatch, (mb_index + 1) * minibatch) of the shuffled pass) WITHOUT touching the
+// parameters: the data-parallel form of the pass.  Each rank calls this, mean-all-reduces grad_dev (the one collective of the
+// training loop) and then rl4rs_policy_adam_step - same arithmetic as the single-GPU pass on the averaged
+// gradient.  Runs phase A + the gradient tiles of k_ppo_pass as one launch when the pass fits (else the per-minibatch kernels).
+// stats_dev (optional): 4 floats, sums of {pi_loss, vf_loss, entropy, kl} over the minibatch.
+int rl4rs_policy_ppo_minibatch_grad(rl4rs_policy* p, int32_t N, int32_t minibatch, int32_t mb_index, const float* obs,
+                                    const uint32_t* mask_bits, const int32_t* actions, const float* adv, const float* ret,
+                                    const float* old_logp, const float* old_value, const float* old_logits, float vf_coeff,
+                                    float ent_coeff, float clip, float vf_clip, float kl_coeff, float* grad_dev,
+                                    float* stats_dev, void* stream) {
+    RL4RS_REQUIRE(p && obs && actions && adv && ret && old_logp && old_value && old_logits && grad_dev,
+                  "policy_ppo_minibatch_grad: null argument");
+    RL4RS_REQUIRE(minibatch > 0 && N >= minibatch && N <= p->max_rows && mb_index >= 0 && (mb_index + 1) * (int64_t)minibatch <= N,
+                  "policy_ppo_minibatch_grad: bad sizes (N=%d, minibatch=%d, mb_index=%d, max_rows=%d)", N, minibatch, mb_index, p->max_rows);
+    const PolDims& d = p->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (pass_fits(p, minibatch, 0.f)) {
+        PpoCall c = {N, minibatch, obs, mask_bits, actions, adv, ret, old_logp, old_value, old_logits,
+                     vf_coeff, ent_coeff, clip, vf_clip, kl_coeff, 0.f, 0.9f, 0.999f, 1e-8f};
+        int rc = launch_ppo_pass(p, c, mb_index, mb_index + 1, 0, grad_dev, st);
+        if (rc) return rc;
+        if (stats_dev) {
+            hipLaunchKernelGGL(k_reduce_terms, dim3(1), dim3(256), 0, st, p->terms + (size_t)mb_index * minibatch, minibatch, stats_dev);
+            RL4RS_LAUNCH_CHECK();
+        }
+        return RL4RS_OK;
+    }
+    const size_t lo = (size_t)mb_index * minibatch;
+    return rl4rs_policy_loss_grad(p, 1, minibatch, obs + lo * d.OD, mask_bits ? mask_bits + lo * d.W : nullptr, actions + lo, adv + lo,
+                                  ret + lo, old_logp + lo, old_value + lo, old_logits + lo * d.A, vf_coeff, ent_coeff, clip, vf_clip,
+                                  kl_coeff, grad_dev, stats_dev, stream);
+}
+
+// Synchronises `stream` and reports (and clears) the handle's sticky status: RL4RS_POLICY_STATUS_PASS_TIMEOUT when a grid
+// barrier of a persistent PPO pass timed out (its workgroups were not co-resident).  The pass stops updating at the barrier
+// that failed, so the parameters are those of the last completed minibatch - but the pass is incomplete: callers treat it as
+// an error (rl4rs_amd.train.Trainer checks after every iteration and in params() / close()).
+int rl4rs_policy_status(rl4rs_policy* p, int32_t* flags, void* stream) {
+    RL4RS_REQUIRE(p && flags, "policy_status: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned v[2] = {0u, 0u};
+    *flags = 0;
+    if (!p->pass_launched) return RL4RS_OK;
+    RL4RS_HIP_TRY(hipMemcpyAsync(v, p->bar, 8, hipMemcpyDeviceToHost, st));
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));
+    if (v[1]) {
+        RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 8, st));
+        *flags = RL4RS_POLICY_STATUS_PASS_TIMEOUT;
     }
     return RL4RS_OK;
 }

@@ -734,6 +734,21 @@ class DeviceRawPolicy(object):
         return lp, v, ent, lg
 
 
+class _DevAlias(object):
+    """__cuda_array_interface__ carrier: lets torch alias device memory owned by a library handle."""
+
+    def __init__(self, ptr, count, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def _alias_f32(ptr, count, device, owner):
+    with torch.cuda.device(device):
+        t = torch.as_tensor(_DevAlias(ptr, count, owner), device=device)
+    assert t.data_ptr() == int(ptr) and t.dtype == torch.float32
+    return t
+
+
 class DeviceRawTrainer(DeviceRawPolicy):
     """rl4rs_rawtrain handle: the raw-state policy with A2C / PPO loss, backward and Adam on the device."""
     A2C, PPO = 0, 1
@@ -790,6 +805,18 @@ class DeviceRawTrainer(DeviceRawPolicy):
 
     def gradients(self):
         return self._split(self._flat('grad'))
+
+    def flat_view(self, which):
+        """ZERO-COPY torch view of the handle's flat parameter ('params') or gradient ('grad') buffer: a data-parallel trainer
+        all-reduces the gradient in place between loss_grad and adam_step, and broadcasts the parameters at start."""
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_rawtrain_params(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        return _alias_f32((p if which == 'params' else g).value, n.value, self.device, self)
+
+    def table_rows(self):
+        """(offset, rows, width) of the two embedding tables inside the flat buffers (cat_emb, seq_emb come first)."""
+        (_, (H, E)) = self.shapes[0]
+        return [(0, H, E), (H * E, H, E)]
 
     def act(self, cat, dense, seqs, mask_bits=None, seed=0, step=0, want_logits=False):
         N, sp = self._inputs(cat, dense, seqs, mask_bits)
@@ -955,11 +982,12 @@ class DevicePolicy(object):
     def ppo_epoch(self, obs, actions, adv, ret, mask_bits, old_logp, old_value, old_logits, minibatch=256, vf_coeff=0.5,
                   ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8,
                   grad_clip=0.0, grad_out=None):
-        """One SGD pass over already shuffled samples (rl4rs_policy_ppo_epoch): returns the stats of the last minibatch."""
+        """One SGD pass over already shuffled samples (rl4rs_policy_ppo_epoch).  Returns 8 floats: [0:4] sums of
+        {pi_loss, vf_loss, entropy, kl} over the last minibatch, [4:8] the same sums over every sample of the pass."""
         N = obs.shape[0]
         m = self._mask(mask_bits, N)
         g = grad_out if grad_out is not None else torch.empty(self.n_params, dtype=torch.float32, device=self.device)
-        stats = torch.empty(4, dtype=torch.float32, device=self.device)
+        stats = torch.empty(8, dtype=torch.float32, device=self.device)
         f = lambda t: t.to(torch.float32).contiguous()
         obs, adv, ret, old_logp, old_value, old_logits = f(obs), f(adv), f(ret), f(old_logp), f(old_value), f(old_logits)
         actions = actions.to(torch.int32).contiguous()
@@ -969,8 +997,54 @@ class DevicePolicy(object):
                                               _stream()))
         return stats
 
+    def ppo_minibatch_grad(self, mb_index, obs, actions, adv, ret, mask_bits, old_logp, old_value, old_logits, minibatch=256,
+                           vf_coeff=0.5, ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2, grad_out=None, stats_out=None):
+        """Data-parallel form of the pass: gradient of minibatch ``mb_index`` of the shuffled samples, parameters untouched
+        (rl4rs_policy_ppo_minibatch_grad).  All inputs must already be contiguous float32 / int32 device tensors of the whole
+        pass (no per-call conversions: this runs once per minibatch).  -> (grad, stats[4] sums)."""
+        N = obs.shape[0]
+        g = grad_out if grad_out is not None else torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        stats = stats_out if stats_out is not None else torch.empty(4, dtype=torch.float32, device=self.device)
+        for t in (obs, adv, ret, old_logp, old_value, old_logits):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert actions.dtype == torch.int32 and actions.is_contiguous()
+        m = self._mask(mask_bits, N)
+        check(self.lib.rl4rs_policy_ppo_minibatch_grad(self.h, N, minibatch, mb_index, _ptr(obs), _ptr(m), _ptr(actions), _ptr(adv),
+                                                       _ptr(ret), _ptr(old_logp), _ptr(old_value), _ptr(old_logits), vf_coeff,
+                                                       ent_coeff, clip, vf_clip, kl_coeff, _ptr(g), _ptr(stats), _stream()))
+        return g, stats
+
     def adam_step(self, grad, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_clip=0.0):
         check(self.lib.rl4rs_policy_adam_step(self.h, _ptr(grad), lr, beta1, beta2, eps, grad_clip, _stream()))
+
+    def check_status(self):
+        """Synchronises; raises if a persistent PPO pass gave up at a grid barrier (its workgroups were not co-resident)."""
+        f = C.c_int32()
+        check(self.lib.rl4rs_policy_status(self.h, C.byref(f), _stream()))
+        if f.value & 1:
+            raise RuntimeError("the persistent PPO pass timed out at a grid barrier (workgroups not co-resident: the GPU is shared or "
+                               "partitioned); the pass is incomplete - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels")
+
+    def adam_state(self):
+        """(m, v) copies of the Adam moments and the step counter."""
+        m, v, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_policy_adam_state(self.h, C.byref(m), C.byref(v), C.byref(t)))
+        om = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        ov = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(om), m, self.n_params * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(_ptr(ov), v, self.n_params * 4, _stream()))
+        return om, ov, int(t.value)
+
+    def set_adam_state(self, m, v, step):
+        pm, pv, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_policy_adam_state(self.h, C.byref(pm), C.byref(pv), C.byref(t)))
+        m = m.to(device=self.device, dtype=torch.float32).contiguous()
+        v = v.to(device=self.device, dtype=torch.float32).contiguous()
+        assert m.numel() == self.n_params and v.numel() == self.n_params
+        check(self.lib.rl4rs_copy_d2d(pm, _ptr(m), self.n_params * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(pv, _ptr(v), self.n_params * 4, _stream()))
+        check(self.lib.rl4rs_policy_set_adam_step(self.h, int(step)))
+        self._keep_adam = (m, v)
 
 
 class DeviceQNet(object):

@@ -45,7 +45,7 @@ def max_over_ranks(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -55,7 +55,7 @@ def sum_over_ranks(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -68,15 +68,78 @@ def world_size():
     return 1
 
 
+def _needs_host_staging(t):
+    """gloo moves host memory: a CUDA tensor goes through a pinned host copy (2 ranks on ONE GPU in the GPU tests, CPU
+    tests); RCCL ("nccl") works on device memory directly."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
 def allreduce_mean_(flat):
     """In-place mean all-reduce of ONE flat fp32 gradient buffer (a single fused collective per optimiser step:
     the mask-model gradient is 140 KB, latency-bound, so bucketing would only add launches)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return flat
+    if _needs_host_staging(flat):
+        h = flat.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat.copy_(h.div_(dist.get_world_size()))
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(dist.get_world_size())
     return flat
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast of rank ``src``'s tensor (initial parameters / optimiser state of a data-parallel trainer)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if _needs_host_staging(t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+        return t
+    dist.broadcast(t, src=src)
+    return t
+
+
+def allreduce_rows_mean_(table_grad, ids):
+    """Mean all-reduce of a SPARSE-ROW gradient: ``table_grad`` [H, E] is zero outside the rows ``ids`` (unique, int64) this
+    rank's minibatch touched (embedding tables of the raw-state policy: 2 x 100000 x 128 floats of which a 256-sample
+    minibatch touches a few thousand rows).  Ranks exchange (ids, rows) with ONE all-gather each instead of all-reducing
+    the 51 MB table; every rank then rebuilds the mean in the same fixed rank order, so the result is bit-identical across
+    ranks.  Falls back to the dense all-reduce when the touched rows are not a small part of the table."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return table_grad
+    W = dist.get_world_size()
+    H, E = table_grad.shape
+    stage = _needs_host_staging(table_grad)
+    cnt = torch.tensor([int(ids.numel())], dtype=torch.int64, device='cpu' if stage else table_grad.device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+    kmax = int(cnt.item())
+    if kmax * W * 2 > H:
+        return allreduce_mean_(table_grad.view(-1)).view(H, E)
+    my_ids = torch.full((kmax,), -1, dtype=torch.int64, device=table_grad.device)
+    my_ids[:ids.numel()] = ids
+    my_rows = torch.zeros((kmax, E), dtype=table_grad.dtype, device=table_grad.device)
+    my_rows[:ids.numel()] = table_grad.index_select(0, ids)
+    if stage:
+        my_ids, my_rows = my_ids.cpu(), my_rows.cpu()
+    all_ids = [torch.empty_like(my_ids) for _ in range(W)]
+    all_rows = [torch.empty_like(my_rows) for _ in range(W)]
+    dist.all_gather(all_ids, my_ids)
+    dist.all_gather(all_rows, my_rows)
+    table_grad.index_fill_(0, ids, 0.0)
+    inv = 1.0 / W
+    for r in range(W):                       # fixed order: every rank performs the same sequence of additions
+        i_r = all_ids[r].to(table_grad.device)
+        ok = i_r >= 0
+        table_grad.index_add_(0, i_r[ok], all_rows[r].to(table_grad.device)[ok] * inv)
+    return table_grad
 
 
 def barrier():

@@ -135,11 +135,16 @@ class LogStore(object):
 
     def _ensure_width(self, rows):
         if self.log_steps is None:
-            # exposed_items width of the file = width of its first parsed record
-            for r in rows:
-                if self.lines[r]:
-                    self.log_steps = len(self.lines[r].split('@')[3].split(','))
-                    break
+            # exposed_items / user_feedback column count of the table = the LONGEST record of the file (one cheap pre-scan of
+            # the fourth '@' field): a later, longer record must not be truncated - offline_reward sums over every logged
+            # item (slate.py:164-174) - and shorter ones are zero padded (their true length stays in exposed_len)
+            width = 0
+            for line in self.lines:
+                if line:
+                    parts = line.split('@', 4)
+                    if len(parts) > 3:
+                        width = max(width, parts[3].count(',') + 1)
+            self.log_steps = max(width, 1)
 
     def _alloc(self, device):
         import torch

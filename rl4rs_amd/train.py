@@ -1,9 +1,19 @@
 """On-device policy training loop over the GPU env (A2C / PPO with the reference's RLlib hyper-parameters,
 script/modelfree_train.py:179-304: gamma = 1, GAE lambda = 1, lr 1e-4, vf_loss_coeff 0.5; A2C entropy 0.01 and
-grad_clip 10; PPO clip 0.3, kl_coeff 0.2, vf_clip 500, one SGD pass over minibatches of 256).
+grad_clip 10; PPO clip 0.3, kl_coeff 0.2 adapted towards kl_target 0.01, vf_clip 500, one SGD pass over minibatches of 256;
+train_batch_size = min(B * T, 1024) timesteps per train call, :409).
 
 Rollout, policy forward/backward and Adam run through librl4rs_hip.so; torch is used for buffers, the reversed
-cumulative sum of rewards and (data-parallel) the single RCCL all-reduce of the flat gradient buffer."""
+cumulative sum of rewards and (data-parallel) the RCCL all-reduce of the flat gradient buffer.
+
+Data parallelism: every rank owns its own env batch and sampling stream (``seed`` differs per rank) and a replica
+of the policy that is IDENTICAL on all ranks: initialised from the shared ``init_seed``, rank 0's parameters / Adam state are
+broadcast at construction, and every optimiser step applies the rank-mean gradient.  A2C: one all-reduce per iteration.
+PPO: one per minibatch (synchronous SGD over the global minibatch of world_size x 256 samples): phase A + the gradient
+tiles of the persistent pass run as ONE launch per minibatch (rl4rs_policy_ppo_minibatch_grad), then all-reduce, then Adam.
+"""
+import math
+
 import numpy as np
 import torch
 
@@ -11,12 +21,43 @@ from . import dist as rdist
 from . import device as D
 
 
+def update_kl_coeff(kl_coeff, sampled_kl, kl_target):
+    """RLlib's adaptive KL penalty (ray 1.5.1 ``KLCoeffMixin.update_kl``, configured by modelfree_train.py:189 kl_coeff 0.2 and
+    :216 kl_target 0.01): x1.5 when the pass-mean KL exceeds 2 x target, x0.5 when it is below target / 2."""
+    if sampled_kl > 2.0 * kl_target:
+        return kl_coeff * 1.5
+    if sampled_kl < 0.5 * kl_target:
+        return kl_coeff * 0.5
+    return kl_coeff
+
+
+def rollouts_per_train_call(batch_size, max_steps, train_batch_size=None):
+    """modelfree_train.py:403-409: rollout_fragment_length = max_steps, batch_mode complete_episodes, train_batch_size =
+    min(B * T, 1024).  One vector-env rollout yields B * T timesteps, RLlib keeps sampling until it holds at least
+    train_batch_size, so the reference's value always means exactly ONE rollout per train call; a larger explicit value asks
+    for ceil(train_batch_size / (B * T)) rollouts."""
+    per = int(batch_size) * int(max_steps)
+    if train_batch_size is None:
+        train_batch_size = min(per, 1024)
+    return max(1, int(math.ceil(float(train_batch_size) / per)))
+
+
+def _returns(rew, R, T, B):
+    """gamma = 1, lambda = 1: reward-to-go within each rollout ([R, T, B] layout of the flat buffers)."""
+    r = rew.view(R, T, B)
+    return torch.flip(torch.cumsum(torch.flip(r, dims=[1]), dim=1), dims=[1]).reshape(-1).to(torch.float32)
+
+
 class RawStateTrainer(object):
     """The same loop for an env with config['rawstate_as_obs'] (+ support_rllib_mask, return_tensors): the policy is the
     raw-state encoder (rllib_rawstate_model.py; modelfree_train.py 'rawstate' variants) acting on the device tensors of the
-    raw features; loss, backward and Adam run through rl4rs_rawtrain_*."""
+    raw features; loss, backward and Adam run through rl4rs_rawtrain_*.
 
-    def __init__(self, env, algo='A2C', seed=0, lr=1e-4, minibatch=256, weights=None):
+    Data-parallel: the gradient lives in the handle's flat buffer [cat_emb | seq_emb | dense layers]; the dense tail
+    (~280 K floats) is mean-all-reduced in place, the two 100000 x 128 embedding tables exchange only the rows the minibatch
+    touched (``dist.allreduce_rows_mean_``)."""
+
+    def __init__(self, env, algo='A2C', seed=0, lr=1e-4, minibatch=256, weights=None, init_seed=0, kl_coeff=0.2, kl_target=0.01):
         from .nets.rawpolicy import init_rawpolicy_weights
         cfg = env.config
         assert cfg.get('return_tensors', False) and cfg.get('rawstate_as_obs', False) and cfg.get('support_rllib_mask', False), \
@@ -26,8 +67,9 @@ class RawStateTrainer(object):
         self.B, self.T, self.A = cfg['batch_size'], cfg['max_steps'], cfg['action_size']
         self.S, self.L = cfg['seq_num'], cfg['maxlen']
         self.seed, self.lr, self.minibatch = seed, lr, minibatch
+        self.kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
         if weights is None:
-            weights = init_rawpolicy_weights(cfg, seed=seed)
+            weights = init_rawpolicy_weights(cfg, seed=init_seed)
         N = self.B * self.T
         self.policy = D.DeviceRawTrainer(cfg, weights, max_rows=max(N, self.B))
         self.iteration = 0
@@ -40,6 +82,10 @@ class RawStateTrainer(object):
                         act=torch.empty(N, dtype=torch.int32, device=dev), logp=torch.empty(N, dtype=torch.float32, device=dev),
                         val=torch.empty(N, dtype=torch.float32, device=dev), rew=torch.empty(N, dtype=torch.float64, device=dev),
                         logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
+        self._grad = None
+        if rdist.world_size() > 1:
+            rdist.broadcast_(self.policy.flat_view('params'), src=0)      # replicas start identical (Adam state is zero)
+            self._grad = self.policy.flat_view('grad')
 
     def _mask_bits(self, mask):
         W = self.policy.W
@@ -72,17 +118,31 @@ class RawStateTrainer(object):
                 b['logits'][sl] = lg
             obs, reward, done, info = self.env.step(a)
             b['rew'][sl] = reward
-        rew = b['rew'].view(T, B)
-        ret = torch.flip(torch.cumsum(torch.flip(rew, dims=[0]), dim=0), dims=[0]).reshape(-1).to(torch.float32)
-        return ret, ret - b['val'], float(rew.sum(dim=0).mean().item())
+        ret = _returns(b['rew'], 1, T, B)
+        return ret, ret - b['val'], float(b['rew'].view(T, B).sum(dim=0).mean().item())
+
+    def _allreduce_gradient(self, cat, seqs):
+        """Mean over ranks of the gradient the last loss_grad left in the handle (no-op on one rank)."""
+        if self._grad is None:
+            return
+        g = self._grad
+        tables = self.policy.table_rows()
+        ids = [torch.unique(cat.reshape(-1).to(torch.int64)),
+               torch.unique(torch.cat([q.reshape(-1) for q in seqs]).to(torch.int64))]
+        for (off, H, E), i in zip(tables, ids):
+            rdist.allreduce_rows_mean_(g[off:off + H * E].view(H, E), i.clamp_(0, H - 1))
+        tail = tables[-1][0] + tables[-1][1] * tables[-1][2]
+        rdist.allreduce_mean_(g[tail:])
 
     def train_iteration(self):
         ret, adv, mean_reward = self.rollout()
         b = self.buf
         N = self.B * self.T
+        kl_mean = 0.0
         if self.algo == D.DeviceRawTrainer.A2C:
             stats = self.policy.loss_grad(self.algo, b['cat'], b['dense'], b['seqs'], b['act'], adv, ret, mask_bits=b['mask'],
                                           vf_coeff=0.5, ent_coeff=0.01)
+            self._allreduce_gradient(b['cat'], b['seqs'])
             self.policy.adam_step(lr=self.lr, grad_clip=10.0)
         else:
             adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)
@@ -90,32 +150,54 @@ class RawStateTrainer(object):
             sh = dict((k, b[k][perm]) for k in ('cat', 'dense', 'mask', 'act', 'logp', 'val', 'logits'))
             shs = [q[perm] for q in b['seqs']]
             adv_s, ret_s = adv_n[perm], ret[perm]
+            kl_sum = torch.zeros((), dtype=torch.float32, device=b['cat'].device)
+            nmb = 0
             for lo in range(0, N - self.minibatch + 1, self.minibatch):
                 hi = lo + self.minibatch
-                stats = self.policy.loss_grad(self.algo, sh['cat'][lo:hi], sh['dense'][lo:hi], [q[lo:hi] for q in shs], sh['act'][lo:hi],
+                seq_mb = [q[lo:hi] for q in shs]
+                stats = self.policy.loss_grad(self.algo, sh['cat'][lo:hi], sh['dense'][lo:hi], seq_mb, sh['act'][lo:hi],
                                               adv_s[lo:hi], ret_s[lo:hi], mask_bits=sh['mask'][lo:hi], old_logp=sh['logp'][lo:hi],
                                               old_value=sh['val'][lo:hi], old_logits=sh['logits'][lo:hi], vf_coeff=0.5,
-                                              ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2)
+                                              ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff)
+                self._allreduce_gradient(sh['cat'][lo:hi], seq_mb)
                 self.policy.adam_step(lr=self.lr)
+                kl_sum += stats[3]
+                nmb += 1
+            kl_mean = rdist.sum_over_ranks(float(kl_sum.item()) / max(nmb * self.minibatch, 1), device=b['cat'].device) / rdist.world_size()
+            self.kl_coeff = update_kl_coeff(self.kl_coeff, kl_mean, self.kl_target)
         self.iteration += 1
         s = stats.cpu().numpy()
         return {'episode_reward_mean': mean_reward, 'policy_loss': float(s[0]), 'vf_loss': float(s[1]), 'entropy': float(s[2]),
-                'kl': float(s[3]), 'iteration': self.iteration}
+                'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self.kl_coeff, 'iteration': self.iteration}
 
 
 class Trainer(object):
-    def __init__(self, env, algo='A2C', hidden=64, seed=0, lr=1e-4, minibatch=256):
+    """A2C / PPO on the action-masked FC policy (rllib_mask_model.py:7-64) over the zero-copy discrete-action env.
+
+    seed       sampling stream of this rank (Gumbel noise, PPO shuffle): pass a different value per rank
+    init_seed  parameter initialisation, shared by all ranks (and rank 0's parameters are broadcast anyway)
+    kl_coeff / kl_target   PPO's adaptive KL penalty (update_kl_coeff above)
+    train_batch_size       timesteps per train call (rollouts_per_train_call above; the reference's value = one rollout)
+    keep_last_batch        keep the shuffled tensors of the last iteration in ``last_batch`` (tests)"""
+
+    def __init__(self, env, algo='A2C', hidden=64, seed=0, lr=1e-4, minibatch=256, init_seed=0, kl_coeff=0.2, kl_target=0.01,
+                 train_batch_size=None, keep_last_batch=False):
         cfg = env.config
         assert cfg.get('return_tensors', False) and not cfg.get('support_conti_env', False), \
             "Trainer needs the zero-copy discrete-action env (config['return_tensors'] = True)"
         self.env = env
         self.algo = {'A2C': D.DevicePolicy.A2C, 'PPO': D.DevicePolicy.PPO}[algo]
         self.B, self.T, self.A = cfg['batch_size'], cfg['max_steps'], cfg['action_size']
+        self.R = rollouts_per_train_call(self.B, self.T, train_batch_size)
         self.seed, self.lr, self.minibatch = seed, lr, minibatch
-        self.policy = D.DevicePolicy(256, hidden, self.A, max_rows=self.B * self.T, seed=seed)
+        self.kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
+        self.keep_last_batch = keep_last_batch
+        self.last_batch = None
+        N = self.R * self.B * self.T
+        self.policy = D.DevicePolicy(256, hidden, self.A, max_rows=N, seed=init_seed)
         self.iteration = 0
+        self._rollouts = 0
         dev = self.policy.device
-        N = self.B * self.T
         self.buf = dict(obs=torch.empty((N, 256), dtype=torch.float32, device=dev),
                         mask=torch.empty((N, self.policy.W), dtype=torch.int32, device=dev),
                         act=torch.empty(N, dtype=torch.int32, device=dev),
@@ -124,66 +206,113 @@ class Trainer(object):
                         rew=torch.empty(N, dtype=torch.float64, device=dev),
                         logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
         self.grad = torch.empty(self.policy.n_params, dtype=torch.float32, device=dev)
+        self._mb_stats = torch.empty(4, dtype=torch.float32, device=dev)
+        if rdist.world_size() > 1:
+            self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """Make every rank's parameters, Adam moments and step counter those of rank ``src``."""
+        p = self.policy.params()
+        m, v, t = self.policy.adam_state()
+        rdist.broadcast_(p, src)
+        rdist.broadcast_(m, src)
+        rdist.broadcast_(v, src)
+        step = torch.tensor([t], dtype=torch.int64)
+        if rdist.world_size() > 1:
+            import torch.distributed as dist
+            if dist.get_backend() != 'gloo':
+                step = step.to(p.device)
+            dist.broadcast(step, src=src)
+        self.policy.set_params(p)
+        self.policy.set_adam_state(m, v, int(step.item()))
+
+    def params(self):
+        """Flat parameters (validated: raises if a persistent pass was cut short)."""
+        self.policy.check_status()
+        return self.policy.params()
+
+    def close(self):
+        try:
+            self.policy.check_status()
+        finally:
+            self.policy.close()
 
     def _mask_bits(self):
         """Packed obs-side action mask (action_mask & location_mask[layer] & special_mask, slate.py:92-97)."""
         return self.env.samples._live().obs_mask_bits()          # packed on the device: no dense [B, A] round trip
 
     def rollout(self):
-        B, T = self.B, self.T
-        obs = self.env.reset()
+        B, T, R = self.B, self.T, self.R
         b = self.buf
-        for t in range(T):
-            obs_t = obs['obs'] if isinstance(obs, dict) else obs
-            sl = slice(t * B, (t + 1) * B)
-            # mask, sampled actions, log-probs, values (and PPO's logits) are written straight into the rollout buffers
-            mask = self.env.samples._live().obs_mask_bits(out=b['mask'][sl])
-            b['obs'][sl] = obs_t
-            ppo = self.algo == D.DevicePolicy.PPO
-            a = self.policy.act(b['obs'][sl], mask, seed=self.seed, step=self.iteration * T + t, want_logits=ppo,
-                                out=(b['act'][sl], b['logp'][sl], b['val'][sl], b['logits'][sl] if ppo else None))[0]
-            obs, reward, done, info = self.env.step(a)
-            b['rew'][sl] = reward
+        ppo = self.algo == D.DevicePolicy.PPO
+        for r in range(R):
+            obs = self.env.reset()
+            for t in range(T):
+                obs_t = obs['obs'] if isinstance(obs, dict) else obs
+                sl = slice((r * T + t) * B, (r * T + t + 1) * B)
+                # mask, sampled actions, log-probs, values (and PPO's logits) are written straight into the rollout buffers
+                mask = self.env.samples._live().obs_mask_bits(out=b['mask'][sl])
+                b['obs'][sl] = obs_t
+                a = self.policy.act(b['obs'][sl], mask, seed=self.seed, step=self._rollouts * T + t, want_logits=ppo,
+                                    out=(b['act'][sl], b['logp'][sl], b['val'][sl], b['logits'][sl] if ppo else None))[0]
+                obs, reward, done, info = self.env.step(a)
+                b['rew'][sl] = reward
+            self._rollouts += 1
         # gamma = 1, lambda = 1: advantage = (sum of future rewards) - V
-        rew = b['rew'].view(T, B)
-        ret = torch.flip(torch.cumsum(torch.flip(rew, dims=[0]), dim=0), dims=[0]).reshape(-1).to(torch.float32)
+        ret = _returns(b['rew'], R, T, B)
         adv = ret - b['val']
-        return ret, adv, float(rew.sum(dim=0).mean().item())
+        return ret, adv, float(b['rew'].view(R, T, B).sum(dim=1).mean().item())
 
     def train_iteration(self):
         ret, adv, mean_reward = self.rollout()
         b = self.buf
-        N = self.B * self.T
-        stats_out = None
+        N = self.R * self.B * self.T
+        world = rdist.world_size()
+        kl_mean = 0.0
         if self.algo == D.DevicePolicy.A2C:
             g, stats = self.policy.loss_grad(self.algo, b['obs'], b['act'], adv, ret, mask_bits=b['mask'],
                                              vf_coeff=0.5, ent_coeff=0.01, grad_out=self.grad)
+            if self.keep_last_batch:
+                self.last_batch = dict(obs=b['obs'].clone(), act=b['act'].clone(), mask=b['mask'].clone(), adv=adv.clone(), ret=ret.clone())
             rdist.allreduce_mean_(g)                         # the ONE collective: flat policy gradient over RCCL
             self.policy.adam_step(g, lr=self.lr, grad_clip=10.0)
-            stats_out = stats
+            s = stats.cpu().numpy()
         else:
             adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)      # RLlib standardises PPO advantages
             perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration).permutation(N)).to(b['obs'].device)
             # shuffle every buffer ONCE (7 gathers per iteration instead of 7 per minibatch): minibatches are then
             # contiguous row ranges that go to the library as plain pointers
             sh = dict((k, b[k][perm]) for k in ('obs', 'act', 'mask', 'logp', 'val', 'logits'))
-            adv_s, ret_s = adv_n[perm], ret[perm]
-            if rdist.world_size() == 1:
+            adv_s, ret_s = adv_n[perm].contiguous(), ret[perm].contiguous()
+            if self.keep_last_batch:
+                self.last_batch = dict(sh, adv=adv_s, ret=ret_s, kl_coeff=self.kl_coeff)
+            MB = self.minibatch
+            nmb = N // MB
+            if world == 1:
                 # single GPU: the whole pass is one library call (no per-minibatch collective to interleave)
-                stats_out = self.policy.ppo_epoch(sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'], sh['val'],
-                                                  sh['logits'], minibatch=self.minibatch, vf_coeff=0.5, ent_coeff=0.0,
-                                                  clip=0.3, vf_clip=500.0, kl_coeff=0.2, lr=self.lr, grad_out=self.grad)
-            for lo in (range(0, N - self.minibatch + 1, self.minibatch) if rdist.world_size() > 1 else ()):
-                hi = lo + self.minibatch
-                g, stats = self.policy.loss_grad(self.algo, sh['obs'][lo:hi], sh['act'][lo:hi], adv_s[lo:hi], ret_s[lo:hi],
-                                                 mask_bits=sh['mask'][lo:hi], old_logp=sh['logp'][lo:hi],
-                                                 old_value=sh['val'][lo:hi], old_logits=sh['logits'][lo:hi],
-                                                 vf_coeff=0.5, ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=0.2,
-                                                 grad_out=self.grad)
-                rdist.allreduce_mean_(g)
-                self.policy.adam_step(g, lr=self.lr)
-                stats_out = stats
+                stats = self.policy.ppo_epoch(sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'], sh['val'],
+                                              sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
+                                              clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff, lr=self.lr, grad_out=self.grad)
+                s8 = stats.cpu().numpy()
+                s = s8[:4]
+                kl_mean = float(s8[7]) / (nmb * MB)
+            else:
+                # data parallel: per minibatch ONE fused gradient launch, ONE all-reduce, ONE Adam launch
+                kl_sum = torch.zeros((), dtype=torch.float32, device=b['obs'].device)
+                for mb in range(nmb):
+                    g, stats = self.policy.ppo_minibatch_grad(mb, sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'],
+                                                              sh['val'], sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
+                                                              clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff,
+                                                              grad_out=self.grad, stats_out=self._mb_stats)
+                    rdist.allreduce_mean_(g)
+                    self.policy.adam_step(g, lr=self.lr)
+                    kl_sum += stats[3]
+                s = stats.cpu().numpy()
+                # every rank must take the same kl_coeff decision: the rule sees the mean over ALL ranks' samples
+                kl_mean = rdist.sum_over_ranks(float(kl_sum.item()) / (nmb * MB), device=b['obs'].device) / world
+            self.kl_coeff = update_kl_coeff(self.kl_coeff, kl_mean, self.kl_target)
+            self.policy.check_status()
         self.iteration += 1
-        s = stats_out.cpu().numpy()
         return {'episode_reward_mean': mean_reward, 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
-                'entropy': float(s[2]), 'kl': float(s[3]), 'iteration': self.iteration}
+                'entropy': float(s[2]), 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self.kl_coeff,
+                'iteration': self.iteration}

@@ -109,3 +109,50 @@ def test_offline_learner_update_is_data_parallel():
     mean = [1.5 * k for k in range(6)]                                   # ranks hold k and 2k
     for _, g, p, steps in res:
         assert g == mean and p == [-0.5 * x for x in mean] and steps == 1
+
+
+def _rows_worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from rl4rs_amd import dist as D
+    D.init('gloo')
+    g = torch.Generator().manual_seed(10 + rank)
+    H, E = 1000, 8
+    ids = torch.unique(torch.randint(0, H, (40,), generator=g))
+    table = torch.zeros(H, E)
+    table[ids] = torch.randn(ids.numel(), E, generator=g)
+    dense = table.clone()
+    D.allreduce_mean_(dense.view(-1))                      # what the sparse-row exchange must reproduce
+    D.allreduce_rows_mean_(table, ids)
+    big = torch.zeros(16, 4)                               # touched rows are most of the table -> dense fallback
+    big_ids = torch.arange(rank, 16, 2)
+    big[big_ids] = float(rank + 1)
+    D.allreduce_rows_mean_(big, big_ids)
+    b = torch.full((5,), float(rank))
+    D.broadcast_(b, src=1)
+    D.barrier()
+    out.put((rank, table.numpy().copy(), dense.numpy().copy(), big.numpy().copy(), b.numpy().copy()))
+
+
+def test_sparse_row_allreduce_and_broadcast_world_2():
+    """dist.allreduce_rows_mean_ (embedding-table gradients of the raw-state policy: only touched rows travel) == the dense
+    mean all-reduce, bit-identical on both ranks; dist.broadcast_."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, d0, b0, bc0), (_, t1, d1, b1, bc1) = [tuple(torch.from_numpy(x) if hasattr(x, 'shape') else x for x in r) for r in res]
+    assert torch.equal(t0, t1) and torch.equal(d0, d1)
+    assert torch.equal(t0, d0)                             # W = 2: x0/2 + x1/2 == (x0 + x1)/2 exactly
+    assert (t0 != 0).any()
+    assert torch.equal(b0, b1) and set(b0.unique().tolist()) == {0.5, 1.0}
+    assert torch.equal(bc0, torch.ones(5)) and torch.equal(bc1, torch.ones(5))

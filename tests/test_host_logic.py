@@ -195,3 +195,22 @@ def test_fileutil_lookup_helpers(tmp_path):
     assert os.path.basename(find_newest_files('train.tfrecord*', path)) == 'train.tfrecord-1'
     assert find_newest_files('nothing*', path) == ''
     assert list(find_match_files('*.txt', str(a))) == []
+
+
+def test_logstore_width_is_the_longest_record(tmp_path):
+    """the exposed/feedback table is as wide as the LONGEST record of the file, not the first parsed one (a later,
+    longer record would be truncated and change offline_reward, slate.py:164-174)."""
+    from rl4rs_amd import synth
+    from rl4rs_amd.env.base import LogStore
+    text = synth.make_catalog_text(seed=4)
+    sp = synth.special_ids_from_text(text)
+    recs = synth.make_records(5, pages=1, seed=1, hash_size=2000, special_ids=sp) + \
+        synth.make_records(3, pages=2, seed=2, hash_size=2000, special_ids=sp)
+    path = os.path.join(str(tmp_path), 'log.csv')
+    synth.write_records(path, recs)
+    store = LogStore(path, 64)
+    store._ensure_width([0])
+    assert store.log_steps == 18
+    store.ensure([0, 6], 'cpu')                         # host tensors: the parser and the table logic need no GPU
+    assert store.exposed_len[0] == 9 and store.exposed_len[6] == 18
+    assert (store._dev['exposed'][0, 9:] == 0).all() and (store._dev['exposed'][6] > 0).all()
