@@ -1458,17 +1458,29 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
                           (size_t)32 * (d.OD | 1) >= 8192 && (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && smem <= (size_t)160 * 1024;
     if (!shape_ok) return false;
     if (!p->pass_attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        // the kernel also has a few bytes of static LDS (the barrier's give-up flag): opt in to exactly what this shape needs
+        if (smem + 64 > (size_t)160 * 1024 ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
             return false;
+        }
         p->pass_attr = true;
     }
     if (p->pass_resident_wgs < 0) {
         int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ppo_pass, 512, smem) != hipSuccess)
-            p->pass_resident_wgs = 0;
-        else
-            p->pass_resident_wgs = per_cu * cus;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            cus = 0;
+        }
+        // blocks per CU: the runtime's occupancy answer, capped by what the LDS alone admits (160 KB per CU); if the query itself
+        // is refused (it is for some > 64 KB dynamic-LDS shapes) the LDS bound with one 512-thread block per CU minimum stands in
+        const int by_lds = (int)((size_t)160 * 1024 / (smem ? smem : 1));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ppo_pass), 512, smem) != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();          // do not leave a sticky error for the next launch check
+            per_cu = by_lds > 0 ? 1 : 0;
+        }
+        if (per_cu > by_lds) per_cu = by_lds;
+        p->pass_resident_wgs = per_cu * cus;
         static const char* cap = getenv("RL4RS_PPO_RESIDENT_WGS");       // tests: pretend a smaller device
         if (cap) p->pass_resident_wgs = atoi(cap);
     }

@@ -150,7 +150,7 @@ def test_ppo_epoch_equals_minibatch_sequence():
     assert diff.max() <= 2 * steps * 1e-3, diff.max()
     moved = np.abs(w1 - flat.astype(np.float64))
     assert np.median(diff[moved > 1e-4]) < 1e-6
-    assert np.allclose(stats1.cpu().numpy(), stats2.cpu().numpy(), rtol=2e-3, atol=1e-4), (stats1, stats2)
+    assert np.allclose(stats1.cpu().numpy(), stats2.cpu().numpy()[:4], rtol=2e-3, atol=1e-4), (stats1, stats2)     # [4:8] = pass-wide sums
     assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
 
 

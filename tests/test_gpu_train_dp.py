@@ -358,4 +358,5 @@ def test_offline_learner_two_ranks_on_one_gpu(tmp_path):
         bc.update(obs, act)
     ref = bc.imitator.weights()
     for k in w0:
-        assert (w0[k] - ref[k].cpu()).abs().max().item() < 2e-6, k
+        # Adam divides by sqrt(v): rounding differences of near-zero gradients are amplified up to ~lr * 1e-2
+        assert (w0[k] - ref[k].cpu()).abs().max().item() < 2e-5, k
