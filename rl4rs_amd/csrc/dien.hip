@@ -36,6 +36,21 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 #ifndef RL4RS_H16_NRES
 #define RL4RS_H16_NRES 14        // weight items of a step kept resident in registers (k_augru_h16)
 #endif
+#ifndef RL4RS_X_NRES
+#define RL4RS_X_NRES 26          // k_augru_x: weight items of a step resident in registers (VGPR / AGPR)
+#endif
+#ifndef RL4RS_X_NLDS
+#define RL4RS_X_NLDS 10          // ... resident in LDS (per wave)
+#endif
+#ifndef RL4RS_X_RING
+#define RL4RS_X_RING 4           // ... register ring of the streamed rest (96 - NRES - NLDS items, a multiple of RING)
+#endif
+#ifndef RL4RS_X2_NRES
+#define RL4RS_X2_NRES 0          // the 64-row form of k_augru_x: registers go to the second row tile's accumulators
+#endif
+#ifndef RL4RS_X2_RING
+#define RL4RS_X2_RING 4
+#endif
 #ifndef RL4RS_H16_RING1
 #define RL4RS_H16_RING1 4        // weight ring depth (items) of k_augru_h16: 3 items = 9 MFMAs ahead;
                                  // measured (ring, resident): (8,10) 60.6 ms, (6,12) 59.5, (4,14) 59.0 per 5 episodes
@@ -670,6 +685,10 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     if (out_of_range && a.range_flag) atomicOr(a.range_flag, 1);
 }
 
+}  // namespace rl4rs
+#include "augru_x.hpp"
+namespace rl4rs {
+
 // -------------------------------------------------------------------------------------------------
 // First-layer GRU with the same fp16x2 operand splitting (scorer_mode fp16x2): NH = E = 128, 4 waves, 32 rows per
 // workgroup, wave w owns hidden columns [32w, 32w+32) of r, u, c and h.  At this size nothing has to stream: the gate
@@ -1107,6 +1126,7 @@ struct rl4rs_dien {
     float* gru_wc16[4];
     bool gru16, gru16_attr;
     bool fp16x2;
+    bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
     float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
@@ -1300,6 +1320,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = false;
     n->fp16x2 = want_fp16x2;
+    n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
     n->din16 = false;
     n->gru16 = false;
     n->gru16_attr = false;
@@ -1472,6 +1493,10 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_NLDS, RL4RS_X_RING>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(1, L, RL4RS_X_NLDS)));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, 0, RL4RS_X2_RING>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(2, L, 0)));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
@@ -1600,7 +1625,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
-#ifdef RL4RS_H16_TRACE
+#if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)
             static unsigned long long* trace_buf = nullptr;
             if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 8 * 4 * 8 * 8); (void)hipMemset(trace_buf, 0, 8 * 4 * 8 * 8); }
             a.trace = trace_buf;
@@ -1612,7 +1637,16 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
                 if (f) { fwrite(host, 1, sizeof(host), f); fclose(f); }
             }
 #endif
-            hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
+            // 64-row workgroups (every weight fragment feeds two row tiles: half the weight bytes per row) once there are enough
+            // row tiles to keep every CU busy with them; 32-row workgroups for the obs-sized launches (one tile per CU)
+            static const int x_mt = getenv("RL4RS_X_MT") ? atoi(getenv("RL4RS_X_MT")) : 0;
+            const bool mt2 = x_mt == 2 || (x_mt == 0 && (int64_t)((R + 63) / 64) * S >= 2 * (int64_t)n->n_cu);
+            if (n->augru_x && mt2)
+                hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, 0, RL4RS_X2_RING>), dim3((R + 63) / 64, S), dim3(256), augru_x_smem(2, L, 0), st, a);
+            else if (n->augru_x)
+                hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_NLDS, RL4RS_X_RING>), grid, dim3(256), augru_x_smem(1, L, RL4RS_X_NLDS), st, a);
+            else
+                hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
         } else
 #ifdef RL4RS_ABLATE      // timing experiments only (tools/ablate_augru.sh builds with -DRL4RS_ABLATE)
         static const int ablate = getenv("RL4RS_AUGRU_ABLATE") ? atoi(getenv("RL4RS_AUGRU_ABLATE")) : 0;

@@ -4,6 +4,7 @@ PyTorch is used for device memory and stream handles only (``tensor.data_ptr()``
 ``torch.cuda.current_stream().cuda_stream``); all compute goes through the C ABI.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -388,6 +389,8 @@ class DeviceDien(object):
 
     @property
     def augru_kernel(self):
+        if self.scorer_mode == 'fp16x2' and os.environ.get('RL4RS_AUGRU', 'x') != 'h16':
+            return 'k_augru_x'                      # dien.hip: the default fp16x2 recurrence (RL4RS_AUGRU=h16 selects the first generation)
         return AUGRU_KERNELS[SCORER_MODES[self.scorer_mode]]
 
 
