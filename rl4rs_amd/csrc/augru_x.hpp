@@ -2,35 +2,32 @@
 //
 // Same arithmetic as k_augru_h16 (rl4rs/nets/utils.py:120-124 via deepctr VecAttGRUCell; operands split into fp16 hi + lo,
 // every product as W_hi*h_hi + W_lo*h_hi + W_hi*h_lo on v_mfma_f32_32x32x16_f16, fp32 accumulation), different machine
-// mapping.  What bounded k_augru_h16 (profiles/r01g_pmc.md: matrix pipe 47-52 % busy): 8 waves per CU pulling 786 KB of weight
-// fragments per recurrence step through the 64 B/clk L1 return path, the two waves of a SIMD in lock step so that no
-// epilogue hid behind the other's MFMAs, a ~6K-cycle exposed candidate epilogue and 384 dword-per-lane projection loads per
-// step.  This kernel:
+// mapping.  What bounded k_augru_h16 (profiles/r01g_pmc.md: matrix pipe 47-52 % busy): the two waves of a SIMD moved through
+// the step in lock step, so neither's epilogue hid behind the other's MFMAs (a ~6K-cycle exposed candidate epilogue per
+// ~20K-cycle step), 786 KB of weight fragments per step through the 64 B/clk L1 return path, and 384 dword-per-lane
+// projection loads per step whose HBM latency sat in the in-order vector-memory queue in front of the weight ring.
 //
-//   * ONE wave per SIMD (4 waves, 256 threads, up to 512 registers each): wave w owns hidden columns [64w, 64w+64) of all three
-//     gates as two 32-column tiles (ct 0 / 1).  The freed registers hold weight fragments for the whole kernel (NRES items of
-//     a step in VGPR/AGPR, NLDS more in the LDS the operand planes leave free): less than 60 % of the 96 weight items of a step
-//     still stream from L2, through a RING-deep register ring.
-//   * TRANSPOSED tiles: the MFMA computes (W^T h^T), A = weight fragment, B = state fragment, so a lane owns ONE batch row and
-//     16 hidden columns in runs of 4.  Per lane: the attention score is one scalar per step, the cached input projections
-//     arrive as 16-byte loads (4 columns of one row), the new state leaves as packed 8-byte LDS writes (4 fp16 values) and the
-//     final state as 16-byte stores.  4x fewer memory / LDS instructions than the row-per-register layout.
-//   * every epilogue in the MFMA shadow.  A step is a fixed sequence of 96 weight items (gate, column tile, k-block):
-//         [ 0,16)  R  k-blocks 2,3 mod 4  ("late" columns: those of the ct = 1 tiles)
-//         [16,48)  U  all k-blocks                        || reset gate r = sigmoid(acc_r), r*h -> fp16 planes
-//         -- barrier (r*h planes complete)
-//         [48,65)  C  tile 0  (+ k-block 0 of tile 1)     || update gate u = (1 - a_t) sigmoid(acc_u)
-//         [65,80)  C  tile 1                              || candidate + blend of tile 0 -> new state planes, "early" columns
-//         -- barrier (early columns of h' complete)
-//         [80,96)  R of the NEXT step, k-blocks 0,1 mod 4 || candidate + blend of tile 1 -> "late" columns
-//         -- barrier
-//     i.e. the next step's reset-gate product starts on the half of the new state that is already written while the other half
-//     is still being blended; nothing but the three barriers is exposed.
-//   * ONE issue window per step for the cached input projections (they come from HBM and vector-memory loads return in
-//     order: a slow load in front of the weight ring stalls every later weight wait).  Right after item 49 the wave requests
-//     all projections of step t+1 - r-gate rows straight into the (retired) r accumulators, u- and c-gate rows into staging
-//     registers that become the C operand of the first MFMA of their chain - and the NRES + NLDS items that follow are exactly
-//     the resident ones: ~3.8K cycles without a vector-memory wait.
+//   * TRANSPOSED tiles: the MFMA computes (W^T h^T) - A = weight fragment, B = state fragment - so a lane owns ONE batch row and
+//     16 hidden columns in runs of 4: the attention score is one scalar per lane and step, new state leaves as packed 8-byte
+//     LDS writes (4 fp16 values), the final state as 16-byte stores.
+//   * ROLES: 8 waves, wave w owns hidden columns [32w, 32w+32) of all three gates.  Waves 0-3 ("early": k-blocks 0..7 of the
+//     state) and 4-7 ("late") land pairwise on the same SIMD (wave k and k+4) and run the candidate phase out of step:
+//         all    R (late k-blocks) , U            || reset gate r = sigmoid(acc_r), r*h -> fp16 planes
+//         -- barrier 1 (r*h planes complete)
+//         early  C || update gate, then candidate + blend -> early columns of h'    (VALU while its partner runs C)
+//         late   update gate, then C                                                 (MFMA while its partner blends)
+//         -- barrier a (early half of h' complete)
+//         all    R of the NEXT step on the early k-blocks;  late: || candidate + blend -> late columns of h'
+//         -- barrier b
+//     so whenever one wave of a SIMD is in an epilogue its partner keeps the matrix pipe busy, and the next step's reset-gate
+//     product starts on the half of the new state that is already written.
+//   * cached input projections through LDS-DMA: one issue window per step (right in front of the register-resident weight
+//     items, i.e. in front of a stretch without vector-memory waits) requests the three gates' rows of step t+1 with
+//     buffer_load ... lds: 4 instructions per gate, each one 8 rows x 128 contiguous bytes (8 cache lines instead of the 32 a
+//     row-per-lane register load touches), no staging registers; a chunk rotation in the SOURCE address makes the lane-linear
+//     LDS image conflict-free for the row-per-lane reads that feed the accumulators (MFMA C-in).
+//   * LDS (all 160 KB): state planes in slab order [k-block][k-half][row][8 halfs] - fragment reads and 8-byte writes are
+//     conflict-free without padding (64 KB) - and 3 x 4 KB of projection staging per wave (96 KB).
 //   * out-of-range rows (|h| >= 6e4: the fp16 planes cannot carry them; or NaN) are POISONED: the whole output row becomes NaN,
 //     so the observation / click probability / reward of that env is NaN on the device without any host synchronisation, and
 //     the sticky status bit is raised as before (rl4rs_dien_status).
@@ -38,27 +35,49 @@
 
 namespace rl4rs {
 namespace xk {
-constexpr int NI = 96;
-constexpr int kb_late(int j) { return (j >> 1) * 4 + 2 + (j & 1); }       // j = 0..7 -> 2,3,6,7,10,11,14,15
-constexpr int kb_early(int j) { return (j >> 1) * 4 + (j & 1); }          //             0,1,4,5, 8, 9,12,13
-constexpr int gate(int i) { return i < 16 ? 0 : (i < 48 ? 1 : (i < 80 ? 2 : 0)); }
-constexpr int ct(int i) { return i < 48 ? (i & 1) : (i == 48 ? 0 : (i == 49 ? 1 : (i < 65 ? 0 : (i < 80 ? 1 : (i & 1))))); }
-constexpr int kb(int i) {
-    return i < 16 ? kb_late(i >> 1) : (i < 48 ? ((i - 16) >> 1) : (i < 50 ? 0 : (i < 65 ? i - 49 : (i < 80 ? i - 64 : kb_early((i - 80) >> 1)))));
+constexpr int NI = 48;                                       // weight items per wave and step
+constexpr int gate(int i) { return i < 8 ? 0 : (i < 24 ? 1 : (i < 40 ? 2 : 0)); }
+constexpr int kb(int i) { return i < 8 ? 8 + i : (i < 24 ? i - 8 : (i < 40 ? i - 24 : i - 40)); }
+constexpr bool from_rh(int i) { return i >= 24 && i < 40; }  // B operand: r*h planes (candidate) or h planes
+constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
+#ifndef RL4RS_X_AB
+#define RL4RS_X_AB 0            // timing ablations (results are WRONG when non-zero): 1 no epilogue math, 2 no weight streaming,
+#endif                          // 4 no projection DMA / reads, 8 no state-fragment reads, 16 no barriers
+#ifndef RL4RS_X_SGB
+#define RL4RS_X_SGB 0           // VALU instructions pinned behind each MFMA of an item that carries epilogue work (0 = compiler's order)
+#endif
+#ifndef RL4RS_X_SPREAD
+#define RL4RS_X_SPREAD 0
+#endif
+// which items of a step keep their weight fragments in registers: a contiguous stretch behind the projection issue window
+// (RL4RS_X_SPREAD = 0) or every (48 / NRES)-th item (1: uniform load on the L1 return path)
+template <int NRES> constexpr bool is_res(int i) {
+    return RL4RS_X_SPREAD ? ((i % (NI / NRES)) == (NI / NRES) - 1 && i / (NI / NRES) < NRES) : (i >= 40 - NRES && i < 40);
 }
-constexpr bool starts_group(int i) { return (i < 48 || i >= 80) ? ((i & 1) == 0) : true; }     // state-fragment groups (64 per step)
-constexpr int group_parity(int i) {
-    int g = 0;
-    for (int k = 0; k <= i; ++k) g += starts_group(k) ? 1 : 0;
-    return (g - 1) & 1;
+// compile-time tables of a step's schedule: index of a resident item in the register file, position of a streamed item in
+// the (cyclic) streamed sequence that starts at the first streamed item >= 40, and its inverse
+struct Sched { int res_idx[NI]; int js_of[NI]; int item_of[NI]; int js_first; };
+template <int NRES> constexpr Sched make_sched() {
+    Sched s = {};
+    int n = 0;
+    for (int i = 0; i < NI; ++i) { s.res_idx[i] = n; n += is_res<NRES>(i) ? 1 : 0; }
+    int k = 40;
+    while (is_res<NRES>(k % NI)) ++k;
+    int js = 0;
+    for (int c = 0; c < NI; ++c) {
+        const int i = (k + c) % NI;
+        s.js_of[i] = js;
+        if (!is_res<NRES>(i)) { s.item_of[js] = i; ++js; }
+    }
+    int f = 0;
+    while (is_res<NRES>(f)) ++f;
+    s.js_first = s.js_of[f];                               // step 0 enters the sequence at its first streamed item >= 0
+    return s;
 }
-constexpr bool from_rh(int i) { return i >= 48 && i < 80; }                 // B operand: r*h planes (candidate) or h planes
-constexpr bool after_barrier(int i) { return i == 0 || i == 48 || i == 80; }
-constexpr int FIRST_RES = 50;                                               // first item after the projection issue window
-constexpr int rel(int i) { return (i - FIRST_RES + NI) % NI; }
 }  // namespace xk
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #ifdef RL4RS_X_TRACE       // s_memtime marks of workgroup (0,0), steps 8..11: [wave][step][mark]
 #define RL4RS_XT(k) do { if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && t >= 8 && t < 12) \
@@ -67,269 +86,242 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 #define RL4RS_XT(k) do { } while (0)
 #endif
 
-template <int MT, int NRES, int NLDS, int RING>
-__global__ __launch_bounds__(256) void k_augru_x(RecurArgs a) {
+template <int NRES, int RING>
+__global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     using namespace xk;
-    constexpr int NH = 256, KB = 16, LDP = NH + 8, MR = MT * 32;
-    constexpr int NS = NI - NRES - NLDS, LA = RING - 1;
-    static_assert(NS > 0 && NS % RING == 0 && RING >= 2 && LA < NS, "weight ring");
-    static_assert(NRES + NLDS <= NI - 50, "the resident items follow the issue window inside one step");
+    constexpr int NH = 256, KB = 16, PLANE = 32 * NH * 2;          // bytes per plane (16 KB)
+    constexpr int NS = NI - NRES, LA = RING - 1, WINDOW = 40 - NRES;     // WINDOW: the item the projection requests are issued in front of
+    constexpr Sched SC = make_sched<NRES>();
+    static_assert(NS > 0 && NS % RING == 0 && RING >= 2 && NRES >= 1 && NRES <= 14 && (!RL4RS_X_SPREAD || NI % NRES == 0), "weight ring / resident items");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* hp_hi = reinterpret_cast<_Float16*>(smem);     // [MR][LDP] each: h planes, r*h planes
-    _Float16* hp_lo = hp_hi + MR * LDP;
-    _Float16* rp_hi = hp_lo + MR * LDP;
-    _Float16* rp_lo = rp_hi + MR * LDP;
-    float* s_att = reinterpret_cast<float*>(rp_lo + MR * LDP);
+    char* hp_hi = smem;                       // planes in slab order: [kb 16][k-half 2][row 32][8 halfs]
+    char* hp_lo = smem + PLANE;
+    char* rp_hi = smem + 2 * PLANE;
+    char* rp_lo = smem + 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, li = lane & 31;
-    const int row0 = blockIdx.x * MR;
+    const int row0 = blockIdx.x * 32;
     const int sq = blockIdx.y;
-    const int L = a.L, LDT = L + 1;
+    const int L = a.L;
     const int xld4 = (int)a.xld * 4;
+    char* stage = smem + 4 * PLANE + wave * (3 * 4096);            // this wave's projection staging: slot g at + g * 4096
     // packed fp16 planes: [ntile][KB][plane hi/lo][64 lanes][8 halfs] -> 1 KB per (ntile, kb, plane) (pack_frag_h16)
     const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
     const int vl16 = lane * 16;
 
-    for (int i = tid; i < 2 * MR * LDP / 2; i += 256) reinterpret_cast<uint32_t*>(hp_hi)[i] = 0u;     // hi and lo planes of h = 0
-    for (int i = tid; i < MR * L; i += 256) {
-        const int r = i / L, t = i - r * L;
-        const int gr = min(row0 + r, a.n_rows - 1);
-        s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
-    }
-    uint32_t* s_bad = reinterpret_cast<uint32_t*>(s_att + MR * LDT);       // [MR] row poison flags
-    if (tid < MR) s_bad[tid] = 0u;
-    char* lds_w = reinterpret_cast<char*>(s_bad + MR) + (size_t)wave * NLDS * 2048;   // this wave's LDS-resident items
-    // byte offset of this lane's row(s) in the projection cache at t = 0, plus the lane's 16-byte column sub-offset
-    int xrow[MT];
+    for (int i = tid; i < 2 * PLANE / 16; i += 512) reinterpret_cast<uint4*>(hp_hi)[i] = make_uint4(0u, 0u, 0u, 0u);     // h = 0
+    // ---- projection staging geometry.  DMA instruction j (0..3) of a gate covers rows 8j .. 8j+7: lane l fetches, for row
+    // r = 8j + l/8, the 16-byte chunk c = (l%8 - r/2) mod 8 of the wave's 128 bytes of that row; it lands at slot + r*128 +
+    // (l%8)*16.  The reader (row li, column run q of half `half`: chunk 2q + half) finds it at position (2q + half + li/2) mod 8.
+    int dma_off[4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int gr = min(row0 + m * 32 + li, a.n_rows - 1);
-        xrow[m] = (int)((uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4) + half * 16;
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        const int gr = min(row0 + r, a.n_rows - 1);
+        const int c = ((lane & 7) - (r >> 1)) & 7;
+        dma_off[j] = (int)((uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4) + c * 16;
     }
-    const int hoff = li * LDP + half * 8;                 // B-fragment offset (halfs) of this lane inside a row tile
-    // weight item i of a step -> buffer + scalar byte offset (+ plane * 1024)
-    int sb_r = (2 * wave) * KB * 2048, sb_u = (8 + 2 * wave) * KB * 2048, sb_c = (2 * wave) * KB * 2048;
-    auto wload = [&](int i, half8_t& hi, half8_t& lo) {
-        const int g = gate(i), off = (ct(i) * KB + kb(i)) * 2048;
-        if (g == 0) { hi = buf_load_h8(rs_wg, vl16, sb_r + off); lo = buf_load_h8(rs_wg, vl16, sb_r + off + 1024); }
-        else if (g == 1) { hi = buf_load_h8(rs_wg, vl16, sb_u + off); lo = buf_load_h8(rs_wg, vl16, sb_u + off + 1024); }
-        else { hi = buf_load_h8(rs_wc, vl16, sb_c + off); lo = buf_load_h8(rs_wc, vl16, sb_c + off + 1024); }
+    const int my_row = min(row0 + li, a.n_rows - 1);
+    const float* att_row = a.att + (size_t)sq * a.att_stride + (size_t)my_row * L;
+    const int xs_base = wave * 128 + a.xoff * 4;                  // byte offset of the wave's 32 columns inside a gate block
+    auto x_dma = [&](int t) {                                      // the three gates' rows of step t -> staging slots
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * 4096 + j * 1024), 16, dma_off[j],
+                                                         t * xld4 + xs_base + g * NH * 4, 0, 0);
     };
-    // item index of streamed-sequence position js (the streamed items are cyclically contiguous in execution order)
-    auto streamed_item = [](int js) { return (FIRST_RES + NRES + NLDS + js) % NI; };
-    // cached input projection of gate block `blk` (0 r, 1 u, 2 c), step t, for tile m / column tile c -> 16 floats, 4 loads of 16 B
-    auto load_x = [&](f32x16& dst, int m, int c, int t, int blk) {
+    auto x_read = [&](f32x16& dst, int g) {                        // staged projection rows -> accumulator (MFMA C-in)
+        const int rot = half + (li >> 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = buf_load4(rs_x, xrow[m], t * xld4 + (a.xoff + blk * NH + (2 * wave + c) * 32 + 8 * q) * 4);
+            const float4 v = *reinterpret_cast<const float4*>(stage + g * 4096 + li * 128 + (((2 * q + rot) & 7) << 4));
             dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
     };
-
-    f32x16 acc_r[MT][2], acc_u[MT][2], acc_c[MT][2], h_own[MT][2], xs_u[MT][2], xs_c[MT][2];
-    half8_t res_h[NRES > 0 ? NRES : 1], res_l[NRES > 0 ? NRES : 1];      // items FIRST_RES .. FIRST_RES + NRES - 1
-    half8_t ring_h[RING], ring_l[RING], lw_h[2], lw_l[2];
-    half8_t bh[2][MT], bl[2][MT];
-    float amax[MT], oma[MT];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NRES; ++i) wload((FIRST_RES + i) % NI, res_h[i], res_l[i]);
-#pragma unroll
-    for (int i = 0; i < NLDS; ++i) {
-        half8_t hi, lo;
-        wload((FIRST_RES + NRES + i) % NI, hi, lo);
-        *reinterpret_cast<half8_t*>(lds_w + i * 2048 + vl16) = hi;
-        *reinterpret_cast<half8_t*>(lds_w + i * 2048 + 1024 + vl16) = lo;
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        amax[m] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h_own[m][c][r] = 0.f;
-            load_x(acc_r[m][c], m, c, 0, 0);          // h = 0: the R products of step 0 vanish, acc_r = x_r(0)
-            load_x(xs_u[m][c], m, c, 0, 1);
-            load_x(xs_c[m][c], m, c, 0, 2);
-        }
-    }
-#pragma unroll
-    for (int js = 0; js < LA; ++js) wload(streamed_item(js), ring_h[js % RING], ring_l[js % RING]);
-
-    auto hfrag = [&](int buf, int i) {                 // state fragments (B operand) of item i's k-block, all row tiles
-        const _Float16* ph = from_rh(i) ? rp_hi : hp_hi;
-        const _Float16* pl = from_rh(i) ? rp_lo : hp_lo;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            bh[buf][m] = *reinterpret_cast<const half8_t*>(ph + m * 32 * LDP + hoff + kb(i) * 16);
-            bl[buf][m] = *reinterpret_cast<const half8_t*>(pl + m * 32 * LDP + hoff + kb(i) * 16);
-        }
+    // weight item i of a step -> buffer + scalar byte offset (the lo plane sits 1 KB behind the hi plane: immediate offset)
+    int sb_r = wave * KB * 2048, sb_u = (8 + wave) * KB * 2048, sb_c = wave * KB * 2048;
+    auto wload = [&](int i, half8_t& hi, half8_t& lo) {
+        const int g = gate(i), off = (RL4RS_X_AB & 32) ? 0 : kb(i) * 2048;       // 32: every streamed load hits the same (L1-resident) fragment
+        if (g == 0) { hi = buf_load_h8(rs_wg, vl16, sb_r + off); lo = buf_load_h8(rs_wg, vl16 + 1024, sb_r + off); }
+        else if (g == 1) { hi = buf_load_h8(rs_wg, vl16, sb_u + off); lo = buf_load_h8(rs_wg, vl16 + 1024, sb_u + off); }
+        else { hi = buf_load_h8(rs_wc, vl16, sb_c + off); lo = buf_load_h8(rs_wc, vl16 + 1024, sb_c + off); }
     };
-    // four consecutive hidden columns of a lane's row -> the fp16 hi / lo planes (8-byte LDS writes)
-    auto plane_store = [&](_Float16* p_hi, _Float16* p_lo, int m, int c, int q, const float* v) {
+    const int foff = half * 512 + li * 16;                         // this lane's fragment inside a (plane, k-block) slab
+
+    f32x16 acc_r, acc_u, acc_c, h_own;
+    half8_t res_h[NRES], res_l[NRES], ring_h[RING], ring_l[RING];
+    half8_t bh[2], bl[2];
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
+    x_dma(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        if (is_res<NRES>(i)) wload(i, res_h[SC.res_idx[i]], res_l[SC.res_idx[i]]);
+#pragma unroll
+    for (int k = 0; k < LA; ++k) {
+        const int js = (SC.js_first + k) % NS;
+        wload(SC.item_of[js], ring_h[js % RING], ring_l[js % RING]);
+    }
+    float att_cur = att_row[0], att_next = 0.f;
+    x_read(acc_r, 0);                                              // h = 0: the R products of step 0 vanish, acc_r = x_r(0)
+    __syncthreads();
+
+    auto hfrag = [&](int buf, int i) {                             // state fragments (B operand) of item i's k-block
+        const char* ph = from_rh(i) ? rp_hi : hp_hi;
+        const char* pl = from_rh(i) ? rp_lo : hp_lo;
+        bh[buf] = *reinterpret_cast<const half8_t*>(ph + kb(i) * 1024 + foff);
+        bl[buf] = *reinterpret_cast<const half8_t*>(pl + kb(i) * 1024 + foff);
+    };
+    // four consecutive hidden columns (run q) of this lane's row -> the fp16 hi / lo planes (8-byte LDS writes)
+    auto plane_store = [&](char* p_hi, char* p_lo, int q, const float* v) {
         half4_t vh, vl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const _Float16 h = (_Float16)v[j];
+            // the value must be ONE rounded fp32 number for both uses below: left transparent, the compiler contracts the
+            // producing multiply into the fp16 conversion for one of them (v_fma_mixlo_f16: single rounding from the exact
+            // product) but not for the other, and hi + lo then misses v by an fp16 ulp in the double-rounding cases
+            float x = v[j];
+            asm volatile("" : "+v"(x));
+            const _Float16 h = (_Float16)x;
             vh[j] = h;
-            vl[j] = (_Float16)(v[j] - (float)h);
+            vl[j] = (_Float16)(x - (float)h);
         }
-        const int o = (m * 32 + li) * LDP + wave * 64 + c * 32 + 8 * q + 4 * half;
+        // column 32w + 8q + 4half + j -> k-block 2w + q/2, k-half q%2, element 4half + j
+        const int o = (2 * wave + (q >> 1)) * 1024 + (q & 1) * 512 + li * 16 + half * 8;
         *reinterpret_cast<half4_t*>(p_hi + o) = vh;
         *reinterpret_cast<half4_t*>(p_lo + o) = vl;
     };
+    float quad[4];
+    auto reset_gate = [&](int r) {                                 // element r of the reset gate: r*h -> planes
+        quad[r & 3] = ((RL4RS_X_AB & 1) ? acc_r[r] : gate_sigmoid(acc_r[r])) * h_own[r];
+        if ((r & 3) == 3) plane_store(rp_hi, rp_lo, r >> 2, quad);
+    };
+    auto update_gate = [&](int r, float oma) {
+        float pre = acc_u[r];
+        asm volatile("" : "+v"(pre));                              // keeps this element's chain where it is written
+        acc_u[r] = oma * ((RL4RS_X_AB & 1) ? pre : gate_sigmoid(pre));
+    };
+    auto blend = [&](int r) {                                      // candidate + state update of element r -> h planes
+        const float cnd = (RL4RS_X_AB & 1) ? acc_c[r] : gate_tanh(acc_c[r]);
+        const float hn = __builtin_fmaf(acc_u[r], h_own[r] - cnd, cnd);           // u h + (1-u) c
+        amax = fmaxf(amax, fabsf(hn));
+        h_own[r] = hn;
+        quad[r & 3] = hn;
+        if ((r & 3) == 3) plane_store(hp_hi, hp_lo, r >> 2, quad);
+    };
 
+    const bool early = wave < 4;
+    const int TL = a.steps > 0 ? a.steps : L;
 #pragma unroll 1
-    for (int t = 0; t < L; ++t) {
-        asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));     // keep the 96 per-item scalar offsets out of SGPR-hoisting
+    for (int t = 0; t < TL; ++t) {
+        asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));     // keep the per-item scalar offsets out of SGPR-hoisting
         RL4RS_XT(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) oma[m] = 1.0f - s_att[(m * 32 + li) * LDT + t];
-        hfrag(group_parity(0), 0);
-        float rq[MT][4], cq[MT][4];
+        const float oma = 1.0f - att_cur;
+        hfrag(0, 0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (i == 16) RL4RS_XT(1);
-            if (i == 48 || i == 80) {
-                if (i == 48) RL4RS_XT(2); else RL4RS_XT(4);
-                __syncthreads();                       // r*h planes complete / early half of the new state complete
-                if (i == 48) RL4RS_XT(3); else RL4RS_XT(5);
-                hfrag(group_parity(i), i);
+            const int g = gate(i), cur = i & 1;
+            if (i == 8) {
+                RL4RS_XT(1);
+                if (!(RL4RS_X_AB & 4)) x_read(acc_u, 1);                                  // x_u(t): staged one step ago
             }
-            const int g = gate(i), c = ct(i), cur = group_parity(i);
-            // ---- fetch ahead: state fragments of the next group, LDS-resident weights one item ahead, streamed weights LA ahead
-            if (i + 1 < NI && starts_group(i + 1) && !after_barrier(i + 1)) hfrag(group_parity(i + 1), i + 1);
-            if (NLDS > 0) {
-                const int rn = rel((i + 1) % NI);
-                if (rn >= NRES && rn < NRES + NLDS) {
-                    lw_h[(rn - NRES) & 1] = *reinterpret_cast<const half8_t*>(lds_w + (rn - NRES) * 2048 + vl16);
-                    lw_l[(rn - NRES) & 1] = *reinterpret_cast<const half8_t*>(lds_w + (rn - NRES) * 2048 + 1024 + vl16);
+            if (i == 24) {
+                RL4RS_XT(2);
+                if (!(RL4RS_X_AB & 16)) __syncthreads();           // r*h planes complete
+                RL4RS_XT(3);
+                if (!(RL4RS_X_AB & 4)) x_read(acc_c, 2);                                  // x_c(t)
+                if (!early) {
+                    // late role: the whole update gate first (VALU only) - its partner on the SIMD is already in its C items
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) update_gate(r, oma);
                 }
+                hfrag(cur, i);
             }
-            const int ri = rel(i);
-            if (ri >= NRES + NLDS) {
-                const int js = ri - NRES - NLDS;
-                wload(streamed_item((js + LA) % NS), ring_h[(js + LA) % RING], ring_l[(js + LA) % RING]);
+            if (i == 40) {
+                if (early) {
+                    // early role: candidate + blend after its C items, while its partner runs C on the matrix pipe
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) blend(r);
+                }
+                RL4RS_XT(4);
+                if (!(RL4RS_X_AB & 16)) __syncthreads();           // early half of the new state complete
+                RL4RS_XT(5);
+                if (!(RL4RS_X_AB & 4)) x_read(acc_r, 0);                                  // x_r(t+1) (requested 12+ items ago)
+                hfrag(cur, i);
             }
+            if (i == WINDOW && t + 1 < L && !(RL4RS_X_AB & 4)) {
+                // ---- the ONE projection issue window of the step: the register-resident items follow (no vector-memory wait)
+                x_dma(t + 1);
+                att_next = att_row[t + 1];
+            }
+            // ---- fetch ahead: state fragments of the next item, streamed weights LA items ahead
+            if (i + 1 < NI && !after_barrier(i + 1) && !(RL4RS_X_AB & 8)) hfrag(cur ^ 1, i + 1);
+            const bool resident = is_res<NRES>(i);
+            const int js = resident ? 0 : SC.js_of[i];             // position in the streamed sequence (if streamed)
+            const int ridx = resident ? SC.res_idx[i] : 0;
+            if (!resident && !(RL4RS_X_AB & 2)) wload(SC.item_of[(js + LA) % NS], ring_h[(js + LA) % RING], ring_l[(js + LA) % RING]);
             __builtin_amdgcn_sched_barrier(0);
-            const half8_t wh = ri < NRES ? res_h[ri < NRES ? ri : 0] : (ri < NRES + NLDS ? lw_h[(ri - NRES) & 1] : ring_h[(ri - NRES - NLDS) % RING]);
-            const half8_t wl = ri < NRES ? res_l[ri < NRES ? ri : 0] : (ri < NRES + NLDS ? lw_l[(ri - NRES) & 1] : ring_l[(ri - NRES - NLDS) % RING]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x16& acc = g == 0 ? acc_r[m][c] : (g == 1 ? acc_u[m][c] : acc_c[m][c]);
-                // the cached input projection enters as the C operand of the first MFMA of a chain
-                const f32x16 cin = (i == 16 || i == 17) ? xs_u[m][c] : ((i == 48 || i == 49) ? xs_c[m][c] : acc);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cur][m], cin, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cur][m], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cur][m], acc, 0, 0, 0);
+            const half8_t wh = resident ? res_h[ridx] : ring_h[js % RING];
+            const half8_t wl = resident ? res_l[ridx] : ring_l[js % RING];
+            f32x16& acc = g == 0 ? acc_r : (g == 1 ? acc_u : acc_c);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cur], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cur], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cur], acc, 0, 0, 0);
+            // ---- epilogue work in this item's MFMA shadow
+            if (i >= 8 && i < 24) {
+                reset_gate(i - 8);
+            } else if (early && i >= 24 && i < 32) {
+                update_gate(2 * (i - 24), oma);
+                update_gate(2 * (i - 24) + 1, oma);
+            } else if (!early && i >= 40) {
+                blend(2 * (i - 40));
+                blend(2 * (i - 40) + 1);
             }
-            // ---- the epilogue work that rides in this item's MFMA shadow
-            int nvalu = 0;
-            if (i >= 16 && i < 48) {                   // reset gate: one element per item, packed per 4 columns
-                const int e = i - 16, ec = e >> 4, r = e & 15;
+#if RL4RS_X_SGB
+            if ((i >= 8 && i < 24) || (early && i >= 24 && i < 32) || (!early && i >= 40)) {
+                // a wave issues in order: spread the VALU chunk over the item's three MFMAs instead of behind the last one
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    rq[m][r & 3] = gate_sigmoid(acc_r[m][ec][r]) * h_own[m][ec][r];
-                    if ((r & 3) == 3) plane_store(rp_hi, rp_lo, m, ec, r >> 2, rq[m]);
-                }
-                nvalu = 3;
-            } else if (i >= 48 && i < 64) {            // update gate: two elements per item
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e = 2 * (i - 48) + k, ec = e >> 4, r = e & 15;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        float pre = acc_u[m][ec][r];
-                        asm volatile("" : "+v"(pre));      // keeps this element's chain inside this item
-                        acc_u[m][ec][r] = oma[m] * gate_sigmoid(pre);
-                    }
-                }
-                nvalu = 4;
-            } else if (i >= 65) {                      // candidate + blend: tile 0 during [65,80), tile 1 during [80,96)
-                const int ec = i < 80 ? 0 : 1;
-                const int e0 = i < 80 ? i - 65 : i - 80, ne = (i == 79) ? 2 : 1;
-#pragma unroll
-                for (int k = 0; k < ne; ++k) {
-                    const int r = e0 + k;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float cnd = gate_tanh(acc_c[m][ec][r]);
-                        const float hn = __builtin_fmaf(acc_u[m][ec][r], h_own[m][ec][r] - cnd, cnd);     // u h + (1-u) c
-                        amax[m] = fmaxf(amax[m], fabsf(hn));
-                        h_own[m][ec][r] = hn;
-                        cq[m][r & 3] = hn;
-                        if ((r & 3) == 3) plane_store(hp_hi, hp_lo, m, ec, r >> 2, cq[m]);
-                    }
-                }
-                nvalu = 4;
-            }
-            if (i == 49 && t + 1 < L) {
-                // ---- the ONE projection issue window of the step (the resident items follow: no vector-memory wait for ~3.8K cycles)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        load_x(acc_r[m][cc], m, cc, t + 1, 0);
-                        load_x(xs_u[m][cc], m, cc, t + 1, 1);
-                        load_x(xs_c[m][cc], m, cc, t + 1, 2);
-                    }
-            }
-            // a wave issues in order: without this the VALU chunk only overlaps the last MFMA of the item
-            if (nvalu == 3) {
-#pragma unroll
-                for (int q = 0; q < 3 * MT; ++q) {
+                for (int q = 0; q < 3; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);         // VALU in its shadow
-                }
-            } else if (nvalu == 4) {
-#pragma unroll
-                for (int q = 0; q < 3 * MT; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, RL4RS_X_SGB, 0);     // VALU in its shadow
                 }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+        att_cur = att_next;
         RL4RS_XT(6);
-        __syncthreads();                               // late half of the new state complete
+        if (!(RL4RS_X_AB & 16)) __syncthreads();                   // late half of the new state complete
         RL4RS_XT(7);
     }
     // ---- poison rows that left the fp16 range (or went NaN) and write the final state (16-byte stores)
-    bool any_bad = false;
+    bool bad = !(amax < 6.0e4f);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        bool bad = !(amax[m] < 6.0e4f);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bad |= !(fabsf(h_own[m][c][r]) < 6.0e4f);
-        if (bad) atomicOr(&s_bad[m * 32 + li], 1u);
-        any_bad |= bad;
-    }
+    for (int r = 0; r < 16; ++r) bad |= !(fabsf(h_own[r]) < 6.0e4f);
+    uint32_t* s_bad = reinterpret_cast<uint32_t*>(rp_hi);          // the planes are dead now
+    if (tid < 32) s_bad[tid] = 0u;
     __syncthreads();
+    if (bad) atomicOr(&s_bad[li], 1u);
+    __syncthreads();
+    const int row = row0 + li;
+    const bool poison = s_bad[li] != 0u;
+    if (row < a.n_rows) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int row = row0 + m * 32 + li;
-        const bool poison = s_bad[m * 32 + li] != 0u;
-        if (row < a.n_rows) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = make_float4(h_own[m][c][4 * q], h_own[m][c][4 * q + 1], h_own[m][c][4 * q + 2], h_own[m][c][4 * q + 3]);
-                    if (poison) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-                    *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + a.out_off + sq * a.out_seq_off + wave * 64 + c * 32 + 8 * q + 4 * half) = v;
-                }
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(h_own[4 * q], h_own[4 * q + 1], h_own[4 * q + 2], h_own[4 * q + 3]);
+            if (poison) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + a.out_off + sq * a.out_seq_off + wave * 32 + 8 * q + 4 * half) = v;
         }
     }
-    if (any_bad && a.range_flag) atomicOr(a.range_flag, 1);
+    if (bad && a.range_flag) atomicOr(a.range_flag, 1);
 }
 
-static size_t augru_x_smem(int mt, int L, int nlds) {
-    return (size_t)4 * mt * 32 * (256 + 8) * 2 + (size_t)(mt * 32 * (L + 1) + mt * 32) * 4 + (size_t)4 * nlds * 2048;
-}
+static size_t augru_x_smem() { return (size_t)4 * 32 * 256 * 2 + (size_t)8 * 3 * 4096; }       // 64 KB planes + 96 KB staging = 160 KB
 
 }  // namespace rl4rs

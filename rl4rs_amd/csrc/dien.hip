@@ -37,19 +37,10 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 #define RL4RS_H16_NRES 14        // weight items of a step kept resident in registers (k_augru_h16)
 #endif
 #ifndef RL4RS_X_NRES
-#define RL4RS_X_NRES 26          // k_augru_x: weight items of a step resident in registers (VGPR / AGPR)
-#endif
-#ifndef RL4RS_X_NLDS
-#define RL4RS_X_NLDS 10          // ... resident in LDS (per wave)
+#define RL4RS_X_NRES 12          // k_augru_x: weight items of a wave's step resident in registers (of 48)
 #endif
 #ifndef RL4RS_X_RING
-#define RL4RS_X_RING 4           // ... register ring of the streamed rest (96 - NRES - NLDS items, a multiple of RING)
-#endif
-#ifndef RL4RS_X2_NRES
-#define RL4RS_X2_NRES 0          // the 64-row form of k_augru_x: registers go to the second row tile's accumulators
-#endif
-#ifndef RL4RS_X2_RING
-#define RL4RS_X2_RING 4
+#define RL4RS_X_RING 4           // ... register ring of the streamed rest (48 - NRES items, a multiple of RING)
 #endif
 #ifndef RL4RS_H16_RING1
 #define RL4RS_H16_RING1 4        // weight ring depth (items) of k_augru_h16: 3 items = 9 MFMAs ahead;
@@ -190,6 +181,7 @@ struct RecurArgs {
     unsigned long long* trace;   // -DRL4RS_H16_TRACE timing experiments only
     int* range_flag;             // k_augru_h16: set to 1 when a state leaves the fp16 range (|h| >= 6e4 or NaN)
     int hard_gates;              // GRU mode: keras hard_sigmoid gates (simnet.hpp) instead of sigmoid
+    int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
 };
 
@@ -565,8 +557,9 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     }
 
     bool out_of_range = false;
+    const int TL = a.steps > 0 ? a.steps : L;
 #pragma unroll 1
-    for (int t = 0; t < L; ++t) {
+    for (int t = 0; t < TL; ++t) {
         asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));
         RL4RS_TR(0);
 #pragma unroll
@@ -1493,10 +1486,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_NLDS, RL4RS_X_RING>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(1, L, RL4RS_X_NLDS)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, 0, RL4RS_X2_RING>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(2, L, 0)));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<RL4RS_X_NRES, RL4RS_X_RING>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem()));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
@@ -1625,6 +1616,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
+            { static const int dbg_steps = getenv("RL4RS_AUGRU_STEPS") ? atoi(getenv("RL4RS_AUGRU_STEPS")) : 0; a.steps = dbg_steps; }
 #if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)
             static unsigned long long* trace_buf = nullptr;
             if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 8 * 4 * 8 * 8); (void)hipMemset(trace_buf, 0, 8 * 4 * 8 * 8); }
@@ -1637,14 +1629,8 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
                 if (f) { fwrite(host, 1, sizeof(host), f); fclose(f); }
             }
 #endif
-            // 64-row workgroups (every weight fragment feeds two row tiles: half the weight bytes per row) once there are enough
-            // row tiles to keep every CU busy with them; 32-row workgroups for the obs-sized launches (one tile per CU)
-            static const int x_mt = getenv("RL4RS_X_MT") ? atoi(getenv("RL4RS_X_MT")) : 0;
-            const bool mt2 = x_mt == 2 || (x_mt == 0 && (int64_t)((R + 63) / 64) * S >= 2 * (int64_t)n->n_cu);
-            if (n->augru_x && mt2)
-                hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, 0, RL4RS_X2_RING>), dim3((R + 63) / 64, S), dim3(256), augru_x_smem(2, L, 0), st, a);
-            else if (n->augru_x)
-                hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_NLDS, RL4RS_X_RING>), grid, dim3(256), augru_x_smem(1, L, RL4RS_X_NLDS), st, a);
+            if (n->augru_x)
+                hipLaunchKernelGGL((k_augru_x<RL4RS_X_NRES, RL4RS_X_RING>), grid, block, augru_x_smem(), st, a);
             else
                 hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
         } else

@@ -185,9 +185,15 @@ def test_scorer_mode_selection(monkeypatch, scorer_precision):
     base = dict(CFG)
     base.pop('scorer_precision')
     monkeypatch.delenv('RL4RS_SCORER', raising=False)
+    monkeypatch.delenv('RL4RS_AUGRU', raising=False)
     net = DeviceDien(base, w, max_rows=8, max_slots=4)
-    assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_h16'      # auto default
+    assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_x'        # auto default: second-generation recurrence
     net.close()
+    monkeypatch.setenv('RL4RS_AUGRU', 'h16')                                       # the first generation stays selectable
+    net = DeviceDien(base, w, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_h16'
+    net.close()
+    monkeypatch.delenv('RL4RS_AUGRU')
     monkeypatch.setenv('RL4RS_SCORER', 'fp32')
     net = DeviceDien(base, w, max_rows=8, max_slots=4)
     assert net.scorer_mode == 'fp32' and net.augru_kernel == 'k_recur<256,augru>'
@@ -245,6 +251,45 @@ def test_fp16_range_status(scorer_precision):
     else:
         net.check_status()
     net.close()
+
+
+def test_fp16_range_poisons_the_rows_on_the_device(scorer_precision):
+    """in tensor mode nobody polls the status bit, so an out-of-range recurrence must not hand back
+    plausible numbers.  k_augru_x writes NaN into every output column of a row whose state left the fp16 range: its
+    observation and click probability are NaN ON THE DEVICE (no host synchronisation), the rows of a sane model are not."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    R = 40
+    rs = np.random.RandomState(2)
+    seq, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+    w = init_dien_weights(CFG, seed=3, emb_scale=0.5)
+    w['att0_b3'] = np.array([-40.0], dtype=np.float32)          # sequence input 0 explodes for every row
+    net = DeviceDien(CFG, w, max_rows=R, max_slots=R)
+    for s in range(2):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    slots = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+    obs, prob = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, want_obs=True, want_prob=True)
+    assert torch.isnan(obs).all(dim=1).all() and torch.isnan(prob).all()
+    net.close()
+    ok = init_dien_weights(CFG, seed=3, emb_scale=0.5)
+    net = DeviceDien(CFG, ok, max_rows=R, max_slots=R)
+    for s in range(2):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    obs, prob = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, want_obs=True, want_prob=True)
+    assert torch.isfinite(obs).all() and torch.isfinite(prob).all()
+    net.check_status()
+    net.close()
+
+
+def test_first_generation_recurrence_still_matches(monkeypatch, scorer_precision):
+    """RL4RS_AUGRU=h16 (k_augru_h16, round 1) stays a selectable fp16x2 recurrence and stays parity-green."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    monkeypatch.setenv('RL4RS_AUGRU', 'h16')
+    test_dien_rowwise_matches_oracle(64)
 
 
 def test_fp16x2_recurrence_with_fp32_attention(monkeypatch, scorer_precision):

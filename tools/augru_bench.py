@@ -50,7 +50,10 @@ def run(kind):
         ms, n = net.profile()[net.augru_kernel]
         net.set_profiling(False)
         out['ms%d' % group] = ms / max(n, 1)
-    net.check_status() if hasattr(net, 'check_status') else None
+    if not os.environ.get('AUGRU_BENCH_NOCHECK'):
+        net.check_status()
+    else:
+        net.set_profiling(False)
     net.close()
     return out
 

@@ -30,8 +30,8 @@ for _ in range(3):      # the dump at launch k holds the marks of launch k-1
     net.forward(R, group, dense, cat, slots, want_obs=True, want_prob=False)
 torch.cuda.synchronize()
 tr = np.fromfile('/tmp/x_trace.bin', dtype=np.uint64).reshape(8, 4, 8).astype(np.int64)
-names = ['R-late', 'U', 'bar1', 'C', 'bar_a', 'R-early', 'bar_b']
-for wv in range(4):
+names = ['R-late', 'U', 'bar1', 'C(+ep)', 'bar_a', 'R-early', 'bar_b']
+for wv in range(8):
     for st in range(3):
         m = tr[wv, st]
         seg = [m[k + 1] - m[k] for k in range(7)]
