@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     const int vl16 = lane * 16;
     const float* __restrict__ w1ac = a.w1ac[sq];
     const int ntile = (L + 31) / 32;    // L <= 64 -> 1 or 2 N tiles
-    const int t0 = li, t1 = min(32 + li, L - 1);
+    const int t0 = min(li, L - 1), t1 = min(32 + li, L - 1);     // clamped: steps >= L re-read the last row (results never stored)
     const int nrows = STAGE ? a.group : 1;
     const int jstep = STAGE ? nw : 1;
 

@@ -299,3 +299,30 @@ def test_fp16x2_recurrence_with_fp32_attention(monkeypatch, scorer_precision):
         pytest.skip('fp16x2 only')
     monkeypatch.setenv('RL4RS_DIN16', '0')
     test_dien_rowwise_matches_oracle(64)
+
+
+@pytest.mark.parametrize('L', [8, 16, 33])
+def test_short_histories_stay_in_bounds(L, scorer_precision):
+    """maxlen < 32: the DIN score kernel used to read first-GRU cache rows past a slot's L steps (lanes 16..31 of its
+    32-step tile); harmless inside a larger allocation, a memory fault when the cache ends on a page boundary
+    (maxlen 16 x 256 slots x 128 floats = exactly 2 MB).  All three recurrences, whole forward vs the fp64 oracle."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from oracle.dien import OracleDien
+    B = 256
+    cfg = dict(CFG, maxlen=L, batch_size=B)
+    w = init_dien_weights(cfg, seed=7, emb_scale=0.5, bias_noise=0.1)
+    rs = np.random.RandomState(L)
+    seq = rs.randint(0, 284, size=(B, 2, L)).astype(np.int32)
+    dense = np.abs(rs.randn(B, cfg['dense_feature_num'])).astype(np.float32)
+    cat = rs.randint(0, 284, size=(B, cfg['category_feature_num'])).astype(np.int32)
+    slots = torch.arange(B, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+    net = DeviceDien(cfg, w, max_rows=B, max_slots=B)
+    for s in range(2):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    obs, _ = net.forward(B, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, want_obs=True, want_prob=False)
+    ref = OracleDien(w, cfg, np.float64).obs(seq, dense, cat)
+    assert np.abs(obs.cpu().numpy() - ref).max() < 5e-5
+    net.check_status()
+    net.close()
