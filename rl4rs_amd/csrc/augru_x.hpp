@@ -46,6 +46,9 @@ constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
 #ifndef RL4RS_X_SGB
 #define RL4RS_X_SGB 0           // VALU instructions pinned behind each MFMA of an item that carries epilogue work (0 = compiler's order)
 #endif
+#ifndef RL4RS_X_PRIO
+#define RL4RS_X_PRIO 0
+#endif
 #ifndef RL4RS_X_SPREAD
 #define RL4RS_X_SPREAD 0
 #endif
@@ -86,7 +89,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define RL4RS_XT(k) do { } while (0)
 #endif
 
-template <int NRES, int RING>
+// MT = 1: 32-row workgroups, per-row projection staging (any row -> slot map).  MT = 2: 64-row workgroups for launches whose
+// rows come in groups of 8 consecutive rows per cache slot (the reward forward: 8 complete-state rows per env): every weight
+// fragment feeds two row tiles (half the weight bytes per row through the L1 return path), and the 8 distinct projection rows
+// of the workgroup are staged once (1 KB per gate and wave, one DMA instruction).
+template <int MT, int NRES, int RING>
 __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     using namespace xk;
     constexpr int NH = 256, KB = 16, PLANE = 32 * NH * 2;          // bytes per plane (16 KB)
@@ -94,52 +101,62 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     constexpr Sched SC = make_sched<NRES>();
     static_assert(NS > 0 && NS % RING == 0 && RING >= 2 && NRES >= 1 && NRES <= 14 && (!RL4RS_X_SPREAD || NI % NRES == 0), "weight ring / resident items");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* hp_hi = smem;                       // planes in slab order: [kb 16][k-half 2][row 32][8 halfs]
+    // planes in slab order [kb 16][k-half 2][row 32][8 halfs]; tile m's four planes (h hi/lo, r*h hi/lo) at m * 4 * PLANE
+    char* hp_hi = smem;
     char* hp_lo = smem + PLANE;
     char* rp_hi = smem + 2 * PLANE;
     char* rp_lo = smem + 3 * PLANE;
+    constexpr int TILE = 4 * PLANE, STG = MT == 1 ? 3 * 4096 : 3 * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, li = lane & 31;
-    const int row0 = blockIdx.x * 32;
+    const int row0 = blockIdx.x * 32 * MT;
     const int sq = blockIdx.y;
     const int L = a.L;
     const int xld4 = (int)a.xld * 4;
-    char* stage = smem + 4 * PLANE + wave * (3 * 4096);            // this wave's projection staging: slot g at + g * 4096
+    char* stage = smem + MT * TILE + wave * STG;                   // this wave's projection staging: gate g at + g * STG / 3
     // packed fp16 planes: [ntile][KB][plane hi/lo][64 lanes][8 halfs] -> 1 KB per (ntile, kb, plane) (pack_frag_h16)
     const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
     const int vl16 = lane * 16;
 
-    for (int i = tid; i < 2 * PLANE / 16; i += 512) reinterpret_cast<uint4*>(hp_hi)[i] = make_uint4(0u, 0u, 0u, 0u);     // h = 0
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        for (int i = tid; i < 2 * PLANE / 16; i += 512) reinterpret_cast<uint4*>(hp_hi + m * TILE)[i] = make_uint4(0u, 0u, 0u, 0u);     // h = 0
     // ---- projection staging geometry.  DMA instruction j (0..3) of a gate covers rows 8j .. 8j+7: lane l fetches, for row
     // r = 8j + l/8, the 16-byte chunk c = (l%8 - r/2) mod 8 of the wave's 128 bytes of that row; it lands at slot + r*128 +
     // (l%8)*16.  The reader (row li, column run q of half `half`: chunk 2q + half) finds it at position (2q + half + li/2) mod 8.
     int dma_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = 8 * j + (lane >> 3);
+        // MT = 1: row r = 8j + l/8, rotated chunk.  MT = 2 (only j = 0 is used): lane l fetches chunk l%8 of distinct row d = l/8,
+        // i.e. of batch row row0 + 8d (rows 8d .. 8d+7 share its cache slot)
+        const int r = MT == 1 ? 8 * j + (lane >> 3) : 8 * (lane >> 3);
         const int gr = min(row0 + r, a.n_rows - 1);
-        const int c = ((lane & 7) - (r >> 1)) & 7;
+        const int c = MT == 1 ? (((lane & 7) - (r >> 1)) & 7) : (lane & 7);
         dma_off[j] = (int)((uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4) + c * 16;
     }
-    const int my_row = min(row0 + li, a.n_rows - 1);
-    const float* att_row = a.att + (size_t)sq * a.att_stride + (size_t)my_row * L;
+    const float* att_row[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        att_row[m] = a.att + (size_t)sq * a.att_stride + (size_t)min(row0 + m * 32 + li, a.n_rows - 1) * L;
     const int xs_base = wave * 128 + a.xoff * 4;                  // byte offset of the wave's 32 columns inside a gate block
-    auto x_dma = [&](int t) {                                      // the three gates' rows of step t -> staging slots
+    auto x_dma = [&](int t) {                                      // the three gates' rows of step t -> staging
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * 4096 + j * 1024), 16, dma_off[j],
+            for (int j = 0; j < (MT == 1 ? 4 : 1); ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * (STG / 3) + j * 1024), 16, dma_off[j],
                                                          t * xld4 + xs_base + g * NH * 4, 0, 0);
     };
-    auto x_read = [&](f32x16& dst, int g) {                        // staged projection rows -> accumulator (MFMA C-in)
+    auto x_read = [&](f32x16& dst, int g, int m) {                 // staged projection rows -> accumulator (MFMA C-in)
         const int rot = half + (li >> 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(stage + g * 4096 + li * 128 + (((2 * q + rot) & 7) << 4));
+            const char* src = MT == 1 ? stage + g * 4096 + li * 128 + (((2 * q + rot) & 7) << 4)
+                                      : stage + g * 1024 + (4 * m + (li >> 3)) * 128 + ((2 * q + half) << 4);
+            const float4 v = *reinterpret_cast<const float4*>(src);
             dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
     };
@@ -153,12 +170,17 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     };
     const int foff = half * 512 + li * 16;                         // this lane's fragment inside a (plane, k-block) slab
 
-    f32x16 acc_r, acc_u, acc_c, h_own;
+    f32x16 acc_r[MT], acc_u[MT], acc_c[MT], h_own[MT];
     half8_t res_h[NRES], res_l[NRES], ring_h[RING], ring_l[RING];
-    half8_t bh[2], bl[2];
-    float amax = 0.f;
+    half8_t bh[2][MT], bl[2][MT];
+    float amax[MT], att_cur[MT], att_next[MT], oma[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
+    for (int m = 0; m < MT; ++m) {
+        amax[m] = 0.f;
+        att_next[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h_own[m][r] = 0.f;
+    }
     x_dma(0);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -168,18 +190,24 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         const int js = (SC.js_first + k) % NS;
         wload(SC.item_of[js], ring_h[js % RING], ring_l[js % RING]);
     }
-    float att_cur = att_row[0], att_next = 0.f;
-    x_read(acc_r, 0);                                              // h = 0: the R products of step 0 vanish, acc_r = x_r(0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        att_cur[m] = att_row[m][0];
+        x_read(acc_r[m], 0, m);                                    // h = 0: the R products of step 0 vanish, acc_r = x_r(0)
+    }
     __syncthreads();
 
     auto hfrag = [&](int buf, int i) {                             // state fragments (B operand) of item i's k-block
         const char* ph = from_rh(i) ? rp_hi : hp_hi;
         const char* pl = from_rh(i) ? rp_lo : hp_lo;
-        bh[buf] = *reinterpret_cast<const half8_t*>(ph + kb(i) * 1024 + foff);
-        bl[buf] = *reinterpret_cast<const half8_t*>(pl + kb(i) * 1024 + foff);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bh[buf][m] = *reinterpret_cast<const half8_t*>(ph + m * TILE + kb(i) * 1024 + foff);
+            bl[buf][m] = *reinterpret_cast<const half8_t*>(pl + m * TILE + kb(i) * 1024 + foff);
+        }
     };
     // four consecutive hidden columns (run q) of this lane's row -> the fp16 hi / lo planes (8-byte LDS writes)
-    auto plane_store = [&](char* p_hi, char* p_lo, int q, const float* v) {
+    auto plane_store = [&](char* p_hi, char* p_lo, int m, int q, const float* v) {
         half4_t vh, vl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -193,53 +221,74 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             vl[j] = (_Float16)(x - (float)h);
         }
         // column 32w + 8q + 4half + j -> k-block 2w + q/2, k-half q%2, element 4half + j
-        const int o = (2 * wave + (q >> 1)) * 1024 + (q & 1) * 512 + li * 16 + half * 8;
+        const int o = m * TILE + (2 * wave + (q >> 1)) * 1024 + (q & 1) * 512 + li * 16 + half * 8;
         *reinterpret_cast<half4_t*>(p_hi + o) = vh;
         *reinterpret_cast<half4_t*>(p_lo + o) = vl;
     };
-    float quad[4];
+    float quad[MT][4];
     auto reset_gate = [&](int r) {                                 // element r of the reset gate: r*h -> planes
-        quad[r & 3] = ((RL4RS_X_AB & 1) ? acc_r[r] : gate_sigmoid(acc_r[r])) * h_own[r];
-        if ((r & 3) == 3) plane_store(rp_hi, rp_lo, r >> 2, quad);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            quad[m][r & 3] = ((RL4RS_X_AB & 1) ? acc_r[m][r] : gate_sigmoid(acc_r[m][r])) * h_own[m][r];
+            if ((r & 3) == 3) plane_store(rp_hi, rp_lo, m, r >> 2, quad[m]);
+        }
     };
-    auto update_gate = [&](int r, float oma) {
-        float pre = acc_u[r];
-        asm volatile("" : "+v"(pre));                              // keeps this element's chain where it is written
-        acc_u[r] = oma * ((RL4RS_X_AB & 1) ? pre : gate_sigmoid(pre));
+    auto update_gate = [&](int r) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float pre = acc_u[m][r];
+            asm volatile("" : "+v"(pre));                          // keeps this element's chain where it is written
+            acc_u[m][r] = oma[m] * ((RL4RS_X_AB & 1) ? pre : gate_sigmoid(pre));
+        }
     };
     auto blend = [&](int r) {                                      // candidate + state update of element r -> h planes
-        const float cnd = (RL4RS_X_AB & 1) ? acc_c[r] : gate_tanh(acc_c[r]);
-        const float hn = __builtin_fmaf(acc_u[r], h_own[r] - cnd, cnd);           // u h + (1-u) c
-        amax = fmaxf(amax, fabsf(hn));
-        h_own[r] = hn;
-        quad[r & 3] = hn;
-        if ((r & 3) == 3) plane_store(hp_hi, hp_lo, r >> 2, quad);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float cnd = (RL4RS_X_AB & 1) ? acc_c[m][r] : gate_tanh(acc_c[m][r]);
+            const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - cnd, cnd);       // u h + (1-u) c
+            amax[m] = fmaxf(amax[m], fabsf(hn));
+            h_own[m][r] = hn;
+            quad[m][r & 3] = hn;
+            if ((r & 3) == 3) plane_store(hp_hi, hp_lo, m, r >> 2, quad[m]);
+        }
     };
 
     const bool early = wave < 4;
+#if RL4RS_X_PRIO
+    // the late waves carry their candidate epilogue next to their own MFMAs (R-early phase) and are the younger half of the
+    // workgroup (the arbitration losers): one static priority raise, no per-phase flips (MI355X_MICROARCH.md, two waves per SIMD #4)
+    if (!early) __builtin_amdgcn_s_setprio(RL4RS_X_PRIO);
+#endif
     const int TL = a.steps > 0 ? a.steps : L;
 #pragma unroll 1
     for (int t = 0; t < TL; ++t) {
         asm volatile("" : "+s"(sb_r), "+s"(sb_u), "+s"(sb_c));     // keep the per-item scalar offsets out of SGPR-hoisting
         RL4RS_XT(0);
-        const float oma = 1.0f - att_cur;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) oma[m] = 1.0f - att_cur[m];
         hfrag(0, 0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = gate(i), cur = i & 1;
             if (i == 8) {
                 RL4RS_XT(1);
-                if (!(RL4RS_X_AB & 4)) x_read(acc_u, 1);                                  // x_u(t): staged one step ago
+                if (!(RL4RS_X_AB & 4)) {                          // x_u(t): staged one step ago
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) x_read(acc_u[m], 1, m);
+                }
             }
             if (i == 24) {
                 RL4RS_XT(2);
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // r*h planes complete
                 RL4RS_XT(3);
-                if (!(RL4RS_X_AB & 4)) x_read(acc_c, 2);                                  // x_c(t)
+                if (!(RL4RS_X_AB & 4)) {                          // x_c(t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) x_read(acc_c[m], 2, m);
+                }
                 if (!early) {
                     // late role: the whole update gate first (VALU only) - its partner on the SIMD is already in its C items
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) update_gate(r, oma);
+                    for (int r = 0; r < 16; ++r) update_gate(r);
                 }
                 hfrag(cur, i);
             }
@@ -252,13 +301,17 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
                 RL4RS_XT(4);
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // early half of the new state complete
                 RL4RS_XT(5);
-                if (!(RL4RS_X_AB & 4)) x_read(acc_r, 0);                                  // x_r(t+1) (requested 12+ items ago)
+                if (!(RL4RS_X_AB & 4)) {                          // x_r(t+1) (requested 12+ items ago)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) x_read(acc_r[m], 0, m);
+                }
                 hfrag(cur, i);
             }
             if (i == WINDOW && t + 1 < L && !(RL4RS_X_AB & 4)) {
                 // ---- the ONE projection issue window of the step: the register-resident items follow (no vector-memory wait)
                 x_dma(t + 1);
-                att_next = att_row[t + 1];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) att_next[m] = att_row[m][t + 1];
             }
             // ---- fetch ahead: state fragments of the next item, streamed weights LA items ahead
             if (i + 1 < NI && !after_barrier(i + 1) && !(RL4RS_X_AB & 8)) hfrag(cur ^ 1, i + 1);
@@ -269,16 +322,20 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             const half8_t wh = resident ? res_h[ridx] : ring_h[js % RING];
             const half8_t wl = resident ? res_l[ridx] : ring_l[js % RING];
-            f32x16& acc = g == 0 ? acc_r : (g == 1 ? acc_u : acc_c);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[cur], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cur], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[cur], acc, 0, 0, 0);
+            // product terms outermost: with two row tiles the dependent MFMAs of one accumulator are a tile apart
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x16& acc = g == 0 ? acc_r[m] : (g == 1 ? acc_u[m] : acc_c[m]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? wl : wh, term == 2 ? bl[cur][m] : bh[cur][m], acc, 0, 0, 0);
+                }
             // ---- epilogue work in this item's MFMA shadow
             if (i >= 8 && i < 24) {
                 reset_gate(i - 8);
             } else if (early && i >= 24 && i < 32) {
-                update_gate(2 * (i - 24), oma);
-                update_gate(2 * (i - 24) + 1, oma);
+                update_gate(2 * (i - 24));
+                update_gate(2 * (i - 24) + 1);
             } else if (!early && i >= 40) {
                 blend(2 * (i - 40));
                 blend(2 * (i - 40) + 1);
@@ -287,7 +344,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             if ((i >= 8 && i < 24) || (early && i >= 24 && i < 32) || (!early && i >= 40)) {
                 // a wave issues in order: spread the VALU chunk over the item's three MFMAs instead of behind the last one
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < 3 * MT; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, RL4RS_X_SGB, 0);     // VALU in its shadow
                 }
@@ -295,33 +352,43 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        att_cur = att_next;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) att_cur[m] = att_next[m];
         RL4RS_XT(6);
         if (!(RL4RS_X_AB & 16)) __syncthreads();                   // late half of the new state complete
         RL4RS_XT(7);
     }
     // ---- poison rows that left the fp16 range (or went NaN) and write the final state (16-byte stores)
-    bool bad = !(amax < 6.0e4f);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bad |= !(fabsf(h_own[r]) < 6.0e4f);
     uint32_t* s_bad = reinterpret_cast<uint32_t*>(rp_hi);          // the planes are dead now
-    if (tid < 32) s_bad[tid] = 0u;
+    if (tid < 32 * MT) s_bad[tid] = 0u;
     __syncthreads();
-    if (bad) atomicOr(&s_bad[li], 1u);
-    __syncthreads();
-    const int row = row0 + li;
-    const bool poison = s_bad[li] != 0u;
-    if (row < a.n_rows) {
+    bool any_bad = false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(h_own[4 * q], h_own[4 * q + 1], h_own[4 * q + 2], h_own[4 * q + 3]);
-            if (poison) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-            *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + a.out_off + sq * a.out_seq_off + wave * 32 + 8 * q + 4 * half) = v;
+    for (int m = 0; m < MT; ++m) {
+        bool bad = !(amax[m] < 6.0e4f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bad |= !(fabsf(h_own[m][r]) < 6.0e4f);
+        if (bad) atomicOr(&s_bad[m * 32 + li], 1u);
+        any_bad |= bad;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = row0 + m * 32 + li;
+        const bool poison = s_bad[m * 32 + li] != 0u;
+        if (row < a.n_rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(h_own[m][4 * q], h_own[m][4 * q + 1], h_own[m][4 * q + 2], h_own[m][4 * q + 3]);
+                if (poison) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + a.out_off + sq * a.out_seq_off + wave * 32 + 8 * q + 4 * half) = v;
+            }
         }
     }
-    if (bad && a.range_flag) atomicOr(a.range_flag, 1);
+    if (any_bad && a.range_flag) atomicOr(a.range_flag, 1);
 }
 
-static size_t augru_x_smem() { return (size_t)4 * 32 * 256 * 2 + (size_t)8 * 3 * 4096; }       // 64 KB planes + 96 KB staging = 160 KB
+// MT = 1: 64 KB planes + 96 KB staging = all 160 KB;  MT = 2: 128 KB planes + 24 KB staging
+static size_t augru_x_smem(int mt) { return (size_t)mt * 4 * 32 * 256 * 2 + (size_t)8 * (mt == 1 ? 3 * 4096 : 3 * 1024); }
 
 }  // namespace rl4rs

@@ -42,6 +42,12 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 #ifndef RL4RS_X_RING
 #define RL4RS_X_RING 4           // ... register ring of the streamed rest (48 - NRES items, a multiple of RING)
 #endif
+#ifndef RL4RS_X2_NRES
+#define RL4RS_X2_NRES 4          // the 64-row form of k_augru_x (registers hold the second row tile's accumulators instead)
+#endif
+#ifndef RL4RS_X2_RING
+#define RL4RS_X2_RING 2
+#endif
 #ifndef RL4RS_H16_RING1
 #define RL4RS_H16_RING1 4        // weight ring depth (items) of k_augru_h16: 3 items = 9 MFMAs ahead;
                                  // measured (ring, resident): (8,10) 60.6 ms, (6,12) 59.5, (4,14) 59.0 per 5 episodes
@@ -1486,8 +1492,10 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<RL4RS_X_NRES, RL4RS_X_RING>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem()));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(1)));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(2)));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
@@ -1629,8 +1637,14 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
                 if (f) { fwrite(host, 1, sizeof(host), f); fclose(f); }
             }
 #endif
-            if (n->augru_x)
-                hipLaunchKernelGGL((k_augru_x<RL4RS_X_NRES, RL4RS_X_RING>), grid, block, augru_x_smem(), st, a);
+            // 64-row workgroups when the rows come in whole groups of 8 per cache slot (the reward forward) and there are enough
+            // of them to keep every CU busy; 32-row workgroups otherwise (obs-sized launches: one 32-row tile per CU)
+            static const int x_mt = getenv("RL4RS_X_MT") ? atoi(getenv("RL4RS_X_MT")) : 0;
+            const bool mt2 = x_mt != 1 && group % 8 == 0 && R % 64 == 0 && (x_mt == 2 || (int64_t)(R / 64) * S >= 2 * (int64_t)n->n_cu);
+            if (n->augru_x && mt2)
+                hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), dim3(R / 64, S), block, augru_x_smem(2), st, a);
+            else if (n->augru_x)
+                hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), grid, block, augru_x_smem(1), st, a);
             else
                 hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
         } else
