@@ -184,7 +184,7 @@ def main():
     for _ in range(args.warmup):
         run_step()
     net = env.sim.model.device_net
-    net.set_profiling(True)
+    net.set_profiling(not os.environ.get('RL4RS_BENCH_NOPROF'))
     net.profile_reset()
 
     rdist.barrier()

@@ -172,6 +172,9 @@ int rl4rs_env_offline_reward(rl4rs_env* env, double* out_dev, void* stream);
 int rl4rs_env_predict_with_mask(rl4rs_env* env, int32_t N, const float* scores_dev, const int32_t* prev_dev,
                                 int32_t prev_cols, const int32_t* cur_step_dev, int32_t* out_dev, void* stream);
 
+/* The configuration the env was created with. */
+int rl4rs_env_get_cfg(const rl4rs_env* env, rl4rs_env_cfg* out);
+
 /* Device views of env-owned buffers (valid until destroy).  `which`: */
 enum {
     RL4RS_BUF_PREV_ACTIONS = 0,   /* int32  [B, max_steps] */
@@ -341,6 +344,33 @@ int rl4rs_simnet_forward(rl4rs_simnet* net, int32_t R, int32_t group, const floa
                          void* stream);
 /* softmax(obs @ out_w + out_b)[:, 1] of already computed 'simulator_obs' rows */
 int rl4rs_simnet_head_prob(rl4rs_simnet* net, int32_t R, const float* obs_dev, float* prob_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One batched transition as ONE call: RecSimBase._step (rl4rs/env/base.py:157-170) = act -> obs_fn -> forward (reward
+ * when due) -> done, for an env bound to its scorer.  Same kernels in the same order as calling rl4rs_env_act_* /
+ * rl4rs_dien_forward / rl4rs_env_build_complete_rows / rl4rs_dien_head_prob / rl4rs_env_reward_split one by one
+ * (bit-identical results); nothing is allocated, nothing synchronises inside.
+ *   slots_dev  int32 [seq_num, batch_size]: cache slot of every env row per sequence input (caller-owned; the caller
+ *              encodes the history sequences with rl4rs_dien_encode after every rl4rs_env_load_batch and keeps row 0
+ *              current; SeqSlate's second input is re-encoded here on the first act of a page, seqslate.py:107-108)
+ *   obs_dev    float32 [B, 256]  'simulator_obs' of the new state (slate.py:265-267)
+ *   reward_dev float64 [B] (optional)  0 unless a reward is due (slate.py:283, seqslate.py:138)
+ *   done_dev   uint8 [B] (optional)    1 once cur_steps (before the act) >= max_steps - 1 (base.py:165-168)
+ *   mask_bits_dev uint32 [B, ceil(A/32)] (optional)  obs-side action mask of the NEXT slot (slate.py:92-97), packed as
+ *              rl4rs_env_obs_mask dtype 4
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rl4rs_stepper rl4rs_stepper;
+int rl4rs_env_attach_scorer(rl4rs_env* env, rl4rs_dien* net, const int32_t* slots_dev, int32_t seq_num,
+                            rl4rs_stepper** out);
+int rl4rs_env_attach_simnet(rl4rs_env* env, rl4rs_simnet* net, const int32_t* slots_dev, int32_t seq_num,
+                            rl4rs_stepper** out);
+int rl4rs_stepper_destroy(rl4rs_stepper* s);
+int rl4rs_env_step_discrete(rl4rs_stepper* s, const int32_t* actions_dev, float* obs_dev, double* reward_dev,
+                            uint8_t* done_dev, uint32_t* mask_bits_dev, void* stream);
+/* continuous actions: [B, action_emb_size] float32 / float64 resolved by the masked float64 K-NN first (slate.py:187-197);
+ * chosen_dev (optional) receives the item ids played */
+int rl4rs_env_step_conti(rl4rs_stepper* s, const void* actions_dev, int is_f64, int32_t* chosen_dev, float* obs_dev,
+                         double* reward_dev, uint8_t* done_dev, uint32_t* mask_bits_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size

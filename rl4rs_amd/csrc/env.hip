@@ -697,6 +697,11 @@ int rl4rs_knn(const void* actions, int is_f64, int32_t n, const double* emb, int
     return knn_launch(actions, is_f64, n, emb, A, E, nullptr, nullptr, nullptr, 0, mask, out, (hipStream_t)stream);
 }
 
+int rl4rs_env_get_cfg(const rl4rs_env* e, rl4rs_env_cfg* out) {
+    RL4RS_REQUIRE(e && out, "env_get_cfg: null argument");
+    *out = e->cfg;
+    return RL4RS_OK;
+}
 int rl4rs_env_complete_rows(const rl4rs_env* e) { return e ? e->n_complete : RL4RS_EINVAL; }
 int rl4rs_env_cur_steps(const rl4rs_env* e) { return e ? e->cur_steps : RL4RS_EINVAL; }
 int rl4rs_env_is_reward_step(const rl4rs_env* e) {

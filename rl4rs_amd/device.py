@@ -239,6 +239,52 @@ def knn(actions, action_emb_dev, mask=None):
 
 
 SCORER_MODES = {'auto': 0, 'fp32': 1, 'fp16x2': 2}       # include/rl4rs_hip.h RL4RS_SCORER_*
+class DeviceStepper(object):
+    """rl4rs_stepper handle: an env bound to its scorer so that one call runs a whole transition
+    (rl4rs_env_step_discrete / rl4rs_env_step_conti = RecSimBase._step, base.py:157-170)."""
+
+    def __init__(self, env, net, slots):
+        self.lib = _lib.load()
+        self.env, self.net, self.slots = env, net, slots          # keep the handles and the slot table alive
+        assert slots.dtype == torch.int32 and slots.is_contiguous() and slots.shape[1] == env.B
+        h = C.c_void_p()
+        attach = self.lib.rl4rs_env_attach_simnet if isinstance(net, DeviceSimnet) else self.lib.rl4rs_env_attach_scorer
+        check(attach(env.h, net.h, _ptr(slots), int(slots.shape[0]), C.byref(h)))
+        self.h = h
+        self.B, self.A, self.E, self.W, self.device = env.B, env.A, env.E, env.W, env.device
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_stepper_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, actions, conti=False, want_reward=True, want_mask_bits=False):
+        """-> (obs f32 [B, 256], reward f64 [B] or None, mask_bits i32 [B, W] or None, chosen i32 [B])."""
+        obs = torch.empty((self.B, 256), dtype=torch.float32, device=self.device)
+        reward = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_reward else None
+        bits = torch.empty((self.B, self.W), dtype=torch.int32, device=self.device) if want_mask_bits else None
+        if conti:
+            a = actions.to(self.device) if isinstance(actions, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(actions)).to(self.device)
+            if a.dtype not in (torch.float32, torch.float64):
+                a = a.to(torch.float64)
+            a = a.contiguous()
+            assert a.shape == (self.B, self.E), (a.shape, (self.B, self.E))
+            chosen = torch.empty(self.B, dtype=torch.int32, device=self.device)
+            check(self.lib.rl4rs_env_step_conti(self.h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(chosen), _ptr(obs),
+                                                _ptr(reward), None, _ptr(bits), _stream()))
+        else:
+            chosen = _dev_tensor(actions, torch.int32, self.device).reshape(-1)
+            assert chosen.numel() == self.B, (chosen.shape, self.B)
+            check(self.lib.rl4rs_env_step_discrete(self.h, _ptr(chosen), _ptr(obs), _ptr(reward), None, _ptr(bits), _stream()))
+        return obs, reward, bits, chosen
+
+
 AUGRU_KERNELS = {1: 'k_recur<256,augru>', 2: 'k_augru_h16'}
 
 

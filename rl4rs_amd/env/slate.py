@@ -103,8 +103,9 @@ class SlateState(RecState):
             # the env -> history map, the scorer encodes each distinct sequence once
             uniq, first, inv = np.unique(np.asarray(records.rows, dtype=np.int64), return_index=True, return_inverse=True)
             if len(uniq) < len(records.rows):
-                self._hist_unique = (cols['history'].index_select(0, torch.from_numpy(first).to(dev)).contiguous(),
-                                     torch.from_numpy(inv.astype(np.int32)).to(dev))
+                from .base import h2d_async
+                self._hist_unique = (cols['history'].index_select(0, h2d_async(first, dev)).contiguous(),
+                                     h2d_async(inv.astype(np.int32), dev))
         else:
             rc = RecordColumns(list(records), self.config['maxlen'])
             cols = dict(exposed=rc.exposed, feedback=rc.feedback, history=rc.history,
@@ -458,6 +459,39 @@ class SlateRecEnv(RecSimBase):
         if d3rl:
             return np.concatenate([obs, state["masked_actions"], state["cur_steps"]], axis=-1)
         return obs
+
+    # -- fused transition ----------------------------------------------------------------------
+    def _fused_ok(self, samples):
+        cfg = self.config
+        return (samples._tensor_mode() and not cfg.get("rawstate_as_obs", False) and not cfg.get("support_d3rl_mask", False)
+                and not cfg.get("simulator_info_fetch", False) and not cfg.get('no_state_row_reuse', False)
+                and not cfg.get('no_fused_step', False) and samples._env.n_complete > 1)
+
+    def _step(self, samples, action, **kwargs):
+        """base.py:157-170.  Zero-copy mode runs the whole transition as ONE library call (rl4rs_env_step_discrete /
+        rl4rs_env_step_conti: act -> obs forward -> reward forward when due); every other mode composes it call by call."""
+        if not self._fused_ok(samples):
+            return RecSimBase._step(self, samples, action, **kwargs)
+        env = samples._live()
+        net, slots = self._net_for(samples)                 # history encoded for this batch, slot table current
+        key = (id(env), id(net), slots.data_ptr())
+        if getattr(self, '_stepper_key', None) != key:
+            if getattr(self, '_stepper', None) is not None:
+                self._stepper.close()
+            self._stepper = D.DeviceStepper(env, net, slots)
+            self._stepper_key = key
+        first_of_page = samples.is_seq and env.cur_steps % samples.page_items == 0
+        conti = bool(self.config.get("support_conti_env", False))
+        obs, reward, _, chosen = self._stepper.step(action, conti=conti)
+        samples.last_actions = chosen
+        if first_of_page:                                   # the library re-encoded the second sequence input
+            samples._seq1_version += 1
+            self._encoded_seq1 = samples._seq1_version
+        self._last_obs = None
+        last = kwargs['step'] >= self.max_steps - 1
+        if self.config.get("support_rllib_mask", False):
+            obs = {"action_mask": samples._obs_mask(), "obs": obs}
+        return obs, reward, [1 if last else 0] * self.batch_size, samples.info
 
     # -- reward --------------------------------------------------------------------------------
     def _reward_due(self, samples):
