@@ -23,8 +23,14 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per AUGRU launch of the default workload, from the PMC passes (None until measured for a mode)
-TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 7.34e8}
+# HBM bytes per AUGRU launch of the default workload, from the PMC passes (profiles/r02*_pmc.md).  fp16x2 (k_augru_x): raw
+# FETCH_SIZE 359 MB per obs-sized / 386 MB per reward-sized launch, x the factor calibrated on this kernel's own LDS-DMA
+# stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for the 64-row form),
+# + WRITE_SIZE 8.4 / 65.6 MB: (10 x 622 + 838) / 11.  fp32 (k_recur): round-1 figure, dword-per-lane loads, uncalibrated.
+TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 6.42e8}
+TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized + 1 reward-sized launches of an episode-batch; rocprofv3 FETCH_SIZE x "
+                "calibration (profiles/r02_fetch_calibration.md) + WRITE_SIZE; algorithmic bytes = 1771 distinct histories x 64 steps x "
+                "768 f32 = 348 MB + 8.4 MB written: duplicate env rows of one history land on different CUs at different times")
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
@@ -70,66 +76,167 @@ def episode(env, T):
     return obs, total
 
 
-def cpu_baseline(cfg, records, seq, sample_batch):
-    """The oracle port (vectorised numpy state machine + float32 numpy DIEN) on the host cores."""
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
+    """SURVEY.md 8(d) CPU baselines, both on a bounded sample of the same workload (rank 0, N = 1 only):
+
+    value            "vectorised": the numpy oracle state machine (oracle/state.py: whole-batch array ops) + a torch-CPU
+                     float32 DIEN (oracle/dien_torch.py) on ALL host cores, one episode-batch of ``sample_batch`` envs
+    faithful_1core   the reference's own control flow (oracle/faithful.py: one python iteration per sample, nested-list
+                     state, per-row padding) + the numpy float32 DIEN, pinned to ONE core, one episode-batch of
+                     ``faithful_batch`` envs
+    The reference itself (TF1 / deepctr) cannot run here or on the GPU box; kind stays "port"."""
     import numpy as np
+    import torch
     from rl4rs_amd.nets.dien import init_dien_weights
     from oracle.dien import OracleDien
     from oracle.env import OracleEnv
-    c = dict(cfg, batch_size=sample_batch)
-    algo = c.get('algo', 'dien')
-    if algo == 'dien':
-        w = init_dien_weights(c, seed=c.get('model_seed', 7))
-        scorer = OracleDien(w, c, np.float32)
-    else:
+    algo = cfg.get('algo', 'dien')
+    T = cfg['max_steps']
+
+    def scorer_for(c, kind):
+        if algo == 'dien':
+            w = init_dien_weights(c, seed=c.get('model_seed', 7))
+            if kind == 'torch':
+                from oracle.dien_torch import TorchDien
+                return TorchDien(w, c)
+            return OracleDien(w, c, np.float32)
         from rl4rs_amd.nets.simnets import init_simnet_weights
         from oracle.simnets import OracleSimnet
-        scorer = OracleSimnet(algo, init_simnet_weights(c, algo, seed=c.get('model_seed', 7)), c, np.float32)
-    env = OracleEnv(c, records[:sample_batch], scorer, seq=seq)
-    T = c['max_steps']
+        return OracleSimnet(algo, init_simnet_weights(c, algo, seed=c.get('model_seed', 7)), c, np.float32)
+
+    # ---- vectorised, all cores
+    c = dict(cfg, batch_size=sample_batch)
+    env = OracleEnv(c, records[:sample_batch], scorer_for(c, 'torch'), seq=seq)
     t0 = time.time()
     env.reset()
     for _ in range(T):
         env.step(np.asarray(env.samples.offline_action))
     dt = time.time() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs, numpy oracle "
-                      "(float32 %s scorer), %.1f s" % (T, sample_batch, algo.upper() if algo == 'dien' else algo, dt)}
+    threads = int(torch.get_num_threads())
+    out = {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs: vectorised numpy state machine + "
+                     "torch-CPU float32 %s on %d threads (os.cpu_count() = %d), %.1f s"
+                     % (T, sample_batch, algo.upper() if algo == 'dien' else algo, threads, os.cpu_count() or 0, dt)}
+    # ---- faithful per-sample loop, one core (Slate only: the bench workload)
+    if not seq and faithful_batch > 0:
+        from oracle.faithful import FaithfulSlateEnv
+        c1 = dict(cfg, batch_size=faithful_batch)
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        except Exception:
+            limit = None
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            fenv = FaithfulSlateEnv(c1, records[:faithful_batch], scorer_for(c1, 'numpy'))
+            t0 = time.time()
+            fenv.reset()
+            for _ in range(T):
+                fenv.step(fenv.offline_action)
+            fdt = time.time() - t0
+            # the same loop without the net (what BASELINE.md section 2 measured for the reference itself: 1.9-3.0 k env-steps/s)
+            class _NoNet(object):
+                def obs(self, seq_, dense, cat):
+                    return np.zeros((len(cat), 256), dtype=np.float32)
+
+                def prob(self, seq_, dense, cat):
+                    return np.full((len(cat),), 0.5, dtype=np.float32)
+            fenv2 = FaithfulSlateEnv(c1, records[:faithful_batch], _NoNet())
+            t0 = time.time()
+            fenv2.reset()
+            for _ in range(T):
+                fenv2.step(fenv2.offline_action)
+            fdt2 = time.time() - t0
+        finally:
+            torch.set_num_threads(nt)
+            if limit is not None:
+                limit.restore_original_limits()
+        out["faithful_1core"] = {"value": faithful_batch * T / fdt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                 "without_net": faithful_batch * T / fdt2,
+                                 "sample": "1 episode-batch of %d envs: per-sample python loop (oracle/faithful.py) + numpy float32 "
+                                           "DIEN, 1 thread, %.1f s (%.2f s without the net)" % (faithful_batch, fdt, fdt2)}
+    return out
 
 
-def fp32_leg(args, cfg, seq, rank, steps=3):
-    """The same workload with the exact-operand fp32 MFMA recurrence (scorer_precision='fp32'), reported next to the
-    default so that both arithmetic forms are on the line: value, ms per episode-batch, AUGRU roofline vs the fp32 peak."""
+def timed_episodes(env, T, steps, warmup=1):
     import torch
-    cfg32 = dict(cfg, scorer_precision='fp32')
-    env = build_env(cfg32, seq)
-    env.seed(1000 + rank)
-    env.sim._recData.store.preload(torch.device('cuda', torch.cuda.current_device()))
-    B, T = cfg['batch_size'], cfg['max_steps']
-    episode(env, T)
-    net = env.sim.model.device_net
-    net.set_profiling(True)
-    net.profile_reset()
+    for _ in range(warmup):
+        episode(env, T)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         episode(env, T)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms, launches = net.profile()[net.augru_kernel]
-    n_complete = T if not seq else cfg['page_items']
-    reward_calls = 1 if not seq else T // cfg['page_items']
-    rows = (T + 1) * B + reward_calls * (n_complete - 1) * B
-    flops = steps * rows * cfg['seq_num'] * cfg['maxlen'] * (2 * cfg['emb_size']) * (6 * cfg['emb_size']) * 2
-    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "dtype": "f32", "roofline": {"bound": "mfma", "kernel": net.augru_kernel, "achieved": tf,
-                                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}}
+    return time.perf_counter() - t0
+
+
+def extra_leg(args, workdir, rank, name, steps=3):
+    """One more workload timed the same way (K episode-batches between two synchronisations, inputs resident), N = 1 only:
+    the BASELINE.json configs the headline does not cover and the variants the verdict asked to disclose."""
+    import copy
+    import torch
+    a = copy.copy(args)
+    a.conti, a.env, a.horizon = False, 'slate', 9
+    train = None
+    extra_cfg = {}
+    if name == 'seq_t32':
+        a.env, a.horizon = 'seq', 32
+    elif name == 'seq_t32_ppo':
+        a.env, a.horizon, train = 'seq', 32, 'PPO'
+    elif name == 'conti':
+        a.conti = True
+    elif name == 'all_distinct':
+        extra_cfg = {'is_eval': True, 'cache_size': a.batch}           # eval mode: the first B lines, no duplicate histories
+    elif name == 'fp32':
+        a.scorer = 'fp32'
+    cfg, _ = make_config(a, workdir, rank)
+    cfg.update(extra_cfg)
+    seq = a.env == 'seq'
+    env = build_env(cfg, seq)
+    env.seed(1000 + rank)
+    env.sim._recData.store.preload(torch.device('cuda', torch.cuda.current_device()))
+    B, T = cfg['batch_size'], cfg['max_steps']
+    if train:
+        from rl4rs_amd.train import Trainer
+        tr = Trainer(env, algo=train, seed=1000 + rank)
+        tr.train_iteration()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.train_iteration()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tr.close()
+    else:
+        dt = timed_episodes(env, T, steps)
+    out = {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "workload": "%s B=%d T=%d%s%s" % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T,
+                                             ', continuous actions -> masked K-NN' if a.conti else '',
+                                             ', PPO rollout + update (configs[2])' if train else ', offline_action replay')}
+    hu = getattr(env.samples, '_hist_unique', None)
+    out["distinct_histories"] = int(hu[0].shape[0]) if hu is not None else B
+    if name == 'fp32':
+        net = env.sim.model.device_net
+        net.set_profiling(2)
+        net.profile_reset()
+        episode(env, T)
+        ms, launches = net.profile()[net.augru_kernel]
+        net.set_profiling(0)
+        rows = (T + 1) * B + (T - 1) * B
+        tf = rows * cfg['seq_num'] * cfg['maxlen'] * (2 * cfg['emb_size']) * (6 * cfg['emb_size']) * 2 / (ms * 1e-3) / 1e12
+        out["dtype"] = "f32"
+        out["roofline"] = {"bound": "mfma", "kernel": net.augru_kernel, "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
+    return out
 
 
 def main():
@@ -141,10 +248,13 @@ def main():
     ap.add_argument('--env', choices=['slate', 'seq'], default='slate')
     ap.add_argument('--horizon', type=int, default=None)
     ap.add_argument('--log-records', type=int, default=8193)
-    ap.add_argument('--cpu-batch', type=int, default=256)
+    ap.add_argument('--cpu-batch', type=int, default=1024,
+                    help='envs of the vectorised cpu_baseline sample (one episode-batch; the faithful 1-core leg uses 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true',
                     help='skip the short extra run of the same workload with the exact-fp32 recurrence (N=1, default mode only)')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help='skip the extra workloads of the default N=1 run (seq_t32, seq_t32_ppo, conti, all_distinct)')
     ap.add_argument('--conti', action='store_true',
                     help="continuous-action env (support_conti_env): actions are 32-d embeddings resolved by the masked K-NN")
     ap.add_argument('--algo', choices=['dien', 'dnn', 'widedeep', 'lstm'], default='dien',
@@ -184,7 +294,9 @@ def main():
     for _ in range(args.warmup):
         run_step()
     net = env.sim.model.device_net
-    net.set_profiling(not os.environ.get('RL4RS_BENCH_NOPROF'))
+    # the timed region carries event pairs around the dominant kernel only (two records per forward); the per-kernel
+    # breakdown comes from a separate short pass afterwards (a pair around EVERY kernel costs ~0.4 ms per episode-batch)
+    net.set_profiling(0 if os.environ.get('RL4RS_BENCH_NOPROF') else 2)
     net.profile_reset()
 
     rdist.barrier()
@@ -194,7 +306,16 @@ def main():
     rdist.barrier()
     elapsed = rdist.max_over_ranks(time.perf_counter() - t0, device='cuda')
     prof = net.profile()
-    net.set_profiling(False)
+    net.set_profiling(0)
+    breakdown, breakdown_steps = None, 3
+    if rank == 0:
+        net.set_profiling(1)
+        net.profile_reset()
+        for _ in range(breakdown_steps):
+            run_step()
+        torch.cuda.synchronize()
+        breakdown = net.profile()
+        net.set_profiling(0)
 
     if rank == 0:
         env_steps = world * B * T * args.steps
@@ -223,12 +344,14 @@ def main():
                         "traffic": None, "launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
                         "kernel_ms_share": ms / (elapsed * 1e3)}
             if not seq and B == 4096 and T == 9 and not trainer:
-                # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
-                # corrected as MI355X_MICROARCH.md prescribes): launch-weighted mean of the 10 obs-sized and the 1
-                # reward-sized launch of an episode (fp32: 897 / 883 MB, fp16x2: 721 / 863 MB)
+                # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE, corrected by the factor
+                # CALIBRATED on this kernel's own access pattern, + WRITE_SIZE): launch-weighted mean of the 10 obs-sized
+                # and the 1 reward-sized launch of an episode-batch
                 roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
-                roofline["traffic_unit"] = "B/launch (PMC: profiles/r01c_pmc.md fp32, profiles/r01f_pmc.md / r01g_pmc.md fp16x2)"
-        kernels = dict((k, {"ms": round(v[0], 3), "launches": int(v[1])}) for k, v in prof.items())
+                roofline["traffic_unit"] = TRAFFIC_NOTE
+        # per-kernel breakdown of ONE episode-batch (separate pass, event pairs around every kernel class)
+        kernels = dict((k, {"ms": round(v[0] / breakdown_steps, 3), "launches": int(v[1] // breakdown_steps)}) for k, v in breakdown.items())
+        kernel_sum = sum(v["ms"] for v in kernels.values())
         # the HBM-bound gather kernel in isolation (complete-state rows, 9B rows x 2016 algorithmic bytes)
         samples = env.samples
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -271,9 +394,20 @@ def main():
             "roofline": roofline if roofline is not None else gather,
             "roofline_gather": gather,
             "kernels": kernels,
+            # everything in an episode-batch that is not one of the scorer's kernels: env-state kernels, torch glue,
+            # launch gaps, host (ms_per_step of the timed region - the scorer kernels' sum from the breakdown pass)
+            "non_scorer_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_sum, 3),
         }
-        if (world == 1 and is_dien and not trainer and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg):
-            out["exact_fp32_scorer"] = fp32_leg(args, cfg, seq, rank)
+        hu = getattr(env.samples, '_hist_unique', None)
+        # RecDataBase.sample draws WITH replacement from the 2048-line cache window (base.py:92-100): distinct user histories
+        # of the last batch (the first GRU / projections run once per distinct history; the AUGRU runs per env row)
+        out["config"]["distinct_histories"] = int(hu[0].shape[0]) if hu is not None else B
+        default_run = world == 1 and is_dien and not trainer and not seq and not args.conti
+        if default_run and not args.no_extra_legs:
+            out["extra"] = dict((name, extra_leg(args, workdir, rank, name))
+                                for name in ('seq_t32', 'seq_t32_ppo', 'conti', 'all_distinct'))
+        if default_run and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg:
+            out["exact_fp32_scorer"] = extra_leg(args, workdir, rank, 'fp32')
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, records, seq, args.cpu_batch)
         print(json.dumps(out))

@@ -283,7 +283,9 @@ int rl4rs_dien_buffer(rl4rs_dien* net, int which, void** dev_ptr, int64_t* n_byt
 /* Per-kernel HIP-event timing (bench.py roofline).  With profiling enabled every kernel class launched
  * by rl4rs_dien_encode / rl4rs_dien_forward is bracketed by an event pair on the caller's stream.
  * rl4rs_dien_profile_read synchronises on the recorded pairs and returns the cumulative milliseconds
- * and launch count of kernel class `which` since the last reset. */
+ * and launch count of kernel class `which` since the last reset.
+ * enable: 0 off; 1 every kernel class (~0.4 ms of event records per episode-batch of the bench workload: a breakdown
+ * pass); 2 only the AUGRU recurrence, the dominant kernel (two records per forward: what a timed region can carry). */
 int rl4rs_dien_set_profiling(rl4rs_dien* net, int enable);
 int rl4rs_dien_kernel_count(void);
 const char* rl4rs_dien_kernel_name(int which);

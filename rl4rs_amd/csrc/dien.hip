@@ -1137,7 +1137,7 @@ struct rl4rs_dien {
     float *allf, *dh, *q, *scores, *obs_tmp;
     std::vector<void*> owned;
     // profiling
-    bool profiling;
+    int profiling;         // 0 off, 1 every kernel class, 2 only the AUGRU recurrence (two event records per forward)
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> pool;
     double ms_total[KID_COUNT];
@@ -1233,7 +1233,7 @@ std::vector<float> pack_frag_h16(const float* w, int ld, int k_off, int K, int N
 
 struct Prof {
     rl4rs_dien* n; int id; hipStream_t st; hipEvent_t a, b; bool on;
-    Prof(rl4rs_dien* n_, int id_, hipStream_t st_) : n(n_), id(id_), st(st_), on(n_->profiling) {
+    Prof(rl4rs_dien* n_, int id_, hipStream_t st_) : n(n_), id(id_), st(st_), on(n_->profiling == 1 || (n_->profiling == 2 && id_ == KID_AUGRU)) {
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -1317,7 +1317,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     const int F = S * NH2 + U + (Cn + 1) * E;
     n->E = E; n->U = U; n->L = L; n->S = S; n->Cn = Cn; n->Dn = Dn; n->H = H; n->K = K; n->F = F;
     n->PLD = PLD; n->NH2 = NH2;
-    n->profiling = false;
+    n->profiling = 0;
     n->fp16x2 = want_fp16x2;
     n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
     n->din16 = false;
@@ -1712,7 +1712,7 @@ int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
 
 int rl4rs_dien_set_profiling(rl4rs_dien* n, int enable) {
     RL4RS_REQUIRE(n, "dien_set_profiling: null handle");
-    n->profiling = enable != 0;
+    n->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return RL4RS_OK;
 }
 int rl4rs_dien_scorer_mode(rl4rs_dien* n, int32_t* mode) {

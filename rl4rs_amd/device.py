@@ -402,7 +402,8 @@ class DeviceDien(object):
 
     # profiling (bench.py roofline)
     def set_profiling(self, on):
-        check(self.lib.rl4rs_dien_set_profiling(self.h, 1 if on else 0))
+        """0 / False off, 1 / True every kernel class, 2 only the AUGRU recurrence (rl4rs_dien_set_profiling)."""
+        check(self.lib.rl4rs_dien_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
 
     def profile_reset(self):
         check(self.lib.rl4rs_dien_profile_reset(self.h))

@@ -136,3 +136,23 @@ def test_keras_gru_restatement_against_step_formula():
     rr = np.clip(0.2 * (xp[:, U:2 * U] + h @ r[:, U:2 * U]) + 0.5, 0, 1)
     hh = np.tanh(xp[:, 2 * U:] + (rr * h) @ r[:, 2 * U:])
     assert np.allclose(keras_gru_last(x2, k, r, b), z * h + (1 - z) * hh)
+
+
+def test_torch_cpu_dien_matches_the_numpy_oracle():
+    """oracle/dien_torch.py (float32 torch-CPU DIEN: the NN of bench.py's vectorised cpu_baseline leg) against the float64
+    numpy restatement on the same seeded weights."""
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from oracle.dien import OracleDien
+    from oracle.dien_torch import TorchDien
+    cfg = {"maxlen": 64, "batch_size": 12, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 500, "seq_num": 2, "emb_size": 128, "hidden_units": 128}
+    w = init_dien_weights(cfg, seed=5, emb_scale=0.5, bias_noise=0.1)
+    rs = np.random.RandomState(1)
+    R = 12
+    seq = rs.randint(0, 284, size=(R, 2, 64)).astype(np.int32)
+    dense = np.abs(rs.randn(R, 432)).astype(np.float32)
+    cat = rs.randint(0, 500, size=(R, 21)).astype(np.int32)
+    ref = OracleDien(w, cfg, np.float64)
+    td = TorchDien(w, cfg)
+    assert np.abs(td.obs(seq, dense, cat) - ref.obs(seq, dense, cat)).max() < 5e-5
+    assert np.abs(td.prob(seq, dense, cat) - ref.prob(seq, dense, cat)).max() < 5e-6

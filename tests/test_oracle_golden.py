@@ -76,3 +76,41 @@ def test_tutorial_known_answers():
     assert len(c.special_items) == 113 and min(c.special_items) >= 62
     assert abs(np.linalg.norm(c.action_emb[1]) - 1) < 1e-12
     assert c.price[1:].min() == 7.0 and c.price.max() == 1478.1
+
+
+@pytest.mark.parametrize('name', ['slate_discrete', 'real_discrete'])
+def test_faithful_per_sample_loop_matches_reference(name):
+    """oracle/faithful.py (the reference's own control flow: one python iteration per sample, nested-list state; the
+    'faithful' cpu_baseline leg of bench.py) against the golden vectors captured from the reference, bit for bit."""
+    from oracle.faithful import FaithfulSlateEnv
+    m, cfg, records, g = load_scenario(name)
+    T = cfg['max_steps']
+
+    class Stub(object):
+        def __init__(self):
+            self.probs = None
+
+        def obs(self, seq, dense, cat):
+            return np.zeros((len(cat), 256), dtype=np.float32)
+
+        def prob(self, seq, dense, cat):
+            return np.asarray(self.probs, dtype=np.float32).reshape(-1)
+
+    stub = Stub()
+    env = FaithfulSlateEnv(cfg, records, stub)
+    seq, dense, cat = env._features(env.state)
+    assert np.array_equal(seq, g['seq_init']) and np.array_equal(dense, g['dense_init']) and np.array_equal(cat, g['cat_init'])
+    for t in range(T):
+        assert np.array_equal(np.asarray(env.offline_action), g['offline_action_%d' % t])
+        stub.probs = g['probs_%d' % t]
+        obs, reward, done, _ = env.step(g['action_in_%d' % t])
+        assert np.array_equal(env.prev_actions, g['prev_actions_%d' % t]), t
+        assert np.array_equal(env.action_mask, g['action_mask_%d' % t]), t
+        assert np.array_equal(env.special_mask, g['special_mask_%d' % t]), t
+        seq, dense, cat = env._features(env.state)
+        assert np.array_equal(seq, g['seq_%d' % t]) and np.array_equal(dense, g['dense_%d' % t]) and np.array_equal(cat, g['cat_%d' % t]), t
+        assert np.array_equal(np.asarray(reward, dtype=np.float64), g['reward_%d' % t]), t
+        assert done == [1 if t == T - 1 else 0] * cfg['batch_size']
+    cs, cd, cc = env._features(env.complete_states())
+    assert np.array_equal(cs, g['c_seq_%d' % (T - 1)]) and np.array_equal(cd, g['c_dense_%d' % (T - 1)]) and np.array_equal(cc, g['c_cat_%d' % (T - 1)])
+    assert np.array_equal(env.violation(), g['violation_end'])
