@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     };
 
     const bool early = wave < 4;
-#if RL4RS_X_PRIO
+#if RL4RS_X_PRIO == 1 || RL4RS_X_PRIO == 2
     // the late waves carry their candidate epilogue next to their own MFMAs (R-early phase) and are the younger half of the
     // workgroup (the arbitration losers): one static priority raise, no per-phase flips (MI355X_MICROARCH.md, two waves per SIMD #4)
     if (!early) __builtin_amdgcn_s_setprio(RL4RS_X_PRIO);
@@ -289,6 +289,9 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
                     // late role: the whole update gate first (VALU only) - its partner on the SIMD is already in its C items
 #pragma unroll
                     for (int r = 0; r < 16; ++r) update_gate(r);
+#if RL4RS_X_PRIO == 3
+                    __builtin_amdgcn_s_setprio(1);        // ... and then must not lose every MFMA arbitration to the (older) early wave
+#endif
                 }
                 hfrag(cur, i);
             }
@@ -299,6 +302,9 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
                     for (int r = 0; r < 16; ++r) blend(r);
                 }
                 RL4RS_XT(4);
+#if RL4RS_X_PRIO == 3
+                if (!early) __builtin_amdgcn_s_setprio(0);
+#endif
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // early half of the new state complete
                 RL4RS_XT(5);
                 if (!(RL4RS_X_AB & 4)) {                          // x_r(t+1) (requested 12+ items ago)

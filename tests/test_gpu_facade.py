@@ -377,3 +377,39 @@ def test_fused_step_is_bit_identical(tmp_path, kind):
         if len(x) == 5 and float(x[1].abs().sum()) > 0:
             n_reward += 1
     assert n_reward == (4 if seq else 2)
+
+
+def test_http_env_round_trip(tmp_path):
+    """the device env behind the reference's HTTP wire format (rl4rs_amd.server: routes of
+    gymHttpServer.py:239-420, HttpEnv of httpEnv.py:9-44), driven through a Flask test client: same observations, rewards
+    and done flags as the in-process env (JSON carries float32 exactly as decimal text -> compare at float32 resolution)."""
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    from rl4rs.server.gymHttpServer import create_app
+    from rl4rs.server.httpEnv import HttpEnv
+    d = str(tmp_path)
+    text = synth.make_catalog_text(seed=4)
+    synth.write_text(os.path.join(d, 'c.csv'), text)
+    recs = synth.make_records(40, seed=3, hash_size=2000, special_ids=synth.special_ids_from_text(text))
+    synth.write_records(os.path.join(d, 'log.csv'), recs)
+    B, T = 8, 9
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 2000, "seq_num": 2, "emb_size": 128, "page_items": 9,
+           "hidden_units": 128, "max_steps": T, "action_emb_size": 32, "sample_file": os.path.join(d, 'log.csv'),
+           "iteminfo_file": os.path.join(d, 'c.csv'), "cache_size": B, "is_eval": True, "model_seed": 3,
+           "support_rllib_mask": True, "remote_base": ""}
+    app = create_app()
+    henv = HttpEnv('SlateRecEnv-v0', cfg, session=app.test_client())
+    env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(dict(cfg), state_cls=SlateState))
+    assert henv.action_space.n == 284 and sorted(henv.observation_space.spaces.keys()) == ['action_mask', 'obs']
+    ho, o = henv.reset(), env.reset()
+    for t in range(T):
+        assert np.array_equal(np.stack([x['obs'] for x in ho]), np.stack([x['obs'] for x in o]).astype(np.float32))
+        assert np.array_equal(np.stack([x['action_mask'] for x in ho]), np.stack([x['action_mask'] for x in o]).astype(np.float32))
+        a = np.asarray(env.offline_action)
+        ho, hr, hd, hi = henv.step(a)
+        o, r, dn, info = env.step(a)
+        assert np.allclose(hr, r, rtol=0, atol=0) and hd == dn and len(hi) == B
+    assert max(hr) > 0
+    henv.close()
