@@ -51,6 +51,8 @@ def make_config(args, workdir, rank):
            "sample_file": log_path, "iteminfo_file": cat_path, "is_eval": False, "cache_size": 2048,
            "model_seed": 7, "return_tensors": True, "scorer_precision": args.scorer,
            "algo": getattr(args, 'algo', 'dien')}
+    if os.environ.get('RL4RS_NO_ORDER'):
+        cfg['no_row_order'] = True            # A/B: without the slot-sorted processing order of the scorer
     if getattr(args, 'conti', False):
         cfg["support_conti_env"] = True       # configs[4]: continuous 32-d actions resolved by the masked K-NN
     return cfg, records

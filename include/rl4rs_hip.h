@@ -280,6 +280,12 @@ enum {
 };
 int rl4rs_dien_buffer(rl4rs_dien* net, int which, void** dev_ptr, int64_t* n_bytes);
 
+/* Processing order of the row groups (envs) of the following forwards: order_dev[i] = group handled at position i, a
+ * permutation of 0..n_groups-1 in caller-owned device memory (NULL = identity).  A locality hint only (results per row are
+ * unchanged): envs sorted by the cache slot of their history make duplicate histories share L2 lines
+ * (RecDataBase.sample draws with replacement, rl4rs/env/base.py:92-100).  Applies when n_groups == R / group. */
+int rl4rs_dien_set_row_order(rl4rs_dien* net, const int32_t* order_dev, int32_t n_groups);
+
 /* Per-kernel HIP-event timing (bench.py roofline).  With profiling enabled every kernel class launched
  * by rl4rs_dien_encode / rl4rs_dien_forward is bracketed by an event pair on the caller's stream.
  * rl4rs_dien_profile_read synchronises on the recorded pairs and returns the cumulative milliseconds

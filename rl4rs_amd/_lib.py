@@ -169,6 +169,7 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_float, _P, _P]),
     'rl4rs_rawtrain_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
+    'rl4rs_dien_set_row_order': (_I, [_P, _P, _I32]),
     'rl4rs_env_get_cfg': (_I, [_P, _P]),
     'rl4rs_env_attach_scorer': (_I, [_P, _P, _P, _I32, _P]),
     'rl4rs_env_attach_simnet': (_I, [_P, _P, _P, _I32, _P]),

@@ -127,20 +127,26 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     // ---- projection staging geometry.  DMA instruction j (0..3) of a gate covers rows 8j .. 8j+7: lane l fetches, for row
     // r = 8j + l/8, the 16-byte chunk c = (l%8 - r/2) mod 8 of the wave's 128 bytes of that row; it lands at slot + r*128 +
     // (l%8)*16.  The reader (row li, column run q of half `half`: chunk 2q + half) finds it at position (2q + half + li/2) mod 8.
+    // processing order: tile position p works on batch row phys(p) - with a row order (rl4rs_dien_set_row_order: env groups sorted
+    // by their history's cache slot) the rows of a tile, and of tiles that run at the same time, share projection rows in L2
+    auto phys = [&](int p) {
+        p = min(p, a.n_rows - 1);
+        return a.order ? a.order[p / a.group] * a.group + p % a.group : p;
+    };
     int dma_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // MT = 1: row r = 8j + l/8, rotated chunk.  MT = 2 (only j = 0 is used): lane l fetches chunk l%8 of distinct row d = l/8,
         // i.e. of batch row row0 + 8d (rows 8d .. 8d+7 share its cache slot)
         const int r = MT == 1 ? 8 * j + (lane >> 3) : 8 * (lane >> 3);
-        const int gr = min(row0 + r, a.n_rows - 1);
+        const int gr = phys(row0 + r);
         const int c = MT == 1 ? (((lane & 7) - (r >> 1)) & 7) : (lane & 7);
         dma_off[j] = (int)((uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4) + c * 16;
     }
     const float* att_row[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-        att_row[m] = a.att + (size_t)sq * a.att_stride + (size_t)min(row0 + m * 32 + li, a.n_rows - 1) * L;
+        att_row[m] = a.att + (size_t)sq * a.att_stride + (size_t)phys(row0 + m * 32 + li) * L;
     const int xs_base = wave * 128 + a.xoff * 4;                  // byte offset of the wave's 32 columns inside a gate block
     auto x_dma = [&](int t) {                                      // the three gates' rows of step t -> staging
 #pragma unroll
@@ -380,9 +386,9 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int row = row0 + m * 32 + li;
+        const int row = phys(row0 + m * 32 + li);
         const bool poison = s_bad[m * 32 + li] != 0u;
-        if (row < a.n_rows) {
+        if (row0 + m * 32 + li < a.n_rows) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v = make_float4(h_own[m][4 * q], h_own[m][4 * q + 1], h_own[m][4 * q + 2], h_own[m][4 * q + 3]);

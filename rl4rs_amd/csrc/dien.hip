@@ -188,6 +188,7 @@ struct RecurArgs {
     int* range_flag;             // k_augru_h16: set to 1 when a state leaves the fp16 range (|h| >= 6e4 or NaN)
     int hard_gates;              // GRU mode: keras hard_sigmoid gates (simnet.hpp) instead of sigmoid
     int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
+    const int32_t* order;        // k_augru_x: processing order of the row groups (NULL = identity)
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
 };
 
@@ -838,6 +839,7 @@ struct DinArgs {
     const float* w1d16[4];       // H16: fp16 hi/lo planes [2][E/16][2][64][8 halfs] (pack_frag_h16)
     const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
     float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
+    const int32_t* order;        // processing order of the row groups (NULL = identity): rl4rs_dien_set_row_order
 };
 
 template <bool STAGE, bool H16>
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     if (tid == 0) s_misc[32] = a.b3[sq][0];
     int g0, slot0 = 0;
     if (STAGE) {
-        g0 = blockIdx.x;
+        g0 = a.order ? a.order[blockIdx.x] : blockIdx.x;
         slot0 = a.slots[(size_t)sq * a.slots_stride + g0];
         const float* h1g = a.h1[sq] + (size_t)slot0 * L * E;
         for (int i = tid; i < L * (E / 4); i += blockDim.x) {
@@ -886,7 +888,8 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     const int jstep = STAGE ? nw : 1;
 
     for (int j = STAGE ? wave : 0; j < nrows; j += jstep) {
-        const int row = STAGE ? g0 * a.group + j : g0 + wave;
+        if (!STAGE && g0 + wave >= a.R) break;
+        const int row = STAGE ? g0 * a.group + j : (a.order ? a.order[g0 + wave] : g0 + wave);
         if (row >= a.R) break;
         const int slot = STAGE ? slot0 : a.slots[(size_t)sq * a.slots_stride + row];
         for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
@@ -1128,6 +1131,7 @@ struct rl4rs_dien {
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
+    const int32_t* row_order; int row_order_n;    // processing order of the row groups of a forward (caller-owned), or NULL
     float* augru_wg[4];    // packed [2*NH2/32][NH2/8][64][4]
     float* augru_wc[4];
     // caches
@@ -1319,6 +1323,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->PLD = PLD; n->NH2 = NH2;
     n->profiling = 0;
     n->fp16x2 = want_fp16x2;
+    n->row_order = nullptr;
+    n->row_order_n = 0;
     n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
     n->din16 = false;
     n->gru16 = false;
@@ -1596,6 +1602,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];
         }
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
+        a.order = (n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
         if (group == 1) {
             const int nw = 4;
             size_t smem = ((size_t)2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
@@ -1624,6 +1631,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
+            a.order = (n->augru_x && n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
             { static const int dbg_steps = getenv("RL4RS_AUGRU_STEPS") ? atoi(getenv("RL4RS_AUGRU_STEPS")) : 0; a.steps = dbg_steps; }
 #if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)
             static unsigned long long* trace_buf = nullptr;
@@ -1707,6 +1715,18 @@ int rl4rs_dien_buffer(rl4rs_dien* n, int which, void** p, int64_t* bytes) {
     }
     *p = ptr;
     if (bytes) *bytes = b;
+    return RL4RS_OK;
+}
+
+// Processing order of the row groups of the following forwards: order_dev[i] = the group (env) handled at position i, a
+// permutation of 0 .. n_groups-1 (caller-owned device memory, NULL = identity).  A pure locality hint - every row's result is
+// unchanged: with the envs sorted by the cache slot of their history, rows that read the same first-GRU states / cached
+// projections sit in the same or in neighbouring tiles, so duplicates hit in L2 instead of going to HBM again.  Used when
+// n_groups matches the forward's R / group.
+int rl4rs_dien_set_row_order(rl4rs_dien* n, const int32_t* order_dev, int32_t n_groups) {
+    RL4RS_REQUIRE(n && n_groups >= 0, "dien_set_row_order: bad argument");
+    n->row_order = order_dev;
+    n->row_order_n = order_dev ? n_groups : 0;
     return RL4RS_OK;
 }
 

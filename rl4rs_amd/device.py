@@ -401,6 +401,14 @@ class DeviceDien(object):
         return out
 
     # profiling (bench.py roofline)
+    def set_row_order(self, order):
+        """Processing order of the env groups of the following forwards (int32 device tensor, a permutation; None = identity):
+        rl4rs_dien_set_row_order - a locality hint, results unchanged."""
+        if order is not None:
+            assert order.dtype == torch.int32 and order.is_contiguous() and order.is_cuda
+        self._row_order = order                     # keep it alive
+        check(self.lib.rl4rs_dien_set_row_order(self.h, _ptr(order), 0 if order is None else int(order.numel())))
+
     def set_profiling(self, on):
         """0 / False off, 1 / True every kernel class, 2 only the AUGRU recurrence (rl4rs_dien_set_profiling)."""
         check(self.lib.rl4rs_dien_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))

@@ -106,6 +106,8 @@ class SlateState(RecState):
                 from .base import h2d_async
                 self._hist_unique = (cols['history'].index_select(0, h2d_async(first, dev)).contiguous(),
                                      h2d_async(inv.astype(np.int32), dev))
+                # envs sorted by their history's slot: the scorer processes duplicates next to each other (L2 locality)
+                self._row_order = h2d_async(np.argsort(inv, kind='stable').astype(np.int32), dev)
         else:
             rc = RecordColumns(list(records), self.config['maxlen'])
             cols = dict(exposed=rc.exposed, feedback=rc.feedback, history=rc.history,
@@ -385,6 +387,8 @@ class SlateRecEnv(RecSimBase):
             self._encoded_batch = (id(net), samples._batch_version)
             self._encoded_seq1 = None
             self._slots_hist = None
+            if hasattr(net, 'set_row_order'):
+                net.set_row_order(None if self.config.get('no_row_order', False) else getattr(samples, '_row_order', None))
         if samples.is_seq:
             if self._encoded_seq1 != samples._seq1_version:
                 p1, _ = env.buffer_ptr(D.BUF_SEQ1)

@@ -219,8 +219,9 @@ def test_history_dedup_is_bit_identical(tmp_path, seq, T):
     share user histories; the scorer encodes each distinct history once.  Must equal one-slot-per-env bit for bit."""
     import torch
     out = []
-    for off in (False, True):
-        cfg, records, w = _setup(tmp_path, seq, 24, T, return_tensors=True, no_history_dedup=off)
+    for off, no_order in ((False, False), (True, False), (False, True)):
+        # third leg: dedup on, but without the slot-sorted processing order (rl4rs_dien_set_row_order): a locality hint only
+        cfg, records, w = _setup(tmp_path, seq, 24, T, return_tensors=True, no_history_dedup=off, no_row_order=no_order)
         cfg.update(is_eval=False, cache_size=7)          # 24 envs drawn from a 7-line window
         env = _make(cfg, seq)
         env.seed(123)
@@ -233,9 +234,9 @@ def test_history_dedup_is_bit_identical(tmp_path, seq, T):
             obs, reward, done, info = env.step(env.offline_action)
             trace += [obs.clone(), reward.clone()]
         out.append((rows, trace))
-    assert out[0][0] == out[1][0]
-    for a, b in zip(out[0][1], out[1][1]):
-        assert torch.equal(a, b)
+    assert out[0][0] == out[1][0] == out[2][0]
+    for a, b, c in zip(out[0][1], out[1][1], out[2][1]):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize('seq,T', [(False, 9), (True, 36)])
