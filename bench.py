@@ -27,10 +27,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 # FETCH_SIZE 359 MB per obs-sized / 386 MB per reward-sized launch, x the factor calibrated on this kernel's own LDS-DMA
 # stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for the 64-row form),
 # + WRITE_SIZE 8.4 / 65.6 MB: (10 x 622 + 838) / 11.  fp32 (k_recur): round-1 figure, dword-per-lane loads, uncalibrated.
-TRAFFIC_B_PER_LAUNCH = {'fp32': 8.96e8, 'fp16x2': 6.42e8}
-TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized + 1 reward-sized launches of an episode-batch; rocprofv3 FETCH_SIZE x "
-                "calibration (profiles/r02_fetch_calibration.md) + WRITE_SIZE; algorithmic bytes = 1771 distinct histories x 64 steps x "
-                "768 f32 = 348 MB + 8.4 MB written: duplicate env rows of one history land on different CUs at different times")
+TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 3.48e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
+TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (332 MB) + 1 reward-sized (506 MB) launches of an episode-batch; "
+                "rocprofv3 FETCH_SIZE x the factor calibrated on this kernel's stream (profiles/r02_fetch_calibration.md) + WRITE_SIZE, "
+                "arithmetic in profiles/r02c_pmc.md; algorithmic bytes = 1746 distinct histories x 64 steps x 768 f32 = 343 MB read + "
+                "8.4 / 67 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
@@ -78,6 +79,10 @@ def episode(env, T):
     return obs, total
 
 
+CPU_ROW_WORKERS = 16      # measured on the bench box at R = 4096: 437 GFLOP/s with 16 row-parallel workers, 234 with 16 intra-op
+                          # threads, 60-110 with 64-256 of either (python GIL / thread-pool overhead of the small per-step ops)
+
+
 def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -108,7 +113,7 @@ def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
             w = init_dien_weights(c, seed=c.get('model_seed', 7))
             if kind == 'torch':
                 from oracle.dien_torch import TorchDien
-                return TorchDien(w, c)
+                return TorchDien(w, c, workers=CPU_ROW_WORKERS)
             return OracleDien(w, c, np.float32)
         from rl4rs_amd.nets.simnets import init_simnet_weights
         from oracle.simnets import OracleSimnet
@@ -122,10 +127,11 @@ def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
     for _ in range(T):
         env.step(np.asarray(env.samples.offline_action))
     dt = time.time() - t0
-    threads = int(torch.get_num_threads())
+    threads = CPU_ROW_WORKERS if algo == 'dien' else int(torch.get_num_threads())
     out = {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
            "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs: vectorised numpy state machine + "
-                     "torch-CPU float32 %s on %d threads (os.cpu_count() = %d), %.1f s"
+                     "torch-CPU float32 %s on %d row-parallel worker threads (the rate peaks there on this host: the 64-step "
+                     "recurrences are chains of small matmuls; os.cpu_count() = %d), %.1f s"
                      % (T, sample_batch, algo.upper() if algo == 'dien' else algo, threads, os.cpu_count() or 0, dt)}
     # ---- faithful per-sample loop, one core (Slate only: the bench workload)
     if not seq and faithful_batch > 0:
@@ -250,7 +256,7 @@ def main():
     ap.add_argument('--env', choices=['slate', 'seq'], default='slate')
     ap.add_argument('--horizon', type=int, default=None)
     ap.add_argument('--log-records', type=int, default=8193)
-    ap.add_argument('--cpu-batch', type=int, default=1024,
+    ap.add_argument('--cpu-batch', type=int, default=2048,
                     help='envs of the vectorised cpu_baseline sample (one episode-batch; the faithful 1-core leg uses 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true',

@@ -10,8 +10,9 @@ import torch
 
 
 class TorchDien(object):
-    def __init__(self, weights, config):
+    def __init__(self, weights, config, workers=1):
         self.config = config
+        self.workers = workers            # row-parallel python threads (bench.py: one per host core)
         self.w = dict((k, torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))) for k, v in weights.items())
         self.seq_num = config['seq_num']
 
@@ -65,22 +66,38 @@ class TorchDien(object):
                                           w['augru%d_cand_b' % i], N, att=s))
         return torch.cat(finals + [d, c], dim=1)
 
-    CHUNK = 4096                 # rows per pass: keeps the [R, L, 2N] step inputs of the recurrences inside the caches / RAM
-
-    def _chunks(self, seq, dense, cat):
+    def _map_rows(self, fn, seq, dense, cat, workers):
+        """Rows are independent: split them over ``workers`` python threads, each running single-threaded torch ops (they
+        release the GIL).  The 64-step recurrences are chains of small matmuls that one intra-op thread pool cannot spread
+        over a 128-core host (measured on the bench box, R = 4096: 234 GFLOP/s at 16 threads, 63 GFLOP/s at 128); row-parallel
+        workers scale."""
         n = len(cat)
-        for lo in range(0, n, self.CHUNK):
-            yield seq[lo:lo + self.CHUNK], dense[lo:lo + self.CHUNK], cat[lo:lo + self.CHUNK]
+        workers = max(1, min(int(workers), (n + 31) // 32))
+        step = (n + workers - 1) // workers
+        chunks = [(seq[lo:lo + step], dense[lo:lo + step], cat[lo:lo + step]) for lo in range(0, n, step)]
+        if len(chunks) == 1:
+            return fn(*chunks[0])
+        from concurrent.futures import ThreadPoolExecutor
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            with ThreadPoolExecutor(len(chunks)) as ex:
+                outs = list(ex.map(lambda c: fn(*c), chunks))
+        finally:
+            torch.set_num_threads(nt)
+        return np.concatenate(outs, axis=0)
+
+    def _obs1(self, seq, dense, cat):
+        with torch.no_grad():
+            return torch.nn.functional.elu(self.features(seq, dense, cat) @ self.w['obs_w'] + self.w['obs_b']).numpy()
+
+    def _prob1(self, seq, dense, cat):
+        with torch.no_grad():
+            o = torch.nn.functional.elu(self.features(seq, dense, cat) @ self.w['obs_w'] + self.w['obs_b'])
+            return torch.softmax(o @ self.w['out_w'] + self.w['out_b'], dim=1)[:, 1].numpy().astype(np.float32)
 
     def obs(self, seq, dense, cat):
-        with torch.no_grad():
-            return np.concatenate([torch.nn.functional.elu(self.features(s, d, c) @ self.w['obs_w'] + self.w['obs_b']).numpy()
-                                   for s, d, c in self._chunks(seq, dense, cat)], axis=0)
+        return self._map_rows(self._obs1, seq, dense, cat, self.workers)
 
     def prob(self, seq, dense, cat):
-        with torch.no_grad():
-            out = []
-            for s, d, c in self._chunks(seq, dense, cat):
-                o = torch.nn.functional.elu(self.features(s, d, c) @ self.w['obs_w'] + self.w['obs_b'])
-                out.append(torch.softmax(o @ self.w['out_w'] + self.w['out_b'], dim=1)[:, 1].numpy().astype(np.float32))
-            return np.concatenate(out)
+        return self._map_rows(self._prob1, seq, dense, cat, self.workers)

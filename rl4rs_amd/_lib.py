@@ -201,14 +201,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get('RL4RS_LIB') or LIB_PATH          # RL4RS_LIB: A/B measurements of differently built libraries
+    if not os.path.exists(lib_path):
         raise Rl4rsHipError(
             "librl4rs_hip.so not found at %s: build it with `python -m rl4rs_amd.build` "
-            "(hipcc --offload-arch=gfx950). rl4rs_amd has no CPU fallback." % LIB_PATH)
+            "(hipcc --offload-arch=gfx950). rl4rs_amd has no CPU fallback." % lib_path)
     # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime this process uses, so import it
     # before dlopen()ing the library (two HIP runtimes in one process cannot see each other's devices).
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(lib_path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
         fn.restype = res

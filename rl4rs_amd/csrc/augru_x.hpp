@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             const int g = gate(i), cur = i & 1;
             if (i == 8) {
                 RL4RS_XT(1);
-                if (!(RL4RS_X_AB & 4)) {                          // x_u(t): staged one step ago
+                if (!(RL4RS_X_AB & (4 | 128))) {                  // x_u(t)   (128: no staging reads, DMA keeps going): staged one step ago
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_u[m], 1, m);
                 }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
                 RL4RS_XT(2);
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // r*h planes complete
                 RL4RS_XT(3);
-                if (!(RL4RS_X_AB & 4)) {                          // x_c(t)
+                if (!(RL4RS_X_AB & (4 | 128))) {                  // x_c(t)
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_c[m], 2, m);
                 }
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
 #endif
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // early half of the new state complete
                 RL4RS_XT(5);
-                if (!(RL4RS_X_AB & 4)) {                          // x_r(t+1) (requested 12+ items ago)
+                if (!(RL4RS_X_AB & (4 | 128))) {                  // x_r(t+1) (requested 12+ items ago)
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_r[m], 0, m);
                 }
                 hfrag(cur, i);
             }
-            if (i == WINDOW && t + 1 < L && !(RL4RS_X_AB & 4)) {
+            if (i == WINDOW && t + 1 < L && !(RL4RS_X_AB & (4 | 64))) {       // 64: no projection DMA (reads keep going)
                 // ---- the ONE projection issue window of the step: the register-resident items follow (no vector-memory wait)
                 x_dma(t + 1);
 #pragma unroll

@@ -26,6 +26,8 @@ dense = {1: torch.from_numpy(np.abs(rs.randn(B, 432)).astype(np.float32)).cuda()
 cat = {1: torch.from_numpy(rs.randint(0, 284, size=(B, 21)).astype(np.int32)).cuda(),
        8: torch.from_numpy(rs.randint(0, 284, size=(8 * B, 21)).astype(np.int32)).cuda()}
 slots = torch.arange(B, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+if os.environ.get('AUGRU_BENCH_SLOTS'):          # all rows share a few cache slots: the projection rows stay in L2
+    slots = (slots % int(os.environ['AUGRU_BENCH_SLOTS'])).contiguous()
 
 
 def run(kind):

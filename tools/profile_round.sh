@@ -6,7 +6,7 @@ repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg"
+cmd="python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-extra-legs"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $cmd > $out/${tag}_kt.log 2>&1
 db=$(find /tmp/prof_kt -name '*.db' | head -1)
 python $repo/tools/rocpd_summary.py $db > $out/${tag}_kernel_stats.md 2>&1
