@@ -620,6 +620,12 @@ int rl4rs_gemm_f32_packed(const float* a_dev, int64_t lda, const float* w_host, 
                           const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
                           int act, void* stream);
 
+/* The fp16x2 form of that GEMM (scorer_mode RL4RS_SCORER_FP16X2: operands as fp16 hi + lo pairs, three f16 MFMAs per
+ * product, fp32 accumulation; an activation outside the fp16 range turns its output row into NaN).  Test entry point. */
+int rl4rs_gemm_h16_packed(const float* a_dev, int64_t lda, const float* w_host, int64_t ldw,
+                          const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                          int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

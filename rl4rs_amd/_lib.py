@@ -192,6 +192,7 @@ SIGNATURES = {
     'rl4rs_qloss_imitation': (_I, [_P, _I32, _P, _P, C.c_float, _P, _P, _P, _P]),
     'rl4rs_qloss_dqn': (_I, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
+    'rl4rs_gemm_h16_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
 }
 

@@ -56,5 +56,45 @@ int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, co
 int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
                        int M, int N, int K, int act, hipStream_t st);
 std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N);
+// fp16x2 form (scorer_mode FP16X2): weights pre-split into fp16 hi / lo fragment planes, activations split while staged
+int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
+                    int M, int N, int K, int act, hipStream_t st);
+std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N);
+
+// fp32 -> fp16 bits, round to nearest even (subnormals kept)
+inline uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // overflow -> inf
+    if (x < 0x38800000u) {                                                   // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                           // 14..24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+}
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
 
 }  // namespace rl4rs

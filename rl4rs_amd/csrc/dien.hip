@@ -1129,6 +1129,7 @@ struct rl4rs_dien {
     bool gru16, gru16_attr;
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
+    bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
     const int32_t* row_order; int row_order_n;    // processing order of the row groups of a forward (caller-owned), or NULL
@@ -1179,41 +1180,6 @@ std::vector<float> pack_frag(const float* w, int ld, int k_off, int K, int N) {
     return out;
 }
 
-// fp32 -> fp16 bits, round to nearest even (subnormals kept)
-uint16_t f32_to_f16(float f) {
-    uint32_t x;
-    memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    x &= 0x7fffffffu;
-    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
-    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // overflow -> inf
-    if (x < 0x38800000u) {                                                   // subnormal half (or zero)
-        if (x < 0x33000000u) return (uint16_t)sign;
-        const int e = (int)(x >> 23);
-        uint32_t m = (x & 0x7fffffu) | 0x800000u;
-        const int shift = 126 - e;                                           // 14..24
-        uint32_t r = m >> shift;
-        const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
-        if (rem > halfway || (rem == halfway && (r & 1))) ++r;
-        return (uint16_t)(sign | r);
-    }
-    uint32_t r = ((x - 0x38000000u) >> 13);
-    const uint32_t rem = x & 0x1fffu;
-    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) ++r;
-    return (uint16_t)(sign | r);
-}
-float f16_to_f32(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
-    if (e == 0) {
-        if (m == 0) x = sign;
-        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
-    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
-    else x = sign | ((e + 112) << 23) | (m << 13);
-    float f;
-    memcpy(&f, &x, 4);
-    return f;
-}
 // pack Wh [K, N] (rows k_off..) into fp16 hi/lo B-fragment planes for v_mfma_f32_32x32x16_f16:
 // [ntile][kb16][plane][lane][8]: element i of lane (j = lane&31, kg = lane>>5) is W[kb16*16 + kg*8 + i][nt*32 + j]
 std::vector<float> pack_frag_h16(const float* w, int ld, int k_off, int K, int N) {
@@ -1233,6 +1199,12 @@ std::vector<float> pack_frag_h16(const float* w, int ld, int k_off, int K, int N
     std::vector<float> f(out.size() / 2);
     memcpy(f.data(), out.data(), out.size() * 2);
     return f;
+}
+
+static int scorer_gemm(rl4rs_dien* n, const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
+                       int M, int N, int K, int act, hipStream_t st) {
+    return n->gemm16 ? launch_gemm_h16(a, lda, wp, bias, c, ldc, M, N, K, act, st)
+                     : launch_gemm_packed(a, lda, wp, bias, c, ldc, M, N, K, act, st);
 }
 
 struct Prof {
@@ -1327,6 +1299,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->row_order_n = 0;
     n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
     n->din16 = false;
+    n->gemm16 = false;
     n->gru16 = false;
     n->gru16_attr = false;
     if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
@@ -1356,6 +1329,22 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             }
         }
         n->gru16 = c->emb_size == 128 && gfin && gmx < 6.0e4f && !(getenv("RL4RS_GRU16") && atoi(getenv("RL4RS_GRU16")) == 0);
+        // the plain GEMMs in the same split form: every weight they use finite and well inside the fp16 range (sums /
+        // differences of two att_w1 entries are formed at load: 3e4).  Activations are split on the fly; one that leaves the
+        // range turns its output row into NaN (gemm.hip).
+        bool wfin = true;
+        auto chk = [&](const float* p, size_t cnt) {
+            for (size_t i = 0; p && i < cnt; ++i) wfin = wfin && fabsf(p[i]) < 3.0e4f;      // false for NaN too
+        };
+        chk(w->dense_w1, (size_t)c->dense_feature_num * c->hidden_units);
+        chk(w->dense_w2, (size_t)c->hidden_units * c->hidden_units);
+        chk(w->obs_w, (size_t)(c->seq_num * 2 * c->emb_size + c->hidden_units + (c->category_feature_num + 1) * c->emb_size) * OBS_DIM);
+        for (int s = 0; s < c->seq_num; ++s) {
+            chk(w->att_w1[s], (size_t)4 * c->emb_size * ATT_H1);
+            chk(w->augru_gate_w[s], (size_t)c->emb_size * 4 * c->emb_size);
+            chk(w->augru_cand_w[s], (size_t)c->emb_size * 2 * c->emb_size);
+        }
+        n->gemm16 = wfin && !(getenv("RL4RS_GEMM16") && atoi(getenv("RL4RS_GEMM16")) == 0);
     }
     {
         float* f = nullptr;
@@ -1378,16 +1367,20 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     keep.reserve(64);
     UP(cat_emb, w->cat_emb, (size_t)H * E);
     UP(seq_emb, w->seq_emb, (size_t)H * E);
-    { auto pk = pack_gemm_weight(w->dense_w1, U, Dn, U); keep.push_back(std::move(pk)); UP(dense_w1, keep.back().data(), keep.back().size()); }
+    // GEMM weights in the fragment order of the form that will run them (k_gemm_h16 in fp16x2 mode, else k_gemm_pk)
+    auto pack_w = [&](const float* src, int64_t ldw, int kk, int nn) {
+        return n->gemm16 ? pack_gemm_weight_h16(src, ldw, kk, nn) : pack_gemm_weight(src, ldw, kk, nn);
+    };
+    { auto pk = pack_w(w->dense_w1, U, Dn, U); keep.push_back(std::move(pk)); UP(dense_w1, keep.back().data(), keep.back().size()); }
     UP(dense_b1, w->dense_b1, U);
-    { auto pk = pack_gemm_weight(w->dense_w2, U, U, U); keep.push_back(std::move(pk)); UP(dense_w2, keep.back().data(), keep.back().size()); }
+    { auto pk = pack_w(w->dense_w2, U, U, U); keep.push_back(std::move(pk)); UP(dense_w2, keep.back().data(), keep.back().size()); }
     UP(dense_b2, w->dense_b2, U);
     // head: table form unless disabled (RL4RS_HEAD_TABLES=0) or the tables would not fit a sane budget (8 GB)
     const int Kh = S * NH2 + U + E;                       // [sequence finals | dense | pooled attention]
     const char* ht = getenv("RL4RS_HEAD_TABLES");
     const bool use_tables = !(ht && atoi(ht) == 0) && ((int64_t)Cn * H * OBS_DIM * 4 <= ((int64_t)8 << 30));
     n->ptab = nullptr;
-    { auto pk = pack_gemm_weight(w->obs_w, OBS_DIM, use_tables ? Kh : F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
+    { auto pk = pack_w(w->obs_w, OBS_DIM, use_tables ? Kh : F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
     if (use_tables) {
         float* d_wflat;      // raw rows [Kh, F) of obs_w = the Cn blocks of E rows each
         if ((rc = upload(n, &d_wflat, w->obs_w + (size_t)Kh * OBS_DIM, (size_t)Cn * E * OBS_DIM, st))) return rc;
@@ -1441,9 +1434,9 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (int j = 0; j < ATT_H1; ++j) bp[j] = w->att_b1[s][j];
         for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j];
         for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
-        keep.push_back(pack_gemm_weight(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
+        keep.push_back(pack_w(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
-        keep.push_back(pack_gemm_weight(wac.data(), ATT_H1, E, ATT_H1));
+        keep.push_back(pack_w(wac.data(), ATT_H1, E, ATT_H1));
         UP(w1ac_pk[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
@@ -1556,7 +1549,7 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
     }
     {
         Prof p(n, KID_PROJ, st);
-        int rc = launch_gemm_packed(n->h1[s] + (size_t)slot_base * L * E, E, n->wproj[s], n->bproj[s],
+        int rc = scorer_gemm(n, n->h1[s] + (size_t)slot_base * L * E, E, n->wproj[s], n->bproj[s],
                                     n->proj[s] + (size_t)slot_base * L * n->PLD, n->PLD, cnt * L, n->PLD, E, 0, st);
         if (rc) return rc;
     }
@@ -1582,8 +1575,8 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     }
     {
         Prof p(n, KID_DENSE, st);
-        if ((rc = launch_gemm_packed(dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
-        if ((rc = launch_gemm_packed(n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
+        if ((rc = scorer_gemm(n, dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
+        if ((rc = scorer_gemm(n, n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
     }
     {
         Prof p(n, KID_DIN, st);
@@ -1594,7 +1587,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         a.qa = n->qa; a.qa_stride = (int64_t)n->c.max_rows * ATT_H1;
         const bool h16 = n->fp16x2 && n->din16;
         for (int s = 0; s < S; ++s) {
-            int rcq = launch_gemm_packed(n->q, E, n->w1ac_pk[s], nullptr, n->qa + (size_t)s * a.qa_stride, ATT_H1, R, ATT_H1, E, 0, st);
+            int rcq = scorer_gemm(n, n->q, E, n->w1ac_pk[s], nullptr, n->qa + (size_t)s * a.qa_stride, ATT_H1, R, ATT_H1, E, 0, st);
             if (rcq) return rcq;
         }
         for (int s = 0; s < S; ++s) {
@@ -1677,11 +1670,11 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         Prof p(n, KID_HEAD, st);
         if (n->ptab) {
             const int Kh = S * NH2 + U + E;
-            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 0, st))) return rc;
+            if ((rc = scorer_gemm(n, n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 0, st))) return rc;
             hipLaunchKernelGGL(k_head_finish, dim3((R + 3) / 4), dim3(256), 0, st, obs_out, R, cat, Cn, n->H, n->ptab, n->obs_b);
             RL4RS_LAUNCH_CHECK();
         } else {
-            if ((rc = launch_gemm_packed(n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, n->F, 1, st))) return rc;
+            if ((rc = scorer_gemm(n, n->allf, F, n->obs_w, n->obs_b, obs_out, OBS_DIM, R, OBS_DIM, n->F, 1, st))) return rc;
         }
     }
     if (prob) {

@@ -11,6 +11,7 @@
 // Block = 256 threads = 2x2 waves, tile 128(M) x 64(N), BK = 32.  A is staged global -> registers ->
 // LDS (double buffered, rows padded to 36 floats: conflict-free for ds_read_b128); W is small and
 // L1/L2 resident, so B fragments come straight from global memory (128-byte coalesced per half-wave).
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -266,6 +267,187 @@ __global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, in
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// fp16x2 form of the packed GEMM (scorer_mode FP16X2): every fp32 operand as an fp16 hi + lo pair, every product as
+// A_hi*W_hi + A_lo*W_hi + A_hi*W_lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the arithmetic of k_augru_x; 16x the
+// MAC rate of v_mfma_f32_32x32x2_f32 for 3x the MACs).  The weights are split and packed once at load
+// (pack_gemm_weight_h16: [ntile][kb16][hi/lo][lane][8 halfs], lane (j, kg) holds W[kb*16 + kg*8 + 0..7][nt*32 + j]); the
+// activations are split while they are staged: a thread converts 8 consecutive k of one row and writes one 16-byte entry
+// into the hi and the lo plane, planes in slab order [kb][k-half][row][8 halfs] so a fragment read is one conflict-free
+// ds_read_b128 (slabs padded by 16 bytes: the 8 entries of one row, written by 8 neighbouring lanes, spread over the banks).
+// A value outside the fp16 range becomes inf in the hi plane and -inf in the lo plane, i.e. NaN in its whole output row:
+// out-of-range inputs can never come back as plausible numbers.
+// Block = 4 waves, wave w owns n-tile blockIdx.y*4 + w for all BM = 32*WM rows; k-tile = 64.
+typedef _Float16 ghalf8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ ghalf8_t gbuf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return __builtin_bit_cast(ghalf8_t, v);
+}
+
+template <int WM>
+__global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, int64_t lda,
+                                                  const char* __restrict__ Wp, int KB,
+                                                  const float* __restrict__ bias, float* __restrict__ C,
+                                                  int64_t ldc, int M, int N, int K, int act) {
+    constexpr int BM = 32 * WM, BK = 64, KBT = BK / 16;
+    constexpr int SLAB = BM * 16 + 16, PLANE = 2 * KBT * SLAB;
+    __shared__ __attribute__((aligned(16))) char As[2][2][PLANE];          // [buffer][hi / lo]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * BM;
+    const int nt = blockIdx.y * 4 + wave;
+    const int NT = (N + 31) / 32;
+    const bool tile_ok = nt < NT;
+    const int col = nt * 32 + li;
+    const bool vec_ok = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const char* wtile = Wp + (size_t)(tile_ok ? nt : 0) * KB * 2048;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wtile), 0, KB * 2048, 0x00020000);
+    const int vl16 = lane * 16;
+
+    f32x16 acc[WM];
+#pragma unroll
+    for (int w = 0; w < WM; ++w)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[w][i] = 0.f;
+
+    float4 stage[2][WM][2];               // tiles kt+1, kt+2 in flight: 8 consecutive k of one row per chunk
+    auto gload = [&](float4 (&st)[WM][2], int kt) {
+#pragma unroll
+        for (int p = 0; p < WM; ++p) {
+            const int c = tid + p * 256;
+            const int r = c >> 3, gr = m0 + r, gk = kt * BK + (c & 7) * 8;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (gr < M && gk < K) {
+                const float* src = A + (size_t)gr * lda + gk;
+                if (vec_ok && gk + 7 < K) {
+                    v0 = *reinterpret_cast<const float4*>(src);
+                    v1 = *reinterpret_cast<const float4*>(src + 4);
+                } else {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = gk + e < K ? src[e] : 0.f;
+                    v0 = make_float4(x[0], x[1], x[2], x[3]);
+                    v1 = make_float4(x[4], x[5], x[6], x[7]);
+                }
+            }
+            st[p][0] = v0; st[p][1] = v1;
+        }
+    };
+    auto lstore = [&](const float4 (&st)[WM][2], int buf) {
+#pragma unroll
+        for (int p = 0; p < WM; ++p) {
+            const int c = tid + p * 256;
+            const int off = (c & 7) * SLAB + (c >> 3) * 16;
+            const float x[8] = {st[p][0].x, st[p][0].y, st[p][0].z, st[p][0].w, st[p][1].x, st[p][1].y, st[p][1].z, st[p][1].w};
+            ghalf8_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 h = (_Float16)x[e];
+                hi[e] = h;
+                lo[e] = (_Float16)(x[e] - (float)h);
+            }
+            *reinterpret_cast<ghalf8_t*>(&As[buf][0][off]) = hi;
+            *reinterpret_cast<ghalf8_t*>(&As[buf][1][off]) = lo;
+        }
+    };
+    ghalf8_t bh[2][KBT], bl[2][KBT];
+    auto load_b = [&](ghalf8_t (&h)[KBT], ghalf8_t (&l)[KBT], int kt) {
+#pragma unroll
+        for (int j = 0; j < KBT; ++j) {
+            h[j] = gbuf_load_h8(rs_w, vl16, (kt * KBT + j) * 2048);
+            l[j] = gbuf_load_h8(rs_w, vl16 + 1024, (kt * KBT + j) * 2048);
+        }
+    };
+    auto compute = [&](const ghalf8_t (&h)[KBT], const ghalf8_t (&l)[KBT], int buf) {
+#pragma unroll
+        for (int j = 0; j < KBT; ++j) {
+            ghalf8_t ah[WM], al[WM];
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                const int off = (j * 2 + half) * SLAB + (w * 32 + li) * 16;
+                ah[w] = *reinterpret_cast<const ghalf8_t*>(&As[buf][0][off]);
+                al[w] = *reinterpret_cast<const ghalf8_t*>(&As[buf][1][off]);
+            }
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[w], h[j], acc[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[w], h[j], acc[w], 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[w], l[j], acc[w], 0, 0, 0);
+        }
+    };
+
+    const int nkt = (K + BK - 1) / BK;
+    gload(stage[0], 0);
+    load_b(bh[0], bl[0], 0);
+    gload(stage[1], 1);
+    lstore(stage[0], 0);
+    __syncthreads();
+    // at the top of step kt: LDS[kt&1] = tile kt, stage[(kt+1)&1] = tile kt+1 (in flight), bh/bl[kt&1] = fragments of tile kt
+#define RL4RS_G16_STEP(KT, P)                                                              \
+    if ((KT) < nkt) {                                                                      \
+        load_b(bh[(P) ^ 1], bl[(P) ^ 1], (KT) + 1);                                        \
+        gload(stage[P], (KT) + 2);                                                         \
+        compute(bh[P], bl[P], P);                                                          \
+        lstore(stage[(P) ^ 1], (P) ^ 1);                                                   \
+        __syncthreads();                                                                   \
+    }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        RL4RS_G16_STEP(kt, 0)
+        RL4RS_G16_STEP(kt + 1, 1)
+    }
+#undef RL4RS_G16_STEP
+    if (tile_ok && col < N) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv, act);
+            }
+    }
+}
+
+// host: split W [K,N] into fp16 hi / lo and pack it into B-fragment order for k_gemm_h16 (K padded to 16, N to 32);
+// returned as floats (NT * KB16 * 512)
+std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N) {
+    const int KB = (K + 15) / 16, NT = (N + 31) / 32;
+    std::vector<uint16_t> out((size_t)NT * KB * 2 * 512, 0);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int k = kb * 16 + (lane >> 5) * 8 + i, j = nt * 32 + (lane & 31);
+                    if (k >= K || j >= N) continue;
+                    const float v = w[(size_t)k * ldw + j];
+                    const uint16_t hi = f32_to_f16(v);
+                    const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                    const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8 + i;
+                    out[base] = hi;
+                    out[base + 512] = lo;
+                }
+    std::vector<float> f(out.size() / 2);
+    memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
+int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
+                    int M, int N, int K, int act, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
+    const int KB = (K + 15) / 16;
+    const int ny = ((N + 31) / 32 + 3) / 4;
+    const char* wp = reinterpret_cast<const char*>(wp16);
+    if ((int64_t)((M + 63) / 64) * ny < 512) {     // small problems: 32-row tiles so that the grid covers the CUs
+        hipLaunchKernelGGL(k_gemm_h16<1>, dim3((M + 31) / 32, ny), dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act);
+    } else {
+        hipLaunchKernelGGL(k_gemm_h16<2>, dim3((M + 63) / 64, ny), dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act);
+    }
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 // host: pack W [K,N] (leading dim ldw) into fragment order; returns floats ( NT * KB * 64 * 4 )
 std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N) {
     const int KB = (K + 7) / 8, NT = (N + 31) / 32;
@@ -335,6 +517,23 @@ extern "C" int rl4rs_gemm_f32_packed(const float* a_dev, int64_t lda, const floa
     hipStream_t st = (hipStream_t)stream;
     RL4RS_HIP_TRY(hipMemcpyAsync(d, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, st));
     rc = rl4rs::launch_gemm_packed(a_dev, lda, d, bias_dev, c_dev, ldc, M, N, K, act, st);
+    RL4RS_HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    return rc;
+}
+
+// fp16x2 variant exposed for tests: splits + packs W on the host, uploads, runs, frees (synchronous).
+extern "C" int rl4rs_gemm_h16_packed(const float* a_dev, int64_t lda, const float* w_host, int64_t ldw,
+                                     const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N,
+                                     int32_t K, int act, void* stream) {
+    RL4RS_REQUIRE(a_dev && w_host && c_dev && M > 0 && N > 0 && K > 0, "rl4rs_gemm_h16_packed: bad argument");
+    std::vector<float> pk = rl4rs::pack_gemm_weight_h16(w_host, ldw, K, N);
+    float* d = nullptr;
+    int rc = rl4rs::dev_alloc(&d, pk.size());
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    RL4RS_HIP_TRY(hipMemcpyAsync(d, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, st));
+    rc = rl4rs::launch_gemm_h16(a_dev, lda, d, bias_dev, c_dev, ldc, M, N, K, act, st);
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     (void)hipFree(d);
     return rc;

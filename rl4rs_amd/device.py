@@ -933,6 +933,19 @@ def gemm_f32_packed(a, w_host, bias=None, act=0):
     return c
 
 
+def gemm_h16_packed(a, w_host, bias=None, act=0):
+    """The fp16x2 form (operands as fp16 hi + lo pairs, three f16 MFMAs per product) of the packed-weight GEMM."""
+    lib = _lib.load()
+    M, K = a.shape
+    w_host = np.ascontiguousarray(w_host, dtype=np.float32)
+    K2, N = w_host.shape
+    assert K == K2
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.rl4rs_gemm_h16_packed(_ptr(a), a.stride(0), w_host.ctypes.data_as(C.c_void_p), N, _ptr(bias), _ptr(c), N,
+                                    M, N, K, act, _stream()))
+    return c
+
+
 class DevicePolicy(object):
     """rl4rs_policy handle: action-masked policy net (rllib_mask_model.py:7-64) with flat parameters."""
     A2C, PPO = 0, 1

@@ -33,3 +33,58 @@ def test_gemm_f32(M, N, K, act):
     c2 = gemm_f32(wide[:, 4:4 + K], w, None, 0)
     ref2 = wide[:, 4:4 + K].double() @ w.double()
     assert (c2.double() - ref2).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('M,N,K,act', [(1, 2, 3, 0), (33, 65, 17, 1), (64, 64, 64, 0), (300, 284, 70, 3), (4096, 128, 432, 1),
+                                       (4096, 256, 768, 0), (32768, 256, 768, 0), (5000, 832, 128, 0), (77, 2, 256, 2)])
+def test_gemm_h16(M, N, K, act):
+    """fp16x2 GEMM (the scorer's GEMMs in scorer_mode fp16x2) vs fp64: same bar as the exact-fp32 kernel, on operands that
+    exercise the split: large and tiny magnitudes next to each other, strided A, row / column / k tails."""
+    import torch
+    from rl4rs_amd.device import gemm_h16_packed, gemm_f32_packed
+    g = torch.Generator().manual_seed(M * 17 + N + K)
+    a = torch.randn(M, K, generator=g)
+    a[:, ::3] *= 30.0                       # activations O(30) next to O(1)
+    a[:, 1::5] *= 1e-3                      # and values whose lo part is an fp16 subnormal
+    w = torch.randn(K, N, generator=g) / np.sqrt(K)
+    w[::7] *= 1e-3
+    b = torch.randn(N, generator=g)
+    wide = torch.zeros(M, K + 8)
+    wide[:, 4:4 + K] = a
+    wide = wide.cuda()
+    av = wide[:, 4:4 + K]                   # a column slice of a wider matrix (lda != K; 16-byte aligned rows)
+    ref = a.double() @ w.double() + b.double()
+    if act == 1:
+        ref = torch.where(ref > 0, ref, torch.expm1(ref))
+    elif act == 2:
+        ref = torch.sigmoid(ref)
+    elif act == 3:
+        ref = torch.tanh(ref)
+    c = gemm_h16_packed(av, w.numpy(), b.cuda(), act)
+    err = (c.double().cpu() - ref).abs().max().item()
+    c32 = gemm_f32_packed(av, w.numpy(), b.cuda(), act)
+    err32 = (c32.double().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err < max(4e-6 * max(scale, 1.0), 2.0 * err32), (err, err32, scale)
+    # unaligned A (scalar load path) gives the same bits
+    odd = torch.zeros(M, K + 9)
+    odd[:, 1:1 + K] = a
+    c_odd = gemm_h16_packed(odd.cuda()[:, 1:1 + K], w.numpy(), b.cuda(), act)
+    assert torch.equal(c_odd, c)
+
+
+def test_gemm_h16_poisons_out_of_range_rows():
+    import torch
+    from rl4rs_amd.device import gemm_h16_packed
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(100, 96, generator=g)
+    a[7, 13] = 7.0e4                         # beyond the fp16 range
+    a[55, 80] = float('nan')
+    w = torch.randn(96, 64, generator=g) / 10
+    c = gemm_h16_packed(a.cuda(), w.numpy(), None, 0).cpu()
+    bad = torch.isnan(c).any(dim=1)
+    assert bad[7] and bad[55] and int(bad.sum()) == 2
+    assert torch.isnan(c[7]).all() and torch.isnan(c[55]).all()
+    ref = a.double() @ w.double()
+    ok = ~bad
+    assert (c[ok].double() - ref[ok]).abs().max().item() < 1e-5
