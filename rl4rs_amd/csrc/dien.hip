@@ -857,6 +857,19 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     float* s_h1 = s_wave + (size_t)nw * (E + ATT_H1);    // STAGE: [L][LDK]
     const int half = lane >> 5, li = lane & 31;
+    if (H16) {
+        // fp16x2 layer 2 on v_mfma_f32_32x32x16_f16: A fragment (m, kb2) of lane (o, kg) = W2[m*32 + crow(kb2*8 + i, kg)][o], i = 0..7
+        // (the 8 layer-1 accumulator registers kb2*8.. of a half-wave ARE the 8 k values of its B fragment); hi / lo planes,
+        // [m*2 + kb2][plane][lane][8 halfs] = 8 KB, the same bytes as the fp32 table
+        _Float16* s_w2h = reinterpret_cast<_Float16*>(smem);
+        for (int i = tid; i < 4 * 64 * 8; i += blockDim.x) {
+            const int e = i & 7, ln = (i >> 3) & 63, f = i >> 9, o = ln & 31;
+            const float v = o < ATT_H2 ? a.w2[sq][((f >> 1) * 32 + crow((f & 1) * 8 + e, ln >> 5)) * ATT_H2 + o] : 0.f;
+            const _Float16 hi = (_Float16)v;
+            s_w2h[(f * 2) * 512 + ln * 8 + e] = hi;
+            s_w2h[(f * 2 + 1) * 512 + ln * 8 + e] = (_Float16)(v - (float)hi);
+        }
+    } else
     for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) {
         const int ln = i & 63, mr = i >> 6, o = ln & 31;
         s_w2[i] = o < ATT_H2 ? a.w2[sq][((mr >> 4) * 32 + crow(mr & 15, ln >> 5)) * ATT_H2 + o] : 0.f;
@@ -951,7 +964,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                     for (int e = 0; e < 8; ++e) {
                         const _Float16 hi = (_Float16)pr[e];
                         bh[n][e] = hi;
-                        bl[n][e] = (_Float16)(pr[e] - (float)hi);
+                        bl[n][e] = (_Float16)__builtin_fmaf((float)hi, -1.0f, pr[e]);      // pr - hi, exact (v_fma_mix_f32)
                     }
                 }
 #define RL4RS_DIN3(acc, m, n)                                                                         \
@@ -1012,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
             for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
+                float hvv[16];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int jr = m * 32 + 8 * r4 + 4 * half;       // hidden units jr..jr+3
@@ -1022,7 +1036,26 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                         const float accv = (n == 0) ? (m == 0 ? acc00[r4 * 4 + rr] : acc10[r4 * 4 + rr])
                                                     : (m == 0 ? acc01[r4 * 4 + rr] : acc11[r4 * 4 + rr]);
                         const float hv = gate_sigmoid(accv + s_qa[jr + rr] + akv[rr]);
-                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(m * 16 + r4 * 4 + rr) * 64 + lane], hv, acc2, 0, 0, 0);
+                        if (H16) hvv[r4 * 4 + rr] = hv;
+                        else acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(m * 16 + r4 * 4 + rr) * 64 + lane], hv, acc2, 0, 0, 0);
+                    }
+                }
+                if (H16) {      // hidden activations in (0, 1): fp16 hi + lo, 3 MFMAs per product like layer 1
+                    const char* s_w2b = smem;
+#pragma unroll
+                    for (int kb2 = 0; kb2 < 2; ++kb2) {
+                        half8_t bh2, bl2;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const _Float16 hi = (_Float16)hvv[kb2 * 8 + e];
+                            bh2[e] = hi;
+                            bl2[e] = (_Float16)__builtin_fmaf((float)hi, -1.0f, hvv[kb2 * 8 + e]);
+                        }
+                        const half8_t ah2 = *reinterpret_cast<const half8_t*>(s_w2b + ((m * 2 + kb2) * 2) * 1024 + lane * 16);
+                        const half8_t al2 = *reinterpret_cast<const half8_t*>(s_w2b + ((m * 2 + kb2) * 2 + 1) * 1024 + lane * 16);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2, bh2, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2, bh2, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2, bl2, acc2, 0, 0, 0);
                     }
                 }
             }
@@ -1312,6 +1345,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (int s = 0; s < c->seq_num && w->att_w1[s]; ++s)
             for (size_t i = (size_t)3 * c->emb_size * ATT_H1; i < (size_t)4 * c->emb_size * ATT_H1; ++i) {
                 const float v = fabsf(w->att_w1[s][i]);
+                fin = fin && v == v; mx = fmaxf(mx, v);
+            }
+        for (int s = 0; s < c->seq_num && w->att_w2[s]; ++s)         // layer 2 runs in the same split form
+            for (size_t i = 0; i < (size_t)ATT_H1 * ATT_H2; ++i) {
+                const float v = fabsf(w->att_w2[s][i]);
                 fin = fin && v == v; mx = fmaxf(mx, v);
             }
         n->din16 = fin && mx < 6.0e4f && !(getenv("RL4RS_DIN16") && atoi(getenv("RL4RS_DIN16")) == 0);
