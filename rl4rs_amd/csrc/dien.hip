@@ -427,6 +427,20 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 struct h8bits { half8_t v; };
 
+// fp16 hi / lo split of two fp32 values: hi = RNE(x) as a packed pair, lo = RNE(x - hi).  The difference comes from ONE
+// v_fma_mix_f32 (f16 source read straight out of the packed pair, exact) instead of a conversion back plus a subtraction.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, half2_t& lo) {
+    unsigned h;
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(x1));
+    unsigned l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(d0), "v"(d1));
+    hi = __builtin_bit_cast(half2_t, h);
+    lo = __builtin_bit_cast(half2_t, l);
+}
 __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return __builtin_bit_cast(half8_t, v);
@@ -831,6 +845,7 @@ struct DinArgs {
     int R, L, E, group, n_groups;
     const int32_t* slots; int64_t slots_stride;     // [n_seq][n_groups]
     const float* h1[4];          // [slot, L, E]
+    const float* h1f[4];         // k_din_x: the same states in fragment order (k_h1_frag)
     const float* proj[4]; int64_t pld;   // [slot*L, pld], AK at column 0
     const float* q;              // [R, E]
     const float* w1ac[4];        // [E, 64]   (W1a + W1c)
@@ -961,10 +976,11 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                     const float pr[8] = {hr[cb][n][0].x * qa4.x, hr[cb][n][0].y * qa4.y, hr[cb][n][0].z * qa4.z, hr[cb][n][0].w * qa4.w,
                                          hr[cb][n][1].x * qb4.x, hr[cb][n][1].y * qb4.y, hr[cb][n][1].z * qb4.z, hr[cb][n][1].w * qb4.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const _Float16 hi = (_Float16)pr[e];
-                        bh[n][e] = hi;
-                        bl[n][e] = (_Float16)__builtin_fmaf((float)hi, -1.0f, pr[e]);      // pr - hi, exact (v_fma_mix_f32)
+                    for (int e = 0; e < 8; e += 2) {
+                        half2_t h2, l2;
+                        split_h16_pair(pr[e], pr[e + 1], h2, l2);
+                        bh[n][e] = h2[0]; bh[n][e + 1] = h2[1];
+                        bl[n][e] = l2[0]; bl[n][e + 1] = l2[1];
                     }
                 }
 #define RL4RS_DIN3(acc, m, n)                                                                         \
@@ -1046,10 +1062,11 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
                     for (int kb2 = 0; kb2 < 2; ++kb2) {
                         half8_t bh2, bl2;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const _Float16 hi = (_Float16)hvv[kb2 * 8 + e];
-                            bh2[e] = hi;
-                            bl2[e] = (_Float16)__builtin_fmaf((float)hi, -1.0f, hvv[kb2 * 8 + e]);
+                        for (int e = 0; e < 8; e += 2) {
+                            half2_t h2, l2;
+                            split_h16_pair(hvv[kb2 * 8 + e], hvv[kb2 * 8 + e + 1], h2, l2);
+                            bh2[e] = h2[0]; bh2[e + 1] = h2[1];
+                            bl2[e] = l2[0]; bl2[e + 1] = l2[1];
                         }
                         const half8_t ah2 = *reinterpret_cast<const half8_t*>(s_w2b + ((m * 2 + kb2) * 2) * 1024 + lane * 16);
                         const half8_t al2 = *reinterpret_cast<const half8_t*>(s_w2b + ((m * 2 + kb2) * 2 + 1) * 1024 + lane * 16);
@@ -1074,6 +1091,19 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+}  // namespace rl4rs
+#ifndef RL4RS_DINX_SGB
+#define RL4RS_DINX_SGB 1
+#endif
+#ifndef RL4RS_DINX_RING
+#define RL4RS_DINX_RING 2       // cache rows requested this many k-blocks ahead
+#endif
+#ifndef RL4RS_DINX_WPE
+#define RL4RS_DINX_WPE 4        // waves per SIMD the register allocation aims at
+#endif
+#include "din_x.hpp"
+namespace rl4rs {
 
 // softmax(obs @ out_w + out_b)[:, 1]  (dien.py:36, slate.py:298).  One wave per row.
 __global__ __launch_bounds__(256) void k_head_prob(const float* __restrict__ obs, int R, int D, int K,
@@ -1162,6 +1192,7 @@ struct rl4rs_dien {
     bool gru16, gru16_attr;
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
+    bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
@@ -1170,6 +1201,7 @@ struct rl4rs_dien {
     float* augru_wc[4];
     // caches
     float* h1[4];          // [max_slots, L, E]
+    float* h1f[4];         // fragment-order copy for k_din_x [max_slots, ceil(L/32), 8, 64, 8] (fp16x2 mode, E = 128)
     float* proj[4];        // [max_slots*L, PLD]
     // scratch
     float *allf, *dh, *q, *scores, *obs_tmp;
@@ -1332,6 +1364,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->row_order_n = 0;
     n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
     n->din16 = false;
+    n->din_x = !(getenv("RL4RS_DIN") && strcmp(getenv("RL4RS_DIN"), "v1") == 0);
     n->gemm16 = false;
     n->gru16 = false;
     n->gru16_attr = false;
@@ -1500,6 +1533,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             UP(augru_wc16[s], keep.back().data(), keep.back().size());
         }
         AL(h1[s], (size_t)c->max_slots * L * E);
+        n->h1f[s] = nullptr;
+        if (n->fp16x2 && n->din16 && n->din_x && E == 128 && L <= 64) AL(h1f[s], (size_t)c->max_slots * ((L + 31) / 32) * 32 * E);
         AL(proj[s], (size_t)c->max_slots * L * PLD);
     }
     // table form: the Flatten(category_emb) columns are never materialised, so the rows are only Kh wide (contiguous
@@ -1535,6 +1570,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(2)));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
+        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_x), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)din_x_smem()));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, true>),
@@ -1583,6 +1620,11 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
             size_t smem = (size_t)(2 * 32 * (E + 4) + 32 * (L + 1) + 32) * 4;
             hipLaunchKernelGGL((k_recur<128, false, GRU_U>), dim3((cnt + 31) / 32, 1), dim3(256), smem, st, a);
         }
+        if (n->h1f[s]) {
+            const int64_t pieces = (int64_t)cnt * ((L + 31) / 32) * 1024;
+            hipLaunchKernelGGL(k_h1_frag, dim3((unsigned)((pieces + 255) / 256 < 8192 ? (pieces + 255) / 256 : 8192)), dim3(256), 0, st,
+                               n->h1[s], n->h1f[s], slot_base, cnt, L);
+        }
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -1629,12 +1671,15 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             if (rcq) return rcq;
         }
         for (int s = 0; s < S; ++s) {
-            a.h1[s] = n->h1[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s]; a.w1d16[s] = n->w1d16[s];
+            a.h1[s] = n->h1[s]; a.h1f[s] = n->h1f[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s]; a.w1d16[s] = n->w1d16[s];
             a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];
         }
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
         a.order = (n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
-        if (group == 1) {
+        if (h16 && n->h1f[0]) {
+            // 16 rows per 8-wave workgroup: an obs-sized launch (R = 4096, two inputs) is two workgroups per CU, one round
+            hipLaunchKernelGGL(k_din_x, dim3((R + 15) / 16, S), dim3(512), din_x_smem(), st, a, 16);
+        } else if (group == 1) {
             const int nw = 4;
             size_t smem = ((size_t)2 * 16 * 64 + 48 + (size_t)nw * (E + ATT_H1)) * 4;
             if (h16) hipLaunchKernelGGL((k_din_scores<false, true>), dim3((R + nw - 1) / nw, S), dim3(64 * nw), smem, st, a);
