@@ -54,6 +54,24 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 #endif
 
 
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+struct h8bits { half8_t v; };
+
+// fp16 hi / lo split of two fp32 values: hi = RNE(x) as a packed pair, lo = RNE(x - hi).  The difference comes from ONE
+// v_fma_mix_f32 (f16 source read straight out of the packed pair, exact) instead of a conversion back plus a subtraction.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, half2_t& lo) {
+    unsigned h;
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(x1));
+    unsigned l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(d0), "v"(d1));
+    hi = __builtin_bit_cast(half2_t, h);
+    lo = __builtin_bit_cast(half2_t, l);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
 // One wave per row; 4 rows per block.  Writes allf[row, off_c : off_c + E] = mean_i(softmax(E E^T) E),
@@ -64,7 +82,7 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ cat, int R, int Cn, int E, int H,
                                                   const float* __restrict__ cat_emb,
                                                   const float* __restrict__ seq_emb, float* __restrict__ allf,
-                                                  int ldf, int off_c, float* __restrict__ q, int write_flat) {
+                                                  int ldf, int off_c, float* __restrict__ q, int write_flat, int h16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, li = lane & 31;
@@ -78,6 +96,36 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
     // embedding gather: ids first (one coalesced load, broadcast by shuffle), then 8 rows' loads in flight at a time
     // (a load-store-load chain per row would expose the full memory latency Cn times)
     const int myid = (lane < Cn) ? min(max(crowp[lane], 0), H - 1) : 0;
+    // the query's own gather (seq_emb rows of the last 10 ids, utils.py:114-115) is requested FIRST and consumed last: its
+    // latency hides behind everything else
+    const int nq = min(10, Cn);
+    float qv0[10], qv1[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        const float* src = seq_emb + (size_t)__shfl(myid, max(Cn - 10 + u, 0)) * E;
+        qv0[u] = src[lane];
+        qv1[u] = E > 64 ? src[lane + 64] : 0.f;
+    }
+    if (Cn <= 24 && E == 128) {
+        // all category rows in flight at once (48 registers): one memory round trip instead of three
+        float v0[24], v1[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const float* src = cat_emb + (size_t)__shfl(myid, min(u, Cn - 1)) * E;
+            v0[u] = src[lane];
+            v1[u] = src[lane + 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u)
+            if (u < Cn) {
+                sE[u * LE + lane] = v0[u];
+                sE[u * LE + lane + 64] = v1[u];
+                if (write_flat) {
+                    frow[E + u * E + lane] = v0[u];
+                    frow[E + u * E + lane + 64] = v1[u];
+                }
+            }
+    } else
     for (int c0 = 0; c0 < Cn; c0 += 8) {
         float v0[8], v1[8];
 #pragma unroll
@@ -107,6 +155,27 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool row_ok = li < Cn;
     const float* erow = sE + (row_ok ? li : 0) * LE + half * 4;
+    if (h16 && E % 16 == 0) {
+        // fp16x2 form of the Gram matrix E E^T (scorer_mode FP16X2; embedding tables range-checked at load): the same
+        // fragment is the A and the B operand, 3 x E/16 f16 MFMAs instead of E/2 fp32 ones
+        const float* er16 = sE + (row_ok ? li : 0) * LE + half * 8;
+        for (int kb = 0; kb < E / 16; ++kb) {
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+            if (row_ok) { f0 = *reinterpret_cast<const float4*>(er16 + kb * 16); f1 = *reinterpret_cast<const float4*>(er16 + kb * 16 + 4); }
+            const float x[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            half8_t fh, fl;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                half2_t h2, l2;
+                split_h16_pair(x[e], x[e + 1], h2, l2);
+                fh[e] = h2[0]; fh[e + 1] = h2[1];
+                fl[e] = l2[0]; fl[e + 1] = l2[1];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, fh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fl, acc, 0, 0, 0);
+        }
+    } else
     for (int kb = 0; kb < E / 8; ++kb) {
         float4 f = row_ok ? *reinterpret_cast<const float4*>(erow + kb * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, f.x, acc, 0, 0, 0);
@@ -148,9 +217,16 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
         for (int j = 0; j < Cn; ++j) s = fmaf(sW[j], sE[j * LE + k], s);
         frow[k] = s * invc;
     }
-    // query = reduce_mean(seq_emb[cat[-10:]]) (utils.py:114-115)
-    const int nq = min(10, Cn);
+    // query = reduce_mean(seq_emb[cat[-10:]]) (utils.py:114-115): rows requested at the top, summed in id order
     const float invq = 1.f / (float)nq;
+    if (E <= 128) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            if (u >= 10 - nq) { s0 += qv0[u]; s1 += qv1[u]; }
+        if (lane < E) q[(size_t)row * E + lane] = s0 * invq;
+        if (lane + 64 < E) q[(size_t)row * E + lane + 64] = s1 * invq;
+    } else
     for (int k = lane; k < E; k += 64) {
         float s = 0.f;
         for (int c = Cn - nq; c < Cn; ++c) s += seq_emb[(size_t)__shfl(myid, c) * E + k];
@@ -424,23 +500,6 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 // (fp32 keeps 2^-24); products are exact in the fp32 accumulator.  h and r*h live in (-1,1), so the un-scaled lo parts
 // only reach fp16 subnormals (absolute error <= 2^-25) - no scaling needed; the weights are range-checked at load.
 // The matrix pipe runs this 16/3 = 5.3x faster than the fp32 form at the SAME weight bytes (2 planes x 2 B).
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-struct h8bits { half8_t v; };
-
-// fp16 hi / lo split of two fp32 values: hi = RNE(x) as a packed pair, lo = RNE(x - hi).  The difference comes from ONE
-// v_fma_mix_f32 (f16 source read straight out of the packed pair, exact) instead of a conversion back plus a subtraction.
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, half2_t& lo) {
-    unsigned h;
-    float d0, d1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(x1));
-    unsigned l;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(d0), "v"(d1));
-    hi = __builtin_bit_cast(half2_t, h);
-    lo = __builtin_bit_cast(half2_t, l);
-}
 __device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return __builtin_bit_cast(half8_t, v);
@@ -849,7 +908,7 @@ struct DinArgs {
     const float* proj[4]; int64_t pld;   // [slot*L, pld], AK at column 0
     const float* q;              // [R, E]
     const float* w1ac[4];        // [E, 64]   (W1a + W1c)
-    const float* qa; int64_t qa_stride;   // [n_seq][qa_stride] rows of 64: q @ (W1a + W1c), precomputed by a GEMM (or NULL)
+    const float* qa; int64_t qa_stride; int qa_ld;   // q @ (W1a + W1c) of input s, row r, unit j at qa[s*qa_stride + r*qa_ld + j] (one GEMM over all inputs)
     const float* w1d[4];         // packed [2][E/8][64][4]
     const float* w1d16[4];       // H16: fp16 hi/lo planes [2][E/16][2][64][8 halfs] (pack_frag_h16)
     const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
@@ -924,7 +983,7 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (a.qa) {   // qa = q @ (W1a + W1c) comes from a GEMM over all rows (a 128-step serial loop per wave otherwise)
-            s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * ATT_H1 + lane];
+            s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * a.qa_ld + lane];
         } else {      // lane = hidden unit
             float s = 0.f;
 #pragma unroll 8
@@ -1180,7 +1239,7 @@ struct rl4rs_dien {
     float* wproj[4];       // [E, PLD]  = [W1b - W1c | augru gate x-side | augru cand x-side]
     float* bproj[4];       // [PLD]
     float* w1ac[4];        // [E, 64]
-    float* w1ac_pk[4];     // the same, packed for k_gemm_pk
+    float* w1ac_all;       // [E, S*64]: the q-side matrices of all sequence inputs side by side, packed (one GEMM per forward)
     float* qa;             // [S, max_rows, 64]
     float* w1d[4];         // packed [2][E/8][64][4]
     float* w1d16[4];       // fp16 hi/lo planes of the same fragments (fp16x2 mode)
@@ -1193,6 +1252,7 @@ struct rl4rs_dien {
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
+    bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
     int* range_flag;       // device int: a k_augru_h16 state left the fp16 range (sticky until read)
@@ -1366,6 +1426,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->din16 = false;
     n->din_x = !(getenv("RL4RS_DIN") && strcmp(getenv("RL4RS_DIN"), "v1") == 0);
     n->gemm16 = false;
+    n->cat16 = false;
     n->gru16 = false;
     n->gru16_attr = false;
     if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
@@ -1416,6 +1477,9 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             chk(w->augru_cand_w[s], (size_t)c->emb_size * 2 * c->emb_size);
         }
         n->gemm16 = wfin && !(getenv("RL4RS_GEMM16") && atoi(getenv("RL4RS_GEMM16")) == 0);
+        bool cfin = true;
+        for (size_t i = 0; i < (size_t)c->category_hash_size * c->emb_size; ++i) cfin = cfin && fabsf(w->cat_emb[i]) < 6.0e4f;
+        n->cat16 = cfin && !(getenv("RL4RS_CAT16") && atoi(getenv("RL4RS_CAT16")) == 0);
     }
     {
         float* f = nullptr;
@@ -1463,6 +1527,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     UP(obs_b, w->obs_b, OBS_DIM);
     UP(out_w, w->out_w, (size_t)OBS_DIM * K);
     UP(out_b, w->out_b, K);
+    std::vector<float> wac_all((size_t)E * S * ATT_H1);
     for (int s = 0; s < S; ++s) {
         RL4RS_REQUIRE(w->gru_gate_w[s] && w->gru_cand_w[s] && w->att_w1[s] && w->augru_gate_w[s] && w->augru_cand_w[s],
                       "dien_create: weights of sequence input %d missing", s);
@@ -1507,8 +1572,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
         keep.push_back(pack_w(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
-        keep.push_back(pack_w(wac.data(), ATT_H1, E, ATT_H1));
-        UP(w1ac_pk[s], keep.back().data(), keep.back().size());
+        for (int k = 0; k < E; ++k)
+            for (int j = 0; j < ATT_H1; ++j) wac_all[(size_t)k * S * ATT_H1 + s * ATT_H1 + j] = wac[(size_t)k * ATT_H1 + j];
         keep.push_back(std::move(wac)); UP(w1ac[s], keep.back().data(), keep.back().size());
         keep.push_back(pack_frag(w1, ATT_H1, 3 * E, E, ATT_H1));
         UP(w1d[s], keep.back().data(), keep.back().size());
@@ -1537,6 +1602,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         if (n->fp16x2 && n->din16 && n->din_x && E == 128 && L <= 64) AL(h1f[s], (size_t)c->max_slots * ((L + 31) / 32) * 32 * E);
         AL(proj[s], (size_t)c->max_slots * L * PLD);
     }
+    keep.push_back(pack_w(wac_all.data(), S * ATT_H1, E, S * ATT_H1));
+    UP(w1ac_all, keep.back().data(), keep.back().size());
     // table form: the Flatten(category_emb) columns are never materialised, so the rows are only Kh wide (contiguous
     // 3 KB rows for the head GEMM instead of 3 KB out of every 13.8 KB)
     n->Fld = n->ptab ? Kh : F;
@@ -1650,7 +1717,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         Prof p(n, KID_CAT, st);
         size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
         hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
-                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1);
+                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0);
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -1664,12 +1731,9 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         memset(&a, 0, sizeof(a));
         a.R = R; a.L = L; a.E = E; a.group = group; a.n_groups = ngroups;
         a.slots = slots; a.slots_stride = ngroups; a.pld = n->PLD; a.q = n->q;
-        a.qa = n->qa; a.qa_stride = (int64_t)n->c.max_rows * ATT_H1;
+        a.qa = n->qa; a.qa_stride = ATT_H1; a.qa_ld = S * ATT_H1;       // one GEMM for the q-side term of every input: [R, S*64]
         const bool h16 = n->fp16x2 && n->din16;
-        for (int s = 0; s < S; ++s) {
-            int rcq = scorer_gemm(n, n->q, E, n->w1ac_pk[s], nullptr, n->qa + (size_t)s * a.qa_stride, ATT_H1, R, ATT_H1, E, 0, st);
-            if (rcq) return rcq;
-        }
+        if ((rc = scorer_gemm(n, n->q, E, n->w1ac_all, nullptr, n->qa, S * ATT_H1, R, S * ATT_H1, E, 0, st))) return rc;
         for (int s = 0; s < S; ++s) {
             a.h1[s] = n->h1[s]; a.h1f[s] = n->h1f[s]; a.proj[s] = n->proj[s]; a.w1ac[s] = n->w1ac[s]; a.w1d[s] = n->w1d[s]; a.w1d16[s] = n->w1d16[s];
             a.w2[s] = n->att_w2[s]; a.b2[s] = n->att_b2[s]; a.w3[s] = n->att_w3[s]; a.b3[s] = n->att_b3[s];

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
         const int slot = a.slots[(size_t)sq * a.slots_stride + gs];
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
-        s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * ATT_H1 + lane];
+        s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * a.qa_ld + lane];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const float* qp = s_q + half * 8;
