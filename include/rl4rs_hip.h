@@ -361,7 +361,8 @@ int rl4rs_simnet_head_prob(rl4rs_simnet* net, int32_t R, const float* obs_dev, f
  *   slots_dev  int32 [seq_num, batch_size]: cache slot of every env row per sequence input (caller-owned; the caller
  *              encodes the history sequences with rl4rs_dien_encode after every rl4rs_env_load_batch and keeps row 0
  *              current; SeqSlate's second input is re-encoded here on the first act of a page, seqslate.py:107-108)
- *   obs_dev    float32 [B, 256]  'simulator_obs' of the new state (slate.py:265-267)
+ *   obs_dev    float32 [B, D]    'simulator_obs' of the new state (slate.py:265-267); D = 256 for the DIEN scorer,
+ *              rl4rs_simnet_obs_dim() for an attached simnet (widedeep: 256 + hidden_units + Cn * emb_size)
  *   reward_dev float64 [B] (optional)  0 unless a reward is due (slate.py:283, seqslate.py:138)
  *   done_dev   uint8 [B] (optional)    1 once cur_steps (before the act) >= max_steps - 1 (base.py:165-168)
  *   mask_bits_dev uint32 [B, ceil(A/32)] (optional)  obs-side action mask of the NEXT slot (slate.py:92-97), packed as

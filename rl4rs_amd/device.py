@@ -252,6 +252,7 @@ class DeviceStepper(object):
         check(attach(env.h, net.h, _ptr(slots), int(slots.shape[0]), C.byref(h)))
         self.h = h
         self.B, self.A, self.E, self.W, self.device = env.B, env.A, env.E, env.W, env.device
+        self.obs_dim = int(getattr(net, 'obs_dim', 256))         # 256 for DIEN / dnn / lstm, 256 + U + Cn*E for widedeep
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -265,8 +266,8 @@ class DeviceStepper(object):
             pass
 
     def step(self, actions, conti=False, want_reward=True, want_mask_bits=False):
-        """-> (obs f32 [B, 256], reward f64 [B] or None, mask_bits i32 [B, W] or None, chosen i32 [B])."""
-        obs = torch.empty((self.B, 256), dtype=torch.float32, device=self.device)
+        """-> (obs f32 [B, obs_dim], reward f64 [B] or None, mask_bits i32 [B, W] or None, chosen i32 [B])."""
+        obs = torch.empty((self.B, self.obs_dim), dtype=torch.float32, device=self.device)
         reward = torch.empty(self.B, dtype=torch.float64, device=self.device) if want_reward else None
         bits = torch.empty((self.B, self.W), dtype=torch.int32, device=self.device) if want_mask_bits else None
         if conti:

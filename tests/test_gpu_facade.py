@@ -317,7 +317,7 @@ def test_model_file_may_be_a_tf_checkpoint_prefix(tmp_path, algo):
         _make(dict(cfg, model_file=os.path.join(str(tmp_path), 'no_such_checkpoint')), False)
 
 
-@pytest.mark.parametrize('kind', ['slate', 'slate_mask', 'seq', 'conti', 'slate_lstm'])
+@pytest.mark.parametrize('kind', ['slate', 'slate_mask', 'seq', 'conti', 'slate_lstm', 'slate_widedeep'])
 def test_fused_step_is_bit_identical(tmp_path, kind):
     """rl4rs_env_step_discrete / rl4rs_env_step_conti (one library call per transition, zero-copy mode) against the composed
     path (act, obs forward, complete rows, reward forward, reward: one call each; config['no_fused_step']): observations,
@@ -345,6 +345,8 @@ def test_fused_step_is_bit_identical(tmp_path, kind):
         cfg['support_conti_env'] = True
     if kind == 'slate_lstm':
         cfg['algo'] = 'lstm'
+    if kind == 'slate_widedeep':                  # the family whose observation is wider than 256 (256 + U + Cn * E)
+        cfg['algo'] = 'widedeep'
 
     def run(fused):
         c = dict(cfg, no_fused_step=not fused)
