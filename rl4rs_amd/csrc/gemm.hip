@@ -284,7 +284,8 @@ __device__ __forceinline__ ghalf8_t gbuf_load_h8(__amdgpu_buffer_rsrc_t rsrc, in
     return __builtin_bit_cast(ghalf8_t, v);
 }
 
-template <int WM>
+// VEC: rows of A are 16-byte aligned (decided by the host: lda % 4 == 0 and A aligned) -> two 16-byte loads per chunk
+template <int WM, bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, int64_t lda,
                                                   const char* __restrict__ Wp, int KB,
                                                   const float* __restrict__ bias, float* __restrict__ C,
@@ -300,7 +301,6 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     const int NT = (N + 31) / 32;
     const bool tile_ok = nt < NT;
     const int col = nt * 32 + li;
-    const bool vec_ok = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const char* wtile = Wp + (size_t)(tile_ok ? nt : 0) * KB * 2048;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wtile), 0, KB * 2048, 0x00020000);
     const int vl16 = lane * 16;
@@ -311,35 +311,48 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[w][i] = 0.f;
 
-    float4 stage[2][WM][2];               // tiles kt+1, kt+2 in flight: 8 consecutive k of one row per chunk
+    // A tiles in flight: 2 register stages of 8 consecutive k of one row per chunk.  WEIGHT fragments: a ring of NB k-tiles
+    // (measured: with one tile of lookahead a 32-row launch waited ~1 us of L2 latency per k-tile - 17 us for the head's 12
+    // k-tiles of 2.4 us of MFMA work; requesting the A tiles deeper changed nothing).  32-row tiles (small launches, one or
+    // two workgroups per CU) keep 4 k-tiles of fragments in flight, 64-row tiles 2.
+    constexpr int NS = 2, NB = WM == 1 ? 4 : 2;
+    float4 stage[NS][WM][2];
+    // A through a buffer descriptor over this workgroup's rows: rows >= M and everything past the last element read as
+    // zero, so the loads are UNCONDITIONAL (no divergent branches: the compiler keeps every requested tile in flight and
+    // waits with exact counts; guarded loads had forced a full drain of the weight ring at every k-tile); columns >= K of
+    // a row (they exist when lda > K) are cleared with selects
+    const int rows_here = min(BM, M - m0);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A + (size_t)m0 * lda), 0, (int)((((int64_t)rows_here - 1) * lda + K) * 4), 0x00020000);
     auto gload = [&](float4 (&st)[WM][2], int kt) {
 #pragma unroll
         for (int p = 0; p < WM; ++p) {
             const int c = tid + p * 256;
-            const int r = c >> 3, gr = m0 + r, gk = kt * BK + (c & 7) * 8;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (gr < M && gk < K) {
-                const float* src = A + (size_t)gr * lda + gk;
-                if (vec_ok && gk + 7 < K) {
-                    v0 = *reinterpret_cast<const float4*>(src);
-                    v1 = *reinterpret_cast<const float4*>(src + 4);
-                } else {
-                    float x[8];
+            const int r = c >> 3, gk = kt * BK + (c & 7) * 8;
+            const int voff = (int)(((int64_t)r * lda + gk) * 4);
+            float x[8];
+            if (VEC) {
+                const float4 v0 = gbuf_load4(rs_a, voff, 0), v1 = gbuf_load4(rs_a, voff + 16, 0);
+                x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = gk + e < K ? src[e] : 0.f;
-                    v0 = make_float4(x[0], x[1], x[2], x[3]);
-                    v1 = make_float4(x[4], x[5], x[6], x[7]);
-                }
+                for (int e = 0; e < 8; ++e) x[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, voff + e * 4, 0, 0));
             }
-            st[p][0] = v0; st[p][1] = v1;
+            st[p][0] = make_float4(x[0], x[1], x[2], x[3]);        // raw: the K-tail selects wait for the data, so they run in lstore
+            st[p][1] = make_float4(x[4], x[5], x[6], x[7]);
         }
     };
-    auto lstore = [&](const float4 (&st)[WM][2], int buf) {
+    auto lstore = [&](const float4 (&st)[WM][2], int buf, int kt) {
 #pragma unroll
         for (int p = 0; p < WM; ++p) {
             const int c = tid + p * 256;
             const int off = (c & 7) * SLAB + (c >> 3) * 16;
-            const float x[8] = {st[p][0].x, st[p][0].y, st[p][0].z, st[p][0].w, st[p][1].x, st[p][1].y, st[p][1].z, st[p][1].w};
+            const int gk = kt * BK + (c & 7) * 8;
+            float x[8] = {st[p][0].x, st[p][0].y, st[p][0].z, st[p][0].w, st[p][1].x, st[p][1].y, st[p][1].z, st[p][1].w};
+            if (gk + 7 >= K) {                   // only the last k-tile of a K that is not a multiple of 8 has such a chunk
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (gk + e < K) ? x[e] : 0.f;
+            }
             ghalf8_t hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
             *reinterpret_cast<ghalf8_t*>(&As[buf][1][off]) = lo;
         }
     };
-    ghalf8_t bh[2][KBT], bl[2][KBT];
+    ghalf8_t bh[NB][KBT], bl[NB][KBT];
     auto load_b = [&](ghalf8_t (&h)[KBT], ghalf8_t (&l)[KBT], int kt) {
 #pragma unroll
         for (int j = 0; j < KBT; ++j) {
@@ -379,25 +392,27 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     };
 
     const int nkt = (K + BK - 1) / BK;
-    gload(stage[0], 0);
-    load_b(bh[0], bl[0], 0);
-    gload(stage[1], 1);
-    lstore(stage[0], 0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) gload(stage[i], i);
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) load_b(bh[i], bl[i], i);
+    lstore(stage[0], 0, 0);
     __syncthreads();
-    // at the top of step kt: LDS[kt&1] = tile kt, stage[(kt+1)&1] = tile kt+1 (in flight), bh/bl[kt&1] = fragments of tile kt
-#define RL4RS_G16_STEP(KT, P)                                                              \
-    if ((KT) < nkt) {                                                                      \
-        load_b(bh[(P) ^ 1], bl[(P) ^ 1], (KT) + 1);                                        \
-        gload(stage[P], (KT) + 2);                                                         \
-        compute(bh[P], bl[P], P);                                                          \
-        lstore(stage[(P) ^ 1], (P) ^ 1);                                                   \
-        __syncthreads();                                                                   \
+    // at the top of step kt: LDS[kt&1] = tile kt, stage[(kt+1)&1] = tile kt+1 (in flight), stage[kt&1] free,
+    // bh/bl[kt%NB .. (kt+NB-2)%NB] = fragments of tiles kt .. kt+NB-2 (in flight)
+    for (int kt0 = 0; kt0 < nkt; kt0 += NB) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int kt = kt0 + i;
+            if (kt < nkt) {
+                gload(stage[i & 1], kt + NS);           // A first: its wait (in-order counter) must not cover the newest B tile
+                load_b(bh[(i + NB - 1) % NB], bl[(i + NB - 1) % NB], kt + NB - 1);
+                compute(bh[i], bl[i], i & 1);
+                lstore(stage[(i & 1) ^ 1], (i & 1) ^ 1, kt + 1);
+                __syncthreads();
+            }
+        }
     }
-    for (int kt = 0; kt < nkt; kt += 2) {
-        RL4RS_G16_STEP(kt, 0)
-        RL4RS_G16_STEP(kt + 1, 1)
-    }
-#undef RL4RS_G16_STEP
     if (tile_ok && col < N) {
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -439,11 +454,13 @@ int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float*
     const int KB = (K + 15) / 16;
     const int ny = ((N + 31) / 32 + 3) / 4;
     const char* wp = reinterpret_cast<const char*>(wp16);
-    if ((int64_t)((M + 63) / 64) * ny < 512) {     // small problems: 32-row tiles so that the grid covers the CUs
-        hipLaunchKernelGGL(k_gemm_h16<1>, dim3((M + 31) / 32, ny), dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act);
-    } else {
-        hipLaunchKernelGGL(k_gemm_h16<2>, dim3((M + 63) / 64, ny), dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act);
-    }
+    const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    const bool small = (int64_t)((M + 63) / 64) * ny < 512;       // small problems: 32-row tiles so that the grid covers the CUs
+    const dim3 grid(small ? (M + 31) / 32 : (M + 63) / 64, ny);
+#define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act)
+    if (small) { if (vec) RL4RS_G16_LAUNCH(1, true); else RL4RS_G16_LAUNCH(1, false); }
+    else { if (vec) RL4RS_G16_LAUNCH(2, true); else RL4RS_G16_LAUNCH(2, false); }
+#undef RL4RS_G16_LAUNCH
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
