@@ -388,7 +388,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if (not is_dien or net.scorer_mode == 'fp32') else "f32 (AUGRU operands as fp16 hi+lo pairs, fp32 accumulate)",
+            "dtype": "f32" if (not is_dien or net.scorer_mode == 'fp32') else "f32 (scorer matrix operands as fp16 hi+lo pairs, three f16 MFMAs per product, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU, 284-item catalogue, 9-slot slate, %d-step horizon, "
                                    "%s simulator scorer, offline_action replay"
