@@ -52,13 +52,14 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
                     float* c, int64_t ldc, int M, int N, int K, int act, hipStream_t st);
 
-// GEMM against a weight matrix pre-packed by pack_gemm_weight (gemm.hip)
+// GEMM against a weight matrix pre-packed by pack_gemm_weight (gemm.hip); C = act(A W + bias + addend) with an optional
+// row-major addend [M, ldadd]
 int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
-                       int M, int N, int K, int act, hipStream_t st);
+                       int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0);
 std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N);
 // fp16x2 form (scorer_mode FP16X2): weights pre-split into fp16 hi / lo fragment planes, activations split while staged
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
-                    int M, int N, int K, int act, hipStream_t st);
+                    int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0);
 std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N);
 
 // fp32 -> fp16 bits, round to nearest even (subnormals kept)

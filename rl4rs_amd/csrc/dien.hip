@@ -82,7 +82,9 @@ __device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, 
 __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ cat, int R, int Cn, int E, int H,
                                                   const float* __restrict__ cat_emb,
                                                   const float* __restrict__ seq_emb, float* __restrict__ allf,
-                                                  int ldf, int off_c, float* __restrict__ q, int write_flat, int h16) {
+                                                  int ldf, int off_c, float* __restrict__ q, int write_flat, int h16,
+                                                  const float* __restrict__ ptab, const float* __restrict__ obs_b,
+                                                  float* __restrict__ tsum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, li = lane & 31;
@@ -150,6 +152,20 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // table half of the head (tsum != NULL): tsum[row] = obs_b + sum_j P_j[cat[row, j]], P_j = cat_emb @ W_obs[flatten slot j]
+    // ([H, 256] per slot, built at load), i.e. the Flatten(category_emb) part of the head as Cn row gathers of 1 KB.  It
+    // depends on the ids only, so it rides in this kernel's latency shadow: 12 rows requested here and summed behind the
+    // Gram matrix, the rest requested there and summed at the end; lane owns 4 consecutive outputs.  The head GEMM adds
+    // tsum in its epilogue.
+    constexpr int TCH = 12;
+    float4 tacc = make_float4(0.f, 0.f, 0.f, 0.f), tv[TCH];
+    const bool do_t = tsum != nullptr && Cn <= 2 * TCH;
+    if (do_t) {
+        tacc = reinterpret_cast<const float4*>(obs_b)[lane];
+#pragma unroll
+        for (int u = 0; u < TCH; ++u)
+            tv[u] = reinterpret_cast<const float4*>(ptab + ((size_t)min(u, Cn - 1) * H + __shfl(myid, min(u, Cn - 1))) * OBS_DIM)[lane];
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -182,6 +198,14 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, f.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, f.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, f.w, acc, 0, 0, 0);
+    }
+    if (do_t) {
+#pragma unroll
+        for (int u = 0; u < TCH; ++u)
+            if (u < Cn) { tacc.x += tv[u].x; tacc.y += tv[u].y; tacc.z += tv[u].z; tacc.w += tv[u].w; }
+#pragma unroll
+        for (int u = 0; u < TCH; ++u)
+            tv[u] = reinterpret_cast<const float4*>(ptab + ((size_t)min(TCH + u, Cn - 1) * H + __shfl(myid, min(TCH + u, Cn - 1))) * OBS_DIM)[lane];
     }
     // lane = query i (column li); register r of half h = key j = crow(r, h).  keras Attention: no scale, no mask.
     float m = -3.4e38f;
@@ -216,6 +240,12 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
         float s = 0.f;
         for (int j = 0; j < Cn; ++j) s = fmaf(sW[j], sE[j * LE + k], s);
         frow[k] = s * invc;
+    }
+    if (do_t) {
+#pragma unroll
+        for (int u = 0; u < TCH; ++u)
+            if (TCH + u < Cn) { tacc.x += tv[u].x; tacc.y += tv[u].y; tacc.z += tv[u].z; tacc.w += tv[u].w; }
+        reinterpret_cast<float4*>(tsum + (size_t)row * OBS_DIM)[lane] = tacc;
     }
     // query = reduce_mean(seq_emb[cat[-10:]]) (utils.py:114-115): rows requested at the top, summed in id order
     const float invq = 1.f / (float)nq;
@@ -1252,6 +1282,7 @@ struct rl4rs_dien {
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
+    float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
     bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
@@ -1613,6 +1644,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     AL(qa, (size_t)S * c->max_rows * ATT_H1);
     AL(scores, (size_t)S * c->max_rows * L);
     AL(obs_tmp, (size_t)c->max_rows * OBS_DIM);
+    n->tsum = nullptr;
+    if (n->ptab && Cn <= 24 && !(getenv("RL4RS_HEAD_FUSED") && atoi(getenv("RL4RS_HEAD_FUSED")) == 0)) AL(tsum, (size_t)c->max_rows * OBS_DIM);
 #undef UP
 #undef AL
     // LDS opt-in above the 64 KB default where needed
@@ -1717,7 +1750,8 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         Prof p(n, KID_CAT, st);
         size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
         hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
-                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0);
+                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
+                           n->ptab, n->obs_b, n->tsum);
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -1815,7 +1849,12 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     float* obs_out = obs ? obs : n->obs_tmp;
     {
         Prof p(n, KID_HEAD, st);
-        if (n->ptab) {
+        if (n->ptab && n->tsum) {     // obs = ELU(allf W + [b + table rows]): the addend was built inside k_cat_attn
+            const int Kh = S * NH2 + U + E;
+            if (n->gemm16) rc = launch_gemm_h16(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 1, st, n->tsum, OBS_DIM);
+            else rc = launch_gemm_packed(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 1, st, n->tsum, OBS_DIM);
+            if (rc) return rc;
+        } else if (n->ptab) {
             const int Kh = S * NH2 + U + E;
             if ((rc = scorer_gemm(n, n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 0, st))) return rc;
             hipLaunchKernelGGL(k_head_finish, dim3((R + 3) / 4), dim3(256), 0, st, obs_out, R, cat, Cn, n->H, n->ptab, n->obs_b);

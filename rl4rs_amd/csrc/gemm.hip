@@ -144,7 +144,8 @@ template <int WM>
 __global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, int64_t lda,
                                                  const float4* __restrict__ Wp, int KB,
                                                  const float* __restrict__ bias, float* __restrict__ C,
-                                                 int64_t ldc, int M, int N, int K, int act) {
+                                                 int64_t ldc, int M, int N, int K, int act,
+                                                 const float* __restrict__ addend, int64_t ldadd) {
     constexpr int BM = 64 * WM;
     constexpr int KPT = GBK / 8;          // k-blocks per k-tile
     __shared__ __attribute__((aligned(16))) float As[2][BM][GLD];
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void k_gemm_pk(const float* __restrict__ A, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = m0 + wm * 32 * WM + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv, act);
+                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv + (addend ? addend[(size_t)row * ldadd + col] : 0.f), act);
             }
     }
 }
@@ -289,7 +290,8 @@ template <int WM, bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, int64_t lda,
                                                   const char* __restrict__ Wp, int KB,
                                                   const float* __restrict__ bias, float* __restrict__ C,
-                                                  int64_t ldc, int M, int N, int K, int act) {
+                                                  int64_t ldc, int M, int N, int K, int act,
+                                                  const float* __restrict__ addend, int64_t ldadd) {
     constexpr int BM = 32 * WM, BK = 64, KBT = BK / 16;
     constexpr int SLAB = BM * 16 + 16, PLANE = 2 * KBT * SLAB;
     __shared__ __attribute__((aligned(16))) char As[2][2][PLANE];          // [buffer][hi / lo]
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv, act);
+                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv + (addend ? addend[(size_t)row * ldadd + col] : 0.f), act);
             }
     }
 }
@@ -449,7 +451,7 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 }
 
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
-                    int M, int N, int K, int act, hipStream_t st) {
+                    int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
     const int KB = (K + 15) / 16;
     const int ny = ((N + 31) / 32 + 3) / 4;
@@ -457,7 +459,7 @@ int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float*
     const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const bool small = (int64_t)((M + 63) / 64) * ny < 512;       // small problems: 32-row tiles so that the grid covers the CUs
     const dim3 grid(small ? (M + 31) / 32 : (M + 63) / 64, ny);
-#define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act)
+#define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act, addend, ldadd)
     if (small) { if (vec) RL4RS_G16_LAUNCH(1, true); else RL4RS_G16_LAUNCH(1, false); }
     else { if (vec) RL4RS_G16_LAUNCH(2, true); else RL4RS_G16_LAUNCH(2, false); }
 #undef RL4RS_G16_LAUNCH
@@ -481,7 +483,7 @@ std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N) {
 }
 
 int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,
-                       int M, int N, int K, int act, hipStream_t st) {
+                       int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
     const int KB = (K + 7) / 8;
     const int ny = ((N + 31) / 32 + 1) / 2;
@@ -490,11 +492,11 @@ int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float
     if (small) {
         dim3 grid((M + 63) / 64, ny);
         hipLaunchKernelGGL(k_gemm_pk<1>, grid, dim3(256), 0, st, a, lda, reinterpret_cast<const float4*>(wp), KB, bias, c,
-                           ldc, M, N, K, act);
+                           ldc, M, N, K, act, addend, ldadd);
     } else {
         dim3 grid((M + 127) / 128, ny);
         hipLaunchKernelGGL(k_gemm_pk<2>, grid, dim3(256), 0, st, a, lda, reinterpret_cast<const float4*>(wp), KB, bias, c,
-                           ldc, M, N, K, act);
+                           ldc, M, N, K, act, addend, ldadd);
     }
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
