@@ -284,8 +284,13 @@ def main():
     rank, local_rank, world = rdist.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    # RL4RS_DIST_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices);
+    # the driver's runs use the default: one rank per GPU over RCCL
+    backend = os.environ.get('RL4RS_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    rdist.init('nccl')
+    rdist.init(backend)
 
     workdir = tempfile.mkdtemp(prefix='rl4rs_bench_')
     cfg, records = make_config(args, workdir, rank)     # log shard / RNG stream of this rank: seed 1000 + rank
