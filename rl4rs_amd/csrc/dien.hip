@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
         const float* src = seq_emb + (size_t)__shfl(myid, max(Cn - 10 + u, 0)) * E;
-        qv0[u] = src[lane];
-        qv1[u] = E > 64 ? src[lane + 64] : 0.f;
+        qv0[u] = lane < E ? src[lane] : 0.f;
+        qv1[u] = lane + 64 < E ? src[lane + 64] : 0.f;
     }
     if (Cn <= 24 && E == 128) {
         // all category rows in flight at once (48 registers): one memory round trip instead of three

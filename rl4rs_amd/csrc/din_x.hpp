@@ -82,10 +82,10 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
         const int row = gs * grp + (idx - g * grp);
         const int slot = a.slots[(size_t)sq * a.slots_stride + gs];
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < E; k += 64) s_q[k] = a.q[(size_t)row * E + k];
-        s_qa[lane] = a.qa[(size_t)sq * a.qa_stride + (size_t)row * a.qa_ld + lane];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the row's q and q-side term are requested here and staged in LDS inside the first tile, behind that tile's own
+        // requests: one memory round trip at the start of a row instead of two
+        const float q_lo = a.q[(size_t)row * E + lane], q_hi = a.q[(size_t)row * E + lane + 64];
+        const float qa_v = a.qa[(size_t)sq * a.qa_stride + (size_t)row * a.qa_ld + lane];
         const float* qp = s_q + half * 8;
 
         for (int n = 0; n < ntile; ++n) {
@@ -128,6 +128,14 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
                 }
 #pragma unroll
             for (int kb = 0; kb < RL4RS_DINX_RING; ++kb) ldh(kb, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n == 0) {
+                s_q[lane] = q_lo;
+                s_q[lane + 64] = q_hi;
+                s_qa[lane] = qa_v;
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
