@@ -61,6 +61,9 @@ std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N);
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
                     int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0);
 std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N);
+// two chained layers in one launch (N1 <= 128, N1 % 16 == 0, N2 <= 128): c2 = act2(act1(a W1 + b1) W2 + b2)
+int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
+                          const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
 
 // fp32 -> fp16 bits, round to nearest even (subnormals kept)
 inline uint16_t f32_to_f16(float f) {

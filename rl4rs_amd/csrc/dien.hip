@@ -1182,9 +1182,6 @@ __global__ __launch_bounds__(256) void k_din_scores(DinArgs a) {
 }
 
 }  // namespace rl4rs
-#ifndef RL4RS_DINX_SGB
-#define RL4RS_DINX_SGB 1
-#endif
 #ifndef RL4RS_DINX_RING
 #define RL4RS_DINX_RING 2       // cache rows requested this many k-blocks ahead
 #endif
@@ -1282,6 +1279,7 @@ struct rl4rs_dien {
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
+    bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
     bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
@@ -1458,6 +1456,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->din_x = !(getenv("RL4RS_DIN") && strcmp(getenv("RL4RS_DIN"), "v1") == 0);
     n->gemm16 = false;
     n->cat16 = false;
+    n->dense_chain = !(getenv("RL4RS_DENSE_FUSED") && atoi(getenv("RL4RS_DENSE_FUSED")) == 0);
     n->gru16 = false;
     n->gru16_attr = false;
     if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
@@ -1756,8 +1755,13 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     }
     {
         Prof p(n, KID_DENSE, st);
-        if ((rc = scorer_gemm(n, dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
-        if ((rc = scorer_gemm(n, n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
+        if (n->gemm16 && n->dense_chain && U <= 128 && U % 16 == 0) {      // both layers in one launch, the hidden tile stays in LDS
+            if ((rc = launch_gemm_h16_chain(dense, n->Dn, n->dense_w1, n->dense_b1, U, n->Dn, 1, n->dense_w2, n->dense_b2,
+                                            n->allf + off_d, F, U, 1, R, st))) return rc;
+        } else {
+            if ((rc = scorer_gemm(n, dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
+            if ((rc = scorer_gemm(n, n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
+        }
     }
     {
         Prof p(n, KID_DIN, st);

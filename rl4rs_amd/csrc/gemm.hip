@@ -285,13 +285,21 @@ __device__ __forceinline__ ghalf8_t gbuf_load_h8(__amdgpu_buffer_rsrc_t rsrc, in
     return __builtin_bit_cast(ghalf8_t, v);
 }
 
+// Optional second layer chained onto the first (the dense tower: Dense+ELU twice, utils.py:48-54): when the first layer's N
+// fits one workgroup (N <= 128, a multiple of 16) its activated output tile never leaves the CU - it is split into the LDS
+// planes the main loop has finished with and multiplied by the second weight matrix (K2 = N, N2 <= 128).  Same values, same
+// k-blocks and the same MFMA sequence as two launches with the intermediate in HBM: bit-identical results, one launch less.
+struct G16Chain {
+    const char* wp2; int kb2; const float* bias2; float* c2; int64_t ldc2; int n2; int act2;
+};
+
 // VEC: rows of A are 16-byte aligned (decided by the host: lda % 4 == 0 and A aligned) -> two 16-byte loads per chunk
 template <int WM, bool VEC>
 __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, int64_t lda,
                                                   const char* __restrict__ Wp, int KB,
                                                   const float* __restrict__ bias, float* __restrict__ C,
                                                   int64_t ldc, int M, int N, int K, int act,
-                                                  const float* __restrict__ addend, int64_t ldadd) {
+                                                  const float* __restrict__ addend, int64_t ldadd, G16Chain chain) {
     constexpr int BM = 32 * WM, BK = 64, KBT = BK / 16;
     constexpr int SLAB = BM * 16 + 16, PLANE = 2 * KBT * SLAB;
     __shared__ __attribute__((aligned(16))) char As[2][2][PLANE];          // [buffer][hi / lo]
@@ -415,6 +423,66 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
             }
         }
     }
+    if (chain.wp2) {        // uniform: chained second layer (gridDim.y == 1, N <= 128, N % 16 == 0: checked by the launcher)
+        const int NT2 = (chain.n2 + 31) / 32;
+        const bool tile2_ok = wave < NT2;
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(chain.wp2 + (size_t)(tile2_ok ? wave : 0) * chain.kb2 * 2048), 0, chain.kb2 * 2048, 0x00020000);
+        ghalf8_t b2h[8], b2l[8];                       // K2 <= 128: every fragment of the second layer requested up front
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            b2h[j] = gbuf_load_h8(rs_w2, vl16, j * 2048);
+            b2l[j] = gbuf_load_h8(rs_w2, vl16 + 1024, j * 2048);
+        }
+        char* p_hi = &As[0][0][0];                     // the main loop's last barrier has passed: its tiles are dead
+        char* p_lo = p_hi + 16 * SLAB;                 // 16 slabs (k / 8) per plane = exactly the two tile buffers
+        if (tile_ok) {
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = (col < N && m0 + rl < M) ? apply_act(acc[w][r] + bv, act) : 0.f;
+                    const _Float16 hi = (_Float16)v;
+                    const int off = (col >> 3) * SLAB + rl * 16 + (col & 7) * 2;
+                    *reinterpret_cast<_Float16*>(p_hi + off) = hi;
+                    *reinterpret_cast<_Float16*>(p_lo + off) = (_Float16)(v - (float)hi);
+                }
+        }
+        __syncthreads();
+        f32x16 acc2[WM];
+#pragma unroll
+        for (int w = 0; w < WM; ++w)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[w][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < chain.kb2) {
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    const int off = (j * 2 + half) * SLAB + (w * 32 + li) * 16;
+                    const ghalf8_t ah = *reinterpret_cast<const ghalf8_t*>(p_hi + off);
+                    const ghalf8_t al = *reinterpret_cast<const ghalf8_t*>(p_lo + off);
+                    acc2[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2h[j], acc2[w], 0, 0, 0);
+                    acc2[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b2h[j], acc2[w], 0, 0, 0);
+                    acc2[w] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2l[j], acc2[w], 0, 0, 0);
+                }
+            }
+        }
+        const int col2 = wave * 32 + li;
+        if (tile2_ok && col2 < chain.n2) {
+            const float bv2 = chain.bias2 ? chain.bias2[col2] : 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < M) chain.c2[(size_t)row * chain.ldc2 + col2] = apply_act(acc2[w][r] + bv2, chain.act2);
+                }
+        }
+        return;
+    }
     if (tile_ok && col < N) {
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -450,8 +518,28 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
     return f;
 }
 
+static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
+                                int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, G16Chain chain);
+
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
                     int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd) {
+    G16Chain none = {};
+    return launch_gemm_h16_impl(a, lda, wp16, bias, c, ldc, M, N, K, act, st, addend, ldadd, none);
+}
+
+// c2 = act2(act1(a W1 + b1) W2 + b2) in one launch; N1 <= 128 and a multiple of 16, N2 <= 128 (else RL4RS_EINVAL)
+int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
+                          const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st) {
+    if (N1 > 128 || (N1 & 15) || N2 > 128 || N1 <= 0 || N2 <= 0) {
+        set_error("gemm_h16_chain: unsupported widths %d -> %d", N1, N2);
+        return RL4RS_EINVAL;
+    }
+    G16Chain ch = {reinterpret_cast<const char*>(wp2), (N1 + 15) / 16, bias2, c2, ldc2, N2, act2};
+    return launch_gemm_h16_impl(a, lda, wp1, bias1, nullptr, 0, M, N1, K1, act1, st, nullptr, 0, ch);
+}
+
+static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
+                                int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, G16Chain chain) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
     const int KB = (K + 15) / 16;
     const int ny = ((N + 31) / 32 + 3) / 4;
@@ -459,7 +547,7 @@ int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float*
     const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
     const bool small = (int64_t)((M + 63) / 64) * ny < 512;       // small problems: 32-row tiles so that the grid covers the CUs
     const dim3 grid(small ? (M + 31) / 32 : (M + 63) / 64, ny);
-#define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act, addend, ldadd)
+#define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act, addend, ldadd, chain)
     if (small) { if (vec) RL4RS_G16_LAUNCH(1, true); else RL4RS_G16_LAUNCH(1, false); }
     else { if (vec) RL4RS_G16_LAUNCH(2, true); else RL4RS_G16_LAUNCH(2, false); }
 #undef RL4RS_G16_LAUNCH

@@ -146,6 +146,43 @@ def test_dien_is_batch_position_invariant():
     net.close()
 
 
+@pytest.mark.parametrize('hidden', [128, 96])
+def test_chained_dense_tower_is_bit_identical(monkeypatch, hidden):
+    """fp16x2 mode runs both dense-tower layers in ONE launch (the hidden tile stays in LDS, k_gemm_h16 chain) - same values,
+    same k-blocks, same MFMA sequence as two launches with the intermediate in HBM: the whole forward must be bit-identical
+    to a handle created with RL4RS_DENSE_FUSED=0.  The head with its table half folded into k_cat_attn (vs the separate
+    k_head_finish pass, RL4RS_HEAD_FUSED=0) sums in a different order: equal within fp32 rounding only."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    cfg = dict(CFG, hidden_units=hidden)
+    B = 70
+    w = init_dien_weights(cfg, seed=5, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(1)
+    seq, dense, cat = _inputs(B, rs, cfg['category_hash_size'])
+
+    def run(env):
+        for k in ('RL4RS_DENSE_FUSED', 'RL4RS_HEAD_FUSED'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = DeviceDien(cfg, w, max_rows=B, max_slots=B + 1)
+        net.encode(0, torch.from_numpy(np.ascontiguousarray(seq[:, 0])).cuda(), 0)
+        net.encode(1, torch.zeros((1, 64), dtype=torch.int32).cuda(), B)
+        sl = torch.full((2, B), B, dtype=torch.int32).cuda()
+        sl[0] = torch.arange(B, dtype=torch.int32).cuda()
+        obs, p = net.forward(B, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), sl.contiguous(), True, True)
+        obs, p = obs.clone(), p.clone()
+        net.close()
+        return obs, p
+
+    o_ref, p_ref = run({})
+    o_two, p_two = run({'RL4RS_DENSE_FUSED': '0'})
+    assert torch.equal(o_ref, o_two) and torch.equal(p_ref, p_two)
+    o_sep, p_sep = run({'RL4RS_HEAD_FUSED': '0'})
+    assert (o_ref - o_sep).abs().max().item() < 2e-5 and (p_ref - p_sep).abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize('variant', [dict(maxlen=33, category_feature_num=13, hidden_units=96, dense_feature_num=61, seq_num=3, class_num=3),
                                      dict(maxlen=64, category_feature_num=7, hidden_units=32, dense_feature_num=432, seq_num=1, class_num=2),
                                      dict(maxlen=16, category_feature_num=32, hidden_units=128, dense_feature_num=40, seq_num=2, class_num=2)])
