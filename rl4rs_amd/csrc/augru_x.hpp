@@ -54,7 +54,12 @@ constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
 #endif
 // which items of a step keep their weight fragments in registers: a contiguous stretch behind the projection issue window
 // (RL4RS_X_SPREAD = 0) or every (48 / NRES)-th item (1: uniform load on the L1 return path)
+// (RL4RS_X_RESMASK: an explicit 48-bit item mask for experiments, 32-row form only, with RL4RS_X_WINDOW = the item the
+// projection requests are issued in front of)
 template <int NRES> constexpr bool is_res(int i) {
+#ifdef RL4RS_X_RESMASK
+    if (NRES == RL4RS_X_NRES) return ((RL4RS_X_RESMASK >> i) & 1ull) != 0;
+#endif
     return RL4RS_X_SPREAD ? ((i % (NI / NRES)) == (NI / NRES) - 1 && i / (NI / NRES) < NRES) : (i >= 40 - NRES && i < 40);
 }
 // compile-time tables of a step's schedule: index of a resident item in the register file, position of a streamed item in
@@ -97,7 +102,11 @@ template <int MT, int NRES, int RING>
 __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     using namespace xk;
     constexpr int NH = 256, KB = 16, PLANE = 32 * NH * 2;          // bytes per plane (16 KB)
+#if defined(RL4RS_X_RESMASK) && defined(RL4RS_X_WINDOW)
+    constexpr int NS = NI - NRES, LA = RING - 1, WINDOW = (MT == 1) ? RL4RS_X_WINDOW : 40 - NRES;
+#else
     constexpr int NS = NI - NRES, LA = RING - 1, WINDOW = 40 - NRES;     // WINDOW: the item the projection requests are issued in front of
+#endif
     constexpr Sched SC = make_sched<NRES>();
     static_assert(NS > 0 && NS % RING == 0 && RING >= 2 && NRES >= 1 && NRES <= 14 && (!RL4RS_X_SPREAD || NI % NRES == 0), "weight ring / resident items");
     extern __shared__ __attribute__((aligned(16))) char smem[];
