@@ -37,9 +37,13 @@ int scorer_encode(rl4rs_stepper* s, int q, const int32_t* ids, int n, void* stre
     return s->dien ? rl4rs_dien_encode(s->dien, q, ids, n, 0, stream) : rl4rs_simnet_encode(s->simnet, q, ids, n, 0, stream);
 }
 
-__global__ void k_fill_u8(uint8_t* p, int n, uint8_t v) {
+// the constant outputs of a transition in one launch: done flags, and the zero reward of a step on which none is due
+__global__ void k_step_tail(uint8_t* done, uint8_t v, double* zero_reward, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i < n) {
+        if (done) done[i] = v;
+        if (zero_reward) zero_reward[i] = 0.0;
+    }
 }
 
 // everything after the act: observation, reward (when due), done, packed obs-side mask
@@ -54,6 +58,7 @@ int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint
             if ((rc = scorer_encode(s, q, s->seq1, B, stream))) return rc;
     }
     if ((rc = scorer_forward(s, B, 1, s->dense, s->cat, obs, nullptr, stream))) return rc;
+    double* zero_reward = nullptr;
     if (reward) {
         if (rl4rs_env_is_reward_step(e) == 1) {
             // the state row just scored IS the last complete-state row (slate.py:205-212 vs :119-130): score n - 1 rows per env
@@ -65,11 +70,12 @@ int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint
             if ((rc = scorer_head_prob(s, B, obs, s->p_last, stream))) return rc;
             if ((rc = rl4rs_env_reward_split(e, m > 0 ? s->probs : s->p_last, m > 0 ? s->p_last : nullptr, reward, stream))) return rc;
         } else {
-            RL4RS_HIP_TRY(hipMemsetAsync(reward, 0, (size_t)B * sizeof(double), st));
+            zero_reward = reward;
         }
     }
-    if (done) {
-        hipLaunchKernelGGL(k_fill_u8, dim3((B + 255) / 256), dim3(256), 0, st, done, B, (uint8_t)(cur_before >= s->cfg.max_steps - 1 ? 1 : 0));
+    if (done || zero_reward) {
+        hipLaunchKernelGGL(k_step_tail, dim3((B + 255) / 256), dim3(256), 0, st, done, (uint8_t)(cur_before >= s->cfg.max_steps - 1 ? 1 : 0),
+                           zero_reward, B);
         RL4RS_LAUNCH_CHECK();
     }
     if (mask_bits && (rc = rl4rs_env_obs_mask(e, mask_bits, 4, stream))) return rc;
