@@ -452,6 +452,10 @@ int rl4rs_policy_ppo_minibatch_grad(rl4rs_policy* pol, int32_t N, int32_t miniba
  * stopped at the last completed minibatch and is incomplete. */
 enum { RL4RS_POLICY_STATUS_PASS_TIMEOUT = 1 };
 int rl4rs_policy_status(rl4rs_policy* pol, int32_t* flags, void* stream);
+/* The same status word without a synchronisation: device pointer to 2 x uint32 owned by the handle, word [1] != 0 <=> a
+ * persistent pass timed out.  A training loop copies it asynchronously together with its loss statistics and looks at it one
+ * iteration later (rl4rs_amd/train.py), so that validating every pass costs no pipeline drain. */
+int rl4rs_policy_status_words(rl4rs_policy* pol, uint32_t** words_dev);
 /* Adam state of the handle (first / second moments, device pointers owned by the handle; same layout as the
  * parameters) and its step counter: a data-parallel trainer broadcasts rank 0's at start, a checkpoint saves them. */
 int rl4rs_policy_adam_state(rl4rs_policy* pol, float** m_dev, float** v_dev, int64_t* step);

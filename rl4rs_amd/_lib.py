@@ -178,6 +178,7 @@ SIGNATURES = {
     'rl4rs_env_step_conti': (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'rl4rs_policy_ppo_minibatch_grad': (_I, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 5 + [_P, _P, _P]),
     'rl4rs_policy_status': (_I, [_P, _P, _P]),
+    'rl4rs_policy_status_words': (_I, [_P, _P]),
     'rl4rs_policy_adam_state': (_I, [_P, _P, _P, _P]),
     'rl4rs_policy_set_adam_step': (_I, [_P, C.c_int64]),
     'rl4rs_qnet_create': (_I, [_P, _FP, _P, _P, _P, _P]),

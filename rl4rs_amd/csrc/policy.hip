@@ -1615,6 +1615,12 @@ int rl4rs_policy_ppo_minibatch_grad(rl4rs_policy* p, int32_t N, int32_t minibatc
 // barrier of a persistent PPO pass timed out (its workgroups were not co-resident).  The pass stops updating at the barrier
 // that failed, so the parameters are those of the last completed minibatch - but the pass is incomplete: callers treat it as
 // an error (rl4rs_amd.train.Trainer checks after every iteration and in params() / close()).
+int rl4rs_policy_status_words(rl4rs_policy* p, uint32_t** words_dev) {
+    RL4RS_REQUIRE(p && words_dev, "policy_status_words: null argument");
+    *words_dev = p->bar;
+    return RL4RS_OK;
+}
+
 int rl4rs_policy_status(rl4rs_policy* p, int32_t* flags, void* stream) {
     RL4RS_REQUIRE(p && flags, "policy_status: null argument");
     hipStream_t st = (hipStream_t)stream;

@@ -1097,6 +1097,17 @@ class DevicePolicy(object):
             raise RuntimeError("the persistent PPO pass timed out at a grid barrier (workgroups not co-resident: the GPU is shared or "
                                "partitioned); the pass is incomplete - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels")
 
+    def status_words(self):
+        """int32 [2] tensor aliasing the handle's status words (word 1 != 0: a persistent pass timed out); no synchronisation."""
+        if getattr(self, '_status_words', None) is None:
+            p = C.c_void_p()
+            check(self.lib.rl4rs_policy_status_words(self.h, C.byref(p)))
+            self._status_words = _alias_f32(p.value, 2, self.device, self).view(torch.int32)
+        return self._status_words
+
+    PASS_TIMEOUT_MESSAGE = ("the persistent PPO pass timed out at a grid barrier (workgroups not co-resident: the GPU is shared or "
+                            "partitioned); the pass is incomplete - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels")
+
     def adam_state(self):
         """(m, v) copies of the Adam moments and the step counter."""
         m, v, t = C.c_void_p(), C.c_void_p(), C.c_int64()

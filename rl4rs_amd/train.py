@@ -171,6 +171,54 @@ class RawStateTrainer(object):
                 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self.kl_coeff, 'iteration': self.iteration}
 
 
+class LazyStats(object):
+    """Mapping over the statistics of one train call.  The numbers live on the device until somebody looks: the train call
+    only enqueues an asynchronous copy into pinned memory + an event, so a loop that does not read its statistics never
+    drains the GPU queue (the next rollout's host work - sampling, de-duplication, launches - overlaps the update pass).
+    Any access (``stats['kl']``, ``dict(stats)``, ``repr``) waits for that one event."""
+
+    def __init__(self, trainer, token):
+        self._trainer, self._token, self._values = trainer, token, None
+
+    def _resolve(self):
+        if self._values is None:
+            self._values = self._trainer._resolve(self._token)
+        return self._values
+
+    def __getitem__(self, k):
+        return self._resolve()[k]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
+
+    def __contains__(self, k):
+        return k in self._resolve()
+
+    def keys(self):
+        return self._resolve().keys()
+
+    def items(self):
+        return self._resolve().items()
+
+    def values(self):
+        return self._resolve().values()
+
+    def get(self, k, default=None):
+        return self._resolve().get(k, default)
+
+    def __repr__(self):
+        return repr(self._resolve())
+
+    def __eq__(self, other):
+        return dict(self._resolve()) == (dict(other._resolve()) if isinstance(other, LazyStats) else other)
+
+    def __reduce__(self):                   # pickles / torch.save as the plain dict of numbers
+        return (dict, (dict(self._resolve()),))
+
+
 class Trainer(object):
     """A2C / PPO on the action-masked FC policy (rllib_mask_model.py:7-64) over the zero-copy discrete-action env.
 
@@ -190,7 +238,8 @@ class Trainer(object):
         self.B, self.T, self.A = cfg['batch_size'], cfg['max_steps'], cfg['action_size']
         self.R = rollouts_per_train_call(self.B, self.T, train_batch_size)
         self.seed, self.lr, self.minibatch = seed, lr, minibatch
-        self.kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
+        self._kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
+        self._pending = []          # train calls whose statistics have not been looked at yet (oldest first)
         self.keep_last_batch = keep_last_batch
         self.last_batch = None
         N = self.R * self.B * self.T
@@ -226,13 +275,64 @@ class Trainer(object):
         self.policy.set_params(p)
         self.policy.set_adam_state(m, v, int(step.item()))
 
+    # ---- deferred statistics ------------------------------------------------------------------------------------
+    @property
+    def kl_coeff(self):
+        """PPO's adaptive KL coefficient AFTER every finished train call (waits for the last call's statistics)."""
+        self._settle()
+        return self._kl_coeff
+
+    @kl_coeff.setter
+    def kl_coeff(self, v):
+        self._settle()
+        self._kl_coeff = float(v)
+
+    def _submit(self, mean_reward, stats, kl_div, extra):
+        """Enqueue the device -> pinned copy of one train call's numbers [mean_reward, stats..., status word] and an event."""
+        dev = stats.device
+        vec = torch.cat([mean_reward.reshape(1).to(torch.float64), stats.reshape(-1).to(torch.float64),
+                         self.policy.status_words()[1:2].to(torch.float64)])
+        pin = torch.empty(vec.shape, dtype=torch.float64, pin_memory=True)
+        pin.copy_(vec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        token = dict(pin=pin, ev=ev, kl_div=kl_div, values=None, iteration=self.iteration, **extra)
+        self._pending.append(token)
+        return token
+
+    def _settle(self):
+        """Finish every outstanding train call in order: wait for its numbers, validate the pass, apply RLlib's KL rule."""
+        while self._pending:
+            tok = self._pending.pop(0)
+            tok['ev'].synchronize()
+            v = tok['pin'].numpy().copy()
+            if v[-1] != 0.0:
+                self.policy.check_status()                  # clears the flag and raises
+                raise RuntimeError(D.DevicePolicy.PASS_TIMEOUT_MESSAGE)
+            s = v[1:-1]
+            kl_mean = 0.0
+            if tok['ppo']:
+                kl_mean = float(s[7]) / tok['kl_div'] if tok['kl_mean'] is None else tok['kl_mean']
+                if tok['kl_mean'] is None:
+                    self._kl_coeff = update_kl_coeff(self._kl_coeff, kl_mean, self.kl_target)
+            tok['values'] = {'episode_reward_mean': float(v[0]), 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
+                             'entropy': float(s[2]), 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self._kl_coeff,
+                             'iteration': tok['iteration']}
+
+    def _resolve(self, token):
+        if token['values'] is None:
+            self._settle()
+        return token['values']
+
     def params(self):
         """Flat parameters (validated: raises if a persistent pass was cut short)."""
+        self._settle()
         self.policy.check_status()
         return self.policy.params()
 
     def close(self):
         try:
+            self._settle()
             self.policy.check_status()
         finally:
             self.policy.close()
@@ -261,14 +361,18 @@ class Trainer(object):
         # gamma = 1, lambda = 1: advantage = (sum of future rewards) - V
         ret = _returns(b['rew'], R, T, B)
         adv = ret - b['val']
-        return ret, adv, float(b['rew'].view(R, T, B).sum(dim=1).mean().item())
+        return ret, adv, b['rew'].view(R, T, B).sum(dim=1).mean()        # mean episode reward stays on the device
 
     def train_iteration(self):
+        """One train call.  Returns a ``LazyStats`` mapping (episode_reward_mean, policy_loss, vf_loss, entropy, kl, kl_mean,
+        kl_coeff, iteration): nothing in here waits for the GPU on one rank - the previous call's numbers (needed for PPO's KL
+        rule and to validate its pass) are collected after this call's rollout has been enqueued, when they are long there."""
         ret, adv, mean_reward = self.rollout()
+        self._settle()                       # previous call: statistics, pass status, kl_coeff (the GPU is busy with the rollout)
         b = self.buf
         N = self.R * self.B * self.T
         world = rdist.world_size()
-        kl_mean = 0.0
+        self.iteration += 1
         if self.algo == D.DevicePolicy.A2C:
             g, stats = self.policy.loss_grad(self.algo, b['obs'], b['act'], adv, ret, mask_bits=b['mask'],
                                              vf_coeff=0.5, ent_coeff=0.01, grad_out=self.grad)
@@ -276,43 +380,38 @@ class Trainer(object):
                 self.last_batch = dict(obs=b['obs'].clone(), act=b['act'].clone(), mask=b['mask'].clone(), adv=adv.clone(), ret=ret.clone())
             rdist.allreduce_mean_(g)                         # the ONE collective: flat policy gradient over RCCL
             self.policy.adam_step(g, lr=self.lr, grad_clip=10.0)
-            s = stats.cpu().numpy()
-        else:
-            adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)      # RLlib standardises PPO advantages
-            perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration).permutation(N)).to(b['obs'].device)
-            # shuffle every buffer ONCE (7 gathers per iteration instead of 7 per minibatch): minibatches are then
-            # contiguous row ranges that go to the library as plain pointers
-            sh = dict((k, b[k][perm]) for k in ('obs', 'act', 'mask', 'logp', 'val', 'logits'))
-            adv_s, ret_s = adv_n[perm].contiguous(), ret[perm].contiguous()
-            if self.keep_last_batch:
-                self.last_batch = dict(sh, adv=adv_s, ret=ret_s, kl_coeff=self.kl_coeff)
-            MB = self.minibatch
-            nmb = N // MB
-            if world == 1:
-                # single GPU: the whole pass is one library call (no per-minibatch collective to interleave)
-                stats = self.policy.ppo_epoch(sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'], sh['val'],
-                                              sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
-                                              clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff, lr=self.lr, grad_out=self.grad)
-                s8 = stats.cpu().numpy()
-                s = s8[:4]
-                kl_mean = float(s8[7]) / (nmb * MB)
-            else:
-                # data parallel: per minibatch ONE fused gradient launch, ONE all-reduce, ONE Adam launch
-                kl_sum = torch.zeros((), dtype=torch.float32, device=b['obs'].device)
-                for mb in range(nmb):
-                    g, stats = self.policy.ppo_minibatch_grad(mb, sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'],
-                                                              sh['val'], sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
-                                                              clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff,
-                                                              grad_out=self.grad, stats_out=self._mb_stats)
-                    rdist.allreduce_mean_(g)
-                    self.policy.adam_step(g, lr=self.lr)
-                    kl_sum += stats[3]
-                s = stats.cpu().numpy()
-                # every rank must take the same kl_coeff decision: the rule sees the mean over ALL ranks' samples
-                kl_mean = rdist.sum_over_ranks(float(kl_sum.item()) / (nmb * MB), device=b['obs'].device) / world
-            self.kl_coeff = update_kl_coeff(self.kl_coeff, kl_mean, self.kl_target)
-            self.policy.check_status()
-        self.iteration += 1
-        return {'episode_reward_mean': mean_reward, 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
-                'entropy': float(s[2]), 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self.kl_coeff,
-                'iteration': self.iteration}
+            return LazyStats(self, self._submit(mean_reward, stats[:4], 1, dict(ppo=False, kl_mean=None)))
+        adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)      # RLlib standardises PPO advantages
+        perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration - 1).permutation(N)).to(b['obs'].device)
+        # shuffle every buffer ONCE (7 gathers per iteration instead of 7 per minibatch): minibatches are then
+        # contiguous row ranges that go to the library as plain pointers
+        sh = dict((k, b[k][perm]) for k in ('obs', 'act', 'mask', 'logp', 'val', 'logits'))
+        adv_s, ret_s = adv_n[perm].contiguous(), ret[perm].contiguous()
+        if self.keep_last_batch:
+            self.last_batch = dict(sh, adv=adv_s, ret=ret_s, kl_coeff=self._kl_coeff)
+        MB = self.minibatch
+        nmb = N // MB
+        if world == 1:
+            # single GPU: the whole pass is one library call (no per-minibatch collective to interleave)
+            stats = self.policy.ppo_epoch(sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'], sh['val'],
+                                          sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
+                                          clip=0.3, vf_clip=500.0, kl_coeff=self._kl_coeff, lr=self.lr, grad_out=self.grad)
+            return LazyStats(self, self._submit(mean_reward, stats, nmb * MB, dict(ppo=True, kl_mean=None)))
+        # data parallel: per minibatch ONE fused gradient launch, ONE all-reduce, ONE Adam launch
+        kl_sum = torch.zeros((), dtype=torch.float32, device=b['obs'].device)
+        for mb in range(nmb):
+            g, stats = self.policy.ppo_minibatch_grad(mb, sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'],
+                                                      sh['val'], sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,
+                                                      clip=0.3, vf_clip=500.0, kl_coeff=self._kl_coeff,
+                                                      grad_out=self.grad, stats_out=self._mb_stats)
+            rdist.allreduce_mean_(g)
+            self.policy.adam_step(g, lr=self.lr)
+            kl_sum += stats[3]
+        # every rank must take the same kl_coeff decision: the rule sees the mean over ALL ranks' samples (a collective, so
+        # this path settles at once)
+        kl_mean = rdist.sum_over_ranks(float(kl_sum.item()) / (nmb * MB), device=b['obs'].device) / world
+        self._kl_coeff = update_kl_coeff(self._kl_coeff, kl_mean, self.kl_target)
+        stats8 = torch.cat([stats.reshape(-1)[:4], torch.zeros(4, dtype=stats.dtype, device=stats.device)])
+        out = LazyStats(self, self._submit(mean_reward, stats8, 1, dict(ppo=True, kl_mean=kl_mean)))
+        self._settle()
+        return out
