@@ -214,3 +214,24 @@ def test_logstore_width_is_the_longest_record(tmp_path):
     store.ensure([0, 6], 'cpu')                         # host tensors: the parser and the table logic need no GPU
     assert store.exposed_len[0] == 9 and store.exposed_len[6] == 18
     assert (store._dev['exposed'][0, 9:] == 0).all() and (store._dev['exposed'][6] > 0).all()
+
+
+def test_lazy_stats_is_a_mapping_that_resolves_once_and_pickles_as_a_dict():
+    """rl4rs_amd.train.LazyStats: what Trainer.train_iteration returns (the numbers stay on the device until read)."""
+    import pickle
+    from rl4rs_amd.train import LazyStats
+
+    class FakeTrainer(object):
+        calls = 0
+
+        def _resolve(self, token):
+            FakeTrainer.calls += 1
+            return {'policy_loss': 1.5, 'kl': 0.25, 'iteration': token}
+
+    st = LazyStats(FakeTrainer(), 7)
+    assert FakeTrainer.calls == 0                       # nothing waited for yet
+    assert st['policy_loss'] == 1.5 and st.get('missing', 3) == 3 and 'kl' in st and len(st) == 3
+    assert sorted(st.keys()) == ['iteration', 'kl', 'policy_loss'] and dict(st)['iteration'] == 7
+    assert FakeTrainer.calls == 1                       # one resolution serves every access
+    back = pickle.loads(pickle.dumps(st))
+    assert type(back) is dict and back == {'policy_loss': 1.5, 'kl': 0.25, 'iteration': 7} and st == back
