@@ -48,7 +48,106 @@ def _returns(rew, R, T, B):
     return torch.flip(torch.cumsum(torch.flip(r, dims=[1]), dim=1), dims=[1]).reshape(-1).to(torch.float32)
 
 
-class RawStateTrainer(object):
+class LazyStats(object):
+    """Mapping over the statistics of one train call.  The numbers live on the device until somebody looks: the train call
+    only enqueues an asynchronous copy into pinned memory + an event, so a loop that does not read its statistics never
+    drains the GPU queue (the next rollout's host work - sampling, de-duplication, launches - overlaps the update pass).
+    Any access (``stats['kl']``, ``dict(stats)``, ``repr``) waits for that one event."""
+
+    def __init__(self, trainer, token):
+        self._trainer, self._token, self._values = trainer, token, None
+
+    def _resolve(self):
+        if self._values is None:
+            self._values = self._trainer._resolve(self._token)
+        return self._values
+
+    def __getitem__(self, k):
+        return self._resolve()[k]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return len(self._resolve())
+
+    def __contains__(self, k):
+        return k in self._resolve()
+
+    def keys(self):
+        return self._resolve().keys()
+
+    def items(self):
+        return self._resolve().items()
+
+    def values(self):
+        return self._resolve().values()
+
+    def get(self, k, default=None):
+        return self._resolve().get(k, default)
+
+    def __repr__(self):
+        return repr(self._resolve())
+
+    def __eq__(self, other):
+        return dict(self._resolve()) == (dict(other._resolve()) if isinstance(other, LazyStats) else other)
+
+    def __reduce__(self):                   # pickles / torch.save as the plain dict of numbers
+        return (dict, (dict(self._resolve()),))
+
+
+class _DeferredStats(object):
+    """Shared by the trainers: statistics of a train call are copied asynchronously and settled one call later (LazyStats)."""
+    @property
+    def kl_coeff(self):
+        """PPO's adaptive KL coefficient AFTER every finished train call (waits for the last call's statistics)."""
+        self._settle()
+        return self._kl_coeff
+
+    @kl_coeff.setter
+    def kl_coeff(self, v):
+        self._settle()
+        self._kl_coeff = float(v)
+
+    def _submit(self, mean_reward, stats, kl_div, extra):
+        """Enqueue the device -> pinned copy of one train call's numbers [mean_reward, stats..., status word] and an event."""
+        dev = stats.device
+        status = (self.policy.status_words()[1:2].to(torch.float64) if hasattr(self.policy, 'status_words')
+                  else torch.zeros(1, dtype=torch.float64, device=dev))
+        vec = torch.cat([mean_reward.reshape(1).to(torch.float64), stats.reshape(-1).to(torch.float64), status])
+        pin = torch.empty(vec.shape, dtype=torch.float64, pin_memory=True)
+        pin.copy_(vec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        token = dict(pin=pin, ev=ev, kl_div=kl_div, values=None, iteration=self.iteration, **extra)
+        self._pending.append(token)
+        return token
+
+    def _settle(self):
+        """Finish every outstanding train call in order: wait for its numbers, validate the pass, apply RLlib's KL rule."""
+        while self._pending:
+            tok = self._pending.pop(0)
+            tok['ev'].synchronize()
+            v = tok['pin'].numpy().copy()
+            if v[-1] != 0.0:
+                self.policy.check_status()                  # clears the flag and raises
+                raise RuntimeError(D.DevicePolicy.PASS_TIMEOUT_MESSAGE)
+            s = v[1:-1]
+            kl_mean = 0.0
+            if tok['ppo']:
+                kl_mean = float(s[7]) / tok['kl_div'] if tok['kl_mean'] is None else tok['kl_mean']
+                if tok['kl_mean'] is None:
+                    self._kl_coeff = update_kl_coeff(self._kl_coeff, kl_mean, self.kl_target)
+            tok['values'] = {'episode_reward_mean': float(v[0]), 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
+                             'entropy': float(s[2]), 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self._kl_coeff,
+                             'iteration': tok['iteration']}
+
+    def _resolve(self, token):
+        if token['values'] is None:
+            self._settle()
+        return token['values']
+
+class RawStateTrainer(_DeferredStats):
     """The same loop for an env with config['rawstate_as_obs'] (+ support_rllib_mask, return_tensors): the policy is the
     raw-state encoder (rllib_rawstate_model.py; modelfree_train.py 'rawstate' variants) acting on the device tensors of the
     raw features; loss, backward and Adam run through rl4rs_rawtrain_*.
@@ -67,7 +166,8 @@ class RawStateTrainer(object):
         self.B, self.T, self.A = cfg['batch_size'], cfg['max_steps'], cfg['action_size']
         self.S, self.L = cfg['seq_num'], cfg['maxlen']
         self.seed, self.lr, self.minibatch = seed, lr, minibatch
-        self.kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
+        self._kl_coeff, self.kl_target = float(kl_coeff), float(kl_target)
+        self._pending = []
         if weights is None:
             weights = init_rawpolicy_weights(cfg, seed=init_seed)
         N = self.B * self.T
@@ -119,7 +219,7 @@ class RawStateTrainer(object):
             obs, reward, done, info = self.env.step(a)
             b['rew'][sl] = reward
         ret = _returns(b['rew'], 1, T, B)
-        return ret, ret - b['val'], float(b['rew'].view(T, B).sum(dim=0).mean().item())
+        return ret, ret - b['val'], b['rew'].view(T, B).sum(dim=0).mean()         # stays on the device (LazyStats)
 
     def _allreduce_gradient(self, cat, seqs):
         """Mean over ranks of the gradient the last loss_grad left in the handle (no-op on one rank)."""
@@ -135,91 +235,49 @@ class RawStateTrainer(object):
         rdist.allreduce_mean_(g[tail:])
 
     def train_iteration(self):
+        """One train call; returns a ``LazyStats`` mapping (see Trainer.train_iteration)."""
         ret, adv, mean_reward = self.rollout()
+        self._settle()
         b = self.buf
         N = self.B * self.T
-        kl_mean = 0.0
+        self.iteration += 1
         if self.algo == D.DeviceRawTrainer.A2C:
             stats = self.policy.loss_grad(self.algo, b['cat'], b['dense'], b['seqs'], b['act'], adv, ret, mask_bits=b['mask'],
                                           vf_coeff=0.5, ent_coeff=0.01)
             self._allreduce_gradient(b['cat'], b['seqs'])
             self.policy.adam_step(lr=self.lr, grad_clip=10.0)
-        else:
-            adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)
-            perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration).permutation(N)).to(b['cat'].device)
-            sh = dict((k, b[k][perm]) for k in ('cat', 'dense', 'mask', 'act', 'logp', 'val', 'logits'))
-            shs = [q[perm] for q in b['seqs']]
-            adv_s, ret_s = adv_n[perm], ret[perm]
-            kl_sum = torch.zeros((), dtype=torch.float32, device=b['cat'].device)
-            nmb = 0
-            for lo in range(0, N - self.minibatch + 1, self.minibatch):
-                hi = lo + self.minibatch
-                seq_mb = [q[lo:hi] for q in shs]
-                stats = self.policy.loss_grad(self.algo, sh['cat'][lo:hi], sh['dense'][lo:hi], seq_mb, sh['act'][lo:hi],
-                                              adv_s[lo:hi], ret_s[lo:hi], mask_bits=sh['mask'][lo:hi], old_logp=sh['logp'][lo:hi],
-                                              old_value=sh['val'][lo:hi], old_logits=sh['logits'][lo:hi], vf_coeff=0.5,
-                                              ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=self.kl_coeff)
-                self._allreduce_gradient(sh['cat'][lo:hi], seq_mb)
-                self.policy.adam_step(lr=self.lr)
-                kl_sum += stats[3]
-                nmb += 1
+            return LazyStats(self, self._submit(mean_reward, stats[:4], 1, dict(ppo=False, kl_mean=None)))
+        adv_n = (adv - adv.mean()) / adv.std().clamp_min(1e-4)
+        perm = torch.from_numpy(np.random.RandomState(self.seed + self.iteration - 1).permutation(N)).to(b['cat'].device)
+        sh = dict((k, b[k][perm]) for k in ('cat', 'dense', 'mask', 'act', 'logp', 'val', 'logits'))
+        shs = [q[perm] for q in b['seqs']]
+        adv_s, ret_s = adv_n[perm], ret[perm]
+        kl_sum = torch.zeros((), dtype=torch.float32, device=b['cat'].device)
+        nmb = 0
+        for lo in range(0, N - self.minibatch + 1, self.minibatch):
+            hi = lo + self.minibatch
+            seq_mb = [q[lo:hi] for q in shs]
+            stats = self.policy.loss_grad(self.algo, sh['cat'][lo:hi], sh['dense'][lo:hi], seq_mb, sh['act'][lo:hi],
+                                          adv_s[lo:hi], ret_s[lo:hi], mask_bits=sh['mask'][lo:hi], old_logp=sh['logp'][lo:hi],
+                                          old_value=sh['val'][lo:hi], old_logits=sh['logits'][lo:hi], vf_coeff=0.5,
+                                          ent_coeff=0.0, clip=0.3, vf_clip=500.0, kl_coeff=self._kl_coeff)
+            self._allreduce_gradient(sh['cat'][lo:hi], seq_mb)
+            self.policy.adam_step(lr=self.lr)
+            kl_sum += stats[3]
+            nmb += 1
+        stats8 = torch.cat([stats.reshape(-1)[:4].to(torch.float32), torch.zeros(3, dtype=torch.float32, device=kl_sum.device),
+                            kl_sum.reshape(1)])
+        if rdist.world_size() > 1:
+            # every rank must take the same kl_coeff decision: the rule sees the mean over ALL ranks' samples (a collective)
             kl_mean = rdist.sum_over_ranks(float(kl_sum.item()) / max(nmb * self.minibatch, 1), device=b['cat'].device) / rdist.world_size()
-            self.kl_coeff = update_kl_coeff(self.kl_coeff, kl_mean, self.kl_target)
-        self.iteration += 1
-        s = stats.cpu().numpy()
-        return {'episode_reward_mean': mean_reward, 'policy_loss': float(s[0]), 'vf_loss': float(s[1]), 'entropy': float(s[2]),
-                'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self.kl_coeff, 'iteration': self.iteration}
+            self._kl_coeff = update_kl_coeff(self._kl_coeff, kl_mean, self.kl_target)
+            out = LazyStats(self, self._submit(mean_reward, stats8, 1, dict(ppo=True, kl_mean=kl_mean)))
+            self._settle()
+            return out
+        return LazyStats(self, self._submit(mean_reward, stats8, max(nmb * self.minibatch, 1), dict(ppo=True, kl_mean=None)))
 
 
-class LazyStats(object):
-    """Mapping over the statistics of one train call.  The numbers live on the device until somebody looks: the train call
-    only enqueues an asynchronous copy into pinned memory + an event, so a loop that does not read its statistics never
-    drains the GPU queue (the next rollout's host work - sampling, de-duplication, launches - overlaps the update pass).
-    Any access (``stats['kl']``, ``dict(stats)``, ``repr``) waits for that one event."""
-
-    def __init__(self, trainer, token):
-        self._trainer, self._token, self._values = trainer, token, None
-
-    def _resolve(self):
-        if self._values is None:
-            self._values = self._trainer._resolve(self._token)
-        return self._values
-
-    def __getitem__(self, k):
-        return self._resolve()[k]
-
-    def __iter__(self):
-        return iter(self._resolve())
-
-    def __len__(self):
-        return len(self._resolve())
-
-    def __contains__(self, k):
-        return k in self._resolve()
-
-    def keys(self):
-        return self._resolve().keys()
-
-    def items(self):
-        return self._resolve().items()
-
-    def values(self):
-        return self._resolve().values()
-
-    def get(self, k, default=None):
-        return self._resolve().get(k, default)
-
-    def __repr__(self):
-        return repr(self._resolve())
-
-    def __eq__(self, other):
-        return dict(self._resolve()) == (dict(other._resolve()) if isinstance(other, LazyStats) else other)
-
-    def __reduce__(self):                   # pickles / torch.save as the plain dict of numbers
-        return (dict, (dict(self._resolve()),))
-
-
-class Trainer(object):
+class Trainer(_DeferredStats):
     """A2C / PPO on the action-masked FC policy (rllib_mask_model.py:7-64) over the zero-copy discrete-action env.
 
     seed       sampling stream of this rank (Gumbel noise, PPO shuffle): pass a different value per rank
@@ -274,55 +332,6 @@ class Trainer(object):
             dist.broadcast(step, src=src)
         self.policy.set_params(p)
         self.policy.set_adam_state(m, v, int(step.item()))
-
-    # ---- deferred statistics ------------------------------------------------------------------------------------
-    @property
-    def kl_coeff(self):
-        """PPO's adaptive KL coefficient AFTER every finished train call (waits for the last call's statistics)."""
-        self._settle()
-        return self._kl_coeff
-
-    @kl_coeff.setter
-    def kl_coeff(self, v):
-        self._settle()
-        self._kl_coeff = float(v)
-
-    def _submit(self, mean_reward, stats, kl_div, extra):
-        """Enqueue the device -> pinned copy of one train call's numbers [mean_reward, stats..., status word] and an event."""
-        dev = stats.device
-        vec = torch.cat([mean_reward.reshape(1).to(torch.float64), stats.reshape(-1).to(torch.float64),
-                         self.policy.status_words()[1:2].to(torch.float64)])
-        pin = torch.empty(vec.shape, dtype=torch.float64, pin_memory=True)
-        pin.copy_(vec, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        token = dict(pin=pin, ev=ev, kl_div=kl_div, values=None, iteration=self.iteration, **extra)
-        self._pending.append(token)
-        return token
-
-    def _settle(self):
-        """Finish every outstanding train call in order: wait for its numbers, validate the pass, apply RLlib's KL rule."""
-        while self._pending:
-            tok = self._pending.pop(0)
-            tok['ev'].synchronize()
-            v = tok['pin'].numpy().copy()
-            if v[-1] != 0.0:
-                self.policy.check_status()                  # clears the flag and raises
-                raise RuntimeError(D.DevicePolicy.PASS_TIMEOUT_MESSAGE)
-            s = v[1:-1]
-            kl_mean = 0.0
-            if tok['ppo']:
-                kl_mean = float(s[7]) / tok['kl_div'] if tok['kl_mean'] is None else tok['kl_mean']
-                if tok['kl_mean'] is None:
-                    self._kl_coeff = update_kl_coeff(self._kl_coeff, kl_mean, self.kl_target)
-            tok['values'] = {'episode_reward_mean': float(v[0]), 'policy_loss': float(s[0]), 'vf_loss': float(s[1]),
-                             'entropy': float(s[2]), 'kl': float(s[3]), 'kl_mean': kl_mean, 'kl_coeff': self._kl_coeff,
-                             'iteration': tok['iteration']}
-
-    def _resolve(self, token):
-        if token['values'] is None:
-            self._settle()
-        return token['values']
 
     def params(self):
         """Flat parameters (validated: raises if a persistent pass was cut short)."""
