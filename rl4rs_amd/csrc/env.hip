@@ -264,6 +264,52 @@ __global__ __launch_bounds__(256) void k_knn(const TA* __restrict__ actions, int
     if (lane == 0) out[b] = best_k;
 }
 
+// The same K-NN with the action-embedding table staged in LDS (A x E doubles = 72 KB for the 284 x 32 catalogue): in k_knn
+// every lane walks its own table row straight from memory, 8 bytes at a 256-byte stride - 64 cache lines per load instruction
+// and the whole table once per env.  Here a workgroup of NW waves copies the table once (coalesced), rows padded to E + 1
+// doubles so the row-per-lane reads are conflict-free.  Same products, same summation order: bit-identical choices.
+template <typename TA>
+__global__ __launch_bounds__(1024) void k_knn_lds(const TA* __restrict__ actions, int n, const double* __restrict__ emb,
+                                                  int A, int E, const uint32_t* __restrict__ amask,
+                                                  const uint32_t* __restrict__ smask, const uint32_t* __restrict__ loc,
+                                                  int W, const uint8_t* __restrict__ dense_mask,
+                                                  int32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int LDE = E + 1;
+    double* s_emb = reinterpret_cast<double*>(smem);            // [A][E + 1]
+    double* s_act = s_emb + (size_t)A * LDE;                    // [NW][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < A * E; i += blockDim.x) s_emb[(i / E) * LDE + (i % E)] = emb[i];
+    double* my = s_act + wave * E;
+    const int b = blockIdx.x * nw + wave;
+    if (b < n)
+        for (int j = lane; j < E; j += 64) my[j] = (double)actions[(size_t)b * E + j];
+    __syncthreads();
+    if (b >= n) return;
+    double best = -1.0e308;
+    int best_k = 0x7fffffff;
+    for (int k = lane; k < A; k += 64) {
+        double s = 0.0;
+        const double* row = s_emb + (size_t)k * LDE;
+        for (int j = 0; j < E; ++j) s = __dadd_rn(s, __dmul_rn(my[j], row[j]));
+        if (amask) {
+            uint32_t m = amask[(size_t)b * W + (k >> 5)] & smask[(size_t)b * W + (k >> 5)] & loc[k >> 5];
+            if (!((m >> (k & 31)) & 1u)) s = -2147483648.0;     // action_score[mask < 0.5] = -2**31
+        }
+        if (dense_mask && !dense_mask[(size_t)b * A + k]) s = -2147483648.0;
+        if (best_k == 0x7fffffff || s > best) { best = s; best_k = k; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {                    // first-max wins: lower index on ties (np.argmax)
+        double os = __shfl_xor(best, off);
+        int ok = __shfl_xor(best_k, off);
+        if (ok != 0x7fffffff && (best_k == 0x7fffffff || os > best || (os == best && ok < best_k))) {
+            best = os;
+            best_k = ok;
+        }
+    }
+    if (lane == 0) out[b] = best_k;
+}
+
 // policy_model.predict_with_mask (rl4rs/policy/policy_model.py:17-41) / CustomVectorEncoder mask rule
 // (rl4rs/nets/cql/encoder.py:42-67): the action mask is re-derived from the observation tail
 // [prev_actions (page_items) | cur_step]: mask = location_mask[cur_step % page_items // 3] with every previous
@@ -664,6 +710,27 @@ int rl4rs_env_act_discrete(rl4rs_env* e, const int32_t* actions, void* stream) {
 static int knn_launch(const void* actions, int is_f64, int n, const double* emb, int A, int E,
                       const uint32_t* amask, const uint32_t* smask, const uint32_t* loc, int W,
                       const uint8_t* dense_mask, int32_t* out, hipStream_t st) {
+    // batches: 16 envs per workgroup around ONE LDS copy of the table; small calls / huge catalogues: one row per lane from memory
+    const size_t lds_bytes = ((size_t)A * (E + 1) + (size_t)16 * E) * sizeof(double);
+    static bool lds_ok[2] = {false, false}, lds_tried[2] = {false, false};
+    if (n >= 64 && lds_bytes <= 150 * 1024) {
+        const int v = is_f64 ? 1 : 0;
+        if (!lds_tried[v]) {
+            lds_tried[v] = true;
+            const void* fn = is_f64 ? reinterpret_cast<const void*>(&k_knn_lds<double>) : reinterpret_cast<const void*>(&k_knn_lds<float>);
+            lds_ok[v] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+            if (!lds_ok[v]) (void)hipGetLastError();
+        }
+        if (lds_ok[v]) {
+            dim3 g16((n + 15) / 16), b1024(1024);
+            if (is_f64)
+                hipLaunchKernelGGL(k_knn_lds<double>, g16, b1024, lds_bytes, st, (const double*)actions, n, emb, A, E, amask, smask, loc, W, dense_mask, out);
+            else
+                hipLaunchKernelGGL(k_knn_lds<float>, g16, b1024, lds_bytes, st, (const float*)actions, n, emb, A, E, amask, smask, loc, W, dense_mask, out);
+            RL4RS_LAUNCH_CHECK();
+            return RL4RS_OK;
+        }
+    }
     dim3 grid((n + 3) / 4), block(256);
     size_t smem = (size_t)4 * E * sizeof(double);
     if (is_f64)

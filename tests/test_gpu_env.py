@@ -157,6 +157,33 @@ def test_knn_known_answer_and_ties():
     assert knn(a, eye).cpu().tolist() == [7, 0, 5]
 
 
+def test_knn_batched_kernel_matches_numpy_and_the_row_kernel():
+    """Batches (n >= 64) run k_knn_lds (table staged in LDS, 16 envs per workgroup), small calls k_knn (one row per lane from
+    memory): the same float64 products in the same order, so the same choices - against numpy's float64 einsum argmax on random
+    actions with and without a dense mask, in both input dtypes, for n that is not a multiple of 16."""
+    import torch
+    from rl4rs_amd.data import CatalogTables
+    from rl4rs_amd.device import knn
+    from helpers import GOLDEN
+    cat = CatalogTables(os.path.join(GOLDEN, 'item_info_real.csv'), 284)
+    emb = torch.from_numpy(cat.action_emb).cuda()
+    rs = np.random.RandomState(3)
+    n = 1000 + 7
+    a = rs.randn(n, 32)
+    mask = (rs.rand(n, 284) < 0.6).astype(np.float64)
+    mask[:, 0] = 1.0
+    for dtype in (np.float64, np.float32):
+        ad = a.astype(dtype)
+        score = np.einsum('ke,ne->nk', cat.action_emb, ad.astype(np.float64))
+        got = knn(ad, emb).cpu().numpy()
+        assert np.array_equal(got, score.argmax(axis=1))
+        masked = np.where(mask >= 0.5, score, -2.0 ** 31)
+        got_m = knn(ad, emb, mask=mask).cpu().numpy()
+        assert np.array_equal(got_m, masked.argmax(axis=1))
+        # the first 40 rows alone take the row kernel: identical picks
+        assert np.array_equal(knn(ad[:40], emb, mask=mask[:40]).cpu().numpy(), got_m[:40])
+
+
 def test_invalid_action_sets_error_flag():
     m, cfg, records, g = load_scenario('slate_discrete')
     env, cat, cols = _mk_env(cfg, records, False)
