@@ -321,14 +321,18 @@ def main():
     prof = net.profile()
     net.set_profiling(0)
     breakdown, breakdown_steps = None, 3
-    if rank == 0:
-        net.set_profiling(1)
-        net.profile_reset()
+    # the per-kernel breakdown pass is rank 0's - except that a train step with world > 1 contains collectives (the gradient
+    # all-reduce), so then every rank has to take the same steps (only rank 0 records events)
+    if rank == 0 or (trainer is not None and world > 1):
+        if rank == 0:
+            net.set_profiling(1)
+            net.profile_reset()
         for _ in range(breakdown_steps):
             run_step()
         torch.cuda.synchronize()
-        breakdown = net.profile()
-        net.set_profiling(0)
+        if rank == 0:
+            breakdown = net.profile()
+            net.set_profiling(0)
 
     if rank == 0:
         env_steps = world * B * T * args.steps
