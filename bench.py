@@ -128,11 +128,29 @@ def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
         env.step(np.asarray(env.samples.offline_action))
     dt = time.time() - t0
     threads = CPU_ROW_WORKERS if algo == 'dien' else int(torch.get_num_threads())
-    out = {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-           "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs: vectorised numpy state machine + "
-                     "torch-CPU float32 %s on %d row-parallel worker threads (the rate peaks there on this host: the 64-step "
-                     "recurrences are chains of small matmuls; os.cpu_count() = %d), %.1f s"
-                     % (T, sample_batch, algo.upper() if algo == 'dien' else algo, threads, os.cpu_count() or 0, dt)}
+    threaded = {"value": sample_batch * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+                "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs: vectorised numpy state machine + "
+                          "torch-CPU float32 %s on %d row-parallel worker THREADS of one process (the rate of one process peaks "
+                          "there on this host: the 64-step recurrences are chains of small matmuls), %.1f s"
+                          % (T, sample_batch, algo.upper() if algo == 'dien' else algo, threads, dt)}
+    # ---- the same port on the WHOLE machine: env rows are independent, so row blocks go to single-threaded worker processes,
+    # one per physical core (oracle/cpu_pool.py); timed from "every worker has built its env" to "last worker done"
+    from oracle.cpu_pool import run_pool
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    workers = max(1, logical // 2) if logical >= 32 else logical
+    rows_per_worker = 32
+    need = workers * rows_per_worker
+    recs = list(records)
+    while len(recs) < need:
+        recs += list(records)
+    pool = run_pool(dict(cfg), recs[:need], seq, workers, rows_per_worker)
+    out = {"value": pool['env_steps'] / pool['seconds'], "unit": "env-steps/s", "cores": workers, "kind": "port",
+           "sample": "1 episode-batch (reset + %d steps incl. reward forward) of %d envs cut into %d row blocks of %d, one "
+                     "single-threaded process per block (vectorised numpy state machine + torch-CPU float32 %s per block; "
+                     "%d workers on %d logical cores, os.cpu_count() = %d), %.1f s wall, slowest worker %.1f s"
+                     % (T, need, workers, rows_per_worker, algo.upper() if algo == 'dien' else algo, workers, logical,
+                        os.cpu_count() or 0, pool['seconds'], pool['slowest_worker_s']),
+           "one_process_%d_threads" % threads: threaded}
     # ---- faithful per-sample loop, one core (Slate only: the bench workload)
     if not seq and faithful_batch > 0:
         from oracle.faithful import FaithfulSlateEnv
@@ -175,14 +193,25 @@ def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
     return out
 
 
-def timed_episodes(env, T, steps, warmup=1):
+def episode_host(env, T):
+    """The same loop through the reference-shaped API (config without return_tensors): lists / ndarrays / dicts come back to
+    the host every step (obs [B, 256] float32, the int64 action mask in rllib-mask mode, rewards as a python list), and the
+    logged actions go in as the python list the reference's offline_action hands out."""
+    env.reset()
+    for _ in range(T):
+        obs, reward, done, info = env.step(env.offline_action)
+    return obs, reward
+
+
+def timed_episodes(env, T, steps, warmup=1, fn=None):
     import torch
+    fn = fn or episode
     for _ in range(warmup):
-        episode(env, T)
+        fn(env, T)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        episode(env, T)
+        fn(env, T)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -206,6 +235,13 @@ def extra_leg(args, workdir, rank, name, steps=3):
         extra_cfg = {'is_eval': True, 'cache_size': a.batch}           # eval mode: the first B lines, no duplicate histories
     elif name == 'fp32':
         a.scorer = 'fp32'
+    elif name == 'compat_numpy':
+        extra_cfg = {'return_tensors': False}
+    elif name == 'compat_rllib_mask':
+        extra_cfg = {'return_tensors': False, 'support_rllib_mask': True}
+    elif name == 'compat_d3rl_mask':
+        extra_cfg = {'return_tensors': False, 'support_d3rl_mask': True}
+    compat = name.startswith('compat_')
     cfg, _ = make_config(a, workdir, rank)
     cfg.update(extra_cfg)
     seq = a.env == 'seq'
@@ -225,11 +261,16 @@ def extra_leg(args, workdir, rank, name, steps=3):
         dt = time.perf_counter() - t0
         tr.close()
     else:
-        dt = timed_episodes(env, T, steps)
+        dt = timed_episodes(env, T, steps, fn=episode_host if compat else None)
     out = {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "workload": "%s B=%d T=%d%s%s" % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T,
                                              ', continuous actions -> masked K-NN' if a.conti else '',
                                              ', PPO rollout + update (configs[2])' if train else ', offline_action replay')}
+    if compat:
+        out["workload"] += (" through the REFERENCE-SHAPED API (no return_tensors%s): one rl4rs_env_step_record call + one pinned "
+                            "device-to-host copy per step; PCIe-inclusive, python list / dict construction included"
+                            % ({'compat_numpy': '', 'compat_rllib_mask': ', support_rllib_mask: list of B {action_mask int64[284], obs} dicts',
+                                'compat_d3rl_mask': ', support_d3rl_mask: float64 [B, 266] observations'}[name]))
     hu = getattr(env.samples, '_hist_unique', None)
     out["distinct_histories"] = int(hu[0].shape[0]) if hu is not None else B
     if name == 'fp32':
@@ -422,7 +463,8 @@ def main():
         default_run = world == 1 and is_dien and not trainer and not seq and not args.conti
         if default_run and not args.no_extra_legs:
             out["extra"] = dict((name, extra_leg(args, workdir, rank, name))
-                                for name in ('seq_t32', 'seq_t32_ppo', 'conti', 'all_distinct'))
+                                for name in ('seq_t32', 'seq_t32_ppo', 'conti', 'all_distinct', 'compat_numpy', 'compat_rllib_mask',
+                                             'compat_d3rl_mask'))
         if default_run and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg:
             out["exact_fp32_scorer"] = extra_leg(args, workdir, rank, 'fp32')
         if world == 1 and not args.no_cpu_baseline:

@@ -172,6 +172,11 @@ int rl4rs_env_offline_reward(rl4rs_env* env, double* out_dev, void* stream);
 int rl4rs_env_predict_with_mask(rl4rs_env* env, int32_t N, const float* scores_dev, const int32_t* prev_dev,
                                 int32_t prev_cols, const int32_t* cur_step_dev, int32_t* out_dev, void* stream);
 
+/* Kernel-path selection of one env handle (A/B measurements; same results): ROWS_VARIANT 0 [default] = the row kernels stage
+ * the catalogue in LDS, 1 = they read it through L1 / L2. */
+enum { RL4RS_ENV_OPT_ROWS_VARIANT = 0 };
+int rl4rs_env_set_option(rl4rs_env* env, int32_t which, int32_t value);
+
 /* The configuration the env was created with. */
 int rl4rs_env_get_cfg(const rl4rs_env* env, rl4rs_env_cfg* out);
 
@@ -209,13 +214,42 @@ typedef struct rl4rs_dien_cfg {
     int32_t max_rows;              /* largest R passed to rl4rs_dien_forward */
     int32_t max_slots;             /* sequence-cache slots per sequence input */
     int32_t scorer_mode;           /* RL4RS_SCORER_* : arithmetic of the AUGRU recurrence (the dominant kernel) */
+    uint32_t kernel_opts;          /* RL4RS_DIEN_OPT_* bits, 0 = the defaults */
 } rl4rs_dien_cfg;
+
+/* Kernel-path selection of ONE scorer handle (A/B measurements, and parity tests that pin a path): configuration, never
+ * process environment, so that handles with different paths can live side by side.  Every combination computes the same
+ * function inside the parity bars of DESIGN.md 2; forms marked (=) are bit-identical to the default.
+ *   AUGRU_H16       first-generation fp16x2 recurrence k_augru_h16 instead of k_augru_x
+ *   AUGRU_ROWS32    k_augru_x: 32-row workgroups for every launch (=)
+ *   AUGRU_ROWS64    k_augru_x: 64-row workgroups whenever the launch shape admits them (R % 64 == 0, rows in whole groups
+ *                   of 8 per cache slot), not only when that still fills the chip twice over (=); see rl4rs_dien_set_augru_rows
+ *   DIN_V1          first-generation attention-score kernel k_din_scores instead of k_din_x
+ *   NO_DIN16 / NO_GRU16 / NO_GEMM16 / NO_CAT16   keep the exact-fp32 MFMA form of the attention MLP / first GRU / plain GEMMs /
+ *                   category self-attention in fp16x2 mode
+ *   NO_DENSE_CHAIN  dense tower as two GEMM launches instead of one chained launch (=)
+ *   NO_HEAD_TABLES  head GEMM over all 3456 inputs instead of the per-category-slot tables
+ *   NO_HEAD_FUSED   k_head_finish as its own launch instead of the table sums inside k_cat_attn */
+enum {
+    RL4RS_DIEN_OPT_AUGRU_H16 = 1 << 0,
+    RL4RS_DIEN_OPT_AUGRU_ROWS32 = 1 << 1,
+    RL4RS_DIEN_OPT_AUGRU_ROWS64 = 1 << 2,
+    RL4RS_DIEN_OPT_DIN_V1 = 1 << 3,
+    RL4RS_DIEN_OPT_NO_DIN16 = 1 << 4,
+    RL4RS_DIEN_OPT_NO_GRU16 = 1 << 5,
+    RL4RS_DIEN_OPT_NO_GEMM16 = 1 << 6,
+    RL4RS_DIEN_OPT_NO_CAT16 = 1 << 7,
+    RL4RS_DIEN_OPT_NO_DENSE_CHAIN = 1 << 8,
+    RL4RS_DIEN_OPT_NO_HEAD_TABLES = 1 << 9,
+    RL4RS_DIEN_OPT_NO_HEAD_FUSED = 1 << 10,
+    RL4RS_DIEN_OPT_ALL = (1 << 11) - 1
+};
 
 /* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):
  *   FP32   v_mfma_f32_32x32x2_f32, operands exact.
  *   FP16X2 operands split into fp16 hi + lo, 3 v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi):
  *          ~2^-22 relative error per product, 2.3x faster.  Needs every AUGRU weight |w| < 6e4 (fp16 range).
- *   AUTO   environment RL4RS_SCORER=fp32|fp16x2 if set, else FP16X2 when the weights allow it, else FP32. */
+ *   AUTO   FP16X2 when the weights allow it, else FP32. */
 enum { RL4RS_SCORER_AUTO = 0, RL4RS_SCORER_FP32 = 1, RL4RS_SCORER_FP16X2 = 2 };
 
 /* Host pointers to float32 arrays, shapes in rl4rs_amd/nets/dien.py (dien_spec). seq arrays have
@@ -241,12 +275,18 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, vo
 int rl4rs_dien_destroy(rl4rs_dien* net);
 /* The mode the handle resolved to (RL4RS_SCORER_FP32 or RL4RS_SCORER_FP16X2). */
 int rl4rs_dien_scorer_mode(rl4rs_dien* net, int32_t* mode);
+/* Row-tile form of k_augru_x for the following forwards of this handle: 0 automatic, 32, 64 (the AUGRU_ROWS* options above,
+ * switchable on a live handle so that one cache can be scored by both forms). */
+int rl4rs_dien_set_augru_rows(rl4rs_dien* net, int32_t rows);
 /* Status bits since the last call (synchronises `stream`, then clears them).  RL4RS_DIEN_STATUS_FP16_RANGE: in
  * FP16X2 mode a recurrent state left the fp16 range (|h| >= 6e4, or NaN) - possible only when the attention scores
  * push the update gate outside [0, 1] until the state diverges; results of the affected forwards are invalid, use
  * RL4RS_SCORER_FP32 for such a model. */
 enum { RL4RS_DIEN_STATUS_FP16_RANGE = 1 };
 int rl4rs_dien_status(rl4rs_dien* net, int32_t* flags, void* stream);
+/* The status word itself: device pointer to ONE int32 owned by the handle, != 0 <=> RL4RS_DIEN_STATUS_FP16_RANGE pending.  A
+ * caller that copies a record to the host every step anyway (rl4rs_env_step_record) reads it there. */
+int rl4rs_dien_status_word(rl4rs_dien* net, int32_t** word_dev);
 
 /* Encode `n` id sequences of sequence input `s` into cache slots [slot_base, slot_base+n):
  * embedding lookup + first GRU over all maxlen steps (utils.py:119-120) and the input-side
@@ -381,6 +421,36 @@ int rl4rs_env_step_discrete(rl4rs_stepper* s, const int32_t* actions_dev, float*
 int rl4rs_env_step_conti(rl4rs_stepper* s, const void* actions_dev, int is_f64, int32_t* chosen_dev, float* obs_dev,
                          double* reward_dev, uint8_t* done_dev, uint32_t* mask_bits_dev, void* stream);
 
+/* Reference-shaped form of the same transition (RecEnvBase.step hands lists / ndarrays to the caller, base.py:256-263,
+ * slate.py:244-279): every output a host-returning caller needs is written into ONE device record, host-visible part first,
+ * so the facade brings a whole transition back with a single device-to-host copy into pinned memory and ONE wait.
+ * `want` selects the optional parts; offsets are bytes from the start of the record, -1 = absent; all parts 64-byte aligned.
+ *   status          int32 [2]: [0] sticky bad-action flag of the env (RL4RS_BUF_ERROR_FLAG), [1] the scorer's fp16-range status
+ *                   (RL4RS_DIEN_STATUS_FP16_RANGE; read and cleared)
+ *   reward          float64 [B]                      done   uint8 [B]          chosen   int32 [B] item ids played
+ *   obs             float32 [B, obs_dim]             'simulator_obs'  (behind host_bytes when D3RL_OBS is wanted)
+ *   obs_d3rl        float64 [B, obs_dim + cols + 1]  support_d3rl_mask observation: obs | masked_actions | cur_steps
+ *                   (slate.py:270-277; cols = max_steps, or page_items for SeqSlate: seqslate.py:18-23)
+ *   mask_i64        int64 [B, action_size]           support_rllib_mask observation-side mask (slate.py:90-97)
+ *   mask_bits       uint32 [B, ceil(A/32)]           the same mask packed
+ *   click_p         float32 [B, n_complete]          simulator_info_fetch (slate.py:299-301); written on reward steps only
+ *   offline_action  int32 [B] (discrete) / float64 [B, action_emb_size] (continuous): the logged action of the NEXT step
+ *                   (slate.py:152-161); written while a next step exists
+ * host_bytes: length of the prefix a host caller copies; total_bytes: size of the record buffer to allocate. */
+enum {
+    RL4RS_STEP_WANT_MASK_I64 = 1, RL4RS_STEP_WANT_MASK_BITS = 2, RL4RS_STEP_WANT_D3RL_OBS = 4, RL4RS_STEP_WANT_CLICK_P = 8,
+    RL4RS_STEP_WANT_OFFLINE_ACTION = 16, RL4RS_STEP_WANT_ALL = 31
+};
+typedef struct rl4rs_step_record {
+    int64_t status, reward, done, chosen, obs, obs_d3rl, mask_i64, mask_bits, click_p, offline_action;
+    int64_t host_bytes, total_bytes;
+    int32_t obs_dim, d3rl_cols;
+} rl4rs_step_record;
+int rl4rs_stepper_record_layout(rl4rs_stepper* s, uint32_t want, int32_t conti, rl4rs_step_record* out);
+/* action_kind: 0 = int32 item ids [B]; 1 / 2 = float32 / float64 action embeddings [B, action_emb_size] (masked K-NN first) */
+int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size
  * logits, value head on the shared hidden layer, logits + max(log(action_mask), float32.min)).
@@ -456,6 +526,17 @@ int rl4rs_policy_status(rl4rs_policy* pol, int32_t* flags, void* stream);
  * persistent pass timed out.  A training loop copies it asynchronously together with its loss statistics and looks at it one
  * iteration later (rl4rs_amd/train.py), so that validating every pass costs no pipeline drain. */
 int rl4rs_policy_status_words(rl4rs_policy* pol, uint32_t** words_dev);
+/* Once a pass has timed out, rl4rs_policy_ppo_epoch / rl4rs_policy_ppo_minibatch_grad return RL4RS_ESTATE (nothing is
+ * launched, the Adam step counter does not advance) until rl4rs_policy_status has reported and cleared the condition: the
+ * kernel raises a pinned host word next to the device flag, which the launch path reads without synchronising.
+ *
+ * Kernel-path selection of ONE handle, for A/B measurements and tests (defaults in brackets):
+ *   TILE          [1] 0 = one-wave-per-sample forward / loss kernels instead of k_policy_tile
+ *   PPO_FUSED     [1] 0 = per-minibatch kernel chain instead of the persistent k_ppo_pass
+ *   PPO_ROWS      [8] samples per workgroup of k_ppo_pass: 8, 16 or 32
+ *   RESIDENT_WGS [-1] >= 0: pretend the device holds only this many workgroups of k_ppo_pass at once (co-residency tests) */
+enum { RL4RS_POLICY_OPT_TILE = 0, RL4RS_POLICY_OPT_PPO_FUSED = 1, RL4RS_POLICY_OPT_PPO_ROWS = 2, RL4RS_POLICY_OPT_RESIDENT_WGS = 3 };
+int rl4rs_policy_set_option(rl4rs_policy* pol, int32_t which, int32_t value);
 /* Adam state of the handle (first / second moments, device pointers owned by the handle; same layout as the
  * parameters) and its step counter: a data-parallel trainer broadcasts rank 0's at start, a checkpoint saves them. */
 int rl4rs_policy_adam_state(rl4rs_policy* pol, float** m_dev, float** v_dev, int64_t* step);

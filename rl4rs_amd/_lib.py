@@ -27,7 +27,15 @@ class EnvCfg(C.Structure):
 class DienCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num',
-        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots', 'scorer_mode')]
+        'category_hash_size', 'seq_num', 'class_num', 'max_rows', 'max_slots', 'scorer_mode')] + [('kernel_opts', C.c_uint32)]
+
+
+# include/rl4rs_hip.h RL4RS_DIEN_OPT_*: kernel-path selection of one scorer handle (config['scorer_kernels'])
+DIEN_OPTS = {'augru_h16': 1 << 0, 'augru_rows32': 1 << 1, 'augru_rows64': 1 << 2, 'din_v1': 1 << 3, 'no_din16': 1 << 4,
+             'no_gru16': 1 << 5, 'no_gemm16': 1 << 6, 'no_cat16': 1 << 7, 'no_dense_chain': 1 << 8, 'no_head_tables': 1 << 9,
+             'no_head_fused': 1 << 10}
+POLICY_OPTS = {'tile': 0, 'ppo_fused': 1, 'ppo_rows': 2, 'resident_wgs': 3}          # RL4RS_POLICY_OPT_*
+ENV_OPTS = {'rows_variant': 0}                                                       # RL4RS_ENV_OPT_*
 
 
 _FP = C.POINTER(C.c_float)
@@ -78,6 +86,14 @@ class RawPolicyWeights(C.Structure):
     _fields_ = [(n, _FP) for n in ('cat_emb', 'seq_emb', 'dense_w1', 'dense_b1', 'dense_w2', 'dense_b2', 'ctx_w', 'ctx_b',
                                    'out_w', 'out_b', 'value_w', 'value_b')]
 
+
+class StepRecord(C.Structure):
+    """rl4rs_step_record: byte offsets of the parts of a transition record (-1 = absent)."""
+    _fields_ = [(n, C.c_int64) for n in ('status', 'reward', 'done', 'chosen', 'obs', 'obs_d3rl', 'mask_i64', 'mask_bits', 'click_p',
+                                         'offline_action', 'host_bytes', 'total_bytes')] + [('obs_dim', C.c_int32), ('d3rl_cols', C.c_int32)]
+
+
+STEP_WANT = {'mask_i64': 1, 'mask_bits': 2, 'd3rl_obs': 4, 'click_p': 8, 'offline_action': 16}      # RL4RS_STEP_WANT_*
 
 _lib = None
 
@@ -170,6 +186,12 @@ SIGNATURES = {
     'rl4rs_rawtrain_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_policy_ppo_epoch': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_float] * 10 + [_P, _P, _P]),
     'rl4rs_dien_set_row_order': (_I, [_P, _P, _I32]),
+    'rl4rs_dien_set_augru_rows': (_I, [_P, _I32]),
+    'rl4rs_dien_status_word': (_I, [_P, C.POINTER(_P)]),
+    'rl4rs_stepper_record_layout': (_I, [_P, C.c_uint32, _I32, C.POINTER(StepRecord)]),
+    'rl4rs_env_step_record': (_I, [_P, _P, _I32, C.c_uint32, _P, _P]),
+    'rl4rs_env_set_option': (_I, [_P, _I32, _I32]),
+    'rl4rs_policy_set_option': (_I, [_P, _I32, _I32]),
     'rl4rs_env_get_cfg': (_I, [_P, _P]),
     'rl4rs_env_attach_scorer': (_I, [_P, _P, _P, _I32, _P]),
     'rl4rs_env_attach_simnet': (_I, [_P, _P, _P, _I32, _P]),

@@ -1277,7 +1277,8 @@ struct rl4rs_dien {
     float* gru_wc16[4];
     bool gru16, gru16_attr;
     bool fp16x2;
-    bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_AUGRU=h16)
+    bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_DIEN_OPT_AUGRU_H16)
+    int augru_rows;        // k_augru_x row-tile form: 0 automatic, 32, 64 (rl4rs_dien_set_augru_rows)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
@@ -1420,15 +1421,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             }
         }
         const bool fits = finite && wmax < 6.0e4f;
-        if (mode == RL4RS_SCORER_AUTO) {
-            const char* sp = getenv("RL4RS_SCORER");
-            if (sp && strcmp(sp, "fp32") == 0) mode = RL4RS_SCORER_FP32;
-            else if (sp && strcmp(sp, "fp16x2") == 0) mode = RL4RS_SCORER_FP16X2;
-            else {
-                RL4RS_REQUIRE(!(sp && *sp), "dien: RL4RS_SCORER must be fp32 or fp16x2 (got '%s')", sp);
-                mode = fits ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
-            }
-        }
+        if (mode == RL4RS_SCORER_AUTO) mode = fits ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
         RL4RS_REQUIRE(mode != RL4RS_SCORER_FP16X2 || fits,
                       "dien: the fp16x2 scorer needs finite AUGRU weights with |w| < 6e4 (max |w| = %g); use fp32", (double)wmax);
         want_fp16x2 = mode == RL4RS_SCORER_FP16X2;
@@ -1451,12 +1444,19 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->fp16x2 = want_fp16x2;
     n->row_order = nullptr;
     n->row_order_n = 0;
-    n->augru_x = !(getenv("RL4RS_AUGRU") && strcmp(getenv("RL4RS_AUGRU"), "h16") == 0);
+    // kernel-path selection: fields of the configuration (RL4RS_DIEN_OPT_*), never the process environment - a test or an A/B
+    // run holds handles with different paths side by side
+    const uint32_t opts = c->kernel_opts;
+    RL4RS_REQUIRE((opts & ~(uint32_t)RL4RS_DIEN_OPT_ALL) == 0, "dien: unknown kernel_opts bits 0x%x", opts & ~(uint32_t)RL4RS_DIEN_OPT_ALL);
+    RL4RS_REQUIRE(!((opts & RL4RS_DIEN_OPT_AUGRU_ROWS32) && (opts & RL4RS_DIEN_OPT_AUGRU_ROWS64)),
+                  "dien: kernel_opts asks for both the 32-row and the 64-row AUGRU form");
+    n->augru_x = !(opts & RL4RS_DIEN_OPT_AUGRU_H16);
+    n->augru_rows = (opts & RL4RS_DIEN_OPT_AUGRU_ROWS32) ? 32 : ((opts & RL4RS_DIEN_OPT_AUGRU_ROWS64) ? 64 : 0);
     n->din16 = false;
-    n->din_x = !(getenv("RL4RS_DIN") && strcmp(getenv("RL4RS_DIN"), "v1") == 0);
+    n->din_x = !(opts & RL4RS_DIEN_OPT_DIN_V1);
     n->gemm16 = false;
     n->cat16 = false;
-    n->dense_chain = !(getenv("RL4RS_DENSE_FUSED") && atoi(getenv("RL4RS_DENSE_FUSED")) == 0);
+    n->dense_chain = !(opts & RL4RS_DIEN_OPT_NO_DENSE_CHAIN);
     n->gru16 = false;
     n->gru16_attr = false;
     if (want_fp16x2) {      // the DIN layer-1 split needs |q * h1| <= max |seq_emb| and the q*k rows of att_w1 inside fp16 range
@@ -1476,7 +1476,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 const float v = fabsf(w->att_w2[s][i]);
                 fin = fin && v == v; mx = fmaxf(mx, v);
             }
-        n->din16 = fin && mx < 6.0e4f && !(getenv("RL4RS_DIN16") && atoi(getenv("RL4RS_DIN16")) == 0);
+        n->din16 = fin && mx < 6.0e4f && !(opts & RL4RS_DIEN_OPT_NO_DIN16);
         // the first GRU in the same split form: E = 128 only, h-side weights inside fp16 range
         float gmx = 0.f;
         bool gfin = true;
@@ -1490,7 +1490,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 gfin = gfin && v == v; gmx = fmaxf(gmx, v);
             }
         }
-        n->gru16 = c->emb_size == 128 && gfin && gmx < 6.0e4f && !(getenv("RL4RS_GRU16") && atoi(getenv("RL4RS_GRU16")) == 0);
+        n->gru16 = c->emb_size == 128 && gfin && gmx < 6.0e4f && !(opts & RL4RS_DIEN_OPT_NO_GRU16);
         // the plain GEMMs in the same split form: every weight they use finite and well inside the fp16 range (sums /
         // differences of two att_w1 entries are formed at load: 3e4).  Activations are split on the fly; one that leaves the
         // range turns its output row into NaN (gemm.hip).
@@ -1506,10 +1506,10 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             chk(w->augru_gate_w[s], (size_t)c->emb_size * 4 * c->emb_size);
             chk(w->augru_cand_w[s], (size_t)c->emb_size * 2 * c->emb_size);
         }
-        n->gemm16 = wfin && !(getenv("RL4RS_GEMM16") && atoi(getenv("RL4RS_GEMM16")) == 0);
+        n->gemm16 = wfin && !(opts & RL4RS_DIEN_OPT_NO_GEMM16);
         bool cfin = true;
         for (size_t i = 0; i < (size_t)c->category_hash_size * c->emb_size; ++i) cfin = cfin && fabsf(w->cat_emb[i]) < 6.0e4f;
-        n->cat16 = cfin && !(getenv("RL4RS_CAT16") && atoi(getenv("RL4RS_CAT16")) == 0);
+        n->cat16 = cfin && !(opts & RL4RS_DIEN_OPT_NO_CAT16);
     }
     {
         float* f = nullptr;
@@ -1540,10 +1540,9 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     UP(dense_b1, w->dense_b1, U);
     { auto pk = pack_w(w->dense_w2, U, U, U); keep.push_back(std::move(pk)); UP(dense_w2, keep.back().data(), keep.back().size()); }
     UP(dense_b2, w->dense_b2, U);
-    // head: table form unless disabled (RL4RS_HEAD_TABLES=0) or the tables would not fit a sane budget (8 GB)
+    // head: table form unless disabled (RL4RS_DIEN_OPT_NO_HEAD_TABLES) or the tables would not fit a sane budget (8 GB)
     const int Kh = S * NH2 + U + E;                       // [sequence finals | dense | pooled attention]
-    const char* ht = getenv("RL4RS_HEAD_TABLES");
-    const bool use_tables = !(ht && atoi(ht) == 0) && ((int64_t)Cn * H * OBS_DIM * 4 <= ((int64_t)8 << 30));
+    const bool use_tables = !(opts & RL4RS_DIEN_OPT_NO_HEAD_TABLES) && ((int64_t)Cn * H * OBS_DIM * 4 <= ((int64_t)8 << 30));
     n->ptab = nullptr;
     { auto pk = pack_w(w->obs_w, OBS_DIM, use_tables ? Kh : F, OBS_DIM); keep.push_back(std::move(pk)); UP(obs_w, keep.back().data(), keep.back().size()); }
     if (use_tables) {
@@ -1644,7 +1643,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     AL(scores, (size_t)S * c->max_rows * L);
     AL(obs_tmp, (size_t)c->max_rows * OBS_DIM);
     n->tsum = nullptr;
-    if (n->ptab && Cn <= 24 && !(getenv("RL4RS_HEAD_FUSED") && atoi(getenv("RL4RS_HEAD_FUSED")) == 0)) AL(tsum, (size_t)c->max_rows * OBS_DIM);
+    if (n->ptab && Cn <= 24 && !(opts & RL4RS_DIEN_OPT_NO_HEAD_FUSED)) AL(tsum, (size_t)c->max_rows * OBS_DIM);
 #undef UP
 #undef AL
     // LDS opt-in above the 64 KB default where needed
@@ -1810,7 +1809,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
             a.order = (n->augru_x && n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
-            { static const int dbg_steps = getenv("RL4RS_AUGRU_STEPS") ? atoi(getenv("RL4RS_AUGRU_STEPS")) : 0; a.steps = dbg_steps; }
+            a.steps = 0;
 #if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)
             static unsigned long long* trace_buf = nullptr;
             if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 8 * 4 * 8 * 8); (void)hipMemset(trace_buf, 0, 8 * 4 * 8 * 8); }
@@ -1825,8 +1824,9 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
 #endif
             // 64-row workgroups when the rows come in whole groups of 8 per cache slot (the reward forward) and there are enough
             // of them to keep every CU busy; 32-row workgroups otherwise (obs-sized launches: one 32-row tile per CU)
-            static const int x_mt = getenv("RL4RS_X_MT") ? atoi(getenv("RL4RS_X_MT")) : 0;
-            const bool mt2 = x_mt != 1 && group % 8 == 0 && R % 64 == 0 && (x_mt == 2 || (int64_t)(R / 64) * S >= 2 * (int64_t)n->n_cu);
+            // (n->augru_rows = 32 / 64 pins the form: rl4rs_dien_cfg.kernel_opts, rl4rs_dien_set_augru_rows)
+            const bool mt2 = n->augru_rows != 32 && group % 8 == 0 && R % 64 == 0 &&
+                             (n->augru_rows == 64 || (int64_t)(R / 64) * S >= 2 * (int64_t)n->n_cu);
             if (n->augru_x && mt2)
                 hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), dim3(R / 64, S), block, augru_x_smem(2), st, a);
             else if (n->augru_x)
@@ -1913,6 +1913,15 @@ int rl4rs_dien_set_row_order(rl4rs_dien* n, const int32_t* order_dev, int32_t n_
     return RL4RS_OK;
 }
 
+// Row-tile form of k_augru_x for the following forwards: 0 = automatic (64-row workgroups for reward-sized launches, see
+// rl4rs_dien_forward), 32 = always 32-row workgroups, 64 = 64-row workgroups whenever the launch shape admits them (rows in
+// whole groups of 8 per cache slot, R % 64 == 0).  Both forms run the same MFMA sequence per row: results are bit-identical.
+int rl4rs_dien_set_augru_rows(rl4rs_dien* n, int32_t rows) {
+    RL4RS_REQUIRE(n && (rows == 0 || rows == 32 || rows == 64), "dien_set_augru_rows: rows must be 0, 32 or 64");
+    n->augru_rows = rows;
+    return RL4RS_OK;
+}
+
 int rl4rs_dien_set_profiling(rl4rs_dien* n, int enable) {
     RL4RS_REQUIRE(n, "dien_set_profiling: null handle");
     n->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
@@ -1932,6 +1941,13 @@ int rl4rs_dien_status(rl4rs_dien* n, int32_t* flags, void* stream) {
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     if (v) RL4RS_HIP_TRY(hipMemsetAsync(n->range_flag, 0, 4, st));
     *flags = v ? RL4RS_DIEN_STATUS_FP16_RANGE : 0;
+    return RL4RS_OK;
+}
+// The status word itself (device pointer owned by the handle, != 0 <=> RL4RS_DIEN_STATUS_FP16_RANGE pending): a caller that
+// already copies a record to the host every step reads it there instead of paying rl4rs_dien_status's synchronisation.
+int rl4rs_dien_status_word(rl4rs_dien* n, int32_t** word_dev) {
+    RL4RS_REQUIRE(n && word_dev, "dien_status_word: null argument");
+    *word_dev = n->range_flag;
     return RL4RS_OK;
 }
 int rl4rs_dien_kernel_count(void) { return KID_COUNT; }

@@ -498,6 +498,7 @@ struct rl4rs_env {
     int cur_steps;
     int n_complete;
     bool catalog_set, batch_set;
+    int rows_variant;          // rl4rs_env_set_option(RL4RS_ENV_OPT_ROWS_VARIANT)
     // owned device memory
     float* item_vec; double* price; double* action_emb; uint32_t* special_bits; uint32_t* loc_bits;
     uint8_t* is_special;
@@ -506,14 +507,6 @@ struct rl4rs_env {
     float* c_dense; int32_t* c_cat; int32_t* err; int32_t* knn_tmp;
 };
 
-static int g_rows_variant = -1;     // RL4RS_ENV_ROWS_VARIANT: 0 = LDS-staged catalogue (default), 1 = catalogue via L1/L2
-static int rows_variant() {
-    if (g_rows_variant < 0) {
-        const char* v = getenv("RL4RS_ENV_ROWS_VARIANT");
-        g_rows_variant = v ? atoi(v) : 0;
-    }
-    return g_rows_variant;
-}
 static size_t rows_smem(const rl4rs_env* e, int waves, bool lds) {
     return (lds ? (((size_t)e->d.A * e->d.D * 4 + 15) & ~size_t(15)) : 0) + (size_t)waves * e->d.T * 4;
 }
@@ -528,7 +521,7 @@ static int check_rows_smem(const rl4rs_env* e) {
 struct RowsLaunch { int grid, threads; size_t smem; bool lds; };
 static RowsLaunch rows_launch(const rl4rs_env* e, int R, int mode) {
     RowsLaunch L;
-    L.lds = (rows_variant() == 0) && mode != 0;
+    L.lds = (e->rows_variant == 0) && mode != 0;    // RL4RS_ENV_OPT_ROWS_VARIANT: 0 = LDS-staged catalogue (default), 1 = catalogue via L1/L2
     int waves = 16;
     if (R < 256 * 16) waves = 4;                 // small batches: more, smaller workgroups
     int grid = (R + waves - 1) / waves;
@@ -627,6 +620,19 @@ int rl4rs_env_create(const rl4rs_env_cfg* c, rl4rs_env** out) {
     d.prev = e->prev; d.amask = e->amask; d.smask = e->smask; d.dense = e->dense; d.cat = e->cat;
     d.seq1 = e->seq1; d.c_dense = e->c_dense; d.c_cat = e->c_cat; d.err = e->err;
     *out = e;
+    return RL4RS_OK;
+}
+
+// Kernel-path selection of one env handle (A/B measurements): RL4RS_ENV_OPT_ROWS_VARIANT 0 = the row kernels stage the catalogue
+// in LDS (default), 1 = they read it through L1 / L2.  Same rows either way.
+int rl4rs_env_set_option(rl4rs_env* e, int32_t which, int32_t value) {
+    RL4RS_REQUIRE(e, "env_set_option: null handle");
+    switch (which) {
+        case RL4RS_ENV_OPT_ROWS_VARIANT:
+            RL4RS_REQUIRE(value == 0 || value == 1, "env_set_option: ROWS_VARIANT must be 0 or 1 (got %d)", value);
+            e->rows_variant = value; break;
+        default: set_error("env_set_option: unknown option %d", which); return RL4RS_EINVAL;
+    }
     return RL4RS_OK;
 }
 

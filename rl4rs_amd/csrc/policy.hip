@@ -516,6 +516,7 @@ struct PassArgs {
     float4* terms;
     float* grad;
     unsigned* bar;
+    unsigned* dead_host;     // pinned host word raised next to bar[1]: the host sees a timeout without synchronising
     float lr, b1, b2, eps;
     long long t0;
     int mb_begin, mb_end;    // minibatches [mb_begin, mb_end) of the pass
@@ -536,7 +537,7 @@ struct PassArgs {
 // then plain loads.
 // Returns false once any workgroup has given up (bar[1] != 0): the caller then stops touching the parameters, so a pass whose
 // workgroups were not co-resident leaves them at the last consistent minibatch instead of running racy updates.
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned nwg, unsigned& gen) {
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen) {
     __shared__ unsigned s_dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -552,8 +553,10 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned nwg, unsign
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
                __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21))     // ~1 us per poll: gives up after a few seconds
+            if (++spins > (1u << 21)) {   // ~1 us per poll: gives up after a few seconds
                 __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dead_host) __hip_atomic_store(dead_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         s_dead = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         const int j = i / AE, c = i - j * AE;
         a.w2t[(size_t)c * HID + j] = W2[i];
     }
-    if (!grid_barrier(a.bar, gridDim.x, gen)) return;
+    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
     for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
         const size_t lo = (size_t)mb * MB;
         // ------------------------------------------------------------------ phase A
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             a.dHpre[(size_t)(r0 + r) * HID + j] = s * (1.f - h * h);
         }
         RL4RS_PT(5);
-        if (!grid_barrier(a.bar, gridDim.x, gen)) return;
+        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
         RL4RS_PT(6);
         // ------------------------------------------------------------------ phase B
         // One task = one 32x32 gradient tile (or 32 bias columns) + the Adam update of its parameters, done by a GROUP of 4
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             }
         }
         RL4RS_PT(7);
-        if (!grid_barrier(a.bar, gridDim.x, gen)) return;
+        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
         RL4RS_PT(8);
     }
 }
@@ -1045,9 +1048,13 @@ struct rl4rs_policy {
     float *H, *dOut, *dHpre, *part, *sumsq, *w2t;
     float4* terms;
     unsigned* bar;
+    unsigned* dead_host;       // pinned host mirror of bar[1] (a persistent pass gave up): read before every pass launch, no sync
     int64_t adam_t;
-    bool train_attr, pass_attr, pass_launched, tile_attr[3];
+    bool train_attr, pass_launched, tile_attr[3];
     int pass_resident_wgs;     // workgroups of k_ppo_pass the device can hold at once (-1 = not queried yet)
+    // rl4rs_policy_set_option (include/rl4rs_hip.h RL4RS_POLICY_OPT_*): kernel-path selection for A/B runs and tests
+    bool opt_tile, opt_ppo_fused;
+    int opt_ppo_rows, opt_resident_cap;
     std::vector<void*> owned;
 };
 
@@ -1073,9 +1080,10 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->nz = (max_rows + p->chunk - 1) / p->chunk;
     p->adam_t = 0;
     p->train_attr = false;
-    p->pass_attr = false;
     p->pass_launched = false;
     p->pass_resident_wgs = -1;
+    p->opt_tile = true; p->opt_ppo_fused = true; p->opt_ppo_rows = 8; p->opt_resident_cap = -1;
+    p->dead_host = nullptr;
     p->tile_attr[0] = p->tile_attr[1] = p->tile_attr[2] = false;
     int rc;
     auto alloc = [&](float** dst, size_t n) {
@@ -1102,6 +1110,8 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_m, 0, (size_t)p->n_params * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_v, 0, (size_t)p->n_params * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 16, st));
+    RL4RS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->dead_host), 64, hipHostMallocDefault));
+    *p->dead_host = 0u;
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     *out = p;
     return RL4RS_OK;
@@ -1110,6 +1120,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
 int rl4rs_policy_destroy(rl4rs_policy* p) {
     if (!p) return RL4RS_OK;
     for (void* q : p->owned) (void)hipFree(q);
+    if (p->dead_host) (void)hipHostFree(p->dead_host);
     delete p;
     return RL4RS_OK;
 }
@@ -1141,11 +1152,11 @@ static size_t fwd_smem(const PolDims& d, int extra) { return (size_t)4 * (d.OD +
 
 namespace {
 
-// does k_policy_tile's tiling fit this policy?  (RL4RS_POLICY_TILE=0 keeps the one-wave-per-sample kernels: A/B measurements)
-bool tile_fits(const PolDims& d) {
-    static const bool off = getenv("RL4RS_POLICY_TILE") && atoi(getenv("RL4RS_POLICY_TILE")) == 0;
+// does k_policy_tile's tiling fit this policy?  (RL4RS_POLICY_OPT_TILE = 0 keeps the one-wave-per-sample kernels: A/B measurements)
+bool tile_fits(const rl4rs_policy* p) {
+    const PolDims& d = p->d;
     const int NT1 = d.HID / 32;
-    return !off && d.HID % 64 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) && d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0;
+    return p->opt_tile && d.HID % 64 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) && d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0;
 }
 size_t tile_smem(const PolDims& d, int mode) {
     return (size_t)(8 * ((d.OD | 1) + (d.HID | 1) + (mode == 2 ? 2 : 1) * (d.AE | 1) + d.W) + 8 * 1024) * 4;
@@ -1171,7 +1182,7 @@ int rl4rs_policy_act(rl4rs_policy* p, int32_t N, const float* obs, const uint32_
                      uint32_t step, int32_t* actions, float* logp, float* value, float* entropy, float* logits,
                      void* stream) {
     RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_act: bad argument");
-    if (tile_fits(p->d)) {
+    if (tile_fits(p)) {
         TileArgs a;
         memset(&a, 0, sizeof(a));
         a.d = p->d; a.N = N; a.prm = p->params; a.obs = obs; a.mask = mask_bits; a.seed = seed; a.step = step;
@@ -1188,7 +1199,7 @@ int rl4rs_policy_evaluate(rl4rs_policy* p, int32_t N, const float* obs, const ui
                           const int32_t* actions, float* logp, float* value, float* entropy, float* logits,
                           void* stream) {
     RL4RS_REQUIRE(p && obs && actions && N > 0, "policy_evaluate: bad argument");
-    if (tile_fits(p->d)) {
+    if (tile_fits(p)) {
         TileArgs a;
         memset(&a, 0, sizeof(a));
         a.d = p->d; a.N = N; a.prm = p->params; a.obs = obs; a.mask = mask_bits;
@@ -1217,7 +1228,7 @@ int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float
     L.actions = actions; L.adv = adv; L.ret = ret; L.old_logp = old_logp; L.old_value = old_value; L.old_logits = old_logits;
     const size_t w2_bytes = (size_t)d.HID * d.AE * 4;
     const int stage_w2 = (fwd_smem(d, d.AE) + w2_bytes <= (size_t)150 * 1024) ? 1 : 0;
-    const bool tiled = tile_fits(d);
+    const bool tiled = tile_fits(p);
     if (tiled) {
         hipLaunchKernelGGL(k_w2_transpose, dim3((d.HID * d.AE + 255) / 256), dim3(256), 0, st, p->params + (size_t)d.OD * d.HID + d.HID,
                            d.HID, d.AE, p->w2t);
@@ -1437,11 +1448,26 @@ struct PpoCall {
 
 size_t pass_smem_bytes(const PolDims& d) { return (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5 + d.W) * 4; }
 
-int pass_rows_per_wg() {
+int pass_rows_per_wg(const rl4rs_policy* p) {
     // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
     // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
-    static const int rows_env = getenv("RL4RS_PPO_ROWS") ? atoi(getenv("RL4RS_PPO_ROWS")) : 8;
-    return (rows_env == 32 || rows_env == 16) ? rows_env : 8;
+    // (RL4RS_POLICY_OPT_PPO_ROWS = 16 / 32 for A/B runs)
+    return (p->opt_ppo_rows == 32 || p->opt_ppo_rows == 16) ? p->opt_ppo_rows : 8;
+}
+
+// k_ppo_pass's dynamic-LDS opt-in is a property of the FUNCTION, not of a handle: raised once per process to the most any
+// policy shape may ask for (160 KB minus the kernel's few bytes of static LDS), never lowered - two handles of different
+// shapes cannot undercut each other.  Residency is still computed per handle with that handle's real LDS size.
+constexpr size_t PASS_SMEM_MAX = (size_t)160 * 1024 - 64;
+bool pass_opt_in() {
+    static const bool ok = [] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
+            (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
+            return false;
+        }
+        return true;
+    }();
+    return ok;
 }
 
 // Does the persistent pass fit this policy / minibatch, and can its whole grid be resident at once?  The software grid barrier
@@ -1451,21 +1477,11 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
     const PolDims& d = p->d;
     const int NT1 = d.HID / 32;
     const size_t smem = pass_smem_bytes(d);
-    static const bool no_fused = getenv("RL4RS_PPO_FUSED") && atoi(getenv("RL4RS_PPO_FUSED")) == 0;     // A/B measurements
-    const int rows = pass_rows_per_wg();
-    const bool shape_ok = !no_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
+    const int rows = pass_rows_per_wg(p);
+    const bool shape_ok = p->opt_ppo_fused && grad_clip <= 0.f && d.HID % 32 == 0 && (NT1 == 1 || NT1 == 2 || NT1 == 4 || NT1 == 8) &&
                           d.OD % 32 == 0 && (d.OD / (8 / NT1)) % 64 == 0 && d.HID % 64 == 0 && minibatch % 128 == 0 && minibatch / rows <= 128 &&
-                          (size_t)32 * (d.OD | 1) >= 8192 && (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && smem <= (size_t)160 * 1024;
-    if (!shape_ok) return false;
-    if (!p->pass_attr) {
-        // the kernel also has a few bytes of static LDS (the barrier's give-up flag): opt in to exactly what this shape needs
-        if (smem + 64 > (size_t)160 * 1024 ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-            (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
-            return false;
-        }
-        p->pass_attr = true;
-    }
+                          (size_t)32 * (d.OD | 1) >= 8192 && (size_t)(8 / NT1) * NT1 * 1024 <= (size_t)32 * (d.AE | 1) && smem <= PASS_SMEM_MAX;
+    if (!shape_ok || !pass_opt_in()) return false;
     if (p->pass_resident_wgs < 0) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
@@ -1481,8 +1497,7 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
         }
         if (per_cu > by_lds) per_cu = by_lds;
         p->pass_resident_wgs = per_cu * cus;
-        static const char* cap = getenv("RL4RS_PPO_RESIDENT_WGS");       // tests: pretend a smaller device
-        if (cap) p->pass_resident_wgs = atoi(cap);
+        if (p->opt_resident_cap >= 0) p->pass_resident_wgs = p->opt_resident_cap;      // tests: pretend a smaller device
     }
     return minibatch / rows <= p->pass_resident_wgs;
 }
@@ -1493,13 +1508,13 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
     PassArgs a;
     memset(&a, 0, sizeof(a));
     a.d = d; a.N = c.N; a.MB = c.minibatch;
-    a.rows = pass_rows_per_wg();
+    a.rows = pass_rows_per_wg(p);
     a.prm = p->params; a.am = p->adam_m; a.av = p->adam_v; a.w2t = p->w2t;
     a.obs = c.obs; a.mask = c.mask_bits;
     a.L.algo = 1; a.L.vf_coeff = c.vf_coeff; a.L.ent_coeff = c.ent_coeff; a.L.clip = c.clip; a.L.vf_clip = c.vf_clip; a.L.kl_coeff = c.kl_coeff;
     a.L.scale = 1.0f / (float)c.minibatch;
     a.L.actions = c.actions; a.L.adv = c.adv; a.L.ret = c.ret; a.L.old_logp = c.old_logp; a.L.old_value = c.old_value; a.L.old_logits = c.old_logits;
-    a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms; a.grad = grad_dev; a.bar = p->bar;
+    a.H = p->H; a.dOut = p->dOut; a.dHpre = p->dHpre; a.terms = p->terms; a.grad = grad_dev; a.bar = p->bar; a.dead_host = p->dead_host;
     a.lr = c.lr; a.b1 = c.beta1; a.b2 = c.beta2; a.eps = c.eps; a.t0 = p->adam_t;
     a.mb_begin = mb_begin; a.mb_end = mb_end; a.apply = apply;
     a.trace = nullptr;
@@ -1508,7 +1523,15 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
     if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 16 * 8);
     a.trace = trace_buf;
 #endif
-    // bar[0] = arrival counter (reset per launch), bar[1] = sticky "a grid barrier timed out" flag (rl4rs_policy_status)
+    // bar[0] = arrival counter (reset per launch), bar[1] = sticky "a grid barrier timed out" flag (rl4rs_policy_status).
+    // A pass that finds bar[1] set leaves at its first grid barrier without updating anything, so launching another one would
+    // hand back stale gradients / statistics as if it had run: the pinned mirror of the flag is looked at first (a plain host
+    // load, no synchronisation) and the call fails until rl4rs_policy_status has reported and cleared the condition.
+    if (p->dead_host && *reinterpret_cast<volatile unsigned*>(p->dead_host) != 0u) {
+        set_error("policy: an earlier persistent PPO pass timed out at a grid barrier (its workgroups were not co-resident); no update was "
+                  "made - call rl4rs_policy_status to acknowledge, then use RL4RS_POLICY_OPT_PPO_FUSED = 0 (per-minibatch kernels)");
+        return RL4RS_ESTATE;
+    }
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
     hipLaunchKernelGGL(k_ppo_pass, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
     RL4RS_LAUNCH_CHECK();
@@ -1631,7 +1654,23 @@ int rl4rs_policy_status(rl4rs_policy* p, int32_t* flags, void* stream) {
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     if (v[1]) {
         RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 8, st));
+        if (p->dead_host) *reinterpret_cast<volatile unsigned*>(p->dead_host) = 0u;
         *flags = RL4RS_POLICY_STATUS_PASS_TIMEOUT;
+    }
+    return RL4RS_OK;
+}
+
+// Kernel-path selection of one handle (RL4RS_POLICY_OPT_*): what used to be process-wide environment switches.
+int rl4rs_policy_set_option(rl4rs_policy* p, int32_t which, int32_t value) {
+    RL4RS_REQUIRE(p, "policy_set_option: null handle");
+    switch (which) {
+        case RL4RS_POLICY_OPT_TILE: p->opt_tile = value != 0; break;
+        case RL4RS_POLICY_OPT_PPO_FUSED: p->opt_ppo_fused = value != 0; break;
+        case RL4RS_POLICY_OPT_PPO_ROWS:
+            RL4RS_REQUIRE(value == 8 || value == 16 || value == 32, "policy_set_option: PPO_ROWS must be 8, 16 or 32 (got %d)", value);
+            p->opt_ppo_rows = value; p->pass_resident_wgs = -1; break;
+        case RL4RS_POLICY_OPT_RESIDENT_WGS: p->opt_resident_cap = value; p->pass_resident_wgs = -1; break;
+        default: set_error("policy_set_option: unknown option %d", which); return RL4RS_EINVAL;
     }
     return RL4RS_OK;
 }

@@ -82,6 +82,35 @@ int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint
     return RL4RS_OK;
 }
 
+// ---- record form: everything a host-returning caller needs from one transition, packed for ONE device-to-host copy
+
+// observation row of the d3rlpy mask mode (slate.py:270-277 / seqslate.py:18-23): float64 [obs (256) | masked_actions | cur_steps]
+__global__ void k_record_d3rl(const float* obs, int obs_dim, const int32_t* prev, int T, int c0, int ncols, int cur, double* out, int B) {
+    const int w = obs_dim + ncols + 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * w) return;
+    const int b = (int)(i / w), c = (int)(i - (int64_t)b * w);
+    double v;
+    if (c < obs_dim) v = (double)obs[(size_t)b * obs_dim + c];
+    else if (c < obs_dim + ncols) v = (double)prev[(size_t)b * T + c0 + (c - obs_dim)];
+    else v = (double)cur;
+    out[i] = v;
+}
+// click probabilities of an env's complete-state rows in slate order (simulator_info_fetch, slate.py:299-301)
+__global__ void k_record_click(const float* probs, const float* p_last, int m, float* out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (m + 1)) return;
+    const int b = i / (m + 1), j = i - b * (m + 1);
+    out[i] = j < m ? probs[(size_t)b * m + j] : p_last[b];
+}
+// status words: [0] the env's sticky bad-action flag, [1] the scorer's fp16-range flag (read AND cleared, like rl4rs_dien_status)
+__global__ void k_record_status(const int32_t* env_err, int32_t* range_flag, int32_t* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = env_err ? *env_err : 0;
+        out[1] = range_flag ? atomicExch(range_flag, 0) : 0;
+    }
+}
+
 int attach(rl4rs_env* env, rl4rs_dien* dien, rl4rs_simnet* simnet, const int32_t* slots_dev, int32_t seq_num, rl4rs_stepper** out) {
     RL4RS_REQUIRE(env && (dien || simnet) && slots_dev && out && seq_num >= 1 && seq_num <= 4, "env_attach_scorer: bad argument");
     rl4rs_stepper* s = new rl4rs_stepper();
@@ -144,6 +173,99 @@ int rl4rs_env_step_conti(rl4rs_stepper* s, const void* actions_dev, int is_f64, 
     int rc = rl4rs_env_act_conti(s->env, actions_dev, is_f64, chosen_dev, stream);
     if (rc) return rc;
     return after_act(s, cur, obs_dev, reward_dev, done_dev, mask_bits_dev, stream);
+}
+
+// ---- reference-shaped (host-returning) transition ---------------------------------------------------------------------
+// The same transition as rl4rs_env_step_discrete / _conti with every output written into ONE device record (byte offsets from
+// rl4rs_stepper_record_layout), host-visible part first: the caller brings the whole transition back with a single copy into
+// pinned memory and one wait, instead of one blocking copy per returned object (obs, reward, mask, flags ...).
+int rl4rs_stepper_record_layout(rl4rs_stepper* s, uint32_t want, int32_t conti, rl4rs_step_record* L) {
+    RL4RS_REQUIRE(s && L, "stepper_record_layout: null argument");
+    RL4RS_REQUIRE((want & ~(uint32_t)RL4RS_STEP_WANT_ALL) == 0, "stepper_record_layout: unknown want bits 0x%x", want);
+    RL4RS_REQUIRE(!((want & RL4RS_STEP_WANT_CLICK_P) && s->n_complete < 2), "stepper_record_layout: click_p needs n_complete >= 2");
+    const int64_t B = s->cfg.batch_size, A = s->cfg.action_size, W = (A + 31) / 32;
+    int32_t od32 = 256;
+    if (!s->dien) { int rc0 = rl4rs_simnet_obs_dim(s->simnet, &od32); if (rc0) return rc0; }
+    const int64_t OD = od32;
+    const int ncols = s->cfg.is_seq ? s->cfg.page_items : s->cfg.max_steps;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off = (off + bytes + 63) & ~(int64_t)63; return o; };
+    memset(L, 0xff, sizeof(*L));                                   // every offset -1 = absent
+    L->status = take(8);
+    L->reward = take(B * 8);
+    L->done = take(B);
+    L->chosen = take(B * 4);
+    const bool d3rl = (want & RL4RS_STEP_WANT_D3RL_OBS) != 0;
+    if (d3rl) L->obs_d3rl = take(B * (OD + ncols + 1) * 8); else L->obs = take(B * OD * 4);
+    if (want & RL4RS_STEP_WANT_MASK_I64) L->mask_i64 = take(B * A * 8);
+    if (want & RL4RS_STEP_WANT_MASK_BITS) L->mask_bits = take(B * W * 4);
+    if (want & RL4RS_STEP_WANT_CLICK_P) L->click_p = take(B * s->n_complete * 4);
+    if (want & RL4RS_STEP_WANT_OFFLINE_ACTION) L->offline_action = take(conti ? B * s->cfg.action_emb_size * 8 : B * 4);
+    L->host_bytes = off;
+    if (d3rl) L->obs = take(B * OD * 4);                           // float32 activations: device-side scratch only in this mode
+    L->total_bytes = off;
+    L->obs_dim = (int32_t)OD;
+    L->d3rl_cols = (int32_t)(OD + ncols + 1);
+    return RL4RS_OK;
+}
+
+int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev, void* stream) {
+    RL4RS_REQUIRE(s && actions_dev && record_dev, "env_step_record: null argument");
+    RL4RS_REQUIRE(action_kind >= 0 && action_kind <= 2, "env_step_record: action_kind must be 0 (int32 ids), 1 (float32) or 2 (float64 embeddings)");
+    rl4rs_step_record L;
+    int rc = rl4rs_stepper_record_layout(s, want, action_kind != 0, &L);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* R = reinterpret_cast<char*>(record_dev);
+    const int B = s->cfg.batch_size;
+    float* obs = reinterpret_cast<float*>(R + L.obs);
+    int32_t* chosen = reinterpret_cast<int32_t*>(R + L.chosen);
+    const int cur = rl4rs_env_cur_steps(s->env);
+    if (action_kind == 0) {
+        RL4RS_HIP_TRY(hipMemcpyAsync(chosen, actions_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+        rc = rl4rs_env_act_discrete(s->env, reinterpret_cast<const int32_t*>(actions_dev), stream);
+    } else {
+        rc = rl4rs_env_act_conti(s->env, actions_dev, action_kind == 2 ? 1 : 0, chosen, stream);
+    }
+    if (rc) return rc;
+    const int reward_step = rl4rs_env_is_reward_step(s->env);
+    if ((rc = after_act(s, cur, obs, reinterpret_cast<double*>(R + L.reward), reinterpret_cast<uint8_t*>(R + L.done),
+                        L.mask_bits >= 0 ? reinterpret_cast<uint32_t*>(R + L.mask_bits) : nullptr, stream))) return rc;
+    if (L.mask_i64 >= 0 && (rc = rl4rs_env_obs_mask(s->env, R + L.mask_i64, 2, stream))) return rc;
+    if (L.obs_d3rl >= 0) {
+        // masked_actions: all of prev_actions (slate.py:100-104) or the current page's columns (seqslate.py:18-23), POST-act step counter
+        const int cur_after = cur + 1, T = s->cfg.max_steps, P = s->cfg.page_items;
+        int c0 = 0, ncols = T;
+        if (s->cfg.is_seq) {
+            const int page_init = cur_after / P * P, page_end = (page_init + P - 1 < T - 1) ? page_init + P - 1 : T - 1;
+            c0 = page_end + 1 - P; ncols = P;
+        }
+        void* pp; int64_t nb;
+        if ((rc = rl4rs_env_buffer(s->env, RL4RS_BUF_PREV_ACTIONS, &pp, &nb))) return rc;
+        const int64_t total = (int64_t)B * L.d3rl_cols;
+        hipLaunchKernelGGL(k_record_d3rl, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, L.obs_dim,
+                           reinterpret_cast<const int32_t*>(pp), T, c0, ncols, cur_after, reinterpret_cast<double*>(R + L.obs_d3rl), B);
+        RL4RS_LAUNCH_CHECK();
+    }
+    if (L.click_p >= 0 && reward_step == 1) {
+        const int m = s->n_complete - 1;
+        hipLaunchKernelGGL(k_record_click, dim3((B * (m + 1) + 255) / 256), dim3(256), 0, st, s->probs, s->p_last, m,
+                           reinterpret_cast<float*>(R + L.click_p), B);
+        RL4RS_LAUNCH_CHECK();
+    }
+    if (L.offline_action >= 0 && cur + 1 < s->cfg.max_steps) {
+        // the logged action of the NEXT step (slate.py:152-161), so a replay loop needs no extra device round trip for it
+        if ((rc = rl4rs_env_offline_action(s->env, action_kind == 0 ? reinterpret_cast<int32_t*>(R + L.offline_action) : nullptr,
+                                           action_kind != 0 ? reinterpret_cast<double*>(R + L.offline_action) : nullptr, stream))) return rc;
+    }
+    {
+        void* ep; int64_t nb; int32_t* rf = nullptr;
+        if ((rc = rl4rs_env_buffer(s->env, RL4RS_BUF_ERROR_FLAG, &ep, &nb))) return rc;
+        if (s->dien && (rc = rl4rs_dien_status_word(s->dien, &rf))) return rc;
+        hipLaunchKernelGGL(k_record_status, dim3(1), dim3(64), 0, st, reinterpret_cast<const int32_t*>(ep), rf, reinterpret_cast<int32_t*>(R + L.status));
+        RL4RS_LAUNCH_CHECK();
+    }
+    return RL4RS_OK;
 }
 
 }  // extern "C"

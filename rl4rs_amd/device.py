@@ -34,6 +34,27 @@ def _dev_tensor(x, dtype, device):
     return torch.from_numpy(np.ascontiguousarray(x)).to(device=device, dtype=dtype).contiguous()
 
 
+def to_device_async(x, dtype, device):
+    """Host data (list / ndarray / CPU tensor) -> device tensor of ``dtype`` through pinned memory, without draining the
+    queue (a pageable ``.to(device)`` blocks until every queued kernel has finished); device tensors pass through."""
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        return x.to(device=device, dtype=dtype).contiguous()
+    np_dtype = {torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64}[dtype]
+    h = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
+    h = torch.from_numpy(np.ascontiguousarray(np.asarray(h), dtype=np_dtype))
+    return h.pin_memory().to(device, non_blocking=True)
+
+
+def to_host(t):
+    """Device tensor -> numpy array through ONE pinned staging block of torch's caching host allocator (a pageable ``.cpu()``
+    goes through an internal bounce buffer at a fraction of the PCIe rate).  The array aliases the pinned block, which goes
+    back to the allocator's cache when the array is released."""
+    h = torch.empty(t.shape, dtype=t.dtype, device='cpu', pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy()
+
+
 class DeviceEnv(object):
     """rl4rs_env handle: SlateState / SeqSlateState device state for one batch."""
 
@@ -67,6 +88,12 @@ class DeviceEnv(object):
                 loc.ctypes.data_as(C.c_void_p), _stream()))
         self.n_complete = self.lib.rl4rs_env_complete_rows(self.h)
         self._keep = None
+        if 'env_rows_variant' in config:                       # A/B runs: catalogue staged in LDS (0, default) or read through L1 / L2 (1)
+            self.set_option('rows_variant', config['env_rows_variant'])
+
+    def set_option(self, name, value):
+        """Kernel-path selection of this handle (rl4rs_env_set_option)."""
+        check(self.lib.rl4rs_env_set_option(self.h, _lib.ENV_OPTS[name], int(value)))
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -285,8 +312,86 @@ class DeviceStepper(object):
             check(self.lib.rl4rs_env_step_discrete(self.h, _ptr(chosen), _ptr(obs), _ptr(reward), None, _ptr(bits), _stream()))
         return obs, reward, bits, chosen
 
+    # ---- reference-shaped transitions: one library call, ONE device-to-host copy, one wait ----------------------------------
+    def _layout(self, want, conti):
+        key = (want, bool(conti))
+        cache = self.__dict__.setdefault('_layouts', {})
+        if key not in cache:
+            L = _lib.StepRecord()
+            check(self.lib.rl4rs_stepper_record_layout(self.h, want, 1 if conti else 0, C.byref(L)))
+            rec = torch.empty(int(L.total_bytes), dtype=torch.uint8, device=self.device)
+            cache[key] = (L, rec)
+        return cache[key]
+
+    def step_record(self, actions, conti=False, want=()):
+        """rl4rs_env_step_record + the copy of the record's host part into a fresh pinned block -> ``StepResult`` of numpy
+        views (obs float32 [B, obs_dim], or float64 [B, obs_dim + cols + 1] when 'd3rl_obs' is wanted; reward float64 [B];
+        done uint8 [B]; chosen int32 [B]; mask int64 [B, A]; mask_bits uint32 [B, W]; click_p float32 [B, n]; offline_action
+        int32 [B] / float64 [B, E]; status int32 [2]).  ``want``: names from rl4rs_amd._lib.STEP_WANT."""
+        bits = 0
+        for name in want:
+            bits |= _lib.STEP_WANT[name]
+        L, rec = self._layout(bits, conti)
+        if conti:
+            a = actions
+            if not (isinstance(a, torch.Tensor) and a.is_cuda):
+                a = np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a)
+                a = to_device_async(a, torch.float32 if a.dtype == np.float32 else torch.float64, self.device)
+            elif a.dtype not in (torch.float32, torch.float64):
+                a = a.to(torch.float64)
+            a = a.contiguous()
+            assert tuple(a.shape) == (self.B, self.E), (a.shape, (self.B, self.E))
+            kind = 2 if a.dtype == torch.float64 else 1
+        else:
+            a = to_device_async(actions, torch.int32, self.device).reshape(-1)
+            assert a.numel() == self.B, (a.shape, self.B)
+            kind = 0
+        check(self.lib.rl4rs_env_step_record(self.h, _ptr(a), kind, bits, _ptr(rec), _stream()))
+        nb = int(L.host_bytes)
+        host = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
+        host.copy_(rec[:nb], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        raw = host.numpy()
+        B = self.B
+
+        def view(off, dtype, shape):
+            if off < 0:
+                return None
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return raw[off:off + n].view(dtype).reshape(shape)
+
+        r = StepResult()
+        r._block = host
+        r.status = view(L.status, np.int32, (2,))
+        r.reward = view(L.reward, np.float64, (B,))
+        r.done = view(L.done, np.uint8, (B,))
+        r.chosen = view(L.chosen, np.int32, (B,))
+        r.obs = (view(L.obs_d3rl, np.float64, (B, int(L.d3rl_cols))) if L.obs_d3rl >= 0 else view(L.obs, np.float32, (B, int(L.obs_dim))))
+        r.mask = view(L.mask_i64, np.int64, (B, self.A))
+        r.mask_bits = view(L.mask_bits, np.uint32, (B, self.W))
+        r.click_p = view(L.click_p, np.float32, (B, self.env.n_complete))
+        r.offline_action = view(L.offline_action, np.float64, (B, self.E)) if conti else view(L.offline_action, np.int32, (B,))
+        return r
+
+
+class StepResult(object):
+    """Host views of one transition record (DeviceStepper.step_record): numpy arrays aliasing ONE pinned block."""
+    __slots__ = ('status', 'reward', 'done', 'chosen', 'obs', 'mask', 'mask_bits', 'click_p', 'offline_action', '_block')
+
 
 AUGRU_KERNELS = {1: 'k_recur<256,augru>', 2: 'k_augru_h16'}
+
+
+def parse_dien_opts(spec):
+    """config['scorer_kernels'] -> sorted tuple of option names (rl4rs_amd._lib.DIEN_OPTS)."""
+    if spec is None:
+        return ()
+    names = [x.strip().lower() for x in spec.split(',')] if isinstance(spec, str) else [str(x).strip().lower() for x in spec]
+    names = sorted(set(n for n in names if n))
+    bad = [n for n in names if n not in _lib.DIEN_OPTS]
+    if bad:
+        raise ValueError("unknown scorer_kernels option(s) %s; known: %s" % (bad, sorted(_lib.DIEN_OPTS)))
+    return tuple(names)
 
 
 class DeviceDien(object):
@@ -305,13 +410,20 @@ class DeviceDien(object):
         self.K = int(config['class_num'])
         self.max_rows, self.max_slots = int(max_rows), int(max_slots)
         self.F = self.S * 2 * self.E + self.U + (self.Cn + 1) * self.E
-        # config['scorer_precision']: 'auto' (default; RL4RS_SCORER env, else fp16x2 when the weights allow it),
+        # config['scorer_precision']: 'auto' (default: fp16x2 when the weights allow it; the RL4RS_SCORER environment variable
+        # overrides the default for A/B runs - read HERE, the library itself never looks at the environment),
         # 'fp32' (exact-operand fp32 MFMA) or 'fp16x2' (fp16 hi+lo operand split, fp32 accumulate)
-        precision = str(config.get('scorer_precision', 'auto')).lower()
+        precision = str(config.get('scorer_precision') or os.environ.get('RL4RS_SCORER') or 'auto').lower()
         if precision not in SCORER_MODES:
             raise ValueError("scorer_precision must be one of %s (got %r)" % (sorted(SCORER_MODES), precision))
+        # config['scorer_kernels']: names of rl4rs_dien_cfg.kernel_opts bits (rl4rs_amd._lib.DIEN_OPTS; include/rl4rs_hip.h
+        # RL4RS_DIEN_OPT_*), an iterable or a comma-separated string; the RL4RS_DIEN_OPTS environment variable is the default
+        self.kernel_opts = parse_dien_opts(config.get('scorer_kernels', os.environ.get('RL4RS_DIEN_OPTS', '')))
+        opt_bits = 0
+        for name in self.kernel_opts:
+            opt_bits |= _lib.DIEN_OPTS[name]
         cfg = _lib.DienCfg(self.L, self.E, self.U, self.Dn, self.Cn, int(config['category_hash_size']),
-                           self.S, self.K, self.max_rows, self.max_slots, SCORER_MODES[precision])
+                           self.S, self.K, self.max_rows, self.max_slots, SCORER_MODES[precision], opt_bits)
         w = _lib.DienWeights()
         keep = []
 
@@ -410,6 +522,10 @@ class DeviceDien(object):
         self._row_order = order                     # keep it alive
         check(self.lib.rl4rs_dien_set_row_order(self.h, _ptr(order), 0 if order is None else int(order.numel())))
 
+    def set_augru_rows(self, rows):
+        """Row-tile form of k_augru_x for the following forwards: 0 automatic, 32 or 64 (rl4rs_dien_set_augru_rows)."""
+        check(self.lib.rl4rs_dien_set_augru_rows(self.h, int(rows)))
+
     def set_profiling(self, on):
         """0 / False off, 1 / True every kernel class, 2 only the AUGRU recurrence (rl4rs_dien_set_profiling)."""
         check(self.lib.rl4rs_dien_set_profiling(self.h, 2 if on == 2 else (1 if on else 0)))
@@ -445,8 +561,8 @@ class DeviceDien(object):
 
     @property
     def augru_kernel(self):
-        if self.scorer_mode == 'fp16x2' and os.environ.get('RL4RS_AUGRU', 'x') != 'h16':
-            return 'k_augru_x'                      # dien.hip: the default fp16x2 recurrence (RL4RS_AUGRU=h16 selects the first generation)
+        if self.scorer_mode == 'fp16x2' and 'augru_h16' not in self.kernel_opts:
+            return 'k_augru_x'                      # dien.hip: the default fp16x2 recurrence ('augru_h16' selects the first generation)
         return AUGRU_KERNELS[SCORER_MODES[self.scorer_mode]]
 
 
@@ -968,6 +1084,16 @@ class DevicePolicy(object):
                                                params.ctypes.data_as(C.c_void_p), _stream(), C.byref(h)))
         self.h = h
         self.W = (self.action_size + 31) // 32
+        # RL4RS_POLICY_OPTS="ppo_fused=0,ppo_rows=16": defaults for A/B runs, read here (the library never reads the environment)
+        for item in filter(None, (x.strip() for x in os.environ.get('RL4RS_POLICY_OPTS', '').split(','))):
+            k, _, v = item.partition('=')
+            self.set_option(k.strip(), int(v))
+
+    def set_option(self, name, value):
+        """Kernel-path selection of this handle (rl4rs_policy_set_option): 'tile', 'ppo_fused', 'ppo_rows', 'resident_wgs'."""
+        if name not in _lib.POLICY_OPTS:
+            raise ValueError("unknown policy option %r; known: %s" % (name, sorted(_lib.POLICY_OPTS)))
+        check(self.lib.rl4rs_policy_set_option(self.h, _lib.POLICY_OPTS[name], int(value)))
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -1095,7 +1221,7 @@ class DevicePolicy(object):
         check(self.lib.rl4rs_policy_status(self.h, C.byref(f), _stream()))
         if f.value & 1:
             raise RuntimeError("the persistent PPO pass timed out at a grid barrier (workgroups not co-resident: the GPU is shared or "
-                               "partitioned); the pass is incomplete - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels")
+                               "partitioned); the pass is incomplete - use DevicePolicy.set_option('ppo_fused', 0) for the per-minibatch kernels")
 
     def status_words(self):
         """int32 [2] tensor aliasing the handle's status words (word 1 != 0: a persistent pass timed out); no synchronisation."""
@@ -1106,7 +1232,7 @@ class DevicePolicy(object):
         return self._status_words
 
     PASS_TIMEOUT_MESSAGE = ("the persistent PPO pass timed out at a grid barrier (workgroups not co-resident: the GPU is shared or "
-                            "partitioned); the pass is incomplete - set RL4RS_PPO_FUSED=0 to use the per-minibatch kernels")
+                            "partitioned); the pass is incomplete - use DevicePolicy.set_option('ppo_fused', 0) for the per-minibatch kernels")
 
     def adam_state(self):
         """(m, v) copies of the Adam moments and the step counter."""

@@ -105,40 +105,57 @@ def broadcast_(t, src=0):
     return t
 
 
-def allreduce_rows_mean_(table_grad, ids):
-    """Mean all-reduce of a SPARSE-ROW gradient: ``table_grad`` [H, E] is zero outside the rows ``ids`` (unique, int64) this
-    rank's minibatch touched (embedding tables of the raw-state policy: 2 x 100000 x 128 floats of which a 256-sample
-    minibatch touches a few thousand rows).  Ranks exchange (ids, rows) with ONE all-gather each instead of all-reducing
-    the 51 MB table; every rank then rebuilds the mean in the same fixed rank order, so the result is bit-identical across
-    ranks.  Falls back to the dense all-reduce when the touched rows are not a small part of the table."""
+def allreduce_rows_mean_(table_grad, ids, cap=None):
+    """Mean all-reduce of a SPARSE-ROW gradient: ``table_grad`` [H, E] is zero outside the rows named by ``ids`` (int64, in
+    [0, H), duplicates allowed) that this rank's minibatch touched (embedding tables of the raw-state policy: 2 x 100000 x 128
+    floats of which a 256-sample minibatch touches a few thousand rows).  Ranks exchange (distinct ids, rows) with ONE
+    all-gather each instead of all-reducing the 51 MB table; every rank then rebuilds the mean in the same fixed rank order,
+    so the result is bit-identical across ranks.
+
+    Nothing in here reads a device value on the host (no ``.item()``, no ``torch.unique`` - both drain the queue once per
+    minibatch): the distinct ids are found by a fixed-shape sort + first-occurrence scatter into buffers of the STATIC size
+    ``cap`` (upper bound on the distinct rows; default: the number of id slots, at most H), padded with -1.  More distinct
+    rows than ``cap`` (only possible with a caller-supplied hint that is wrong) turn the exchanged rows into NaN: a loud
+    failure instead of silently dropped rows.  ``cap`` (or, without it, ``ids.numel()``) must be the same on every rank -
+    it sizes the all-gather buffers; a trainer's minibatch shape is.  When ``cap`` rows per rank are not a small part of the table (a static
+    decision) the dense all-reduce is used."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return table_grad
     W = dist.get_world_size()
     H, E = table_grad.shape
-    stage = _needs_host_staging(table_grad)
-    cnt = torch.tensor([int(ids.numel())], dtype=torch.int64, device='cpu' if stage else table_grad.device)
-    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-    kmax = int(cnt.item())
-    if kmax * W * 2 > H:
+    ids = ids.reshape(-1)
+    n = int(ids.numel())
+    cap = min(H, n if cap is None else int(cap))
+    if n == 0 or cap * W * 2 > H:
         return allreduce_mean_(table_grad.view(-1)).view(H, E)
-    my_ids = torch.full((kmax,), -1, dtype=torch.int64, device=table_grad.device)
-    my_ids[:ids.numel()] = ids
-    my_rows = torch.zeros((kmax, E), dtype=table_grad.dtype, device=table_grad.device)
-    my_rows[:ids.numel()] = table_grad.index_select(0, ids)
+    dev = table_grad.device
+    srt, _ = ids.to(device=dev, dtype=torch.int64).sort()
+    first = torch.ones(n, dtype=torch.bool, device=dev)
+    first[1:] = srt[1:] != srt[:-1]
+    pos = first.cumsum(0) - 1                                     # rank of every id among the distinct ones
+    overflow = pos[-1] >= cap                                     # device scalar, never read on the host
+    slot = torch.where(first & (pos < cap), pos, torch.full_like(pos, cap))          # repeats / overflow -> trash slot `cap`
+    buf = torch.full((cap + 1,), -1, dtype=torch.int64, device=dev)
+    buf.scatter_(0, slot, srt)
+    my_ids = buf[:cap].contiguous()
+    valid = my_ids >= 0
+    safe = my_ids.clamp_min(0)
+    my_rows = table_grad.index_select(0, safe) * valid[:, None].to(table_grad.dtype)
+    my_rows = torch.where(overflow, torch.full_like(my_rows, float('nan')), my_rows)
+    stage = _needs_host_staging(table_grad)
     if stage:
         my_ids, my_rows = my_ids.cpu(), my_rows.cpu()
     all_ids = [torch.empty_like(my_ids) for _ in range(W)]
     all_rows = [torch.empty_like(my_rows) for _ in range(W)]
     dist.all_gather(all_ids, my_ids)
     dist.all_gather(all_rows, my_rows)
-    table_grad.index_fill_(0, ids, 0.0)
+    table_grad.index_fill_(0, safe, 0.0)                          # (padding names row 0: zero already unless touched, and then listed)
     inv = 1.0 / W
     for r in range(W):                       # fixed order: every rank performs the same sequence of additions
-        i_r = all_ids[r].to(table_grad.device)
-        ok = i_r >= 0
-        table_grad.index_add_(0, i_r[ok], all_rows[r].to(table_grad.device)[ok] * inv)
+        i_r = all_ids[r].to(dev).clamp_min(0)                     # padded entries carry zero rows: they add 0 to row 0
+        table_grad.index_add_(0, i_r, all_rows[r].to(dev) * inv)
     return table_grad
 
 

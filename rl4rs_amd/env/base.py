@@ -37,15 +37,34 @@ except Exception:                      # pragma: no cover - depends on the image
             _Space.__init__(self, low, high, shape=shape)
             self.low, self.high, self.dtype = low, high, dtype
 
+        def contains(self, x):                      # gym.spaces.Box.contains: shape and bounds
+            try:
+                x = np.asarray(x, dtype=np.float64)
+            except (TypeError, ValueError):
+                return False
+            return bool(tuple(x.shape) == tuple(self.shape) and np.all(x >= self.low) and np.all(x <= self.high))
+
     class _Discrete(_Space):
         def __init__(self, n):
             _Space.__init__(self, n)
             self.n = n
 
+        def contains(self, x):                      # gym.spaces.Discrete.contains
+            if isinstance(x, (int, np.integer)):
+                v = int(x)
+            elif isinstance(x, np.ndarray) and x.shape == () and np.issubdtype(x.dtype, np.integer):
+                v = int(x)
+            else:
+                return False
+            return 0 <= v < self.n
+
     class _Dict(_Space):
         def __init__(self, spaces):
             _Space.__init__(self, spaces)
             self.spaces = dict(spaces)
+
+        def contains(self, x):
+            return isinstance(x, dict) and set(x) == set(self.spaces) and all(sp.contains(x[k]) for k, sp in self.spaces.items())
 
     class _spaces(object):
         Box, Discrete, Dict = _Box, _Discrete, _Dict

@@ -187,7 +187,7 @@ class SlateState(RecState):
     def _obs_mask(self):
         import torch
         m = self._live().obs_mask(torch.int64)
-        return m if self._tensor_mode() else m.cpu().numpy()
+        return m if self._tensor_mode() else D.to_host(m)
 
     def _masked_actions(self):
         """slate.py:98-104"""
@@ -239,10 +239,15 @@ class SlateState(RecState):
         if env.cur_steps < self.max_steps and env.cur_steps >= self._exposed_len_min:
             raise IndexError('list index out of range')       # exposed_items[cur_step], slate.py:154-156
         conti = bool(self.config.get("support_conti_env", False))
-        out = env.offline_action(conti=conti)
-        if self._tensor_mode():
-            return out
-        out = out.cpu().numpy()
+        cache = getattr(self, '_offline_cache', None)
+        if (not self._tensor_mode() and cache is not None and cache[0] == self._batch_version and cache[1] == env.cur_steps
+                and cache[2] is not None and env.cur_steps < self.max_steps):
+            out = cache[2]                                  # came back with the last transition record (rl4rs_env_step_record)
+        else:
+            out = env.offline_action(conti=conti)
+            if self._tensor_mode():
+                return out
+            out = D.to_host(out)
         return [row for row in out] if conti else out.tolist()
 
     @property
@@ -456,26 +461,34 @@ class SlateRecEnv(RecSimBase):
                 import torch
                 return torch.cat([obs.double(), state["masked_actions"].double(), state["cur_steps"].double()], dim=-1)
             return obs
-        obs = obs.cpu().numpy()
+        obs = D.to_host(obs)
         if masked:
-            am = state["action_mask"]
-            return [{"action_mask": am[i], "obs": obs[i]} for i in range(B)]
+            return [{"action_mask": m, "obs": o} for m, o in zip(state["action_mask"], obs)]
         if d3rl:
             return np.concatenate([obs, state["masked_actions"], state["cur_steps"]], axis=-1)
         return obs
 
     # -- fused transition ----------------------------------------------------------------------
+    def _stock_methods(self, samples):
+        """The fused entry points re-implement act / obs_fn / forward / _reward_due of THIS package's classes inside the
+        library.  A subclass that overrides one of them (state_cls and the env class are the reference's extension points) must
+        see its override run: such an env takes the composed path (RecSimBase._step)."""
+        from .seqslate import SeqSlateState, SeqSlateRecEnv
+        st, ev = type(samples), type(self)
+        stock_state = SeqSlateState if samples.is_seq else SlateState
+        stock_env = SeqSlateRecEnv if samples.is_seq else SlateRecEnv
+        return (st.act is stock_state.act and st.state is stock_state.state and st.get_complete_states is SlateState.get_complete_states
+                and st._masked_actions is stock_state._masked_actions
+                and ev.obs_fn is SlateRecEnv.obs_fn and ev.forward is SlateRecEnv.forward and ev._reward_due is stock_env._reward_due)
+
     def _fused_ok(self, samples):
         cfg = self.config
-        return (samples._tensor_mode() and not cfg.get("rawstate_as_obs", False) and not cfg.get("support_d3rl_mask", False)
-                and not cfg.get("simulator_info_fetch", False) and not cfg.get('no_state_row_reuse', False)
-                and not cfg.get('no_fused_step', False) and samples._env.n_complete > 1)
+        return (not cfg.get("rawstate_as_obs", False) and not cfg.get('no_state_row_reuse', False)
+                and not cfg.get('no_fused_step', False) and samples._env.n_complete > 1
+                and not (samples._tensor_mode() and (cfg.get("support_d3rl_mask", False) or cfg.get("simulator_info_fetch", False)))
+                and self._stock_methods(samples))
 
-    def _step(self, samples, action, **kwargs):
-        """base.py:157-170.  Zero-copy mode runs the whole transition as ONE library call (rl4rs_env_step_discrete /
-        rl4rs_env_step_conti: act -> obs forward -> reward forward when due); every other mode composes it call by call."""
-        if not self._fused_ok(samples):
-            return RecSimBase._step(self, samples, action, **kwargs)
+    def _stepper_for(self, samples):
         env = samples._live()
         net, slots = self._net_for(samples)                 # history encoded for this batch, slot table current
         key = (id(env), id(net), slots.data_ptr())
@@ -484,17 +497,60 @@ class SlateRecEnv(RecSimBase):
                 self._stepper.close()
             self._stepper = D.DeviceStepper(env, net, slots)
             self._stepper_key = key
+        return env, net, self._stepper
+
+    def _step(self, samples, action, **kwargs):
+        """base.py:157-170.  The whole transition is ONE library call whenever this package's own act / obs_fn / forward are in
+        charge: rl4rs_env_step_discrete / _conti in zero-copy mode (device tensors in and out, no host round trip),
+        rl4rs_env_step_record in the reference's own list / ndarray modes (plain, support_rllib_mask, support_d3rl_mask,
+        simulator_info_fetch): every output lands in one device record that ONE copy into pinned memory and ONE wait bring
+        back.  Anything else (raw-state observations, overridden plug-in methods) composes it call by call."""
+        if not self._fused_ok(samples):
+            return RecSimBase._step(self, samples, action, **kwargs)
+        env, net, stepper = self._stepper_for(samples)
         first_of_page = samples.is_seq and env.cur_steps % samples.page_items == 0
         conti = bool(self.config.get("support_conti_env", False))
-        obs, reward, _, chosen = self._stepper.step(action, conti=conti)
-        samples.last_actions = chosen
+        last = kwargs['step'] >= self.max_steps - 1
+        masked = self.config.get("support_rllib_mask", False)
+        if samples._tensor_mode():
+            obs, reward, _, chosen = stepper.step(action, conti=conti)
+            samples.last_actions = chosen
+            if masked:
+                obs = {"action_mask": samples._obs_mask(), "obs": obs}
+        else:
+            d3rl = (not masked) and self.config.get("support_d3rl_mask", False)
+            fetch = bool(self.config.get("simulator_info_fetch", False))
+            want = ['offline_action']
+            if masked:
+                want.append('mask_i64')
+            if d3rl:
+                want.append('d3rl_obs')
+            if fetch:
+                want.append('click_p')
+            r = stepper.step_record(action, conti=conti, want=want)
+            if r.status[0]:
+                raise IndexError("an action id outside [0, action_size) was passed to act() "
+                                 "(numpy would raise at rl4rs/env/slate.py:199)")
+            import torch
+            samples.last_actions = torch.from_numpy(r.chosen)
+            samples._offline_cache = (samples._batch_version, env.cur_steps, r.offline_action)
+            due = self._reward_due(samples)
+            samples._range_seen = getattr(samples, '_range_seen', 0) | int(r.status[1])      # the record read-and-cleared the flag
+            if due and samples._range_seen:
+                raise D._lib.Rl4rsHipError(
+                    "fp16x2 scorer: a recurrent state left the fp16 range (|h| >= 6e4 or NaN); the affected forwards are "
+                    "invalid - use config['scorer_precision'] = 'fp32' for this model")
+            if fetch and due:
+                for i in range(self.batch_size):
+                    samples.info[i].update({'click_p': r.click_p[i]})
+            obs = r.obs
+            if masked:
+                obs = [{"action_mask": m, "obs": o} for m, o in zip(r.mask, obs)]
+            reward = r.reward.tolist() if due else [0] * self.batch_size
         if first_of_page:                                   # the library re-encoded the second sequence input
             samples._seq1_version += 1
             self._encoded_seq1 = samples._seq1_version
         self._last_obs = None
-        last = kwargs['step'] >= self.max_steps - 1
-        if self.config.get("support_rllib_mask", False):
-            obs = {"action_mask": samples._obs_mask(), "obs": obs}
         return obs, reward, [1 if last else 0] * self.batch_size, samples.info
 
     # -- reward --------------------------------------------------------------------------------

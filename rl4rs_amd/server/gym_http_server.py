@@ -138,8 +138,8 @@ class Envs(object):
         return np.random.uniform(np.asarray(sp.low, dtype=np.float64), np.asarray(sp.high, dtype=np.float64), size=tuple(sp.shape)).tolist()
 
     def action_space_contains(self, instance_id, x):
-        sp = self._lookup_env(instance_id).action_space
-        return bool(0 <= int(x) < sp.n) if hasattr(sp, 'n') else False
+        # gymHttpServer.py:107-109: env.action_space.contains(int(x)) - the space decides (a Box answers False for a scalar)
+        return bool(self._lookup_env(instance_id).action_space.contains(int(x)))
 
     def observation_space_contains(self, instance_id, j):
         info = self.observation_space_info(instance_id)

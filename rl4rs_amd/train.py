@@ -171,6 +171,9 @@ class RawStateTrainer(_DeferredStats):
         if weights is None:
             weights = init_rawpolicy_weights(cfg, seed=init_seed)
         N = self.B * self.T
+        if algo == 'PPO' and N < minibatch:
+            raise ValueError("PPO needs at least one full minibatch per train call: batch_size * max_steps = %d < minibatch = %d"
+                             % (N, minibatch))
         self.policy = D.DeviceRawTrainer(cfg, weights, max_rows=max(N, self.B))
         self.iteration = 0
         dev = self.policy.device
@@ -227,10 +230,11 @@ class RawStateTrainer(_DeferredStats):
             return
         g = self._grad
         tables = self.policy.table_rows()
-        ids = [torch.unique(cat.reshape(-1).to(torch.int64)),
-               torch.unique(torch.cat([q.reshape(-1) for q in seqs]).to(torch.int64))]
-        for (off, H, E), i in zip(tables, ids):
-            rdist.allreduce_rows_mean_(g[off:off + H * E].view(H, E), i.clamp_(0, H - 1))
+        # ids clamped the way the kernels clamp them; allreduce_rows_mean_ finds the distinct rows itself with fixed-shape
+        # device ops (torch.unique would drain the queue once per minibatch)
+        flat = [cat.reshape(-1).to(torch.int64), torch.cat([q.reshape(-1) for q in seqs]).to(torch.int64)]
+        for (off, H, E), i in zip(tables, flat):
+            rdist.allreduce_rows_mean_(g[off:off + H * E].view(H, E), i.clamp(0, H - 1))
         tail = tables[-1][0] + tables[-1][1] * tables[-1][2]
         rdist.allreduce_mean_(g[tail:])
 
@@ -301,6 +305,11 @@ class Trainer(_DeferredStats):
         self.keep_last_batch = keep_last_batch
         self.last_batch = None
         N = self.R * self.B * self.T
+        if algo == 'PPO' and N < minibatch:
+            # (N // minibatch == 0 would leave the data-parallel pass without a single step: undefined statistics, a division
+            # by zero, ranks failing at different points around a collective)
+            raise ValueError("PPO needs at least one full minibatch per train call: %d rollouts x batch_size x max_steps = %d < "
+                             "minibatch = %d" % (self.R, N, minibatch))
         self.policy = D.DevicePolicy(256, hidden, self.A, max_rows=N, seed=init_seed)
         self.iteration = 0
         self._rollouts = 0

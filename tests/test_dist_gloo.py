@@ -124,7 +124,22 @@ def _rows_worker(rank, world, port, out):
     table[ids] = torch.randn(ids.numel(), E, generator=g)
     dense = table.clone()
     D.allreduce_mean_(dense.view(-1))                      # what the sparse-row exchange must reproduce
-    D.allreduce_rows_mean_(table, ids)
+    # the ids as a trainer hands them over: every id slot of the minibatch, repeats included, unsorted; one rank touches row 0
+    slots = torch.cat([ids, ids[:7], ids[3:5]])[torch.randperm(ids.numel() + 9, generator=g)]
+    if rank == 1:
+        table[0] = 3.0
+        dense2 = torch.zeros(H, E); dense2[0] = 3.0
+        slots = torch.cat([slots, torch.zeros(2, dtype=torch.int64)])
+    else:
+        dense2 = torch.zeros(H, E)
+    D.allreduce_mean_(dense2.view(-1))
+    dense += dense2
+    D.allreduce_rows_mean_(table, slots, cap=64)           # buffer sizes must agree across ranks: the slot counts differ here
+    # a distinct-row hint that is too small must fail loudly (NaN rows), never drop rows silently
+    bad = torch.zeros(H, E)
+    bad[ids] = 1.0
+    D.allreduce_rows_mean_(bad, ids, cap=3)
+    assert torch.isnan(bad).any()
     big = torch.zeros(16, 4)                               # touched rows are most of the table -> dense fallback
     big_ids = torch.arange(rank, 16, 2)
     big[big_ids] = float(rank + 1)

@@ -147,11 +147,11 @@ def test_dien_is_batch_position_invariant():
 
 
 @pytest.mark.parametrize('hidden', [128, 96])
-def test_chained_dense_tower_is_bit_identical(monkeypatch, hidden):
+def test_chained_dense_tower_is_bit_identical(hidden):
     """fp16x2 mode runs both dense-tower layers in ONE launch (the hidden tile stays in LDS, k_gemm_h16 chain) - same values,
     same k-blocks, same MFMA sequence as two launches with the intermediate in HBM: the whole forward must be bit-identical
-    to a handle created with RL4RS_DENSE_FUSED=0.  The head with its table half folded into k_cat_attn (vs the separate
-    k_head_finish pass, RL4RS_HEAD_FUSED=0) sums in a different order: equal within fp32 rounding only."""
+    to a handle created with scorer_kernels='no_dense_chain'.  The head with its table half folded into k_cat_attn (vs the
+    separate k_head_finish pass, 'no_head_fused') sums in a different order: equal within fp32 rounding only."""
     import torch
     from rl4rs_amd.nets.dien import init_dien_weights
     from rl4rs_amd.device import DeviceDien
@@ -161,12 +161,8 @@ def test_chained_dense_tower_is_bit_identical(monkeypatch, hidden):
     rs = np.random.RandomState(1)
     seq, dense, cat = _inputs(B, rs, cfg['category_hash_size'])
 
-    def run(env):
-        for k in ('RL4RS_DENSE_FUSED', 'RL4RS_HEAD_FUSED'):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        net = DeviceDien(cfg, w, max_rows=B, max_slots=B + 1)
+    def run(kernels):
+        net = DeviceDien(dict(cfg, scorer_kernels=kernels), w, max_rows=B, max_slots=B + 1)
         net.encode(0, torch.from_numpy(np.ascontiguousarray(seq[:, 0])).cuda(), 0)
         net.encode(1, torch.zeros((1, 64), dtype=torch.int32).cuda(), B)
         sl = torch.full((2, B), B, dtype=torch.int32).cuda()
@@ -176,10 +172,10 @@ def test_chained_dense_tower_is_bit_identical(monkeypatch, hidden):
         net.close()
         return obs, p
 
-    o_ref, p_ref = run({})
-    o_two, p_two = run({'RL4RS_DENSE_FUSED': '0'})
+    o_ref, p_ref = run('')
+    o_two, p_two = run('no_dense_chain')
     assert torch.equal(o_ref, o_two) and torch.equal(p_ref, p_two)
-    o_sep, p_sep = run({'RL4RS_HEAD_FUSED': '0'})
+    o_sep, p_sep = run(['no_head_fused'])
     assert (o_ref - o_sep).abs().max().item() < 2e-5 and (p_ref - p_sep).abs().max().item() < 2e-6
 
 
@@ -322,19 +318,96 @@ def test_fp16_range_poisons_the_rows_on_the_device(scorer_precision):
 
 
 def test_first_generation_recurrence_still_matches(monkeypatch, scorer_precision):
-    """RL4RS_AUGRU=h16 (k_augru_h16, round 1) stays a selectable fp16x2 recurrence and stays parity-green."""
+    """scorer_kernels='augru_h16' (k_augru_h16, round 1) stays a selectable fp16x2 recurrence and stays parity-green."""
     if scorer_precision != 'fp16x2':
         pytest.skip('fp16x2 only')
-    monkeypatch.setenv('RL4RS_AUGRU', 'h16')
+    monkeypatch.setitem(CFG, 'scorer_kernels', 'augru_h16')
     test_dien_rowwise_matches_oracle(64)
+
+
+@pytest.mark.parametrize('kernels', ['din_v1', 'no_gru16', 'no_gemm16,no_cat16', 'no_head_tables'])
+def test_other_kernel_paths_match_the_oracle(monkeypatch, scorer_precision, kernels):
+    """Every selectable kernel path of rl4rs_dien_cfg.kernel_opts against the same fp64 oracle and the same bars."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    monkeypatch.setitem(CFG, 'scorer_kernels', kernels)
+    test_dien_rowwise_matches_oracle(64)
+
+
+def test_kernel_options_are_validated():
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from rl4rs_amd._lib import Rl4rsHipError
+    w = init_dien_weights(CFG, seed=1)
+    with pytest.raises(ValueError, match='scorer_kernels'):
+        DeviceDien(dict(CFG, scorer_kernels='augru_rows48'), w, max_rows=8, max_slots=4)
+    with pytest.raises(Rl4rsHipError, match='32-row and the 64-row'):
+        DeviceDien(dict(CFG, scorer_kernels='augru_rows32,augru_rows64'), w, max_rows=8, max_slots=4)
+    net = DeviceDien(CFG, w, max_rows=8, max_slots=4)
+    with pytest.raises(Rl4rsHipError, match='rows must be'):
+        net.set_augru_rows(48)
+    net.close()
+
+
+@pytest.mark.parametrize('B', [64, 136])
+def test_augru_64_row_form_every_row_against_the_oracle(B, scorer_precision):
+    """The 64-row form of k_augru_x (two row tiles per weight fragment - what the reward forward of the headline batch runs,
+    41 % of the AUGRU time) PINNED with scorer_kernels='augru_rows64' at launch sizes where the automatic rule would pick the
+    32-row form: R = 8 B rows in groups of 8 per cache slot (512 and 1088 rows), EVERY row's AUGRU final states (<= 5e-6),
+    observation (<= 5e-5) and click probability (<= 5e-6) against the fp64 oracle; then the same cache scored by the 32-row
+    form on the same handle (rl4rs_dien_set_augru_rows) and under a row-order permutation: bit-identical."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien, DIEN_ALL_FEATURE
+    from oracle.dien import OracleDien
+    G = 8
+    R = B * G
+    w = init_dien_weights(CFG, seed=13, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(B)
+    seq_env, _, _ = _inputs(B, rs, CFG['category_hash_size'])
+    seq_env[:, 1, :] = 0
+    _, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+    net = DeviceDien(dict(CFG, scorer_kernels='augru_rows64'), w, max_rows=R, max_slots=B + 1)
+    net.encode(0, torch.from_numpy(np.ascontiguousarray(seq_env[:, 0])).cuda(), 0)
+    net.encode(1, torch.zeros((1, 64), dtype=torch.int32).cuda(), B)
+    sl = torch.full((2, B), B, dtype=torch.int32).cuda()
+    sl[0] = torch.arange(B, dtype=torch.int32).cuda()
+    sl = sl.contiguous()
+    d, c = torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda()
+    obs64, p64 = net.forward(R, G, d, c, sl, True, True)
+    af64 = net.snapshot(DIEN_ALL_FEATURE, R)[:R, :512].clone()
+    seq_rows = np.repeat(seq_env, G, axis=0)
+    orc = OracleDien(w, CFG, np.float64)
+    _, parts = orc.features(seq_rows, dense, cat, return_parts=True)
+    a = af64.cpu().numpy()
+    assert np.abs(a[:, :256] - parts['h2_0']).max() < 5e-6
+    assert np.abs(a[:, 256:512] - parts['h2_1']).max() < 5e-6
+    assert np.abs(obs64.cpu().numpy() - orc.obs(seq_rows, dense, cat)).max() < 5e-5
+    assert np.abs(p64.cpu().numpy() - orc.reward_probs(seq_rows, dense, cat)[:, 1]).max() < 5e-6
+    # the 32-row form over the same cache: same MFMA sequence per row
+    net.set_augru_rows(32)
+    obs32, p32 = net.forward(R, G, d, c, sl, True, True)
+    af32 = net.snapshot(DIEN_ALL_FEATURE, R)[:R, :512].clone()
+    assert torch.equal(af32, af64) and torch.equal(obs32, obs64) and torch.equal(p32, p64)
+    # a processing order (locality hint) must not change any row, in either form
+    order = torch.from_numpy(np.random.RandomState(1).permutation(B).astype(np.int32)).cuda()
+    net.set_row_order(order)
+    for rows in (64, 32):
+        net.set_augru_rows(rows)
+        o, p = net.forward(R, G, d, c, sl, True, True)
+        assert torch.equal(o, obs64) and torch.equal(p, p64), rows
+    net.check_status()
+    net.close()
 
 
 def test_fp16x2_recurrence_with_fp32_attention(monkeypatch, scorer_precision):
     """fp16x2 AUGRU combined with the exact-fp32 DIN layer 1 (what the library falls back to when the sequence embedding
-    table or the q*k rows of att_w1 leave the fp16 range; forced here with RL4RS_DIN16=0)."""
+    table or the q*k rows of att_w1 leave the fp16 range; forced here with scorer_kernels='no_din16')."""
     if scorer_precision != 'fp16x2':
         pytest.skip('fp16x2 only')
-    monkeypatch.setenv('RL4RS_DIN16', '0')
+    monkeypatch.setitem(CFG, 'scorer_kernels', 'no_din16')
     test_dien_rowwise_matches_oracle(64)
 
 

@@ -416,3 +416,129 @@ def test_http_env_round_trip(tmp_path):
         assert np.allclose(hr, r, rtol=0, atol=0) and hd == dn and len(hi) == B
     assert max(hr) > 0
     henv.close()
+
+
+def _deep_equal(u, v):
+    """Bit-level equality of the nested list / dict / ndarray / scalar objects the reference-shaped API returns, types included."""
+    if isinstance(u, dict):
+        return isinstance(v, dict) and set(u) == set(v) and all(_deep_equal(u[k], v[k]) for k in u)
+    if isinstance(u, (list, tuple)):
+        return isinstance(v, (list, tuple)) and len(u) == len(v) and all(_deep_equal(a, b) for a, b in zip(u, v))
+    if isinstance(u, np.ndarray):
+        return isinstance(v, np.ndarray) and u.dtype == v.dtype and u.shape == v.shape and np.array_equal(u, v, equal_nan=True)
+    return type(u) == type(v) and u == v
+
+
+@pytest.mark.parametrize('kind', ['plain', 'rllib_mask', 'd3rl_mask', 'info_fetch', 'conti', 'conti_mask', 'seq', 'seq_d3rl', 'seq_mask_fetch',
+                                  'widedeep', 'one_env'])
+def test_reference_shaped_step_is_one_record_and_bit_identical(tmp_path, kind):
+    """The reference-shaped modes (lists / ndarrays / dicts out, base.py:256-263, slate.py:244-279) through
+    rl4rs_env_step_record - ONE library call, one device record, one copy into pinned memory per transition - against the
+    composed path (config['no_fused_step']): every returned object identical in value, dtype, shape and python type over two
+    episodes; info['click_p'] under simulator_info_fetch; the host-side offline_action cache; batch-of-one unwrapping."""
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    from rl4rs_amd.env.seqslate import SeqSlateRecEnv, SeqSlateState
+    d = str(tmp_path)
+    text = synth.make_catalog_text(seed=4)
+    synth.write_text(os.path.join(d, 'c.csv'), text)
+    seq = kind.startswith('seq')
+    T = 18 if seq else 9
+    recs = synth.make_records(200, pages=2 if seq else 1, seed=3, hash_size=2000, special_ids=synth.special_ids_from_text(text))
+    synth.write_records(os.path.join(d, 'log.csv'), recs)
+    B = 1 if kind == 'one_env' else 40
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 2000, "seq_num": 2, "emb_size": 128, "page_items": 9,
+           "hidden_units": 128, "max_steps": T, "action_emb_size": 32, "sample_file": os.path.join(d, 'log.csv'),
+           "iteminfo_file": os.path.join(d, 'c.csv'), "cache_size": 128, "model_seed": 3}
+    if kind in ('rllib_mask', 'conti_mask', 'seq_mask_fetch', 'one_env'):
+        cfg['support_rllib_mask'] = True
+    if kind in ('d3rl_mask', 'seq_d3rl'):
+        cfg['support_d3rl_mask'] = True
+    if kind in ('info_fetch', 'seq_mask_fetch'):
+        cfg['simulator_info_fetch'] = True
+    if kind in ('conti', 'conti_mask'):
+        cfg['support_conti_env'] = True
+    if kind == 'widedeep':
+        cfg['algo'] = 'widedeep'
+
+    def run(fused):
+        c = dict(cfg, no_fused_step=not fused)
+        if seq:
+            env = rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=SeqSlateRecEnv(c, state_cls=SeqSlateState))
+        else:
+            env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(c, state_cls=SlateState))
+        env.seed(11)
+        out = []
+        for ep in range(2):
+            out.append(env.reset())
+            for t in range(T):
+                a = env.offline_action
+                obs, reward, done, info = env.step(a)
+                info_copy = [dict((k, np.array(v)) for k, v in i.items()) for i in (info if isinstance(info, list) else [info])]
+                out.append((a, obs, reward, done, info_copy, np.asarray(env.samples.last_actions.cpu().numpy())))
+            out.append((env.samples.prev_actions, env.samples.get_violation(), env.offline_reward))
+        assert (getattr(env.sim, '_stepper', None) is not None) == fused
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert _deep_equal(x, y), (kind, i)
+    steps = [x for x in a if isinstance(x, tuple) and len(x) == 6]
+    assert any(np.sum(np.abs(np.asarray(s[2], dtype=np.float64))) > 0 for s in steps)            # rewards were paid
+    if 'fetch' in kind:
+        assert any('click_p' in s[4][0] and s[4][0]['click_p'].shape == (9,) for s in steps)
+    if kind == 'd3rl_mask':
+        assert steps[0][1].dtype == np.float64 and steps[0][1].shape == (B, 256 + 9 + 1)
+
+
+def test_overridden_plugin_methods_are_honoured(tmp_path):
+    """state_cls / the env class are the reference's extension points: a subclass that overrides act (or obs_fn / forward /
+    _reward_due) must see its override run - such an env leaves the fused entry points alone and composes the transition."""
+    import torch
+    import rl4rs_amd
+    from rl4rs_amd import synth
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    d = str(tmp_path)
+    text = synth.make_catalog_text(seed=4)
+    synth.write_text(os.path.join(d, 'c.csv'), text)
+    recs = synth.make_records(60, seed=3, hash_size=2000, special_ids=synth.special_ids_from_text(text))
+    synth.write_records(os.path.join(d, 'log.csv'), recs)
+    B, T = 16, 9
+    cfg = {"maxlen": 64, "batch_size": B, "action_size": 284, "class_num": 2, "dense_feature_num": 432,
+           "category_feature_num": 21, "category_hash_size": 2000, "seq_num": 2, "emb_size": 128, "page_items": 9,
+           "hidden_units": 128, "max_steps": T, "action_emb_size": 32, "sample_file": os.path.join(d, 'log.csv'),
+           "iteminfo_file": os.path.join(d, 'c.csv'), "cache_size": 32, "model_seed": 3}
+    calls = {'act': 0, 'forward': 0}
+
+    class CountingState(SlateState):
+        def act(self, actions):
+            calls['act'] += 1
+            SlateState.act(self, actions)
+
+    class DoubledReward(SlateRecEnv):
+        def forward(self, model, samples):
+            calls['forward'] += 1
+            r = SlateRecEnv.forward(self, model, samples)
+            return r * 2 if torch.is_tensor(r) else [2 * x for x in r]
+
+    for tensors in (False, True):
+        c = dict(cfg, return_tensors=tensors)
+        ref = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(dict(c), state_cls=SlateState))
+        e1 = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(dict(c), state_cls=CountingState))
+        e2 = rl4rs_amd.make('SlateRecEnv-v0', recsim=DoubledReward(dict(c), state_cls=SlateState))
+        for e in (ref, e1, e2):
+            e.seed(5)
+            e.reset()
+        calls.update(act=0, forward=0)
+        for t in range(T):
+            a = ref.offline_action
+            _, r0, _, _ = ref.step(a)
+            _, r1, _, _ = e1.step(a)
+            _, r2, _, _ = e2.step(a)
+        assert calls['act'] == T and calls['forward'] == T
+        assert getattr(ref.sim, '_stepper', None) is not None and getattr(e1.sim, '_stepper', None) is None
+        r0, r1, r2 = [np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype=np.float64) for x in (r0, r1, r2)]
+        assert r0.max() > 0 and np.array_equal(r0, r1) and np.array_equal(2 * r0, r2)

@@ -109,3 +109,21 @@ def test_http_env_round_trip_over_the_wire_format(masked):
     assert float(o[0]) == 1.0
     env.close()
     assert app.envs.envs == {}
+
+
+def test_action_space_contains_delegates_to_the_space():
+    """gymHttpServer.py:107-109: member = env.action_space.contains(int(x)) - a Box (continuous-action env) answers for itself
+    (a scalar is never a member of a 32-d Box), a Discrete checks the range."""
+    from rl4rs_amd.server import create_app
+
+    class ContiStub(StubEnv):
+        def __init__(self, config):
+            StubEnv.__init__(self, config)
+            self.action_space = _spaces.Box(-1, 1, shape=(32,))
+
+    app = create_app(make_env=lambda env_id, config: ContiStub(config))
+    c = app.test_client()
+    iid = c.post('/v1/envs/', json={'env_id': 'SlateRecEnv-v0', 'config': {'batch_size': 2, 'action_size': 284}}).get_json()['instance_id']
+    assert c.get('/v1/envs/%s/action_space/contains/0' % iid).get_json() == {'member': False}
+    assert _spaces.Box(-1, 1, shape=(2,)).contains([0.5, -1.0]) and not _spaces.Box(-1, 1, shape=(2,)).contains([0.5, 1.5])
+    assert _spaces.Discrete(4).contains(3) and not _spaces.Discrete(4).contains(4) and not _spaces.Discrete(4).contains(1.0)
