@@ -1,6 +1,7 @@
 // Shared host-side helpers for librl4rs_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -64,6 +65,20 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 // two chained layers in one launch (N1 <= 128, N1 % 16 == 0, N2 <= 128): c2 = act2(act1(a W1 + b1) W2 + b2)
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
                           const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
+
+// Power-of-two prescale of a matrix that goes through the fp16 hi + lo split: s = 2^k with max |w| * s in [2^13, 2^14) (1 for an
+// all-zero or non-finite matrix).  Multiplying by s is exact in fp32, hi = fp16(w s) is then never out of range and
+// lo = fp16(w s - hi) stays a NORMAL fp16 number for every |w| >= 2^-17 max |w|: the split keeps its 22 significand bits
+// whatever the scale of a checkpoint (unscaled, a weight of 1e-3 has only a subnormal lo part, one of 7e4 no hi part at all).
+inline float pow2_prescale(float maxabs) {
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
+    int e = 0;
+    (void)frexpf(maxabs, &e);             // maxabs = m * 2^e, m in [0.5, 1)  ->  maxabs * 2^(14 - e) in [2^13, 2^14)
+    int k = 14 - e;
+    if (k > 100) k = 100;                 // keep s (and s * other weights) far from the fp32 range ends
+    if (k < -100) k = -100;
+    return ldexpf(1.f, k);
+}
 
 // fp32 -> fp16 bits, round to nearest even (subnormals kept)
 inline uint16_t f32_to_f16(float f) {

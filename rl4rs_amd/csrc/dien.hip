@@ -296,6 +296,12 @@ struct RecurArgs {
     int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
     const int32_t* order;        // k_augru_x: processing order of the row groups (NULL = identity)
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
+    // fp16x2 AUGRU kernels: the gate / candidate weight matrices (and the cached x-side projections, biases folded) are stored
+    // multiplied by a power of two s_g / s_c (rl4rs_dien_create: max |w| * s in [2^13, 2^14), so the fp16 hi + lo split keeps its
+    // 22 bits whatever the scale of a checkpoint's weights, and no weight is "too large for fp16").  The pre-activation is
+    // acc / s; the division rides on the constant the activation multiplies by anyway: sigmoid(acc / s) = 1 / (1 + exp2(acc * sig_k)),
+    // sig_k = -log2(e) / s_g, tanh_k = 2 log2(e) / s_c - exact (powers of two), same instruction count.
+    float sig_k[4], tanh_k[4];
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -310,6 +316,9 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
     return 1.f / (1.f + expf(-x));
 #endif
 }
+// activations of a pre-activation that is stored scaled by a power of two (k = -log2(e) / s resp. 2 log2(e) / s, RecurArgs)
+__device__ __forceinline__ float gate_sigmoid_k(float x, float k) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * x)); }
+__device__ __forceinline__ float gate_tanh_k(float x, float k) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * x)); }
 __device__ __forceinline__ float gate_tanh(float x) {
 #if RL4RS_FAST_ACT
     // 1 - 2/(exp(2x)+1); exp2 saturates cleanly to 0 / inf
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     }
 
     bool out_of_range = false;
+    const float sig_k = a.sig_k[sq], tanh_k = a.tanh_k[sq];       // activations of power-of-two prescaled pre-activations (RecurArgs)
     const int TL = a.steps > 0 ? a.steps : L;
 #pragma unroll 1
     for (int t = 0; t < TL; ++t) {
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
             if (g == 1) {            // shadow: reset gate, accumulator register kb of every tile
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const float rg = gate_sigmoid(acc_r[m][kb]);
+                    const float rg = gate_sigmoid_k(acc_r[m][kb], sig_k);
                     const float v = rg * h_own[m][kb];
                     const _Float16 vh = (_Float16)v;
                     rp_hi[(m * 32 + crow(kb, half)) * LDP + col] = vh;
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
                 for (int m = 0; m < MT; ++m) {
                     float pre = acc_u[m][kb];
                     asm volatile("" : "+v"(pre));      // keeps element kb's chain in item kb (else all 16 cluster up front)
-                    acc_u[m][kb] = (1.0f - s_att[(m * 32 + crow(kb, half)) * LDT + t]) * gate_sigmoid(pre);
+                    acc_u[m][kb] = (1.0f - s_att[(m * 32 + crow(kb, half)) * LDT + t]) * gate_sigmoid_k(pre, sig_k);
                 }
             }
             if (g != 0) {
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float c = gate_tanh(acc_c[m][r]);
+                const float c = gate_tanh_k(acc_c[m][r], tanh_k);
                 const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - c, c);     // u h + (1-u) c
                 out_of_range |= !(fabsf(hn) < 6.0e4f);      // fp16 planes cannot carry it (also catches NaN)
                 h_own[m][r] = hn;
@@ -1279,6 +1289,7 @@ struct rl4rs_dien {
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_DIEN_OPT_AUGRU_H16)
     int augru_rows;        // k_augru_x row-tile form: 0 automatic, 32, 64 (rl4rs_dien_set_augru_rows)
+    float augru_sg[4], augru_sc[4];   // fp16x2: power-of-two prescale of the AUGRU gate / candidate matrices (1 in fp32 mode)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
@@ -1420,10 +1431,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 finite = finite && v == v; wmax = fmaxf(wmax, v);
             }
         }
-        const bool fits = finite && wmax < 6.0e4f;
+        // every fp16x2 matrix is stored multiplied by its own power of two (pow2_prescale below), so the split form has no
+        // weight-range condition left: any FINITE checkpoint runs in fp16x2
+        const bool fits = finite;
         if (mode == RL4RS_SCORER_AUTO) mode = fits ? RL4RS_SCORER_FP16X2 : RL4RS_SCORER_FP32;
-        RL4RS_REQUIRE(mode != RL4RS_SCORER_FP16X2 || fits,
-                      "dien: the fp16x2 scorer needs finite AUGRU weights with |w| < 6e4 (max |w| = %g); use fp32", (double)wmax);
+        RL4RS_REQUIRE(mode != RL4RS_SCORER_FP16X2 || fits, "dien: the fp16x2 scorer needs finite AUGRU weights (max |w| = %g)", (double)wmax);
         want_fp16x2 = mode == RL4RS_SCORER_FP16X2;
     }
     int ndev = rl4rs_device_count();
@@ -1491,12 +1503,12 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             }
         }
         n->gru16 = c->emb_size == 128 && gfin && gmx < 6.0e4f && !(opts & RL4RS_DIEN_OPT_NO_GRU16);
-        // the plain GEMMs in the same split form: every weight they use finite and well inside the fp16 range (sums /
-        // differences of two att_w1 entries are formed at load: 3e4).  Activations are split on the fly; one that leaves the
+        // the plain GEMMs in the same split form: every weight finite (each packed matrix carries its own power-of-two
+        // prescale, pack_gemm_weight_h16: no range condition).  Activations are split on the fly; one that leaves the fp16
         // range turns its output row into NaN (gemm.hip).
         bool wfin = true;
         auto chk = [&](const float* p, size_t cnt) {
-            for (size_t i = 0; p && i < cnt; ++i) wfin = wfin && fabsf(p[i]) < 3.0e4f;      // false for NaN too
+            for (size_t i = 0; p && i < cnt; ++i) wfin = wfin && fabsf(p[i]) < 1.0e30f;      // false for NaN / inf too
         };
         chk(w->dense_w1, (size_t)c->dense_feature_num * c->hidden_units);
         chk(w->dense_w2, (size_t)c->hidden_units * c->hidden_units);
@@ -1585,6 +1597,17 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             keep.push_back(pack_frag_h16(w->gru_cand_w[s], E, E, E, E));
             UP(gru_wc16[s], keep.back().data(), keep.back().size());
         }
+        // ---- power-of-two prescale of the AUGRU's recurrent (h-side) matrices in fp16x2 mode (pow2_prescale)
+        float sg = 1.f, sc = 1.f;
+        if (n->fp16x2) {
+            float mg = 0.f, mc = 0.f;
+            for (size_t i = (size_t)E * 2 * NH2; i < (size_t)(E + NH2) * 2 * NH2; ++i) mg = fmaxf(mg, fabsf(w->augru_gate_w[s][i]));
+            for (size_t i = (size_t)E * NH2; i < (size_t)(E + NH2) * NH2; ++i) mc = fmaxf(mc, fabsf(w->augru_cand_w[s][i]));
+            sg = pow2_prescale(mg);
+            sc = pow2_prescale(mc);
+        }
+        n->augru_sg[s] = sg;
+        n->augru_sc[s] = sc;
         // ---- projections of h1: [W1b - W1c | augru gate x-side | augru cand x-side], bias [b1 | bg | bc]
         std::vector<float> wp((size_t)E * PLD), bp(PLD), wac((size_t)E * ATT_H1);
         const float* w1 = w->att_w1[s];    // rows: q [0,E) | k [E,2E) | q-k [2E,3E) | q*k [3E,4E)
@@ -1593,12 +1616,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 wp[(size_t)k * PLD + j] = w1[(size_t)(E + k) * ATT_H1 + j] - w1[(size_t)(2 * E + k) * ATT_H1 + j];
                 wac[(size_t)k * ATT_H1 + j] = w1[(size_t)k * ATT_H1 + j] + w1[(size_t)(2 * E + k) * ATT_H1 + j];
             }
-            for (int j = 0; j < 2 * NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + j] = w->augru_gate_w[s][(size_t)k * 2 * NH2 + j];
-            for (int j = 0; j < NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + 2 * NH2 + j] = w->augru_cand_w[s][(size_t)k * NH2 + j];
+            // (fp16x2: the AUGRU sections arrive at the recurrence as MFMA C-in next to products of PRESCALED weights: same scale)
+            for (int j = 0; j < 2 * NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + j] = w->augru_gate_w[s][(size_t)k * 2 * NH2 + j] * sg;
+            for (int j = 0; j < NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + 2 * NH2 + j] = w->augru_cand_w[s][(size_t)k * NH2 + j] * sc;
         }
         for (int j = 0; j < ATT_H1; ++j) bp[j] = w->att_b1[s][j];
-        for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j];
-        for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j];
+        for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j] * sg;
+        for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j] * sc;
         keep.push_back(pack_w(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
         for (int k = 0; k < E; ++k)
@@ -1621,9 +1645,13 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         UP(augru_wc[s], keep.back().data(), keep.back().size());
         n->augru_wg16[s] = n->augru_wc16[s] = nullptr;
         if (n->fp16x2) {
-            keep.push_back(pack_frag_h16(w->augru_gate_w[s], 2 * NH2, E, NH2, 2 * NH2));
+            std::vector<float> hs((size_t)NH2 * 2 * NH2);
+            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_gate_w[s][(size_t)E * 2 * NH2 + i] * sg;
+            keep.push_back(pack_frag_h16(hs.data(), 2 * NH2, 0, NH2, 2 * NH2));
             UP(augru_wg16[s], keep.back().data(), keep.back().size());
-            keep.push_back(pack_frag_h16(w->augru_cand_w[s], NH2, E, NH2, NH2));
+            hs.resize((size_t)NH2 * NH2);
+            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_cand_w[s][(size_t)E * NH2 + i] * sc;
+            keep.push_back(pack_frag_h16(hs.data(), NH2, 0, NH2, NH2));
             UP(augru_wc16[s], keep.back().data(), keep.back().size());
         }
         AL(h1[s], (size_t)c->max_slots * L * E);
@@ -1808,6 +1836,7 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
+            for (int s = 0; s < S; ++s) { a.sig_k[s] = -1.4426950408889634f / n->augru_sg[s]; a.tanh_k[s] = 2.8853900817779268f / n->augru_sc[s]; }
             a.order = (n->augru_x && n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
             a.steps = 0;
 #if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)

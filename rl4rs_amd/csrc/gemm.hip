@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     const bool tile_ok = nt < NT;
     const int col = nt * 32 + li;
     const char* wtile = Wp + (size_t)(tile_ok ? nt : 0) * KB * 2048;
+    const float inv_s = reinterpret_cast<const float*>(Wp)[(size_t)NT * KB * 512];     // 1 / (the matrix's power-of-two prescale)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wtile), 0, KB * 2048, 0x00020000);
     const int vl16 = lane * 16;
 
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     if (chain.wp2) {        // uniform: chained second layer (gridDim.y == 1, N <= 128, N % 16 == 0: checked by the launcher)
         const int NT2 = (chain.n2 + 31) / 32;
         const bool tile2_ok = wave < NT2;
+        const float inv_s2 = reinterpret_cast<const float*>(chain.wp2)[(size_t)NT2 * chain.kb2 * 512];
         const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(chain.wp2 + (size_t)(tile2_ok ? wave : 0) * chain.kb2 * 2048), 0, chain.kb2 * 2048, 0x00020000);
         ghalf8_t b2h[8], b2l[8];                       // K2 <= 128: every fragment of the second layer requested up front
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float v = (col < N && m0 + rl < M) ? apply_act(acc[w][r] + bv, act) : 0.f;
+                    const float v = (col < N && m0 + rl < M) ? apply_act(acc[w][r] * inv_s + bv, act) : 0.f;
                     const _Float16 hi = (_Float16)v;
                     const int off = (col >> 3) * SLAB + rl * 16 + (col & 7) * 2;
                     *reinterpret_cast<_Float16*>(p_hi + off) = hi;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < M) chain.c2[(size_t)row * chain.ldc2 + col2] = apply_act(acc2[w][r] + bv2, chain.act2);
+                    if (row < M) chain.c2[(size_t)row * chain.ldc2 + col2] = apply_act(acc2[w][r] * inv_s2 + bv2, chain.act2);
                 }
         }
         return;
@@ -490,23 +492,30 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] + bv + (addend ? addend[(size_t)row * ldadd + col] : 0.f), act);
+                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] * inv_s + bv + (addend ? addend[(size_t)row * ldadd + col] : 0.f), act);
             }
     }
 }
 
 // host: split W [K,N] into fp16 hi / lo and pack it into B-fragment order for k_gemm_h16 (K padded to 16, N to 32);
 // returned as floats (NT * KB16 * 512)
+// The matrix is stored multiplied by its own power of two s (pow2_prescale: max |w| s in [2^13, 2^14), exact), so there is no
+// weight-range condition and small weights keep a normal lo part; 1 / s follows the fragments as ONE float (4 with padding) and
+// the kernel's epilogue multiplies the accumulator by it - exact - before bias / addend / activation.
 std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N) {
     const int KB = (K + 15) / 16, NT = (N + 31) / 32;
-    std::vector<uint16_t> out((size_t)NT * KB * 2 * 512, 0);
+    float mx = 0.f;
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < N; ++j) mx = fmaxf(mx, fabsf(w[(size_t)k * ldw + j]));
+    const float scale = pow2_prescale(mx);
+    std::vector<uint16_t> out((size_t)NT * KB * 2 * 512 + 8, 0);
     for (int nt = 0; nt < NT; ++nt)
         for (int kb = 0; kb < KB; ++kb)
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 8; ++i) {
                     const int k = kb * 16 + (lane >> 5) * 8 + i, j = nt * 32 + (lane & 31);
                     if (k >= K || j >= N) continue;
-                    const float v = w[(size_t)k * ldw + j];
+                    const float v = w[(size_t)k * ldw + j] * scale;
                     const uint16_t hi = f32_to_f16(v);
                     const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
                     const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8 + i;
@@ -515,6 +524,7 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
                 }
     std::vector<float> f(out.size() / 2);
     memcpy(f.data(), out.data(), out.size() * 2);
+    f[(size_t)NT * KB * 512] = 1.0f / scale;          // trailer: read by k_gemm_h16 as Wp_f32[NT * KB * 512]
     return f;
 }
 

@@ -208,7 +208,8 @@ def test_dien_other_configurations(variant):
 
 
 def test_scorer_mode_selection(monkeypatch, scorer_precision):
-    """scorer_precision / RL4RS_SCORER / fp16 weight-range rule of rl4rs_dien_create (include/rl4rs_hip.h)."""
+    """scorer_precision / scorer_kernels / RL4RS_SCORER (a default the PYTHON layer reads; the library never looks at the
+    environment) and the rule of rl4rs_dien_create: any finite checkpoint runs in fp16x2 (power-of-two prescale per matrix)."""
     if scorer_precision != 'fp32':
         pytest.skip('mode-independent')
     from rl4rs_amd.nets.dien import init_dien_weights
@@ -218,15 +219,13 @@ def test_scorer_mode_selection(monkeypatch, scorer_precision):
     base = dict(CFG)
     base.pop('scorer_precision')
     monkeypatch.delenv('RL4RS_SCORER', raising=False)
-    monkeypatch.delenv('RL4RS_AUGRU', raising=False)
+    monkeypatch.delenv('RL4RS_DIEN_OPTS', raising=False)
     net = DeviceDien(base, w, max_rows=8, max_slots=4)
     assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_x'        # auto default: second-generation recurrence
     net.close()
-    monkeypatch.setenv('RL4RS_AUGRU', 'h16')                                       # the first generation stays selectable
-    net = DeviceDien(base, w, max_rows=8, max_slots=4)
+    net = DeviceDien(dict(base, scorer_kernels='augru_h16'), w, max_rows=8, max_slots=4)    # the first generation stays selectable
     assert net.scorer_mode == 'fp16x2' and net.augru_kernel == 'k_augru_h16'
     net.close()
-    monkeypatch.delenv('RL4RS_AUGRU')
     monkeypatch.setenv('RL4RS_SCORER', 'fp32')
     net = DeviceDien(base, w, max_rows=8, max_slots=4)
     assert net.scorer_mode == 'fp32' and net.augru_kernel == 'k_recur<256,augru>'
@@ -235,20 +234,81 @@ def test_scorer_mode_selection(monkeypatch, scorer_precision):
     assert net.scorer_mode == 'fp16x2'
     net.close()
     monkeypatch.setenv('RL4RS_SCORER', 'bf16')
-    with pytest.raises(Rl4rsHipError, match='RL4RS_SCORER'):
+    with pytest.raises(ValueError, match='scorer_precision'):
         DeviceDien(base, w, max_rows=8, max_slots=4)
     monkeypatch.delenv('RL4RS_SCORER')
     with pytest.raises(ValueError, match='scorer_precision'):
         DeviceDien(dict(base, scorer_precision='tf32'), w, max_rows=8, max_slots=4)
-    # a weight outside fp16 range: auto falls back to fp32, explicit fp16x2 is refused
+    # weights outside the fp16 range: fp16x2 is KEPT (each matrix is stored times its own power of two)
     big = dict(w)
     big['augru0_cand_w'] = w['augru0_cand_w'].copy()
     big['augru0_cand_w'][5, 7] = 7.0e4
+    big['augru1_gate_w'] = w['augru1_gate_w'].copy()
+    big['augru1_gate_w'][200, 300] = -3.0e5
     net = DeviceDien(base, big, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp16x2'
+    net.close()
+    net = DeviceDien(dict(base, scorer_precision='fp16x2'), big, max_rows=8, max_slots=4)
+    assert net.scorer_mode == 'fp16x2'
+    net.close()
+    # only a non-finite weight cannot be carried
+    bad = dict(w)
+    bad['augru0_cand_w'] = w['augru0_cand_w'].copy()
+    bad['augru0_cand_w'][5, 7] = np.inf
+    net = DeviceDien(base, bad, max_rows=8, max_slots=4)
     assert net.scorer_mode == 'fp32'
     net.close()
-    with pytest.raises(Rl4rsHipError, match='fp16x2'):
-        DeviceDien(dict(base, scorer_precision='fp16x2'), big, max_rows=8, max_slots=4)
+    with pytest.raises(Rl4rsHipError, match='finite'):
+        DeviceDien(dict(base, scorer_precision='fp16x2'), bad, max_rows=8, max_slots=4)
+
+
+@pytest.mark.parametrize('variant', ['outliers', 'tiny', 'gru_outlier'])
+def test_split_form_is_total_over_weight_scales(variant, scorer_precision):
+    """the fp16x2 form must not depend on the scale of a checkpoint.  'outliers': recurrent AUGRU weights of
+    7e4 / -3e5 and x-side / head weights of 1e5 / 9e4 (all beyond fp16; weights that would push an ACTIVATION beyond fp16
+    are a different matter: that row is NaN-poisoned and reported) - the handle stays in fp16x2 and every
+    intermediate and output meets the SAME bars against the fp64 oracle; 'tiny': every AUGRU weight times 2^-12 (unscaled,
+    their fp16 hi parts would be subnormal: 3 % relative error per weight); 'gru_outlier': a first-GRU weight beyond fp16
+    (that piece alone falls back to its exact-fp32 kernel, the rest stays split)."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only')
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien, DIEN_ALL_FEATURE
+    from oracle.dien import OracleDien
+    R = 96
+    w = init_dien_weights(CFG, seed=21, emb_scale=0.5, bias_noise=0.2)
+    w = dict((k, np.array(v, copy=True)) for k, v in w.items())
+    if variant == 'outliers':
+        w['augru0_cand_w'][128 + 5, 7] = 7.0e4           # h-side rows start at E = 128: a saturated candidate column
+        w['augru1_gate_w'][128 + 200, 300] = -3.0e5      # a saturated update-gate column
+        w['augru0_gate_w'][3, 40] = 1.0e5                # x-side (projection GEMM)
+        w['obs_w'][600, 9] = 9.0e4                       # head GEMM, on a dense-tower feature (bounded by ELU inputs)
+    elif variant == 'tiny':
+        for s in range(2):
+            w['augru%d_gate_w' % s] *= np.float32(2.0 ** -12)
+            w['augru%d_cand_w' % s] *= np.float32(2.0 ** -12)
+    else:
+        w['gru0_cand_w'][128 + 9, 11] = 8.0e4
+    rs = np.random.RandomState(5)
+    seq, dense, cat = _inputs(R, rs, CFG['category_hash_size'])
+    net = DeviceDien(CFG, w, max_rows=R, max_slots=R)
+    assert net.scorer_mode == 'fp16x2'
+    for s in range(2):
+        net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+    slots = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+    obs, prob = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), slots, want_obs=True, want_prob=True)
+    orc = OracleDien(w, CFG, np.float64)
+    allf, parts = orc.features(seq, dense, cat, return_parts=True)
+    af = net.snapshot(DIEN_ALL_FEATURE, R).cpu().numpy()[:R]
+    assert np.abs(af[:, :256] - parts['h2_0']).max() < 5e-6
+    assert np.abs(af[:, 256:512] - parts['h2_1']).max() < 5e-6
+    obs_ref = orc.obs(seq, dense, cat)
+    tol = 5e-5 * max(1.0, np.abs(obs_ref).max() / 10.0)      # the 9e4 head weight makes some activations O(1e4)
+    assert np.abs(obs.cpu().numpy() - obs_ref).max() < tol
+    assert np.abs(prob.cpu().numpy() - orc.reward_probs(seq, dense, cat)[:, 1]).max() < 5e-6
+    net.check_status()
+    net.close()
 
 
 def test_fp16_range_status(scorer_precision):

@@ -88,3 +88,34 @@ def test_gemm_h16_poisons_out_of_range_rows():
     ref = a.double() @ w.double()
     ok = ~bad
     assert (c[ok].double() - ref[ok]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('k', [-12, 12, 17])
+def test_gemm_h16_is_scale_invariant(k):
+    """Every packed fp16x2 weight matrix carries its own power-of-two prescale (pack_gemm_weight_h16: max |w| s in [2^13, 2^14)),
+    so the hi / lo bit patterns - and therefore the relative precision - do not depend on the scale of the weights:
+    gemm(A, 2^k W) == 2^k gemm(A, W) BIT FOR BIT, for weights of 2.4e-5 (where an unscaled fp16 hi part is subnormal) as for
+    weights of 400 or 1.3e4 x 10 (where it would overflow)."""
+    import torch
+    from rl4rs_amd.device import gemm_h16_packed
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(300, 200, generator=g).cuda()
+    w = (torch.randn(200, 96, generator=g) / 10).numpy()
+    base = gemm_h16_packed(a, w, None, 0)
+    scaled = gemm_h16_packed(a, (w * np.float32(2.0 ** k)).astype(np.float32), None, 0)
+    assert torch.equal(scaled, base * float(2.0 ** k))
+
+
+def test_gemm_h16_takes_weights_beyond_the_fp16_range():
+    """|w| >= 6.5e4 used to force the exact-fp32 GEMM; with the prescale it is just another scale: same bar against fp64."""
+    import torch
+    from rl4rs_amd.device import gemm_h16_packed
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(257, 128, generator=g)
+    w = torch.randn(128, 64, generator=g) / 10
+    w[5, 7] = 7.0e4
+    w[100, 3] = -2.5e5
+    c = gemm_h16_packed(a.cuda(), w.numpy(), None, 0).cpu()
+    ref = a.double() @ w.double()
+    assert torch.isfinite(c).all()
+    assert ((c.double() - ref).abs() / (a.double().abs() @ w.double().abs())).max().item() < 1e-6

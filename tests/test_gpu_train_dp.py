@@ -196,38 +196,47 @@ def test_ppo_minibatch_grad_matches_pass_and_chain():
     p2.check_status()
 
 
-def test_pass_falls_back_when_the_grid_cannot_be_resident(monkeypatch):
+def test_pass_falls_back_when_the_grid_cannot_be_resident():
     """ADVICE r1: the persistent pass is only used when its whole grid fits the device at once (runtime occupancy x CU count);
-    a smaller device takes the per-minibatch kernels and gives the same parameters within rounding."""
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch
-from rl4rs_amd.device import DevicePolicy
-from rl4rs_amd.nets.policy import init_policy_params
-rs = np.random.RandomState(0)
-N, MB, A = 256, 128, 284
-flat = init_policy_params(256, 64, A, 2)
-t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
-obs = t(rs.normal(size=(N, 256)).astype(np.float32))
-p = DevicePolicy(256, 64, A, max_rows=N, params=flat)
-a, lp, v, ent, lg = p.act(obs, None, seed=1, step=0, want_logits=True)
-adv = t(rs.normal(size=N).astype(np.float32)); ret = t(rs.normal(size=N).astype(np.float32))
-p.ppo_epoch(obs, a, adv, ret, None, lp, v, lg, minibatch=MB, lr=1e-3)
-p.check_status()
-np.save(OUT, p.params().cpu().numpy())
-'''
-    outs = []
-    for cap in (None, '4'):
-        env = dict(os.environ)
-        if cap:
-            env['RL4RS_PPO_RESIDENT_WGS'] = cap
-        path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'rl4rs_pass_%s.npy' % (cap or 'full'))
-        subprocess.check_call([sys.executable, '-c', code.replace('OUT', repr(path))], env=env,
-                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        outs.append(np.load(path))
-    assert np.isfinite(outs[0]).all()
-    assert np.abs(outs[0] - outs[1]).max() < 5e-6
+    a smaller device (pretended per handle: rl4rs_policy_set_option RESIDENT_WGS) takes the per-minibatch kernels and gives
+    the same parameters within rounding.  Also ADVICE r2: two handles of DIFFERENT shapes in one process - the pass kernel's
+    dynamic-LDS opt-in is per function, so the smaller policy must not undercut the larger one's launches."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    rs = np.random.RandomState(0)
+    N, MB, A = 256, 128, 284
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    obs = t(rs.normal(size=(N, 256)).astype(np.float32))
+    adv, ret = t(rs.normal(size=N).astype(np.float32)), t(rs.normal(size=N).astype(np.float32))
+
+    def run(hidden, cap=None, fused=None):
+        p = DevicePolicy(256, hidden, A, max_rows=N, params=init_policy_params(256, hidden, A, 2))
+        if cap is not None:
+            p.set_option('resident_wgs', cap)
+        if fused is not None:
+            p.set_option('ppo_fused', fused)
+        a, lp, v, ent, lg = p.act(obs, None, seed=1, step=0, want_logits=True)
+        return p, (a, lp, v, lg)
+
+    big, bi = run(128)                     # larger LDS footprint: opts in first ...
+    small, si = run(64)                    # ... then a smaller policy runs its own pass
+    capped, ci = run(64, cap=4)
+    chain, hi = run(64, fused=0)
+    for _ in range(2):                     # interleaved: big - small - big
+        for p, (a, lp, v, lg) in ((big, bi), (small, si), (capped, ci), (chain, hi)):
+            p.ppo_epoch(obs, a, adv, ret, None, lp, v, lg, minibatch=MB, lr=1e-3)
+    for p in (big, small, capped, chain):
+        p.check_status()
+    ps = [p.params().cpu().numpy() for p in (big, small, capped, chain)]
+    assert all(np.isfinite(x).all() for x in ps)
+    assert np.abs(ps[1] - ps[2]).max() < 5e-6 and np.abs(ps[1] - ps[3]).max() < 5e-6
+    big2, b2 = run(128, fused=0)           # the larger policy's pass really ran: equal to its own kernel chain
+    for _ in range(2):
+        big2.ppo_epoch(obs, b2[0], adv, ret, None, b2[1], b2[2], b2[3], minibatch=MB, lr=1e-3)
+    assert np.abs(ps[0] - big2.params().cpu().numpy()).max() < 5e-6
+    with pytest.raises(ValueError):
+        small.set_option('no_such_option', 1)
 
 
 def test_trainer_tracks_fp64_ppo_restatement(tmp_path):

@@ -34,8 +34,9 @@ def run(kind):
     if kind == 'fp32':
         cfg = dict(CFG, scorer_precision='fp32')
     else:
-        os.environ['RL4RS_AUGRU'] = kind
-        cfg = dict(CFG, scorer_precision='fp16x2')
+        # kind: 'x' (k_augru_x, default), 'h16' (first generation), 'x32' / 'x64' (k_augru_x pinned to one row-tile form)
+        opts = {'x': '', 'h16': 'augru_h16', 'x32': 'augru_rows32', 'x64': 'augru_rows64'}[kind]
+        cfg = dict(CFG, scorer_precision='fp16x2', scorer_kernels=opts)
     net = DeviceDien(cfg, w, max_rows=8 * B, max_slots=B)
     for s in range(2):
         net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)

@@ -1,5 +1,5 @@
 """Time one PPO SGD pass (rl4rs_policy_ppo_epoch) on synthetic samples: ms per pass and us per minibatch.
-RL4RS_PPO_FUSED=0 selects the per-minibatch kernel chain instead of the persistent k_ppo_pass."""
+RL4RS_POLICY_OPTS=ppo_fused=0 selects the per-minibatch kernel chain instead of the persistent k_ppo_pass."""
 import sys
 import time
 
