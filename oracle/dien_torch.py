@@ -1,4 +1,6 @@
-"""DIEN scorer on torch-CPU (float32, all host cores) - the NN half of bench.py's ``cpu_baseline`` "vectorised" leg.
+"""DIEN scorer on torch-CPU (float32 by default, all host cores) - the NN half of bench.py's ``cpu_baseline`` "vectorised"
+leg; with ``dtype=torch.float64`` the multi-threaded fp64 checker of the full-size GPU parity tests (the numpy oracle is
+single-threaded: hundreds of envs per check need the host's cores).
 ORACLE - test infrastructure only (see oracle/__init__.py).
 
 Same topology and cell equations as ``oracle/dien.py`` (rl4rs/nets/dien.py:8-45, rl4rs/nets/utils.py:16-25,48-54,100-129;
@@ -10,16 +12,18 @@ import torch
 
 
 class TorchDien(object):
-    def __init__(self, weights, config, workers=1):
+    def __init__(self, weights, config, workers=1, dtype=torch.float32):
         self.config = config
         self.workers = workers            # row-parallel python threads (bench.py: one per host core)
-        self.w = dict((k, torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))) for k, v in weights.items())
+        self.dtype = dtype
+        self.np_dtype = np.float64 if dtype == torch.float64 else np.float32
+        self.w = dict((k, torch.from_numpy(np.ascontiguousarray(v, dtype=self.np_dtype))) for k, v in weights.items())
         self.seq_num = config['seq_num']
 
     def _cell_loop(self, X, Wg, bg, Wc, bc, N, att=None, keep=False):
         R, L, E = X.shape
-        h = torch.zeros((R, N), dtype=torch.float32)
-        out = torch.empty((R, L, N), dtype=torch.float32) if keep else None
+        h = torch.zeros((R, N), dtype=self.dtype)
+        out = torch.empty((R, L, N), dtype=self.dtype) if keep else None
         # the input half of both matmuls for all steps at once ([x, h] W = x W[:E] + h W[E:])
         Xg = (X.reshape(R * L, E) @ Wg[:E]).reshape(R, L, -1) + bg
         Xc = (X.reshape(R * L, E) @ Wc[:E]).reshape(R, L, -1) + bc
@@ -39,7 +43,7 @@ class TorchDien(object):
         w = self.w
         seq = torch.as_tensor(np.asarray(seq).astype(np.int64))
         cat = torch.as_tensor(np.asarray(cat).astype(np.int64))
-        dense = torch.as_tensor(np.asarray(dense, dtype=np.float32))
+        dense = torch.as_tensor(np.asarray(dense, dtype=self.np_dtype))
         R = cat.shape[0]
         Ec = w['cat_emb'][cat]                                                   # [R, Cn, E]
         att = torch.softmax(Ec @ Ec.transpose(1, 2), dim=-1) @ Ec
@@ -94,7 +98,7 @@ class TorchDien(object):
     def _prob1(self, seq, dense, cat):
         with torch.no_grad():
             o = torch.nn.functional.elu(self.features(seq, dense, cat) @ self.w['obs_w'] + self.w['obs_b'])
-            return torch.softmax(o @ self.w['out_w'] + self.w['out_b'], dim=1)[:, 1].numpy().astype(np.float32)
+            return torch.softmax(o @ self.w['out_w'] + self.w['out_b'], dim=1)[:, 1].numpy().astype(self.np_dtype)
 
     def obs(self, seq, dense, cat):
         return self._map_rows(self._obs1, seq, dense, cat, self.workers)

@@ -182,6 +182,24 @@ def run_scenario(name, state_cls, FeatureUtil, cfg, records, seq, conti, rs, mas
     return g
 
 
+def compact(g, min_bytes=200000, head_rows=8):
+    """Large float feature arrays of a big-batch scenario are committed as a digest: '<key>__sha1' (sha1 of the C-order bytes),
+    '<key>__shape', '<key>__dtype' and the first rows '<key>__head' - bit-exact comparison needs no more than that, and the
+    fixture stays small.  tests/helpers.py::golden_equal understands both forms."""
+    import hashlib
+    out = {}
+    for k, v in g.items():
+        v = np.ascontiguousarray(v)
+        if v.dtype.kind == 'f' and v.nbytes >= min_bytes:
+            out[k + '__sha1'] = np.frombuffer(hashlib.sha1(v.tobytes()).digest(), dtype=np.uint8).copy()
+            out[k + '__shape'] = np.asarray(v.shape, dtype=np.int64)
+            out[k + '__dtype'] = np.array(str(v.dtype))
+            out[k + '__head'] = v[:head_rows].copy()
+        else:
+            out[k] = v
+    return out
+
+
 def main():
     install_stubs()
     from rl4rs.env.slate import SlateState
@@ -219,6 +237,16 @@ def main():
                              np.random.RandomState(11), flag)
             cfg['iteminfo_file'] = 'catalog_synth.csv'
             emit('seq%d_%s' % (T, tag), g, cfg, True, conti, flag, 'catalog_synth.csv', 'records_seq.txt')
+
+    # ---------------- BASELINE configs[0]: SlateRecEnv-v0 batch = 256, offline_action replay (the mask flags only change which
+    # view of the state `state` returns - both views, obsmask_* and d3rl_*, are recorded at every step - so ONE episode serves
+    # the plain, support_rllib_mask and support_d3rl_mask forms of the config)
+    rec_c = synth.make_records(256, pages=1, seed=3000, illegal_frac=0.2, special_ids=sp)
+    synth.write_records(os.path.join(HERE, 'records_slate256.txt'), rec_c)
+    cfg = base_config(iteminfo_file=cat_path, batch_size=256)
+    g = run_scenario('slate256_discrete', SlateState, FeatureUtil, cfg, rec_c, False, False, np.random.RandomState(13), 'support_rllib_mask')
+    cfg['iteminfo_file'] = 'catalog_synth.csv'
+    emit('slate256_discrete', compact(g), cfg, False, False, 'support_rllib_mask', 'catalog_synth.csv', 'records_slate256.txt')
 
     # ---------------- real data known answers (tutorial.ipynb cell 4 record + dataset/item_info.csv)
     # RL4RS dataset (c) fuxiAIlab, CC BY-SA 4.0 (reference LICENSE); one record and the public catalogue.

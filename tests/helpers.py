@@ -25,5 +25,22 @@ def load_scenario(name):
     return m, cfg, records, g
 
 
+def golden_equal(g, key, arr):
+    """Bit-exact comparison of ``arr`` with golden array ``key``: stored whole, or (large float arrays of the batch-256
+    scenario, make_golden.py::compact) as sha1 digest + shape + dtype + first rows."""
+    import hashlib
+    if key in g.files:
+        return np.array_equal(arr, g[key])
+    a = np.ascontiguousarray(arr)
+    head = g[key + '__head']
+    return (tuple(a.shape) == tuple(g[key + '__shape'].tolist()) and str(a.dtype) == str(g[key + '__dtype'])
+            and np.array_equal(a[:len(head)], head)
+            and hashlib.sha1(a.tobytes()).digest() == g[key + '__sha1'].tobytes())
+
+
+def golden_has(g, key):
+    return key in g.files or (key + '__sha1') in g.files
+
+
 SCENARIOS = ['slate_discrete', 'slate_conti', 'seq36_discrete', 'seq36_conti', 'seq32_discrete',
-             'seq32_conti', 'real_discrete', 'real_conti']
+             'seq32_conti', 'real_discrete', 'real_conti', 'slate256_discrete']

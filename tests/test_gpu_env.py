@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import SCENARIOS, load_scenario
+from helpers import SCENARIOS, load_scenario, golden_equal, golden_has
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +41,7 @@ def test_hip_env_matches_reference_golden(name):
 
     s0, s1, dense, catf = feats()
     assert np.array_equal(np.stack([s0, s1], 1), g['seq_init'])
-    assert np.array_equal(dense, g['dense_init'])
+    assert golden_equal(g, 'dense_init', dense)
     assert np.array_equal(catf, g['cat_init'])
     assert np.array_equal(env.obs_mask().cpu().numpy(), g['obsmask_init'])
     assert np.array_equal(cat.action_emb, g['action_emb'])
@@ -59,20 +59,20 @@ def test_hip_env_matches_reference_golden(name):
         assert np.array_equal(env.bits_to_mask(env.snapshot(D.BUF_SPECIAL_MASK)), g['special_mask_%d' % t]), t
         s0, s1, dense, catf = feats()
         assert np.array_equal(np.stack([s0, s1], 1), g['seq_%d' % t]), t
-        assert np.array_equal(dense, g['dense_%d' % t]), t
+        assert golden_equal(g, 'dense_%d' % t, dense), t
         assert np.array_equal(catf, g['cat_%d' % t]), t
         assert np.array_equal(env.obs_mask().cpu().numpy(), g['obsmask_%d' % t]), t
         assert np.array_equal(env.obs_mask(torch.uint8).cpu().numpy(), g['obsmask_%d' % t]), t
         if env.is_reward_step():
             env.build_complete()
-            assert np.array_equal(env.snapshot(D.BUF_C_DENSE).cpu().numpy(), g['c_dense_%d' % t]), t
+            assert golden_equal(g, 'c_dense_%d' % t, env.snapshot(D.BUF_C_DENSE).cpu().numpy()), t
             assert np.array_equal(env.snapshot(D.BUF_C_CATEGORY).cpu().numpy(), g['c_cat_%d' % t]), t
             probs = torch.from_numpy(g['probs_%d' % t]).cuda().reshape(-1).contiguous()
             r = env.reward(probs).cpu().numpy()
             assert np.array_equal(r, g['reward_%d' % t]), (t, r, g['reward_%d' % t])   # bit-exact f64
             assert np.array_equal(env.violation().cpu().numpy(), g['violation_%d' % t]), t
         else:
-            assert ('c_dense_%d' % t) not in g
+            assert not golden_has(g, 'c_dense_%d' % t)
             assert not np.any(g['reward_%d' % t])
         assert np.array_equal(env.offline_reward().cpu().numpy(), g['offline_reward_%d' % t]), t
     off = env.offline_action(conti=conti).cpu().numpy()

@@ -542,3 +542,49 @@ def test_overridden_plugin_methods_are_honoured(tmp_path):
         assert getattr(ref.sim, '_stepper', None) is not None and getattr(e1.sim, '_stepper', None) is None
         r0, r1, r2 = [np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype=np.float64) for x in (r0, r1, r2)]
         assert r0.max() > 0 and np.array_equal(r0, r1) and np.array_equal(2 * r0, r2)
+
+
+@pytest.mark.parametrize('flag', [None, 'support_rllib_mask', 'support_d3rl_mask'])
+def test_configs0_batch_256_replay_against_reference_vectors(flag):
+    """BASELINE configs[0] (SlateRecEnv-v0, batch 256, 9-slot, offline_action replay) through the gym facade in the reference's
+    own list / ndarray modes, against vectors the REFERENCE's SlateState produced for these 256 records
+    (tests/golden/slate256_discrete.npz, make_golden.py): logged actions, the observation-side mask rows of the rllib mode, the
+    masked_actions | cur_steps tail of the d3rlpy mode, prev_actions, violation and the logged reward - bit for bit."""
+    import rl4rs_amd
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    from helpers import load_scenario, GOLDEN
+    m, cfg, records, g = load_scenario('slate256_discrete')
+    cfg = dict(cfg, sample_file=os.path.join(GOLDEN, m['records']), is_eval=True, cache_size=256, model_seed=3,
+               category_hash_size=2000)
+    for k in ('support_rllib_mask', 'support_d3rl_mask'):
+        cfg.pop(k, None)
+    if flag:
+        cfg[flag] = True
+    B, T = cfg['batch_size'], cfg['max_steps']
+    assert B == 256 and T == 9
+    env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
+    obs = env.reset(reset_file=True)
+    if flag == 'support_rllib_mask':
+        assert np.array_equal(np.stack([o['action_mask'] for o in obs]), g['obsmask_init'])
+    for t in range(T):
+        a = env.offline_action
+        assert np.array_equal(np.asarray(a), g['offline_action_%d' % t]), t
+        obs, reward, done, info = env.step(a)
+        if flag == 'support_rllib_mask':
+            assert np.array_equal(np.stack([o['action_mask'] for o in obs]), g['obsmask_%d' % t]), t
+            assert obs[0]['action_mask'].dtype == np.int64 and obs[0]['obs'].dtype == np.float32
+        elif flag == 'support_d3rl_mask':
+            assert obs.dtype == np.float64 and obs.shape == (B, 256 + T + 1)
+            assert np.array_equal(obs[:, 256:256 + T], g['d3rl_prev_%d' % t].astype(np.float64)), t
+            assert np.array_equal(obs[:, -1:], g['d3rl_cur_%d' % t].astype(np.float64)), t
+        else:
+            assert obs.dtype == np.float32 and obs.shape == (B, 256)
+        assert np.array_equal(env.samples.prev_actions, g['prev_actions_%d' % t]), t
+        assert np.array_equal(np.asarray(env.offline_reward, dtype=np.float64), g['offline_reward_%d' % t]), t
+    assert getattr(env.sim, '_stepper', None) is not None
+    assert np.array_equal(env.samples.action_mask, g['action_mask_%d' % (T - 1)])
+    assert np.array_equal(env.samples.special_mask, g['special_mask_%d' % (T - 1)])
+    assert np.array_equal(env.samples.get_violation(), g['violation_end'])
+    viol = g['violation_end']
+    r = np.asarray(reward, dtype=np.float64)
+    assert (r[viol == 0] == 0).all() and (r[viol == 1] > 0).all()

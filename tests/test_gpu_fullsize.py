@@ -1,12 +1,25 @@
 """BASELINE.json full size (SlateRecEnv-v0, B=4096, 284 items, 9 slots, hash 100000): integer state bit-exact vs the
-numpy oracle on the whole batch; observations / rewards vs the fp64 DIEN oracle on a random subset of envs (rows are
-independent, so a subset is a valid check of the full-size launch geometry); duplicate-record invariance."""
+numpy oracle on the whole batch; observations / rewards of NPICK = 512 envs vs the fp64 DIEN oracle (oracle/dien_torch.py in
+float64 on the host's threads; rows are independent, so a subset is a valid check of the full-size launch geometry - 512 of
+4096 envs cover every workgroup position class of the 32- and 64-row kernels); duplicate-record invariance; and the BENCH's
+own configuration (train-mode sampling with duplicates, history dedup, row-order hint, fused step)."""
 import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+NPICK = 512
+
+
+def _fp64_scorer(cfg, seed=7):
+    """The fp64 checker: same restatement as oracle/dien.py (tests/test_oracle_dien.py pins the two together to 1e-11), on
+    row-parallel host threads so that hundreds of envs per step stay within seconds."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from oracle.dien_torch import TorchDien
+    return TorchDien(init_dien_weights(cfg, seed=seed), cfg, workers=max(1, min(32, (os.cpu_count() or 2) // 2)), dtype=torch.float64)
 
 
 def test_full_size_slate_episode(tmp_path):
@@ -33,9 +46,8 @@ def test_full_size_slate_episode(tmp_path):
     env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
     obs = env.reset(reset_file=True)
     st = OracleState(cfg, recs)
-    w = init_dien_weights(cfg, seed=7)
-    orc = OracleDien(w, cfg, np.float64)
-    pick = np.sort(np.random.RandomState(0).choice(B, 24, replace=False))
+    orc = _fp64_scorer(cfg)
+    pick = np.sort(np.random.RandomState(0).choice(B, NPICK, replace=False))
 
     def check_obs(o):
         seq, dense, cat = st.features()
@@ -83,7 +95,7 @@ def _full_cfg(d, B, T, recs, **extra):
 def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
     """BASELINE configs[2]: SeqSlateRecEnv-v0, B=4096, 32-step horizon (pages of 9: rewards after steps 9, 18, 27; the last 5
     steps never pay, seqslate.py:138).  Integer state of the WHOLE batch bit-exact vs the oracle at every step, observations
-    and page rewards of a 24-env subset vs the fp64 DIEN oracle, then one PPO train call of the on-device loop on the same env
+    and page rewards of a 512-env subset vs the fp64 DIEN oracle, then one PPO train call of the on-device loop on the same env
     (script/modelfree_train.py:42-44,179-247)."""
     import torch
     import rl4rs_amd
@@ -104,8 +116,8 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
     env = rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=SeqSlateRecEnv(cfg, state_cls=SeqSlateState))
     obs = env.reset(reset_file=True)
     st = OracleState(cfg, recs, seq=True)
-    orc = OracleDien(init_dien_weights(cfg, seed=7), cfg, np.float64)
-    pick = np.sort(np.random.RandomState(1).choice(B, 24, replace=False))
+    orc = _fp64_scorer(cfg)
+    pick = np.sort(np.random.RandomState(1).choice(B, NPICK, replace=False))
     pick_t = torch.from_numpy(pick).cuda()
 
     def check_obs(o, full):
@@ -122,7 +134,7 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
         assert np.array_equal(a.cpu().numpy(), np.asarray(st.offline_action))
         obs, reward, done, info = env.step(a)
         st.act(a.cpu().numpy())
-        # observations against the fp64 scorer on the first page, at every page boundary and at the end (each costs 24
+        # observations against the fp64 scorer on the first page, at every page boundary and at the end (each costs NPICK
         # fp64 DIEN rows on the host); masks and integer state at EVERY step
         check_obs(obs, t < 10 or t % 9 in (0, 8) or t == T - 1)
         assert np.array_equal(env.samples.prev_actions, st.prev_actions) if t % 8 == 7 or t == T - 1 else True
@@ -161,7 +173,7 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
 def test_full_size_continuous_action_episode(tmp_path):
     """BASELINE configs[4], its 1-GPU half: SlateRecEnv-v0 with continuous 32-d actions resolved by the masked float64 K-NN,
     B=4096.  Chosen items / integer state bit-exact vs the oracle on the whole batch (actions = logged items' embeddings
-    plus noise, so the K-NN and its masks decide), observations and rewards of a 24-env subset vs the fp64 DIEN oracle."""
+    plus noise, so the K-NN and its masks decide), observations and rewards of a 512-env subset vs the fp64 DIEN oracle."""
     import torch
     import rl4rs_amd
     from rl4rs_amd import synth
@@ -180,8 +192,8 @@ def test_full_size_continuous_action_episode(tmp_path):
     env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(cfg, state_cls=SlateState))
     obs = env.reset(reset_file=True)
     st = OracleState(cfg, recs)
-    orc = OracleDien(init_dien_weights(cfg, seed=7), cfg, np.float64)
-    pick = np.sort(np.random.RandomState(2).choice(B, 24, replace=False))
+    orc = _fp64_scorer(cfg)
+    pick = np.sort(np.random.RandomState(2).choice(B, NPICK, replace=False))
     pick_t = torch.from_numpy(pick).cuda()
     rs = np.random.RandomState(5)
     for t in range(T):
@@ -209,3 +221,76 @@ def test_full_size_continuous_action_episode(tmp_path):
     assert (r[viol == 0] == 0).all()
     # the masked K-NN can only return legal, unused items: no slate violates the rules
     assert viol.all()
+
+
+def test_the_bench_configuration_itself(tmp_path):
+    """The path the headline number runs: bench.py's own config and env construction - train-mode sampling
+    (np.random.choice of 4096 envs from a 2048-line cache window, base.py:92-100: ~57 % of the envs share a user history with
+    another env), history de-duplication + the env -> slot table, the row-order hint (rl4rs_dien_set_row_order), zero-copy
+    tensors, the fused step entry point, the automatic 32- / 64-row AUGRU forms - over TWO episode-batches on the same handles.
+    Integer state of all 4096 envs bit-exact against the oracle replaying the very records the env sampled; observations of
+    512 envs at every step and their rewards against the fp64 scorer; envs that drew the same log line carry bit-identical
+    observation rows and rewards."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle.state import OracleState
+    from oracle.env import reward_from_probs
+
+    class Args(object):
+        env, batch, horizon, log_records, scorer, algo, conti = 'slate', 4096, 9, 8193, 'auto', 'dien', False
+
+    cfg, _ = bench.make_config(Args(), str(tmp_path), 0)
+    assert cfg['is_eval'] is False and cfg['cache_size'] == 2048 and cfg['return_tensors'] and 'no_row_order' not in cfg
+    B, T = cfg['batch_size'], cfg['max_steps']
+    env = bench.build_env(cfg, False)
+    env.seed(1000)
+    env.sim._recData.store.preload(torch.device('cuda', torch.cuda.current_device()))
+    orc = _fp64_scorer(cfg, seed=cfg['model_seed'])
+    rs = np.random.RandomState(3)
+    for episode in range(2):
+        obs = env.reset()
+        recs = list(env.samples.records)                      # what RecDataBase.sample drew for this batch
+        rows = np.asarray(env.samples.records.rows)
+        uniq, first, inv, counts = np.unique(rows, return_index=True, return_inverse=True, return_counts=True)
+        assert 1500 < len(uniq) < 2048 and env.samples._hist_unique[0].shape[0] == len(uniq)
+        assert getattr(env.samples, '_row_order', None) is not None
+        st = OracleState(cfg, recs)
+        # picked envs: half of them from histories that several envs share, the rest at random
+        shared = np.flatnonzero(counts[inv] > 1)
+        pick = np.unique(np.concatenate([rs.choice(shared, NPICK // 2, replace=False), rs.choice(B, NPICK // 2, replace=False)]))
+        pick_t = torch.from_numpy(pick).cuda()
+        # one representative per log line, to compare every duplicate env with
+        rep_t = torch.from_numpy(first[inv]).cuda()
+
+        def check_obs(o, t):
+            seq, dense, cat = st.features()
+            ref = orc.obs(seq[pick], dense[pick], cat[pick])
+            assert np.abs(o[pick_t].cpu().numpy() - ref).max() < 5e-5, (episode, t)
+            assert torch.equal(o, o[rep_t]), (episode, t)                  # same log line + same actions -> same bits
+
+        check_obs(obs, -1)
+        for t in range(T):
+            a = env.offline_action
+            assert np.array_equal(a.cpu().numpy(), np.asarray(st.offline_action))
+            obs, reward, done, info = env.step(a)
+            st.act(a.cpu().numpy())
+            check_obs(obs, t)
+        assert getattr(env.sim, '_stepper', None) is not None              # the fused entry point ran
+        assert np.array_equal(env.samples.prev_actions, st.prev_actions)
+        assert np.array_equal(env.samples.action_mask, st.action_mask)
+        assert np.array_equal(env.samples.special_mask, st.special_mask)
+        assert np.array_equal(env.samples.get_violation(), st.get_violation())
+        assert np.array_equal(np.asarray(env.offline_reward.cpu()), np.asarray(st.offline_reward))
+        cs, cd, cc = st.complete_features()
+        crow = (pick[:, None] * 9 + np.arange(9)[None, :]).reshape(-1)
+        probs = np.zeros((B, 9), dtype=np.float64)
+        probs[pick] = orc.prob(cs[crow], cd[crow], cc[crow]).reshape(-1, 9)
+        ref = np.asarray(reward_from_probs(st, probs.astype(np.float32)))
+        r = reward.cpu().numpy()
+        assert np.allclose(r[pick], ref[pick], rtol=1e-5, atol=1e-5), episode
+        assert np.array_equal(r, r[first[inv]])
+        viol = st.get_violation()
+        assert (r[viol == 0] == 0).all() and (r[viol == 1] > 0).all()
+        env.sim.model.device_net.check_status()

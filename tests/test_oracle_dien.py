@@ -156,3 +156,11 @@ def test_torch_cpu_dien_matches_the_numpy_oracle():
     td = TorchDien(w, cfg)
     assert np.abs(td.obs(seq, dense, cat) - ref.obs(seq, dense, cat)).max() < 5e-5
     assert np.abs(td.prob(seq, dense, cat) - ref.prob(seq, dense, cat)).max() < 5e-6
+    # the float64 form (the multi-threaded checker of the full-size GPU tests) agrees with the numpy fp64 oracle to rounding,
+    # with and without row-parallel workers
+    import torch
+    for workers in (1, 3):
+        t64 = TorchDien(w, cfg, workers=workers, dtype=torch.float64)
+        o = t64.obs(seq, dense, cat)
+        assert o.dtype == np.float64 and np.abs(o - ref.obs(seq, dense, cat)).max() < 1e-11
+        assert np.abs(t64.prob(seq, dense, cat) - ref.reward_probs(seq, dense, cat)[:, 1]).max() < 1e-12

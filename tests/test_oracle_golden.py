@@ -5,7 +5,7 @@ import pytest
 
 from oracle.env import reward_from_probs, is_reward_step
 from oracle.state import OracleState, nearest_neighbor
-from helpers import SCENARIOS, load_scenario
+from helpers import SCENARIOS, load_scenario, golden_equal, golden_has
 
 
 @pytest.mark.parametrize('name', SCENARIOS)
@@ -15,7 +15,7 @@ def test_oracle_matches_reference(name):
     T = cfg['max_steps']
     seq, dense, cat = st.features()
     assert np.array_equal(seq, g['seq_init'])
-    assert np.array_equal(dense, g['dense_init']) and dense.dtype == np.float32
+    assert golden_equal(g, 'dense_init', dense) and dense.dtype == np.float32
     assert np.array_equal(cat, g['cat_init'])
     assert np.array_equal(st.obs_action_mask(), g['obsmask_init'])
     assert np.array_equal(st.action_emb, g['action_emb'])
@@ -29,7 +29,7 @@ def test_oracle_matches_reference(name):
         assert np.array_equal(st.special_mask, g['special_mask_%d' % t]), t
         seq, dense, cat = st.features()
         assert np.array_equal(seq, g['seq_%d' % t]), t
-        assert np.array_equal(dense, g['dense_%d' % t]), t
+        assert golden_equal(g, 'dense_%d' % t, dense), t
         assert np.array_equal(cat, g['cat_%d' % t]), t
         assert np.array_equal(st.obs_action_mask(), g['obsmask_%d' % t]), t
         pa, cur = st.masked_actions()
@@ -40,11 +40,11 @@ def test_oracle_matches_reference(name):
         if is_reward_step(st):
             cs, cd, cc = st.complete_features()
             assert np.array_equal(cs, g['c_seq_%d' % t]), t
-            assert np.array_equal(cd, g['c_dense_%d' % t]), t
+            assert golden_equal(g, 'c_dense_%d' % t, cd), t
             assert np.array_equal(cc, g['c_cat_%d' % t]), t
             assert np.array_equal(st.get_violation(), g['violation_%d' % t]), t
         else:
-            assert ('c_dense_%d' % t) not in g
+            assert not golden_has(g, 'c_dense_%d' % t)
         assert np.array_equal(np.asarray(st.offline_reward, dtype=np.float64), g['offline_reward_%d' % t]), t
     assert np.array_equal(np.asarray(st.offline_action), g['offline_action_end'])
     assert np.array_equal(st.get_violation(), g['violation_end'])
@@ -99,7 +99,7 @@ def test_faithful_per_sample_loop_matches_reference(name):
     stub = Stub()
     env = FaithfulSlateEnv(cfg, records, stub)
     seq, dense, cat = env._features(env.state)
-    assert np.array_equal(seq, g['seq_init']) and np.array_equal(dense, g['dense_init']) and np.array_equal(cat, g['cat_init'])
+    assert np.array_equal(seq, g['seq_init']) and golden_equal(g, 'dense_init', dense) and np.array_equal(cat, g['cat_init'])
     for t in range(T):
         assert np.array_equal(np.asarray(env.offline_action), g['offline_action_%d' % t])
         stub.probs = g['probs_%d' % t]
@@ -108,9 +108,9 @@ def test_faithful_per_sample_loop_matches_reference(name):
         assert np.array_equal(env.action_mask, g['action_mask_%d' % t]), t
         assert np.array_equal(env.special_mask, g['special_mask_%d' % t]), t
         seq, dense, cat = env._features(env.state)
-        assert np.array_equal(seq, g['seq_%d' % t]) and np.array_equal(dense, g['dense_%d' % t]) and np.array_equal(cat, g['cat_%d' % t]), t
+        assert np.array_equal(seq, g['seq_%d' % t]) and golden_equal(g, 'dense_%d' % t, dense) and np.array_equal(cat, g['cat_%d' % t]), t
         assert np.array_equal(np.asarray(reward, dtype=np.float64), g['reward_%d' % t]), t
         assert done == [1 if t == T - 1 else 0] * cfg['batch_size']
     cs, cd, cc = env._features(env.complete_states())
-    assert np.array_equal(cs, g['c_seq_%d' % (T - 1)]) and np.array_equal(cd, g['c_dense_%d' % (T - 1)]) and np.array_equal(cc, g['c_cat_%d' % (T - 1)])
+    assert np.array_equal(cs, g['c_seq_%d' % (T - 1)]) and golden_equal(g, 'c_dense_%d' % (T - 1), cd) and np.array_equal(cc, g['c_cat_%d' % (T - 1)])
     assert np.array_equal(env.violation(), g['violation_end'])
