@@ -554,8 +554,7 @@ def test_configs0_batch_256_replay_against_reference_vectors(flag):
     from rl4rs_amd.env.slate import SlateRecEnv, SlateState
     from helpers import load_scenario, GOLDEN
     m, cfg, records, g = load_scenario('slate256_discrete')
-    cfg = dict(cfg, sample_file=os.path.join(GOLDEN, m['records']), is_eval=True, cache_size=256, model_seed=3,
-               category_hash_size=2000)
+    cfg = dict(cfg, sample_file=os.path.join(GOLDEN, m['records']), is_eval=True, cache_size=256, model_seed=3)
     for k in ('support_rllib_mask', 'support_d3rl_mask'):
         cfg.pop(k, None)
     if flag:
