@@ -314,6 +314,10 @@ def main():
     ap.add_argument('--train', choices=['none', 'a2c', 'ppo'], default='none',
                     help='none: offline_action replay (BASELINE configs[1]); a2c/ppo: policy rollout + update with the '
                          'flat-gradient all-reduce over RCCL (configs[2]/[3])')
+    ap.add_argument('--minibatch', type=int, default=256,
+                    help='--train ppo: SGD minibatch per rank (RLlib: 256).  With N > 1 every minibatch costs one gradient '
+                         'all-reduce (synchronous SGD over N x minibatch samples): 512 / 1024 halve / quarter the collectives '
+                         'per pass at the price of a larger effective minibatch (DESIGN.md 6)')
     args = ap.parse_args()
     if args.horizon is None:
         args.horizon = 9 if args.env == 'slate' else 32
@@ -343,7 +347,7 @@ def main():
     trainer = None
     if args.train != 'none':
         from rl4rs_amd.train import Trainer
-        trainer = Trainer(env, algo=args.train.upper(), seed=1000 + rank)
+        trainer = Trainer(env, algo=args.train.upper(), seed=1000 + rank, minibatch=args.minibatch)
     run_step = (lambda: trainer.train_iteration()) if trainer else (lambda: episode(env, T))
     for _ in range(args.warmup):
         run_step()

@@ -1,0 +1,39 @@
+"""N > 1 control flow of bench.py (barriers, max-over-ranks timing, rank-0 reporting, the gradient all-reduce of the training
+legs) dry-run with TWO ranks sharing the one GPU of the test box over gloo (RL4RS_DIST_BACKEND=gloo): every leg the driver may
+launch at N = 2 / 4 / 8 over RCCL is executed here with the same command line shape, under a hard timeout - a rank waiting in a
+collective the others never enter (the round-2 bug of `--train` at N > 1) fails the test instead of hanging the round."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('leg', [[], ['--train', 'a2c'], ['--train', 'ppo'], ['--env', 'seq', '--horizon', '18'], ['--conti'],
+                                 ['--train', 'ppo', '--minibatch', '512']])
+def test_bench_two_ranks_over_gloo(leg):
+    env = dict(os.environ, RL4RS_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '256', '--log-records', '700', '--no-cpu-baseline'] + leg
+    out = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]              # ONE line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['value'] > 0 and rec['scaling'] == 'weak'
+    assert rec['unit'] == 'env-steps/s' and rec['roofline'] is not None
