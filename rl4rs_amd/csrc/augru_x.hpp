@@ -240,12 +240,12 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         *reinterpret_cast<half4_t*>(p_hi + o) = vh;
         *reinterpret_cast<half4_t*>(p_lo + o) = vl;
     };
-    const float sig_k = a.sig_k[sq], tanh_k = a.tanh_k[sq];       // activations of power-of-two prescaled pre-activations (RecurArgs)
+    const float k_r = a.k_r[sq][wave], k_u = a.k_u[sq][wave], k_c = a.k_c[sq][wave];   // activations of prescaled pre-activations (RecurArgs)
     float quad[MT][4];
     auto reset_gate = [&](int r) {                                 // element r of the reset gate: r*h -> planes
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            quad[m][r & 3] = ((RL4RS_X_AB & 1) ? acc_r[m][r] : gate_sigmoid_k(acc_r[m][r], sig_k)) * h_own[m][r];
+            quad[m][r & 3] = ((RL4RS_X_AB & 1) ? acc_r[m][r] : gate_sigmoid_k(acc_r[m][r], k_r)) * h_own[m][r];
             if ((r & 3) == 3) plane_store(rp_hi, rp_lo, m, r >> 2, quad[m]);
         }
     };
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         for (int m = 0; m < MT; ++m) {
             float pre = acc_u[m][r];
             asm volatile("" : "+v"(pre));                          // keeps this element's chain where it is written
-            acc_u[m][r] = oma[m] * ((RL4RS_X_AB & 1) ? pre : gate_sigmoid_k(pre, sig_k));
+            acc_u[m][r] = oma[m] * ((RL4RS_X_AB & 1) ? pre : gate_sigmoid_k(pre, k_u));
         }
     };
     auto blend = [&](int r) {                                      // candidate + state update of element r -> h planes
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const float cnd = (RL4RS_X_AB & 1) ? acc_c[m][r] : gate_tanh_k(acc_c[m][r], tanh_k);
+            const float cnd = (RL4RS_X_AB & 1) ? acc_c[m][r] : gate_tanh_k(acc_c[m][r], k_c);
             const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - cnd, cnd);       // u h + (1-u) c
             amax[m] = fmaxf(amax[m], fabsf(hn));
             h_own[m][r] = hn;

@@ -296,12 +296,14 @@ struct RecurArgs {
     int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
     const int32_t* order;        // k_augru_x: processing order of the row groups (NULL = identity)
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
-    // fp16x2 AUGRU kernels: the gate / candidate weight matrices (and the cached x-side projections, biases folded) are stored
-    // multiplied by a power of two s_g / s_c (rl4rs_dien_create: max |w| * s in [2^13, 2^14), so the fp16 hi + lo split keeps its
-    // 22 bits whatever the scale of a checkpoint's weights, and no weight is "too large for fp16").  The pre-activation is
-    // acc / s; the division rides on the constant the activation multiplies by anyway: sigmoid(acc / s) = 1 / (1 + exp2(acc * sig_k)),
-    // sig_k = -log2(e) / s_g, tanh_k = 2 log2(e) / s_c - exact (powers of two), same instruction count.
-    float sig_k[4], tanh_k[4];
+    // fp16x2 AUGRU kernels: every 32-column tile of the reset / update / candidate weight matrices (and the same columns of the
+    // cached x-side projections, biases folded) is stored multiplied by its own power of two s (rl4rs_dien_create: max |w| * s in
+    // [2^13, 2^14) over the tile), so the fp16 hi + lo split keeps its 22 bits whatever the scale of a checkpoint's weights, no
+    // weight is "too large for fp16", and an outlier costs precision in its own tile only.  A wave owns exactly one tile per
+    // gate, so its three constants are wave-uniform scalars.  The pre-activation is acc / s; the division rides on the constant
+    // the activation multiplies by anyway: sigmoid(acc / s) = 1 / (1 + exp2(acc * k)), k = -log2(e) / s; tanh: k = 2 log2(e) / s -
+    // exact (powers of two), same instruction count.
+    float k_r[4][8], k_u[4][8], k_c[4][8];         // [sequence input][column tile = wave]
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     }
 
     bool out_of_range = false;
-    const float sig_k = a.sig_k[sq], tanh_k = a.tanh_k[sq];       // activations of power-of-two prescaled pre-activations (RecurArgs)
+    const float k_r = a.k_r[sq][wave], k_u = a.k_u[sq][wave], k_c = a.k_c[sq][wave];   // activations of prescaled pre-activations (RecurArgs)
     const int TL = a.steps > 0 ? a.steps : L;
 #pragma unroll 1
     for (int t = 0; t < TL; ++t) {
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
             if (g == 1) {            // shadow: reset gate, accumulator register kb of every tile
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const float rg = gate_sigmoid_k(acc_r[m][kb], sig_k);
+                    const float rg = gate_sigmoid_k(acc_r[m][kb], k_r);
                     const float v = rg * h_own[m][kb];
                     const _Float16 vh = (_Float16)v;
                     rp_hi[(m * 32 + crow(kb, half)) * LDP + col] = vh;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
                 for (int m = 0; m < MT; ++m) {
                     float pre = acc_u[m][kb];
                     asm volatile("" : "+v"(pre));      // keeps element kb's chain in item kb (else all 16 cluster up front)
-                    acc_u[m][kb] = (1.0f - s_att[(m * 32 + crow(kb, half)) * LDT + t]) * gate_sigmoid_k(pre, sig_k);
+                    acc_u[m][kb] = (1.0f - s_att[(m * 32 + crow(kb, half)) * LDT + t]) * gate_sigmoid_k(pre, k_u);
                 }
             }
             if (g != 0) {
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float c = gate_tanh_k(acc_c[m][r], tanh_k);
+                const float c = gate_tanh_k(acc_c[m][r], k_c);
                 const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - c, c);     // u h + (1-u) c
                 out_of_range |= !(fabsf(hn) < 6.0e4f);      // fp16 planes cannot carry it (also catches NaN)
                 h_own[m][r] = hn;
@@ -1289,7 +1291,7 @@ struct rl4rs_dien {
     bool fp16x2;
     bool augru_x;          // fp16x2 mode: k_augru_x (default) or the first-generation k_augru_h16 (RL4RS_DIEN_OPT_AUGRU_H16)
     int augru_rows;        // k_augru_x row-tile form: 0 automatic, 32, 64 (rl4rs_dien_set_augru_rows)
-    float augru_sg[4], augru_sc[4];   // fp16x2: power-of-two prescale of the AUGRU gate / candidate matrices (1 in fp32 mode)
+    float augru_s[4][3][8];   // fp16x2: power-of-two prescale of the AUGRU's reset / update / candidate column tiles (1 in fp32 mode)
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
@@ -1424,11 +1426,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             RL4RS_REQUIRE(w->augru_gate_w[s] && w->augru_cand_w[s], "dien_create: null AUGRU weights for sequence input %d", s);
             for (size_t i = 0; i < (e + nh2) * 2 * nh2; ++i) {
                 float v = fabsf(w->augru_gate_w[s][i]);
-                finite = finite && v == v; wmax = fmaxf(wmax, v);
+                finite = finite && v < 3.0e38f; wmax = fmaxf(wmax, v);
             }
             for (size_t i = 0; i < (e + nh2) * nh2; ++i) {
                 float v = fabsf(w->augru_cand_w[s][i]);
-                finite = finite && v == v; wmax = fmaxf(wmax, v);
+                finite = finite && v < 3.0e38f; wmax = fmaxf(wmax, v);
             }
         }
         // every fp16x2 matrix is stored multiplied by its own power of two (pow2_prescale below), so the split form has no
@@ -1598,16 +1600,23 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             UP(gru_wc16[s], keep.back().data(), keep.back().size());
         }
         // ---- power-of-two prescale of the AUGRU's recurrent (h-side) matrices in fp16x2 mode (pow2_prescale)
-        float sg = 1.f, sc = 1.f;
+        // one scale per 32-column tile of the reset / update / candidate matrices = per (wave, gate) of the recurrence kernels
+        std::vector<float> sgc(2 * NH2, 1.f), scc(NH2, 1.f);          // per-column view of the tile scales
+        for (int g = 0; g < 3; ++g)
+            for (int t = 0; t < 8; ++t) n->augru_s[s][g][t] = 1.f;
         if (n->fp16x2) {
-            float mg = 0.f, mc = 0.f;
-            for (size_t i = (size_t)E * 2 * NH2; i < (size_t)(E + NH2) * 2 * NH2; ++i) mg = fmaxf(mg, fabsf(w->augru_gate_w[s][i]));
-            for (size_t i = (size_t)E * NH2; i < (size_t)(E + NH2) * NH2; ++i) mc = fmaxf(mc, fabsf(w->augru_cand_w[s][i]));
-            sg = pow2_prescale(mg);
-            sc = pow2_prescale(mc);
+            RL4RS_REQUIRE(NH2 == 256, "dien: the fp16x2 recurrence is built for 2 * emb_size = 256 hidden units");
+            for (int g = 0; g < 3; ++g)
+                for (int t = 0; t < NH2 / 32; ++t) {
+                    float mx = 0.f;
+                    for (int k = E; k < E + NH2; ++k)
+                        for (int j = 32 * t; j < 32 * t + 32; ++j)
+                            mx = fmaxf(mx, fabsf(g < 2 ? w->augru_gate_w[s][(size_t)k * 2 * NH2 + g * NH2 + j] : w->augru_cand_w[s][(size_t)k * NH2 + j]));
+                    const float sc_t = pow2_prescale(mx);
+                    n->augru_s[s][g][t] = sc_t;
+                    for (int j = 32 * t; j < 32 * t + 32; ++j) { if (g < 2) sgc[g * NH2 + j] = sc_t; else scc[j] = sc_t; }
+                }
         }
-        n->augru_sg[s] = sg;
-        n->augru_sc[s] = sc;
         // ---- projections of h1: [W1b - W1c | augru gate x-side | augru cand x-side], bias [b1 | bg | bc]
         std::vector<float> wp((size_t)E * PLD), bp(PLD), wac((size_t)E * ATT_H1);
         const float* w1 = w->att_w1[s];    // rows: q [0,E) | k [E,2E) | q-k [2E,3E) | q*k [3E,4E)
@@ -1617,12 +1626,12 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
                 wac[(size_t)k * ATT_H1 + j] = w1[(size_t)k * ATT_H1 + j] + w1[(size_t)(2 * E + k) * ATT_H1 + j];
             }
             // (fp16x2: the AUGRU sections arrive at the recurrence as MFMA C-in next to products of PRESCALED weights: same scale)
-            for (int j = 0; j < 2 * NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + j] = w->augru_gate_w[s][(size_t)k * 2 * NH2 + j] * sg;
-            for (int j = 0; j < NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + 2 * NH2 + j] = w->augru_cand_w[s][(size_t)k * NH2 + j] * sc;
+            for (int j = 0; j < 2 * NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + j] = w->augru_gate_w[s][(size_t)k * 2 * NH2 + j] * sgc[j];
+            for (int j = 0; j < NH2; ++j) wp[(size_t)k * PLD + ATT_H1 + 2 * NH2 + j] = w->augru_cand_w[s][(size_t)k * NH2 + j] * scc[j];
         }
         for (int j = 0; j < ATT_H1; ++j) bp[j] = w->att_b1[s][j];
-        for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j] * sg;
-        for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j] * sc;
+        for (int j = 0; j < 2 * NH2; ++j) bp[ATT_H1 + j] = w->augru_gate_b[s][j] * sgc[j];
+        for (int j = 0; j < NH2; ++j) bp[ATT_H1 + 2 * NH2 + j] = w->augru_cand_b[s][j] * scc[j];
         keep.push_back(pack_w(wp.data(), PLD, E, PLD)); UP(wproj[s], keep.back().data(), keep.back().size());
         keep.push_back(std::move(bp)); UP(bproj[s], keep.back().data(), keep.back().size());
         for (int k = 0; k < E; ++k)
@@ -1646,11 +1655,11 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         n->augru_wg16[s] = n->augru_wc16[s] = nullptr;
         if (n->fp16x2) {
             std::vector<float> hs((size_t)NH2 * 2 * NH2);
-            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_gate_w[s][(size_t)E * 2 * NH2 + i] * sg;
+            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_gate_w[s][(size_t)E * 2 * NH2 + i] * sgc[i % (2 * NH2)];
             keep.push_back(pack_frag_h16(hs.data(), 2 * NH2, 0, NH2, 2 * NH2));
             UP(augru_wg16[s], keep.back().data(), keep.back().size());
             hs.resize((size_t)NH2 * NH2);
-            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_cand_w[s][(size_t)E * NH2 + i] * sc;
+            for (size_t i = 0; i < hs.size(); ++i) hs[i] = w->augru_cand_w[s][(size_t)E * NH2 + i] * scc[i % NH2];
             keep.push_back(pack_frag_h16(hs.data(), NH2, 0, NH2, NH2));
             UP(augru_wc16[s], keep.back().data(), keep.back().size());
         }
@@ -1836,7 +1845,12 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         if (n->fp16x2) {
             for (int s = 0; s < S; ++s) { a.wg[s] = n->augru_wg16[s]; a.wc[s] = n->augru_wc16[s]; }
             a.range_flag = n->range_flag;
-            for (int s = 0; s < S; ++s) { a.sig_k[s] = -1.4426950408889634f / n->augru_sg[s]; a.tanh_k[s] = 2.8853900817779268f / n->augru_sc[s]; }
+            for (int s = 0; s < S; ++s)
+                for (int t = 0; t < 8; ++t) {
+                    a.k_r[s][t] = -1.4426950408889634f / n->augru_s[s][0][t];
+                    a.k_u[s][t] = -1.4426950408889634f / n->augru_s[s][1][t];
+                    a.k_c[s][t] = 2.8853900817779268f / n->augru_s[s][2][t];
+                }
             a.order = (n->augru_x && n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
             a.steps = 0;
 #if defined(RL4RS_H16_TRACE) || defined(RL4RS_X_TRACE)

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     const bool tile_ok = nt < NT;
     const int col = nt * 32 + li;
     const char* wtile = Wp + (size_t)(tile_ok ? nt : 0) * KB * 2048;
-    const float inv_s = reinterpret_cast<const float*>(Wp)[(size_t)NT * KB * 512];     // 1 / (the matrix's power-of-two prescale)
+    const float inv_s = reinterpret_cast<const float*>(Wp)[(size_t)NT * KB * 512 + (tile_ok ? col : 0)];     // 1 / (this column's power-of-two prescale)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wtile), 0, KB * 2048, 0x00020000);
     const int vl16 = lane * 16;
 
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     if (chain.wp2) {        // uniform: chained second layer (gridDim.y == 1, N <= 128, N % 16 == 0: checked by the launcher)
         const int NT2 = (chain.n2 + 31) / 32;
         const bool tile2_ok = wave < NT2;
-        const float inv_s2 = reinterpret_cast<const float*>(chain.wp2)[(size_t)NT2 * chain.kb2 * 512];
+        const float inv_s2 = reinterpret_cast<const float*>(chain.wp2)[(size_t)NT2 * chain.kb2 * 512 + (tile2_ok ? wave * 32 + li : 0)];
         const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(chain.wp2 + (size_t)(tile2_ok ? wave : 0) * chain.kb2 * 2048), 0, chain.kb2 * 2048, 0x00020000);
         ghalf8_t b2h[8], b2l[8];                       // K2 <= 128: every fragment of the second layer requested up front
@@ -499,23 +499,27 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
 
 // host: split W [K,N] into fp16 hi / lo and pack it into B-fragment order for k_gemm_h16 (K padded to 16, N to 32);
 // returned as floats (NT * KB16 * 512)
-// The matrix is stored multiplied by its own power of two s (pow2_prescale: max |w| s in [2^13, 2^14), exact), so there is no
-// weight-range condition and small weights keep a normal lo part; 1 / s follows the fragments as ONE float (4 with padding) and
-// the kernel's epilogue multiplies the accumulator by it - exact - before bias / addend / activation.
+// Every COLUMN j is stored multiplied by its own power of two s_j (pow2_prescale: max_k |w[k][j]| s_j in [2^13, 2^14), exact), so
+// there is no weight-range condition, small weights keep a normal lo part, and an outlier costs precision in its own column
+// only (the scorer's projection matrix is a concatenation of sections of very different scales).  The 1 / s_j follow the
+// fragments as NT * 32 floats; the kernel's epilogue multiplies a lane's accumulators by its column's value - exact - before
+// bias / addend / activation.
 std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N) {
     const int KB = (K + 15) / 16, NT = (N + 31) / 32;
-    float mx = 0.f;
-    for (int k = 0; k < K; ++k)
-        for (int j = 0; j < N; ++j) mx = fmaxf(mx, fabsf(w[(size_t)k * ldw + j]));
-    const float scale = pow2_prescale(mx);
-    std::vector<uint16_t> out((size_t)NT * KB * 2 * 512 + 8, 0);
+    std::vector<float> scale((size_t)NT * 32, 1.f);
+    for (int j = 0; j < N; ++j) {
+        float mx = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(w[(size_t)k * ldw + j]));
+        scale[j] = pow2_prescale(mx);
+    }
+    std::vector<uint16_t> out(((size_t)NT * KB * 512 + (size_t)NT * 32) * 2, 0);
     for (int nt = 0; nt < NT; ++nt)
         for (int kb = 0; kb < KB; ++kb)
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 8; ++i) {
                     const int k = kb * 16 + (lane >> 5) * 8 + i, j = nt * 32 + (lane & 31);
                     if (k >= K || j >= N) continue;
-                    const float v = w[(size_t)k * ldw + j] * scale;
+                    const float v = w[(size_t)k * ldw + j] * scale[j];
                     const uint16_t hi = f32_to_f16(v);
                     const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
                     const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8 + i;
@@ -524,7 +528,7 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
                 }
     std::vector<float> f(out.size() / 2);
     memcpy(f.data(), out.data(), out.size() * 2);
-    f[(size_t)NT * KB * 512] = 1.0f / scale;          // trailer: read by k_gemm_h16 as Wp_f32[NT * KB * 512]
+    for (int j = 0; j < NT * 32; ++j) f[(size_t)NT * KB * 512 + j] = 1.0f / scale[j];     // trailer: Wp_f32[NT * KB * 512 + column]
     return f;
 }
 

@@ -40,9 +40,15 @@ def to_device_async(x, dtype, device):
     if isinstance(x, torch.Tensor) and x.is_cuda:
         return x.to(device=device, dtype=dtype).contiguous()
     np_dtype = {torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64}[dtype]
-    h = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
-    h = torch.from_numpy(np.ascontiguousarray(np.asarray(h), dtype=np_dtype))
-    return h.pin_memory().to(device, non_blocking=True)
+    if isinstance(x, list) and dtype == torch.int32 and x and type(x[0]) is int:
+        import array                                # a python list of ints (what offline_action hands out): half the cost of np.asarray
+        h = np.frombuffer(array.array('i', x), dtype=np.int32)
+    else:
+        h = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x
+        h = np.ascontiguousarray(np.asarray(h), dtype=np_dtype)
+    p = torch.empty(h.shape, dtype=dtype, device='cpu', pin_memory=True)       # caching host allocator: no page pinning per call
+    p.numpy()[...] = h
+    return p.to(device, non_blocking=True)
 
 
 def to_host(t):
@@ -323,11 +329,14 @@ class DeviceStepper(object):
             cache[key] = (L, rec)
         return cache[key]
 
-    def step_record(self, actions, conti=False, want=()):
+    def step_record(self, actions, conti=False, want=(), shadow=None):
         """rl4rs_env_step_record + the copy of the record's host part into a fresh pinned block -> ``StepResult`` of numpy
         views (obs float32 [B, obs_dim], or float64 [B, obs_dim + cols + 1] when 'd3rl_obs' is wanted; reward float64 [B];
         done uint8 [B]; chosen int32 [B]; mask int64 [B, A]; mask_bits uint32 [B, W]; click_p float32 [B, n]; offline_action
-        int32 [B] / float64 [B, E]; status int32 [2]).  ``want``: names from rl4rs_amd._lib.STEP_WANT."""
+        int32 [B] / float64 [B, E]; status int32 [2]).  ``want``: names from rl4rs_amd._lib.STEP_WANT.
+        ``shadow(result)`` (optional) runs after everything is enqueued and BEFORE the wait: the views exist (they alias the
+        pinned block) but hold no data yet - the place for host work that only needs the objects, e.g. building the list of
+        per-env dicts the reference's mask mode returns, while the GPU computes."""
         bits = 0
         for name in want:
             bits |= _lib.STEP_WANT[name]
@@ -350,7 +359,6 @@ class DeviceStepper(object):
         nb = int(L.host_bytes)
         host = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
         host.copy_(rec[:nb], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
         raw = host.numpy()
         B = self.B
 
@@ -371,6 +379,9 @@ class DeviceStepper(object):
         r.mask_bits = view(L.mask_bits, np.uint32, (B, self.W))
         r.click_p = view(L.click_p, np.float32, (B, self.env.n_complete))
         r.offline_action = view(L.offline_action, np.float64, (B, self.E)) if conti else view(L.offline_action, np.int32, (B,))
+        if shadow is not None:
+            shadow(r)
+        torch.cuda.current_stream().synchronize()
         return r
 
 

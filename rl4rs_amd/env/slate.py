@@ -527,7 +527,15 @@ class SlateRecEnv(RecSimBase):
                 want.append('d3rl_obs')
             if fetch:
                 want.append('click_p')
-            r = stepper.step_record(action, conti=conti, want=want)
+            built = {}
+
+            def in_the_gpu_shadow(rec):
+                # python objects that only need the (still empty) views: built while the kernels run
+                if masked:
+                    built['obs'] = [{"action_mask": m, "obs": o} for m, o in zip(rec.mask, rec.obs)]
+                built['done'] = [1 if last else 0] * self.batch_size
+
+            r = stepper.step_record(action, conti=conti, want=want, shadow=in_the_gpu_shadow)
             if r.status[0]:
                 raise IndexError("an action id outside [0, action_size) was passed to act() "
                                  "(numpy would raise at rl4rs/env/slate.py:199)")
@@ -543,9 +551,7 @@ class SlateRecEnv(RecSimBase):
             if fetch and due:
                 for i in range(self.batch_size):
                     samples.info[i].update({'click_p': r.click_p[i]})
-            obs = r.obs
-            if masked:
-                obs = [{"action_mask": m, "obs": o} for m, o in zip(r.mask, obs)]
+            obs = built['obs'] if masked else r.obs
             reward = r.reward.tolist() if due else [0] * self.batch_size
         if first_of_page:                                   # the library re-encoded the second sequence input
             samples._seq1_version += 1
