@@ -94,6 +94,17 @@ int rl4rs_env_set_catalog(rl4rs_env* env, const float* item_vec_host, const doub
 int rl4rs_env_load_batch(rl4rs_env* env, const int32_t* exposed_dev, const int32_t* feedback_dev,
                          const int32_t* history_dev, const float* user_dense_dev,
                          const int32_t* user_cat_dev, void* stream);
+/* The same as ONE launch when the log is resident on the device (rl4rs_amd LogStore: the sample file parsed once into
+ * columnar tables of n_lines rows): gathers the sampled lines line_idx_dev int32 [B] (RecDataBase.sample, base.py:92-100) into
+ * the batch buffers, writes the start-of-episode state (prev_actions = 0, both masks all ones; slate.py:8-27) so that the
+ * following rl4rs_env_reset only builds the state rows, and - optionally - copies the histories of the batch's n_uniq DISTINCT
+ * lines uniq_idx_dev int32 [n_uniq] to hist_unique_dev int32 [n_uniq, maxlen] (what the scorer encodes once per history).
+ * store_*: exposed / feedback int32 [n_lines, log_steps], history int32 [n_lines, maxlen], user_dense float32
+ * [n_lines, user_dense_dim], user_cat int32 [n_lines, user_cat_dim]. */
+int rl4rs_env_load_lines(rl4rs_env* env, const int32_t* store_exposed, const int32_t* store_feedback, const int32_t* store_history,
+                         const float* store_user_dense, const int32_t* store_user_cat, int32_t n_lines, int32_t store_log_steps,
+                         const int32_t* line_idx_dev, const int32_t* uniq_idx_dev, int32_t n_uniq, int32_t* hist_unique_dev,
+                         void* stream);
 
 /* HOST-side parser of a text buffer of '\n'-separated '@'-records (blank lines skipped) into the columnar HOST
  * arrays above: FeatureUtil.record_split (datautil.py:20-32) + records_to_state (slate.py:67-83) + pad_sequences

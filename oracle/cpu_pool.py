@@ -10,19 +10,19 @@ import os
 import time
 
 
-def _worker(idx, cfg, records, seq, algo, go, out_q):
-    os.environ['OMP_NUM_THREADS'] = '1'
-    os.environ['MKL_NUM_THREADS'] = '1'
-    os.environ['OPENBLAS_NUM_THREADS'] = '1'
+def _worker(idx, cfg, records, seq, algo, go, out_q, threads=1):
+    os.environ['OMP_NUM_THREADS'] = str(threads)
+    os.environ['MKL_NUM_THREADS'] = str(threads)
+    os.environ['OPENBLAS_NUM_THREADS'] = str(threads)
     try:
         import numpy as np
         import torch
-        torch.set_num_threads(1)
+        torch.set_num_threads(threads)
         from oracle.env import OracleEnv
         if algo == 'dien':
             from rl4rs_amd.nets.dien import init_dien_weights
             from oracle.dien_torch import TorchDien
-            scorer = TorchDien(init_dien_weights(cfg, seed=cfg.get('model_seed', 7)), cfg, workers=1)
+            scorer = TorchDien(init_dien_weights(cfg, seed=cfg.get('model_seed', 7)), cfg, workers=threads)     # row-parallel threads inside the block
         else:
             from rl4rs_amd.nets.simnets import init_simnet_weights
             from oracle.simnets import OracleSimnet
@@ -41,7 +41,7 @@ def _worker(idx, cfg, records, seq, algo, go, out_q):
         out_q.put((idx, 0.0, 0, repr(e)))
 
 
-def run_pool(cfg, records, seq, workers, rows_per_worker):
+def run_pool(cfg, records, seq, workers, rows_per_worker, threads=1):
     """One episode-batch of ``workers * rows_per_worker`` envs over ``workers`` single-threaded processes.
     -> dict(env_steps, seconds, workers, rows_per_worker, slowest_worker_s)."""
     import multiprocessing as mp
@@ -54,7 +54,7 @@ def run_pool(cfg, records, seq, workers, rows_per_worker):
     procs = []
     for i in range(workers):
         c = dict(cfg, batch_size=rows_per_worker)
-        p = ctx.Process(target=_worker, args=(i, c, records[i * rows_per_worker:(i + 1) * rows_per_worker], seq, algo, go, q),
+        p = ctx.Process(target=_worker, args=(i, c, records[i * rows_per_worker:(i + 1) * rows_per_worker], seq, algo, go, q, threads),
                         daemon=True)
         p.start()
         procs.append(p)
@@ -88,5 +88,5 @@ def run_pool(cfg, records, seq, workers, rows_per_worker):
             p.join(timeout=10)
             if p.is_alive():
                 p.terminate()
-    return {'env_steps': sum(r[2] for r in res), 'seconds': dt, 'workers': workers, 'rows_per_worker': rows_per_worker,
+    return {'env_steps': sum(r[2] for r in res), 'seconds': dt, 'workers': workers, 'rows_per_worker': rows_per_worker, 'threads': threads,
             'slowest_worker_s': max(r[1] for r in res)}

@@ -111,6 +111,7 @@ SIGNATURES = {
     'rl4rs_env_destroy': (_I, [_P]),
     'rl4rs_env_set_catalog': (_I, [_P, _P, _P, _P, _P, _P, _P]),
     'rl4rs_env_load_batch': (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_env_load_lines': (_I, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P]),
     'rl4rs_parse_records': (_I, [C.c_char_p, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, C.POINTER(_I32)]),
     'rl4rs_crc32c': (C.c_uint32, [_P, _I64, C.c_uint32]),
     'rl4rs_env_reset': (_I, [_P, _P]),

@@ -484,6 +484,41 @@ __global__ void k_offline_reward(EnvDev e, int cur, double* out) {
     out[b] = r;
 }
 
+// RecDataBase.sample + SlateState.__init__ (base.py:92-100, slate.py:8-27) as ONE launch: the sampled log lines' columns
+// from the resident log tables into the env's batch buffers, the episode state reset (prev_actions = 0, both masks all ones),
+// and the batch's DISTINCT histories (what the scorer encodes once each) into a caller buffer.  One wave per row.
+__global__ __launch_bounds__(256) void k_load_lines(EnvDev e, const int32_t* __restrict__ s_exposed, const int32_t* __restrict__ s_feedback,
+                                                    const int32_t* __restrict__ s_hist, const float* __restrict__ s_ud,
+                                                    const int32_t* __restrict__ s_ucat, int n_lines, const int32_t* __restrict__ line_idx,
+                                                    const int32_t* __restrict__ uniq_idx, int n_uniq, int32_t* __restrict__ hist_unique) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r < e.B) {
+        int line = line_idx[r];
+        line = line < 0 ? 0 : (line >= n_lines ? n_lines - 1 : line);
+        // (EnvDev carries the batch columns read-only for every other kernel: this is the one that fills them)
+        int32_t* d_exposed = const_cast<int32_t*>(e.exposed);
+        int32_t* d_feedback = const_cast<int32_t*>(e.feedback);
+        int32_t* d_hist = const_cast<int32_t*>(e.hist);
+        float* d_ud = const_cast<float*>(e.ud);
+        int32_t* d_ucat = const_cast<int32_t*>(e.ucat);
+        for (int j = lane; j < e.logT; j += 64) {
+            d_exposed[(size_t)r * e.logT + j] = s_exposed[(size_t)line * e.logT + j];
+            d_feedback[(size_t)r * e.logT + j] = s_feedback[(size_t)line * e.logT + j];
+        }
+        for (int j = lane; j < e.L; j += 64) d_hist[(size_t)r * e.L + j] = s_hist[(size_t)line * e.L + j];
+        for (int j = lane; j < e.UD; j += 64) d_ud[(size_t)r * e.UD + j] = s_ud[(size_t)line * e.UD + j];
+        for (int j = lane; j < e.UC; j += 64) d_ucat[(size_t)r * e.UC + j] = s_ucat[(size_t)line * e.UC + j];
+        for (int j = lane; j < e.T; j += 64) e.prev[(size_t)r * e.T + j] = 0;
+        for (int j = lane; j < e.W; j += 64) { e.amask[(size_t)r * e.W + j] = 0xffffffffu; e.smask[(size_t)r * e.W + j] = 0xffffffffu; }
+    } else if (r - e.B < n_uniq) {
+        const int u = r - e.B;
+        int line = uniq_idx[u];
+        line = line < 0 ? 0 : (line >= n_lines ? n_lines - 1 : line);
+        for (int j = lane; j < e.L; j += 64) hist_unique[(size_t)u * e.L + j] = s_hist[(size_t)line * e.L + j];
+    }
+}
+
 }  // namespace rl4rs
 
 // =================================================================================================
@@ -498,6 +533,7 @@ struct rl4rs_env {
     int cur_steps;
     int n_complete;
     bool catalog_set, batch_set;
+    bool state_fresh;          // rl4rs_env_load_lines already wrote prev_actions = 0 and the all-ones masks: reset skips its memsets
     int rows_variant;          // rl4rs_env_set_option(RL4RS_ENV_OPT_ROWS_VARIANT)
     // owned device memory
     float* item_vec; double* price; double* action_emb; uint32_t* special_bits; uint32_t* loc_bits;
@@ -681,6 +717,23 @@ int rl4rs_env_load_batch(rl4rs_env* e, const int32_t* exposed, const int32_t* fe
     if (d.UD) RL4RS_HIP_TRY(hipMemcpyAsync(e->ud, ud, (size_t)d.B * d.UD * 4, hipMemcpyDeviceToDevice, st));
     if (d.UC) RL4RS_HIP_TRY(hipMemcpyAsync(e->ucat, ucat, (size_t)d.B * d.UC * 4, hipMemcpyDeviceToDevice, st));
     e->batch_set = true;
+    e->state_fresh = false;
+    return RL4RS_OK;
+}
+
+int rl4rs_env_load_lines(rl4rs_env* e, const int32_t* s_exposed, const int32_t* s_feedback, const int32_t* s_hist, const float* s_ud,
+                         const int32_t* s_ucat, int32_t n_lines, int32_t store_log_steps, const int32_t* line_idx_dev,
+                         const int32_t* uniq_idx_dev, int32_t n_uniq, int32_t* hist_unique_dev, void* stream) {
+    RL4RS_REQUIRE(e && s_exposed && s_feedback && s_hist && s_ud && s_ucat && line_idx_dev && n_lines > 0, "load_lines: null argument");
+    RL4RS_REQUIRE(store_log_steps == e->d.logT, "load_lines: the log tables have %d logged steps per line, the env was created for %d",
+                  store_log_steps, e->d.logT);
+    RL4RS_REQUIRE(n_uniq >= 0 && (n_uniq == 0 || (uniq_idx_dev && hist_unique_dev)), "load_lines: distinct-history outputs missing");
+    const int rows = e->d.B + n_uniq;
+    hipLaunchKernelGGL(k_load_lines, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->d, s_exposed, s_feedback, s_hist, s_ud,
+                       s_ucat, n_lines, line_idx_dev, uniq_idx_dev, n_uniq, hist_unique_dev);
+    RL4RS_LAUNCH_CHECK();
+    e->batch_set = true;
+    e->state_fresh = true;
     return RL4RS_OK;
 }
 
@@ -692,10 +745,13 @@ int rl4rs_env_reset(rl4rs_env* e, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     const EnvDev& d = e->d;
-    RL4RS_HIP_TRY(hipMemsetAsync(e->prev, 0, (size_t)d.B * d.T * 4, st));
-    // all-ones masks; bits >= A of the last word are irrelevant but kept clear by page resets
-    RL4RS_HIP_TRY(hipMemsetAsync(e->amask, 0xff, (size_t)d.B * d.W * 4, st));
-    RL4RS_HIP_TRY(hipMemsetAsync(e->smask, 0xff, (size_t)d.B * d.W * 4, st));
+    if (!e->state_fresh) {
+        RL4RS_HIP_TRY(hipMemsetAsync(e->prev, 0, (size_t)d.B * d.T * 4, st));
+        // all-ones masks; bits >= A of the last word are irrelevant but kept clear by page resets
+        RL4RS_HIP_TRY(hipMemsetAsync(e->amask, 0xff, (size_t)d.B * d.W * 4, st));
+        RL4RS_HIP_TRY(hipMemsetAsync(e->smask, 0xff, (size_t)d.B * d.W * 4, st));
+    }
+    e->state_fresh = false;
     e->cur_steps = 0;
     return launch_rows<0>(e, d.B, nullptr, 0, 0, 0, st);
 }

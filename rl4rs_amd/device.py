@@ -51,13 +51,54 @@ def to_device_async(x, dtype, device):
     return p.to(device, non_blocking=True)
 
 
+def wait_stream():
+    """Wait for everything queued on the current stream by POLLING an event (hipStreamSynchronize parks the thread and pays a
+    wake-up of tens of microseconds; a reference-shaped env.step waits once per transition, so that latency is per step)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    while not ev.query():
+        pass
+
+
+class OfflineActionList(list):
+    """The python list ``offline_action`` hands out in the reference-shaped modes, remembering the device-side copy of the
+    same ids (part of the last transition record): handed back to ``env.step`` unchanged - the reference's canonical replay
+    loop - the ids never cross PCIe again.  Any in-place change drops the device reference, so a modified list is converted
+    and uploaded like any other."""
+    __slots__ = ('_dev', '_tag')
+
+    def __init__(self, values, dev=None, tag=None):
+        list.__init__(self, values)
+        self._dev, self._tag = dev, tag
+
+    def _drop(self):
+        self._dev = None
+
+    def __reduce__(self):                       # pickles / copies as the plain list it is
+        return (list, (list(self),))
+
+
+def _mutator(name):
+    base = getattr(list, name)
+
+    def f(self, *a, **k):
+        self._drop()
+        return base(self, *a, **k)
+    f.__name__ = name
+    return f
+
+
+for _n in ('__setitem__', '__delitem__', '__iadd__', '__imul__', 'append', 'extend', 'insert', 'pop', 'remove', 'reverse', 'sort', 'clear'):
+    setattr(OfflineActionList, _n, _mutator(_n))
+
+
 def to_host(t):
     """Device tensor -> numpy array through ONE pinned staging block of torch's caching host allocator (a pageable ``.cpu()``
     goes through an internal bounce buffer at a fraction of the PCIe rate).  The array aliases the pinned block, which goes
     back to the allocator's cache when the array is released."""
     h = torch.empty(t.shape, dtype=t.dtype, device='cpu', pin_memory=True)
     h.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    wait_stream()
     return h.numpy()
 
 
@@ -124,6 +165,22 @@ class DeviceEnv(object):
         assert hi.shape == (self.B, self.L) and ud.shape == (self.B, 32) and uc.shape == (self.B, 10)
         check(self.lib.rl4rs_env_load_batch(self.h, _ptr(ex), _ptr(fb), _ptr(hi), _ptr(ud), _ptr(uc), _stream()))
         self._keep = (ex, fb, hi, ud, uc)     # keep sources alive until the async copies ran
+
+    def load_lines(self, tables, n_lines, line_idx, uniq_idx=None, hist_unique=None):
+        """rl4rs_env_load_lines: the sampled lines of the resident log tables -> batch buffers + start-of-episode state, and the
+        batch's distinct histories -> ``hist_unique`` (int32 [n_uniq, L]), in ONE launch.  ``tables``: dict of the LogStore's
+        device tensors; ``line_idx`` / ``uniq_idx``: int32 device tensors."""
+        assert line_idx.dtype == torch.int32 and line_idx.numel() == self.B and line_idx.is_contiguous()
+        n_uniq = 0 if uniq_idx is None else int(uniq_idx.numel())
+        if n_uniq:
+            assert uniq_idx.dtype == torch.int32 and uniq_idx.is_contiguous()
+            assert hist_unique.dtype == torch.int32 and tuple(hist_unique.shape) == (n_uniq, self.L) and hist_unique.is_contiguous()
+        ex = tables['exposed']
+        assert ex.shape[1] == self.log_steps and tables['history'].shape[1] == self.L
+        check(self.lib.rl4rs_env_load_lines(self.h, _ptr(ex), _ptr(tables['feedback']), _ptr(tables['history']),
+                                            _ptr(tables['user_dense']), _ptr(tables['user_cat']), int(n_lines), int(ex.shape[1]),
+                                            _ptr(line_idx), _ptr(uniq_idx), n_uniq, _ptr(hist_unique), _stream()))
+        self._keep = (line_idx, uniq_idx, hist_unique)
 
     def reset(self):
         check(self.lib.rl4rs_env_reset(self.h, _stream()))
@@ -318,6 +375,16 @@ class DeviceStepper(object):
             check(self.lib.rl4rs_env_step_discrete(self.h, _ptr(chosen), _ptr(obs), _ptr(reward), None, _ptr(bits), _stream()))
         return obs, reward, bits, chosen
 
+    def offline_action_view(self):
+        """Device view of the logged next-step actions the LAST step_record left in its record (int32 [B]; None if it wrote
+        none).  Valid until the next step_record has read it: that call consumes its action ids before it rewrites this part."""
+        last = getattr(self, '_last_record', None)
+        if last is None or last[0].offline_action < 0:
+            return None
+        L, rec = last
+        off = int(L.offline_action)
+        return rec[off:off + self.B * 4].view(torch.int32)
+
     # ---- reference-shaped transitions: one library call, ONE device-to-host copy, one wait ----------------------------------
     def _layout(self, want, conti):
         key = (want, bool(conti))
@@ -355,6 +422,7 @@ class DeviceStepper(object):
             a = to_device_async(actions, torch.int32, self.device).reshape(-1)
             assert a.numel() == self.B, (a.shape, self.B)
             kind = 0
+        self._last_record = (L, rec)
         check(self.lib.rl4rs_env_step_record(self.h, _ptr(a), kind, bits, _ptr(rec), _stream()))
         nb = int(L.host_bytes)
         host = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
@@ -381,7 +449,7 @@ class DeviceStepper(object):
         r.offline_action = view(L.offline_action, np.float64, (B, self.E)) if conti else view(L.offline_action, np.int32, (B,))
         if shadow is not None:
             shadow(r)
-        torch.cuda.current_stream().synchronize()
+        wait_stream()
         return r
 
 

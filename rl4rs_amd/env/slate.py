@@ -92,22 +92,36 @@ class SlateState(RecState):
     def _bind_device(self, records):
         import torch
         store = getattr(records, 'store', None)
+        fused = None
         if store is not None:
             dev = torch.device('cuda', torch.cuda.current_device())
-            cols = store.gather(records.rows, dev)
+            rows = np.asarray(records.rows, dtype=np.int64)
+            store.ensure(rows, dev)
             log_steps = store.log_steps
-            self._exposed_len_min = int(store.exposed_len[np.asarray(records.rows)].min())
+            self._exposed_len_min = int(store.exposed_len[rows].min())
             self._users = None
+            self._store_rows = (store, rows)
             # RecDataBase.sample draws the batch WITH replacement from a cache window (base.py:92-100; 4096 envs from
             # 2048 lines at the bench config), so many envs share one user history: keep the distinct histories and
             # the env -> history map, the scorer encodes each distinct sequence once
-            uniq, first, inv = np.unique(np.asarray(records.rows, dtype=np.int64), return_index=True, return_inverse=True)
-            if len(uniq) < len(records.rows):
-                from .base import h2d_async
-                self._hist_unique = (cols['history'].index_select(0, h2d_async(first, dev)).contiguous(),
-                                     h2d_async(inv.astype(np.int32), dev))
+            uniq, inv = np.unique(rows, return_inverse=True)
+            dedup = len(uniq) < len(rows)
+            # ONE pinned block, one host-to-device copy: [line of every env | distinct lines | env -> history slot | envs sorted
+            # by slot]; ONE gather launch (rl4rs_env_load_lines) instead of a dozen index_select / copy / memset launches
+            B, U = len(rows), (len(uniq) if dedup else 0)
+            from .base import h2d_async
+            packed = np.empty(B + U + (2 * B if dedup else 0), dtype=np.int32)
+            packed[:B] = rows
+            if dedup:
+                packed[B:B + U] = uniq
+                packed[B + U:2 * B + U] = inv
                 # envs sorted by their history's slot: the scorer processes duplicates next to each other (L2 locality)
-                self._row_order = h2d_async(np.argsort(inv, kind='stable').astype(np.int32), dev)
+                packed[2 * B + U:] = np.argsort(inv, kind='stable')
+            pk = h2d_async(packed, dev)
+            fused = (store._dev, store.n, pk[:B], pk[B:B + U] if dedup else None)
+            if dedup:
+                self._hist_unique = (torch.empty((U, self.config['maxlen']), dtype=torch.int32, device=dev), pk[B + U:2 * B + U])
+                self._row_order = pk[2 * B + U:]
         else:
             rc = RecordColumns(list(records), self.config['maxlen'])
             cols = dict(exposed=rc.exposed, feedback=rc.feedback, history=rc.history,
@@ -115,6 +129,7 @@ class SlateState(RecState):
             log_steps = rc.log_steps
             self._exposed_len_min = int(rc.exposed_len.min())
             self._users = rc.users
+            self._feedback_cols = cols['feedback']
         key = ('env', self.is_seq, log_steps, self.batch_size, self.max_steps, self._violation_zeroes_reward())
         env = self._ctx.get(key)
         if env is None:
@@ -122,12 +137,27 @@ class SlateState(RecState):
             self._ctx[key] = env
         self._env = env
         self._ctx['owner'] = self
-        env.load_batch(cols['exposed'], cols['feedback'], cols['history'], cols['user_dense'], cols['user_cat'])
-        self._feedback = cols['feedback']          # logged click labels [B, log_steps] (simulator training, rl4rs_amd/simtrain.py)
+        if fused is not None:
+            hu = getattr(self, '_hist_unique', None)
+            env.load_lines(fused[0], fused[1], fused[2], fused[3], hu[0] if hu is not None else None)
+        else:
+            env.load_batch(cols['exposed'], cols['feedback'], cols['history'], cols['user_dense'], cols['user_cat'])
         env.reset()
         self._seq1_version = 0
         self._batch_version = self._ctx.get('batch_version', 0) + 1
         self._ctx['batch_version'] = self._batch_version
+
+    @property
+    def _feedback(self):
+        """Logged click labels of the batch, int32 [B, log_steps] on the device (simulator training, rl4rs_amd/simtrain.py)."""
+        fb = getattr(self, '_feedback_cols', None)
+        if fb is None:
+            import torch
+            from .base import h2d_async
+            store, rows = self._store_rows
+            fb = store._dev['feedback'].index_select(0, h2d_async(rows, store._dev['feedback'].device))
+            self._feedback_cols = fb
+        return fb
 
     def _live(self):
         if self._ctx.get('owner') is not self:
@@ -243,6 +273,9 @@ class SlateState(RecState):
         if (not self._tensor_mode() and cache is not None and cache[0] == self._batch_version and cache[1] == env.cur_steps
                 and cache[2] is not None and env.cur_steps < self.max_steps):
             out = cache[2]                                  # came back with the last transition record (rl4rs_env_step_record)
+            if not conti and cache[3] is not None and self.batch_size > 1:
+                # the same ids also sit in the device record: a list that remembers it (until somebody changes it)
+                return D.OfflineActionList(out.tolist(), dev=cache[3], tag=(self._batch_version, env.cur_steps))
         else:
             out = env.offline_action(conti=conti)
             if self._tensor_mode():
@@ -535,13 +568,17 @@ class SlateRecEnv(RecSimBase):
                     built['obs'] = [{"action_mask": m, "obs": o} for m, o in zip(rec.mask, rec.obs)]
                 built['done'] = [1 if last else 0] * self.batch_size
 
+            if (isinstance(action, D.OfflineActionList) and action._dev is not None
+                    and action._tag == (samples._batch_version, env.cur_steps)):
+                action = action._dev                        # offline_action handed back unchanged: its device-side copy
             r = stepper.step_record(action, conti=conti, want=want, shadow=in_the_gpu_shadow)
             if r.status[0]:
                 raise IndexError("an action id outside [0, action_size) was passed to act() "
                                  "(numpy would raise at rl4rs/env/slate.py:199)")
             import torch
             samples.last_actions = torch.from_numpy(r.chosen)
-            samples._offline_cache = (samples._batch_version, env.cur_steps, r.offline_action)
+            samples._offline_cache = (samples._batch_version, env.cur_steps, r.offline_action,
+                                      None if conti else stepper.offline_action_view())
             due = self._reward_due(samples)
             samples._range_seen = getattr(samples, '_range_seen', 0) | int(r.status[1])      # the record read-and-cleared the flag
             if due and samples._range_seen:
