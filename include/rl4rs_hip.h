@@ -259,8 +259,11 @@ enum {
 /* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):
  *   FP32   v_mfma_f32_32x32x2_f32, operands exact.
  *   FP16X2 operands split into fp16 hi + lo, 3 v_mfma_f32_32x32x16_f16 per product (hi*hi + hi*lo + lo*hi):
- *          ~2^-22 relative error per product, 2.3x faster.  Needs every AUGRU weight |w| < 6e4 (fp16 range).
- *   AUTO   FP16X2 when the weights allow it, else FP32. */
+ *          ~2^-22 relative error per product, 2.3x faster.  No weight-range condition: a weight tile that would not fit
+ *          fp16 (max |w| >= 2^14) is stored times a power of two and the accumulator divided by it, exactly (32-column tiles
+ *          of the recurrent matrices, columns of the plain GEMMs).  Only NON-FINITE weights need FP32.  ACTIVATIONS are
+ *          range-checked at run time: a row whose state / GEMM input leaves the fp16 range comes back NaN + status bit.
+ *   AUTO   FP16X2 for every finite checkpoint, else FP32. */
 enum { RL4RS_SCORER_AUTO = 0, RL4RS_SCORER_FP32 = 1, RL4RS_SCORER_FP16X2 = 2 };
 
 /* Host pointers to float32 arrays, shapes in rl4rs_amd/nets/dien.py (dien_spec). seq arrays have

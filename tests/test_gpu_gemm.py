@@ -90,20 +90,25 @@ def test_gemm_h16_poisons_out_of_range_rows():
     assert (c[ok].double() - ref[ok]).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize('k', [-12, 12, 17])
-def test_gemm_h16_is_scale_invariant(k):
-    """Every packed fp16x2 weight matrix carries its own power-of-two prescale (pack_gemm_weight_h16: max |w| s in [2^13, 2^14)),
-    so the hi / lo bit patterns - and therefore the relative precision - do not depend on the scale of the weights:
-    gemm(A, 2^k W) == 2^k gemm(A, W) BIT FOR BIT, for weights of 2.4e-5 (where an unscaled fp16 hi part is subnormal) as for
-    weights of 400 or 1.3e4 x 10 (where it would overflow)."""
+@pytest.mark.parametrize('k', [-12, 0, 12, 17, 30])
+def test_gemm_h16_over_weight_scales(k):
+    """The packed fp16x2 GEMM has no weight-range condition: a column whose weights would not fit fp16 is stored times a power
+    of two (pack_gemm_weight_h16) and the accumulator divided by it.  Weights of 2.4e-5 ... 1e8: same bar relative to the
+    result's scale as at the natural scale, and the scaled-DOWN cases reproduce each other bit for bit (same hi / lo bit
+    patterns, exact power-of-two factors)."""
     import torch
     from rl4rs_amd.device import gemm_h16_packed
     g = torch.Generator().manual_seed(3)
-    a = torch.randn(300, 200, generator=g).cuda()
-    w = (torch.randn(200, 96, generator=g) / 10).numpy()
-    base = gemm_h16_packed(a, w, None, 0)
-    scaled = gemm_h16_packed(a, (w * np.float32(2.0 ** k)).astype(np.float32), None, 0)
-    assert torch.equal(scaled, base * float(2.0 ** k))
+    a = torch.randn(300, 200, generator=g)
+    w = torch.randn(200, 96, generator=g) / 10
+    ws = (w * float(2.0 ** k)).numpy().astype(np.float32)
+    c = gemm_h16_packed(a.cuda(), ws, None, 0).cpu()
+    ref = a.double() @ torch.from_numpy(ws).double()
+    assert torch.isfinite(c).all()
+    assert ((c.double() - ref).abs().max() / ref.abs().max()).item() < 4e-6
+    if k >= 17:
+        c2 = gemm_h16_packed(a.cuda(), (ws * np.float32(8.0)).astype(np.float32), None, 0).cpu()
+        assert torch.equal(c2, c * 8.0)
 
 
 def test_gemm_h16_takes_weights_beyond_the_fp16_range():
