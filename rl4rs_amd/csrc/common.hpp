@@ -66,20 +66,21 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
                           const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
 
-// Power-of-two prescale of a weight tile that goes through the fp16 hi + lo split: s = 1 while the tile fits fp16 comfortably
-// (max |w| < 2^14), else s = 2^k with max |w| * s in [2^13, 2^14) - multiplying by s is exact in fp32, hi = fp16(w s) is then
-// never out of range, and the kernels divide the accumulator by s (exactly) in their epilogues: the split form has no
-// weight-range condition.  Tiles are only ever scaled DOWN.  Scaling ordinary weights UP (so that their lo parts become normal
-// fp16 numbers with all 10 mantissa bits in use instead of subnormals) was measured: no error against the fp64 oracle to gain
-// (obs 2.2e-6 either way - the fp32 accumulation dominates), and the denser operand bits cost 2 % of the recurrence's speed on
-// this power-limited kernel (same-box A/B); -DRL4RS_PRESCALE_UP builds that form.
+// Power-of-two prescale of a weight tile that goes through the fp16 hi + lo split: s = 1 while the tile sits comfortably inside
+// fp16 (2^-6 <= max |w| < 2^14), else s = 2^k with max |w| * s in [2^13, 2^14) - multiplying by s is exact in fp32, hi = fp16(w s)
+// is then neither out of range (large tiles) nor a subnormal with a handful of significant bits (tiny tiles), and the kernels
+// divide the accumulator by s (exactly) in their epilogues: the split form has no weight-range condition.  ORDINARY tiles are
+// left alone on purpose.  Normalising every tile (so that every lo part becomes a normal fp16 number with all 10 mantissa bits
+// in use) was measured: nothing to gain against the fp64 oracle (obs 2.2e-6 either way - the fp32 accumulation dominates),
+// and the denser operand bits cost 2 % of the recurrence's speed on this power-limited kernel (same-box A/B);
+// -DRL4RS_PRESCALE_UP builds that form.
 inline float pow2_prescale(float maxabs) {
     if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
     int e = 0;
     (void)frexpf(maxabs, &e);             // maxabs = m * 2^e, m in [0.5, 1)  ->  maxabs * 2^(14 - e) in [2^13, 2^14)
     int k = 14 - e;
 #ifndef RL4RS_PRESCALE_UP
-    if (k > 0) k = 0;
+    if (e <= 14 && e > -6) k = 0;         // 2^-6 <= maxabs < 2^14: as is
 #endif
     if (k > 100) k = 100;                 // keep s (and s * other weights) far from the fp32 range ends
     if (k < -100) k = -100;
