@@ -66,6 +66,31 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
                           const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
 
+// Training-mode recurrences as persistent kernels (recur_train.hpp, compiled into dien.hip; called from dientrain.hpp).
+// Arrays are per sequence input (S <= 4 inputs run in ONE launch, grid.y = S); saved tensors are [N * L, Hd] row-major.
+struct RecurTrainFwd {
+    int N, L, S, Hd;
+    const int32_t* iota;                  // device [N]: 0, 1, 2, ... (row n reads row block n of its input's pre-activations)
+    const float* a1[4];                   // x-side pre-activations incl. bias, [N * L, 3 Hd] = [r | u | c]
+    const float* wg[4]; const float* wc[4];      // h-side weights in MFMA fragment order (launch_pack_frag): [Hd x 2Hd], [Hd x Hd]
+    const float* att[4];                  // attention rows [N, L] (AUGRU) or NULL (GRU)
+    float *R[4], *U[4], *C[4], *H[4], *RH[4];    // out
+};
+struct RecurTrainBwd {
+    int N, L, S, Hd;
+    const float *R[4], *U[4], *C[4], *H[4];
+    const float* att[4];
+    const float* up_last[4]; int64_t ld_up;      // gradient of the final state (row stride ld_up) or NULL
+    const float* up_all[4];               // gradient of every state or NULL
+    const float* wcT[4]; const float* wgT[4];    // transposed h-side weights in fragment order: [Hd x Hd], [2Hd x Hd]
+    float *dAg[4], *dAc[4];               // out: pre-activation gradients [N * L, 2Hd], [N * L, Hd]
+    float* d_score[4];                    // out (AUGRU): d a_t [N, L] or NULL
+};
+int launch_recur_train_fwd(const RecurTrainFwd& f, hipStream_t st);
+int launch_recur_train_bwd(const RecurTrainBwd& b, hipStream_t st);
+// W rows k_off.. (leading dim ld) -> fragment order; transpose = 1 packs W^T (K = columns of W, N = rows taken)
+int launch_pack_frag(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, hipStream_t st);
+
 // Power-of-two prescale of a weight tile that goes through the fp16 hi + lo split: s = 1 while the tile sits comfortably inside
 // fp16 (2^-6 <= max |w| < 2^14), else s = 2^k with max |w| * s in [2^13, 2^14) - multiplying by s is exact in fp32, hi = fp16(w s)
 // is then neither out of range (large tiles) nor a subnormal with a handful of significant bits (tiny tiles), and the kernels

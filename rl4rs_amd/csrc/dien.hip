@@ -304,6 +304,11 @@ struct RecurArgs {
     // the activation multiplies by anyway: sigmoid(acc / s) = 1 / (1 + exp2(acc * k)), k = -log2(e) / s; tanh: k = 2 log2(e) / s -
     // exact (powers of two), same instruction count.
     float k_r[4][8], k_u[4][8], k_c[4][8];         // [sequence input][column tile = wave]
+    // k_recur<..., SAVE = true> (training forward, recur_train.hpp): per sequence input the attention rows [n_rows, L] (NULL = 0:
+    // a plain GRU) and, per (row, step), everything BPTT needs - reset gate, update gate BEFORE the attention factor, candidate,
+    // new state, r * h_prev - each [n_rows * L, NH] row-major.
+    const float* sv_att[4];
+    float *sv_r[4], *sv_u[4], *sv_c[4], *sv_h[4], *sv_rh[4];
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -345,7 +350,7 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, int voff
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
 }
 
-template <int NH, bool AUGRU, int U, int AB = 0>
+template <int NH, bool AUGRU, int U, int AB = 0, bool SAVE = false>
 __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
     constexpr int U2 = 2 * U;
     constexpr int NW = NH / 32, KB = NH / 8, LDH = NH + 4, NG = KB / U, NG2 = KB / U2;
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
     for (int i = tid; i < 32 * L; i += NH * 2) {
         int r = i / L, t = i - r * L;
         int gr = min(row0 + r, a.n_rows - 1);
-        if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
+        if (SAVE) s_att[r * LDT + t] = a.sv_att[sq] ? a.sv_att[sq][(size_t)gr * L + t] : 0.f;
+        else if (AUGRU) s_att[r * LDT + t] = a.att[(size_t)sq * a.att_stride + (size_t)gr * L + t];
         else s_ids[r * LDT + t] = a.ids[(size_t)gr * L + t];
     }
     // byte offset of each row's x-projection at t = 0 (AUGRU: slot * L * xld)
@@ -466,6 +472,12 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
             }
             acc_u[r] = ug;
             rhb[crow(r, half) * LDH + col] = rg * h_own[r];
+            if (SAVE && row0 + crow(r, half) < a.n_rows) {
+                const size_t si = ((size_t)(row0 + crow(r, half)) * L + t) * NH + col;
+                a.sv_r[sq][si] = rg;
+                a.sv_u[sq][si] = ug;
+                a.sv_rh[sq][si] = rg * h_own[r];
+            }
         }
         if (!(AB & 8)) __syncthreads();
         // ---- phase 2: candidate + state update
@@ -514,6 +526,11 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
             float hn = u * h_own[r] + (1.0f - u) * c;
             h_own[r] = hn;
             hb[crow(r, half) * LDH + col] = hn;
+            if (SAVE && row0 + crow(r, half) < a.n_rows) {
+                const size_t si = ((size_t)(row0 + crow(r, half)) * L + t) * NH + col;
+                a.sv_c[sq][si] = c;
+                a.sv_h[sq][si] = hn;
+            }
             if (!AUGRU && row0 + crow(r, half) < a.n_rows) {
                 if (!a.final_only) {
                     int64_t orow = ((int64_t)a.slot_base + row0 + crow(r, half)) * L + t;
@@ -525,7 +542,7 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
         }
         if (!(AB & 8)) __syncthreads();
     }
-    if (AUGRU) {
+    if (AUGRU && !SAVE) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (row0 + crow(r, half) < a.n_rows)
@@ -2025,4 +2042,5 @@ int rl4rs_dien_profile_reset(rl4rs_dien* n) {
 
 }  // extern "C"
 
+#include "recur_train.hpp"
 #include "simnet.hpp"

@@ -2,9 +2,10 @@
 // device: training-mode forward, keras binary_crossentropy, hand-written backward through the head, the category
 // self-attention, the dense tower (with its Dropout), and per sequence input the DIN attention MLP, the AUGRU and the first
 // GRU (explicit BPTT), Adam.  Same style as simtrain.hpp (included before this file): every x-side product and every
-// parameter gradient is one GEMM / one sample-axis reduction over all (row, step) pairs; only the h-side recurrences run
-// step by step (two small GEMMs + two element-wise kernels per step and direction).  Launch-bound at the reference's batch
-// of 256 - this is the functional, gradient-checked form, not a tuned one.
+// parameter gradient is one GEMM / one sample-axis reduction over all (row, step) pairs; the h-side recurrences run as
+// PERSISTENT kernels (recur_train.hpp: one launch per layer and direction for all sequence inputs - forwards the inference
+// recurrence kernel with its per-step gates saved, backwards a BPTT kernel with the state gradient in registers) instead of
+// nine dependent launches per step.
 //
 // Cells (TF 1.15 GRUCell / deepctr VecAttGRUCell, as restated for the scorer in dien.hip):
 //   [r, u] = sigmoid([x, h] Wg + bg);  c = tanh([x, r*h] Wc + bc);  AUGRU: u <- (1 - a_t) u;  h' = u h + (1 - u) c
@@ -16,77 +17,6 @@
 namespace rl4rs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__global__ void k_tf_gates(const float* __restrict__ a1g, const float* __restrict__ g, const float* __restrict__ hprev, int64_t ldh,
-                           float* __restrict__ R, float* __restrict__ Ug, float* __restrict__ RH, int N, int Hd, int len, int t) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Hd) return;
-    const int n = i / Hd, c = i - n * Hd;
-    const size_t s2 = ((size_t)n * len + t) * 2 * Hd, s1 = ((size_t)n * len + t) * Hd;
-    const float r = sigm(a1g[s2 + c] + g[(size_t)n * 2 * Hd + c]);
-    const float u = sigm(a1g[s2 + Hd + c] + g[(size_t)n * 2 * Hd + Hd + c]);
-    R[s1 + c] = r; Ug[s1 + c] = u;
-    RH[s1 + c] = r * hprev[(size_t)n * ldh + c];
-}
-
-__global__ void k_tf_update(const float* __restrict__ a1c, const float* __restrict__ gc, const float* __restrict__ hprev, int64_t ldh,
-                            const float* __restrict__ Ug, const float* __restrict__ att, float* __restrict__ C, float* __restrict__ Hs,
-                            int N, int Hd, int len, int t) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Hd) return;
-    const int n = i / Hd, c = i - n * Hd;
-    const size_t s1 = ((size_t)n * len + t) * Hd;
-    const float cc = tanhf(a1c[s1 + c] + gc[i]);
-    float u = Ug[s1 + c];
-    if (att) u = (1.0f - att[(size_t)n * len + t]) * u;
-    C[s1 + c] = cc;
-    Hs[s1 + c] = u * hprev[(size_t)n * ldh + c] + (1.0f - u) * cc;
-}
-
-// BPTT step, part 1.  dh = dh_a + dh_b + upstream(last step) + upstream(every step);  writes the candidate pre-activation
-// gradient, the update-gate pre-activation gradient, and -d(u') * u (whose row sum is d a_t for the AUGRU)
-__global__ void k_tf_bwd_pre(const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* __restrict__ up_last,
-                             int64_t ld_up, const float* __restrict__ up_all, float* __restrict__ dh,
-                             const float* __restrict__ hprev, int64_t ldh, const float* __restrict__ Ug, const float* __restrict__ C,
-                             const float* __restrict__ att, float* __restrict__ dAg, float* __restrict__ dAc,
-                             float* __restrict__ du_neg, int N, int Hd, int len, int t) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Hd) return;
-    const int n = i / Hd, c = i - n * Hd;
-    const size_t s2 = ((size_t)n * len + t) * 2 * Hd, s1 = ((size_t)n * len + t) * Hd;
-    float d = (dh_a ? dh_a[i] : 0.f) + (dh_b ? dh_b[i] : 0.f);
-    if (up_last) d += up_last[(size_t)n * ld_up + c];
-    if (up_all) d += up_all[s1 + c];
-    dh[i] = d;
-    const float u = Ug[s1 + c], cc = C[s1 + c], a = att ? att[(size_t)n * len + t] : 0.f;
-    const float up = (1.0f - a) * u;
-    dAc[s1 + c] = d * (1.0f - up) * (1.0f - cc * cc);
-    const float dup = d * (hprev[(size_t)n * ldh + c] - cc);
-    dAg[s2 + Hd + c] = dup * (1.0f - a) * u * (1.0f - u);
-    if (du_neg) du_neg[i] = -dup * u;
-}
-
-__global__ __launch_bounds__(256) void k_rowsum_to(const float* __restrict__ x, int N, int W, float* __restrict__ out, int len, int t) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int c = lane; c < W; c += 64) s += x[(size_t)n * W + c];
-    s = wave_sum(s);
-    if (lane == 0) out[(size_t)n * len + t] = s;
-}
-
-__global__ void k_tf_bwd_mid(const float* __restrict__ dh, const float* __restrict__ d_rh, const float* __restrict__ hprev,
-                             int64_t ldh, const float* __restrict__ R, const float* __restrict__ Ug, const float* __restrict__ att,
-                             float* __restrict__ dAg, float* __restrict__ dh_part, int N, int Hd, int len, int t) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Hd) return;
-    const int n = i / Hd, c = i - n * Hd;
-    const size_t s2 = ((size_t)n * len + t) * 2 * Hd, s1 = ((size_t)n * len + t) * Hd;
-    const float r = R[s1 + c], q = d_rh[i], a = att ? att[(size_t)n * len + t] : 0.f;
-    dAg[s2 + c] = q * hprev[(size_t)n * ldh + c] * r * (1.0f - r);
-    dh_part[i] = dh[i] * (1.0f - a) * Ug[s1 + c] + q * r;
-}
 
 __global__ void k_shift_prev_w(const float* __restrict__ h, float* __restrict__ hprev, int N, int W, int len) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +143,7 @@ enum { DQ_GRU_GW = 0, DQ_GRU_GB, DQ_GRU_CW, DQ_GRU_CB, DQ_ATT_W1, DQ_ATT_B1, DQ_
        DQ_AUG_GW, DQ_AUG_GB, DQ_AUG_CW, DQ_AUG_CB };
 
 struct CellSave {      // one recurrent layer of one sequence input, training mode
-    float *A1g, *A1c, *R, *Ug, *C, *Hs, *RH;
+    float *A1, *R, *Ug, *C, *Hs, *RH;      // A1 [N*L, 3 Hd] = x-side pre-activations [r | u | c] incl. bias; the rest [N*L, Hd]
     int Hd, pgw;       // hidden width, flat-parameter slot of its gate_w (gate_b, cand_w, cand_b follow)
 };
 
@@ -230,41 +160,74 @@ struct rl4rs_dientrain {
     int32_t* ids10;
     uint8_t *mask1, *mask2;
     // backward scratch
-    float *d_logits, *d_obs, *d_allf, *d_h1, *d_h2, *d_score, *d_hid2, *d_hid1, *d_inp, *dK, *dq, *dAg, *dAc, *dX, *hprev;
-    float *s_G, *s_Gc, *s_dh, *s_dhp, *s_dhg, *s_drh, *s_du, *s_zero, *s_wgT, *s_wcT, *s_tmpw, *loss_rows, *lr_dummy;
+    float *d_logits, *d_obs, *d_allf, *d_h1, *d_h2, *d_hid2, *d_hid1, *d_inp, *dq, *dX, *hprev;
+    float *d_score[4], *dK[4], *dAg[4], *dAc[4];            // per sequence input: the inputs' recurrences run in one launch
+    float *pk_g[4], *pk_c[4], *pkT_g[4], *pkT_c[4];         // h-side weights in MFMA fragment order (forward) / transposed (backward)
+    int32_t* iota;
+    float *s_tmpw, *loss_rows, *lr_dummy;
     int64_t adam_t;
     std::vector<void*> owned;
 };
 
 namespace {
 
-int cell_forward(rl4rs_dientrain* t, int N, const CellSave& cl, const float* Xin, const float* att, hipStream_t st) {
-    const int E = t->c.emb_size, L = t->c.maxlen, Hd = cl.Hd;
-    const float* Wg = t->params + t->off[cl.pgw];
-    const float* bg = t->params + t->off[cl.pgw + 1];
-    const float* Wc = t->params + t->off[cl.pgw + 2];
-    const float* bc = t->params + t->off[cl.pgw + 3];
+// Forward of one recurrent layer for ALL sequence inputs: x-side pre-activations by GEMM, h-side weights into fragment order,
+// then ONE persistent launch (grid.y = S) that also saves the per-step gates.  which = 0: first GRU, 1: AUGRU.
+int layer_forward(rl4rs_dientrain* t, int N, int which, const float* const* Xin, const float* const* att, hipStream_t st) {
+    const int E = t->c.emb_size, L = t->c.maxlen, S = t->c.seq_num;
+    RecurTrainFwd f;
+    memset(&f, 0, sizeof(f));
+    f.N = N; f.L = L; f.S = S; f.iota = t->iota;
     int rc;
-    if ((rc = launch_gemm_f32(Xin, E, Wg, 2 * Hd, bg, cl.A1g, 2 * Hd, N * L, 2 * Hd, E, 0, st))) return rc;
-    if ((rc = launch_gemm_f32(Xin, E, Wc, Hd, bc, cl.A1c, Hd, N * L, Hd, E, 0, st))) return rc;
-    const dim3 ew((N * Hd + 255) / 256), b256(256);
-    for (int ts = 0; ts < L; ++ts) {
-        const float* hprev = ts == 0 ? t->s_zero : cl.Hs + (size_t)(ts - 1) * Hd;
-        const int64_t ldh = ts == 0 ? Hd : (int64_t)L * Hd;
-        if ((rc = launch_gemm_f32(hprev, ldh, Wg + (size_t)E * 2 * Hd, 2 * Hd, nullptr, t->s_G, 2 * Hd, N, 2 * Hd, Hd, 0, st))) return rc;
-        hipLaunchKernelGGL(k_tf_gates, ew, b256, 0, st, cl.A1g, t->s_G, hprev, ldh, cl.R, cl.Ug, cl.RH, N, Hd, L, ts);
-        if ((rc = launch_gemm_f32(cl.RH + (size_t)ts * Hd, (int64_t)L * Hd, Wc + (size_t)E * Hd, Hd, nullptr, t->s_Gc, Hd, N, Hd, Hd, 0, st)))
-            return rc;
-        hipLaunchKernelGGL(k_tf_update, ew, b256, 0, st, cl.A1c, t->s_Gc, hprev, ldh, cl.Ug, att, cl.C, cl.Hs, N, Hd, L, ts);
+    for (int s = 0; s < S; ++s) {
+        const CellSave& cl = which == 0 ? t->gru[s] : t->aug[s];
+        const int Hd = cl.Hd;
+        f.Hd = Hd;
+        const float* Wg = t->params + t->off[cl.pgw];
+        const float* bg = t->params + t->off[cl.pgw + 1];
+        const float* Wc = t->params + t->off[cl.pgw + 2];
+        const float* bc = t->params + t->off[cl.pgw + 3];
+        if ((rc = launch_gemm_f32(Xin[s], E, Wg, 2 * Hd, bg, cl.A1, 3 * Hd, N * L, 2 * Hd, E, 0, st))) return rc;
+        if ((rc = launch_gemm_f32(Xin[s], E, Wc, Hd, bc, cl.A1 + 2 * Hd, 3 * Hd, N * L, Hd, E, 0, st))) return rc;
+        if ((rc = launch_pack_frag(Wg, 2 * Hd, E, Hd, 2 * Hd, 0, t->pk_g[s], st))) return rc;
+        if ((rc = launch_pack_frag(Wc, Hd, E, Hd, Hd, 0, t->pk_c[s], st))) return rc;
+        f.a1[s] = cl.A1; f.wg[s] = t->pk_g[s]; f.wc[s] = t->pk_c[s]; f.att[s] = att ? att[s] : nullptr;
+        f.R[s] = cl.R; f.U[s] = cl.Ug; f.C[s] = cl.C; f.H[s] = cl.Hs; f.RH[s] = cl.RH;
     }
-    RL4RS_LAUNCH_CHECK();
-    return RL4RS_OK;
+    return launch_recur_train_fwd(f, st);
 }
 
-// BPTT of one layer.  up_last [N, Hd] (row stride ld_up) = gradient of the final state, up_all [N*L, Hd] = gradient of every
-// state (either may be NULL).  Accumulates dXin [N*L, E] INTO dXin_acc, writes d a_t into d_score (AUGRU: att != NULL).
-int cell_backward(rl4rs_dientrain* t, int N, const CellSave& cl, const float* Xin, const float* up_last, int64_t ld_up,
-                  const float* up_all, const float* att, float* d_score, float* dXin_acc, bool accumulate, hipStream_t st) {
+// BPTT of one recurrent layer for ALL sequence inputs in ONE persistent launch: up_last[s] [N, Hd] (row stride ld_up) =
+// gradient of the final state, up_all[s] [N*L, Hd] = gradient of every state (either may be NULL); writes the pre-activation
+// gradients dAg[s] / dAc[s] of every (row, step) and (AUGRU) d a_t into d_score[s].
+int layer_backward(rl4rs_dientrain* t, int N, int which, const float* const* up_last, int64_t ld_up, const float* const* up_all,
+                   const float* const* att, hipStream_t st) {
+    const int E = t->c.emb_size, L = t->c.maxlen, S = t->c.seq_num;
+    RecurTrainBwd b;
+    memset(&b, 0, sizeof(b));
+    b.N = N; b.L = L; b.S = S; b.ld_up = ld_up;
+    int rc;
+    for (int s = 0; s < S; ++s) {
+        const CellSave& cl = which == 0 ? t->gru[s] : t->aug[s];
+        const int Hd = cl.Hd;
+        b.Hd = Hd;
+        const float* Wg = t->params + t->off[cl.pgw];
+        const float* Wc = t->params + t->off[cl.pgw + 2];
+        // h-side weights transposed, in fragment order: Wc[E:, :]^T [Hd x Hd], Wg[E:, :]^T [2Hd x Hd]
+        if ((rc = launch_pack_frag(Wc, Hd, E, Hd, Hd, 1, t->pkT_c[s], st))) return rc;
+        if ((rc = launch_pack_frag(Wg, 2 * Hd, E, 2 * Hd, Hd, 1, t->pkT_g[s], st))) return rc;
+        b.R[s] = cl.R; b.U[s] = cl.Ug; b.C[s] = cl.C; b.H[s] = cl.Hs; b.att[s] = att ? att[s] : nullptr;
+        b.up_last[s] = up_last ? up_last[s] : nullptr; b.up_all[s] = up_all ? up_all[s] : nullptr;
+        b.wcT[s] = t->pkT_c[s]; b.wgT[s] = t->pkT_g[s];
+        b.dAg[s] = t->dAg[s]; b.dAc[s] = t->dAc[s]; b.d_score[s] = att ? t->d_score[s] : nullptr;
+    }
+    return launch_recur_train_bwd(b, st);
+}
+
+// Parameter gradients and the gradient of the layer input of one cell from its pre-activation gradients (sample-axis GEMM
+// reductions over all N * L (row, step) pairs).  Accumulates dXin [N*L, E] INTO dXin_acc (accumulate) or overwrites it.
+int cell_backward_post(rl4rs_dientrain* t, int N, const CellSave& cl, const float* Xin, const float* dAg, const float* dAc,
+                       float* dXin_acc, bool accumulate, hipStream_t st) {
     const int E = t->c.emb_size, L = t->c.maxlen, Hd = cl.Hd;
     const float* Wg = t->params + t->off[cl.pgw];
     const float* Wc = t->params + t->off[cl.pgw + 2];
@@ -273,40 +236,21 @@ int cell_backward(rl4rs_dientrain* t, int N, const CellSave& cl, const float* Xi
     float* gWc = t->grad + t->off[cl.pgw + 2];
     float* gbc = t->grad + t->off[cl.pgw + 3];
     int rc;
-    const dim3 ew((N * Hd + 255) / 256), b256(256);
-    // h-side weights transposed once: Wg[E:, :]^T -> [2Hd, Hd], Wc[E:, :]^T -> [Hd, Hd]
-    hipLaunchKernelGGL(k_transpose, dim3((Hd * 2 * Hd + 255) / 256), b256, 0, st, Wg + (size_t)E * 2 * Hd, (int64_t)2 * Hd, Hd, 2 * Hd, t->s_wgT);
-    hipLaunchKernelGGL(k_transpose, dim3((Hd * Hd + 255) / 256), b256, 0, st, Wc + (size_t)E * Hd, (int64_t)Hd, Hd, Hd, t->s_wcT);
-    const float* dh_a = nullptr;
-    const float* dh_b = nullptr;
-    for (int ts = L - 1; ts >= 0; --ts) {
-        const float* hprev = ts == 0 ? t->s_zero : cl.Hs + (size_t)(ts - 1) * Hd;
-        const int64_t ldh = ts == 0 ? Hd : (int64_t)L * Hd;
-        hipLaunchKernelGGL(k_tf_bwd_pre, ew, b256, 0, st, dh_a, dh_b, ts == L - 1 ? up_last : (const float*)nullptr, ld_up, up_all, t->s_dh,
-                           hprev, ldh, cl.Ug, cl.C, att, t->dAg, t->dAc, att ? t->s_du : (float*)nullptr, N, Hd, L, ts);
-        if (att) hipLaunchKernelGGL(k_rowsum_to, dim3((N + 3) / 4), b256, 0, st, t->s_du, N, Hd, d_score, L, ts);
-        if ((rc = launch_gemm_f32(t->dAc + (size_t)ts * Hd, (int64_t)L * Hd, t->s_wcT, Hd, nullptr, t->s_drh, Hd, N, Hd, Hd, 0, st))) return rc;
-        hipLaunchKernelGGL(k_tf_bwd_mid, ew, b256, 0, st, t->s_dh, t->s_drh, hprev, ldh, cl.R, cl.Ug, att, t->dAg, t->s_dhp, N, Hd, L, ts);
-        if (ts > 0)
-            if ((rc = launch_gemm_f32(t->dAg + (size_t)ts * 2 * Hd, (int64_t)L * 2 * Hd, t->s_wgT, Hd, nullptr, t->s_dhg, Hd, N, Hd, 2 * Hd, 0, st)))
-                return rc;
-        dh_a = t->s_dhp;
-        dh_b = t->s_dhg;
-    }
+    const dim3 b256(256);
     const int Ns = N * L;
     hipLaunchKernelGGL(k_shift_prev_w, dim3((Ns * Hd + 255) / 256), b256, 0, st, cl.Hs, t->hprev, N, Hd, L);
     // gate_w = [x rows ; h rows] x 2Hd columns, cand_w likewise x Hd columns
-    st_tn(t->cx, st, Xin, E, E, t->dAg, 2 * Hd, 2 * Hd, Ns, gWg);
-    st_tn(t->cx, st, t->hprev, Hd, Hd, t->dAg, 2 * Hd, 2 * Hd, Ns, gWg + (size_t)E * 2 * Hd);
-    st_cs(t->cx, st, t->dAg, 2 * Hd, 2 * Hd, Ns, gbg);
-    st_tn(t->cx, st, Xin, E, E, t->dAc, Hd, Hd, Ns, gWc);
-    st_tn(t->cx, st, cl.RH, Hd, Hd, t->dAc, Hd, Hd, Ns, gWc + (size_t)E * Hd);
-    st_cs(t->cx, st, t->dAc, Hd, Hd, Ns, gbc);
+    st_tn(t->cx, st, Xin, E, E, dAg, 2 * Hd, 2 * Hd, Ns, gWg);
+    st_tn(t->cx, st, t->hprev, Hd, Hd, dAg, 2 * Hd, 2 * Hd, Ns, gWg + (size_t)E * 2 * Hd);
+    st_cs(t->cx, st, dAg, 2 * Hd, 2 * Hd, Ns, gbg);
+    st_tn(t->cx, st, Xin, E, E, dAc, Hd, Hd, Ns, gWc);
+    st_tn(t->cx, st, cl.RH, Hd, Hd, dAc, Hd, Hd, Ns, gWc + (size_t)E * Hd);
+    st_cs(t->cx, st, dAc, Hd, Hd, Ns, gbc);
     // gradient of the layer input: dAg Wg[:E]^T + dAc Wc[:E]^T
     float* dst = accumulate ? t->dX : dXin_acc;
-    if ((rc = st_back(t->cx, st, t->dAg, 2 * Hd, 2 * Hd, Wg, 2 * Hd, E, dst, E, Ns))) return rc;
+    if ((rc = st_back(t->cx, st, dAg, 2 * Hd, 2 * Hd, Wg, 2 * Hd, E, dst, E, Ns))) return rc;
     if (accumulate) hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, t->dX, Ns * E);
-    if ((rc = st_back(t->cx, st, t->dAc, Hd, Hd, Wc, Hd, E, t->dX, E, Ns))) return rc;
+    if ((rc = st_back(t->cx, st, dAc, Hd, Hd, Wc, Hd, E, t->dX, E, Ns))) return rc;
     hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, t->dX, Ns * E);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
@@ -326,6 +270,8 @@ int rl4rs_dientrain_destroy(rl4rs_dientrain* t) {
 int rl4rs_dientrain_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, int32_t max_batch, void* stream,
                            rl4rs_dientrain** out) {
     RL4RS_REQUIRE(c && w && out && max_batch > 0, "dientrain_create: bad argument");
+    RL4RS_REQUIRE(c->emb_size == 128, "dientrain: emb_size must be 128 (the recurrence kernels are built for hidden widths 128 / 256), got %d",
+                  c->emb_size);
     RL4RS_REQUIRE(c->emb_size > 0 && c->emb_size % 2 == 0 && c->hidden_units > 0 && c->maxlen >= 1 && c->seq_num >= 1 && c->seq_num <= 4 &&
                   c->category_feature_num >= 10 && c->category_feature_num <= 32 && c->category_hash_size > 0 &&
                   c->dense_feature_num > 0 && c->class_num >= 2 && c->class_num <= 8, "dientrain: bad sizes");
@@ -392,9 +338,19 @@ int rl4rs_dientrain_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w,
             CellSave& cl = *cells[k];
             cl.Hd = k == 0 ? (int)E : (int)NH2;
             cl.pgw = DP_SEQ0 + s * DP_PER_SEQ + (k == 0 ? DQ_GRU_GW : DQ_AUG_GW);
-            DT_FAIL(al(&cl.A1g, Ns * 2 * cl.Hd)); DT_FAIL(al(&cl.A1c, Ns * cl.Hd)); DT_FAIL(al(&cl.R, Ns * cl.Hd));
+            DT_FAIL(al(&cl.A1, Ns * 3 * cl.Hd)); DT_FAIL(al(&cl.R, Ns * cl.Hd));
             DT_FAIL(al(&cl.Ug, Ns * cl.Hd)); DT_FAIL(al(&cl.C, Ns * cl.Hd)); DT_FAIL(al(&cl.Hs, Ns * cl.Hd)); DT_FAIL(al(&cl.RH, Ns * cl.Hd));
         }
+        DT_FAIL(al(&t->d_score[s], Ns)); DT_FAIL(al(&t->dK[s], Ns * E)); DT_FAIL(al(&t->dAg[s], Ns * 2 * NH2)); DT_FAIL(al(&t->dAc[s], Ns * NH2));
+        DT_FAIL(al(&t->pk_g[s], NH2 * 2 * NH2)); DT_FAIL(al(&t->pk_c[s], NH2 * NH2));
+        DT_FAIL(al(&t->pkT_g[s], 2 * NH2 * NH2)); DT_FAIL(al(&t->pkT_c[s], NH2 * NH2));
+    }
+    {
+        float* p; DT_FAIL(al(&p, B)); t->iota = reinterpret_cast<int32_t*>(p);
+        std::vector<int32_t> io(B);
+        for (size_t i = 0; i < B; ++i) io[i] = (int32_t)i;
+        DT_HIP(hipMemcpyAsync(t->iota, io.data(), B * 4, hipMemcpyHostToDevice, st));
+        DT_HIP(hipStreamSynchronize(st));              // io is a local
     }
     DT_FAIL(al(&t->q, B * E)); DT_FAIL(al(&t->allf, B * t->F)); DT_FAIL(al(&t->h1, B * U)); DT_FAIL(al(&t->h1d, B * U));
     DT_FAIL(al(&t->h2, B * U)); DT_FAIL(al(&t->obs, B * 256)); DT_FAIL(al(&t->logits, B * K)); DT_FAIL(al(&t->dC, B * Cn * E));
@@ -402,14 +358,11 @@ int rl4rs_dientrain_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w,
     { float* p; DT_FAIL(al(&p, (B * U + 3) / 4 + 1)); t->mask1 = reinterpret_cast<uint8_t*>(p);
       DT_FAIL(al(&p, (B * U + 3) / 4 + 1)); t->mask2 = reinterpret_cast<uint8_t*>(p); }
     DT_FAIL(al(&t->d_logits, B * K)); DT_FAIL(al(&t->d_obs, B * 256)); DT_FAIL(al(&t->d_allf, B * t->F)); DT_FAIL(al(&t->d_h1, B * U));
-    DT_FAIL(al(&t->d_h2, B * U)); DT_FAIL(al(&t->d_score, Ns)); DT_FAIL(al(&t->d_hid2, Ns * 16)); DT_FAIL(al(&t->d_hid1, Ns * 64));
-    DT_FAIL(al(&t->d_inp, Ns * 4 * E)); DT_FAIL(al(&t->dK, Ns * E)); DT_FAIL(al(&t->dq, B * E)); DT_FAIL(al(&t->dAg, Ns * 2 * NH2));
-    DT_FAIL(al(&t->dAc, Ns * NH2)); DT_FAIL(al(&t->dX, Ns * E)); DT_FAIL(al(&t->hprev, Ns * NH2));
-    DT_FAIL(al(&t->s_G, B * 2 * NH2)); DT_FAIL(al(&t->s_Gc, B * NH2)); DT_FAIL(al(&t->s_dh, B * NH2)); DT_FAIL(al(&t->s_dhp, B * NH2));
-    DT_FAIL(al(&t->s_dhg, B * NH2)); DT_FAIL(al(&t->s_drh, B * NH2)); DT_FAIL(al(&t->s_du, B * NH2)); DT_FAIL(al(&t->s_zero, B * NH2));
-    DT_FAIL(al(&t->s_wgT, 2 * NH2 * NH2)); DT_FAIL(al(&t->s_wcT, NH2 * NH2)); DT_FAIL(al(&t->s_tmpw, 4)); DT_FAIL(al(&t->loss_rows, B));
+    DT_FAIL(al(&t->d_h2, B * U)); DT_FAIL(al(&t->d_hid2, Ns * 16)); DT_FAIL(al(&t->d_hid1, Ns * 64));
+    DT_FAIL(al(&t->d_inp, Ns * 4 * E)); DT_FAIL(al(&t->dq, B * E));
+    DT_FAIL(al(&t->dX, Ns * E)); DT_FAIL(al(&t->hprev, Ns * NH2));
+    DT_FAIL(al(&t->s_tmpw, 4)); DT_FAIL(al(&t->loss_rows, B));
     DT_FAIL(al(&t->lr_dummy, 4));
-    DT_HIP(hipMemsetAsync(t->s_zero, 0, B * NH2 * 4, st));
     // reduction scratch: the largest M x Nc of any weight gradient, times the number of 512-sample chunks of N * L
     int64_t wmax = (int64_t)t->F * 256;
     if (Dn * U > wmax) wmax = Dn * U;
@@ -462,19 +415,26 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
     // query = mean of the sequence-table embeddings of the last 10 category ids (dien.py:29-30, utils.py:114-115)
     RL4RS_HIP_TRY(hipMemcpy2DAsync(t->ids10, 10 * 4, cat + (Cn - 10), (size_t)Cn * 4, 10 * 4, N, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_emb_mean, g4, b256, 0, st, t->ids10, N, 10, H, E, P + o[DP_SEQ_EMB], t->q, (int64_t)E, 0);
+    const float* Xs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* Ks[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* scs[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int s = 0; s < S; ++s) {
+        hipLaunchKernelGGL(k_emb_flatten, g4, b256, 0, st, seq[s], N, L, H, E, P + o[DP_SEQ_EMB], t->X[s], (int64_t)L * E, 0);
+        Xs[s] = t->X[s]; Ks[s] = t->gru[s].Hs; scs[s] = t->score[s];
+    }
+    if ((rc = layer_forward(t, N, 0, Xs, nullptr, st))) return rc;         // first GRU of every sequence input: one launch
     for (int s = 0; s < S; ++s) {
         const int pb = DP_SEQ0 + s * DP_PER_SEQ;
-        hipLaunchKernelGGL(k_emb_flatten, g4, b256, 0, st, seq[s], N, L, H, E, P + o[DP_SEQ_EMB], t->X[s], (int64_t)L * E, 0);
-        if ((rc = cell_forward(t, N, t->gru[s], t->X[s], nullptr, st))) return rc;
         const float* Kk = t->gru[s].Hs;                                     // keys = first-GRU states [N*L, E]
         hipLaunchKernelGGL(k_att_inp, ew(Ns * E), b256, 0, st, t->q, Kk, t->inp[s], N, L, E);
         if ((rc = launch_gemm_f32(t->inp[s], 4 * E, P + o[pb + DQ_ATT_W1], 64, P + o[pb + DQ_ATT_B1], t->hid1[s], 64, Ns, 64, 4 * E, 2, st))) return rc;
         if ((rc = launch_gemm_f32(t->hid1[s], 64, P + o[pb + DQ_ATT_W2], 16, P + o[pb + DQ_ATT_B2], t->hid2[s], 16, Ns, 16, 64, 2, st))) return rc;
         if ((rc = launch_gemm_f32(t->hid2[s], 16, P + o[pb + DQ_ATT_W3], 1, P + o[pb + DQ_ATT_B3], t->score[s], 1, Ns, 1, 16, 0, st))) return rc;
-        if ((rc = cell_forward(t, N, t->aug[s], Kk, t->score[s], st))) return rc;
+    }
+    if ((rc = layer_forward(t, N, 1, Ks, scs, st))) return rc;              // AUGRU of every sequence input: one launch
+    for (int s = 0; s < S; ++s)
         RL4RS_HIP_TRY(hipMemcpy2DAsync(t->allf + s * NH2, (size_t)F * 4, t->aug[s].Hs + (size_t)(L - 1) * NH2, (size_t)L * NH2 * 4,
                                        (size_t)NH2 * 4, N, hipMemcpyDeviceToDevice, st));
-    }
     if ((rc = launch_gemm_f32(dense, Dn, P + o[DP_DW1], U, P + o[DP_DB1], t->h1, U, N, U, Dn, 1, st))) return rc;
     RL4RS_HIP_TRY(hipMemcpyAsync(t->h1d, t->h1, (size_t)N * U * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_dropout, ew(N * U), b256, 0, st, t->h1d, t->mask1, N * U, U, dropout_rate, seed, step, 0u);
@@ -514,17 +474,22 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
     hipLaunchKernelGGL(k_elu_bwd, ew(N * U), b256, 0, st, t->d_h1, (int64_t)U, t->h1, (int64_t)U, t->mask1, dropout_rate, N * U, U);
     st_tn(t->cx, st, dense, Dn, Dn, t->d_h1, U, U, N, G + o[DP_DW1]);
     st_cs(t->cx, st, t->d_h1, U, U, N, G + o[DP_DB1]);
-    // sequence inputs
+    // sequence inputs.  AUGRU of every input in one launch: gradient of the final state in, d a_t and dAg / dAc out
+    const float* ups[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* dKs[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int s = 0; s < S; ++s) { ups[s] = t->d_allf + s * NH2; dKs[s] = t->dK[s]; }
+    if ((rc = layer_backward(t, N, 1, ups, (int64_t)F, nullptr, scs, st))) return rc;
     for (int s = 0; s < S; ++s) {
         const int pb = DP_SEQ0 + s * DP_PER_SEQ;
         const float* Kk = t->gru[s].Hs;
-        // AUGRU: gradient of the final state; yields d a_t and the gradient of its inputs (= the keys)
-        if ((rc = cell_backward(t, N, t->aug[s], Kk, t->d_allf + s * NH2, (int64_t)F, nullptr, t->score[s], t->d_score, t->dK, false, st)))
-            return rc;
+        float* d_score = t->d_score[s];
+        float* dK = t->dK[s];
+        // AUGRU parameter gradients; the gradient of its inputs (= the keys) starts dK
+        if ((rc = cell_backward_post(t, N, t->aug[s], Kk, t->dAg[s], t->dAc[s], dK, false, st))) return rc;
         // attention MLP (LocalActivationUnit, att_hidden_units = (64, 16), sigmoid; raw score)
-        st_tn(t->cx, st, t->hid2[s], 16, 16, t->d_score, 1, 1, Ns, G + o[pb + DQ_ATT_W3]);
-        st_cs(t->cx, st, t->d_score, 1, 1, Ns, G + o[pb + DQ_ATT_B3]);
-        if ((rc = st_back(t->cx, st, t->d_score, 1, 1, P + o[pb + DQ_ATT_W3], 1, 16, t->d_hid2, 16, Ns))) return rc;
+        st_tn(t->cx, st, t->hid2[s], 16, 16, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_W3]);
+        st_cs(t->cx, st, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_B3]);
+        if ((rc = st_back(t->cx, st, d_score, 1, 1, P + o[pb + DQ_ATT_W3], 1, 16, t->d_hid2, 16, Ns))) return rc;
         hipLaunchKernelGGL(k_sig_bwd, ew(Ns * 16), b256, 0, st, t->d_hid2, t->hid2[s], Ns * 16);
         st_tn(t->cx, st, t->hid1[s], 64, 64, t->d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_W2]);
         st_cs(t->cx, st, t->d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_B2]);
@@ -533,10 +498,13 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
         st_tn(t->cx, st, t->inp[s], 4 * E, 4 * E, t->d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_W1]);
         st_cs(t->cx, st, t->d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_B1]);
         if ((rc = st_back(t->cx, st, t->d_hid1, 64, 64, P + o[pb + DQ_ATT_W1], 64, 4 * E, t->d_inp, 4 * E, Ns))) return rc;
-        hipLaunchKernelGGL(k_att_inp_bwd, ew(N * E), b256, 0, st, t->d_inp, t->q, Kk, t->dK, t->dq, N, L, E);
-        // first GRU: every state has an upstream gradient (it is a key and an AUGRU input); its inputs are embedding rows
-        if ((rc = cell_backward(t, N, t->gru[s], t->X[s], nullptr, 0, t->dK, nullptr, nullptr, t->d_inp /* scratch [N*L, E] */, false, st)))
-            return rc;
+        hipLaunchKernelGGL(k_att_inp_bwd, ew(N * E), b256, 0, st, t->d_inp, t->q, Kk, dK, t->dq, N, L, E);
+    }
+    // first GRU of every input in one launch: every state has an upstream gradient (it is a key and an AUGRU input)
+    if ((rc = layer_backward(t, N, 0, nullptr, 0, dKs, nullptr, st))) return rc;
+    for (int s = 0; s < S; ++s) {
+        // its inputs are embedding rows
+        if ((rc = cell_backward_post(t, N, t->gru[s], t->X[s], t->dAg[s], t->dAc[s], t->d_inp /* scratch [N*L, E] */, false, st))) return rc;
         hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, seq[s], N, L, H, E, t->d_inp, (int64_t)L * E, G + o[DP_SEQ_EMB]);
     }
     hipLaunchKernelGGL(k_emb_mean_bwd, g4, b256, 0, st, t->ids10, N, 10, H, E, t->dq, (int64_t)E, G + o[DP_SEQ_EMB]);
