@@ -75,6 +75,8 @@ struct RecurTrainFwd {
     const float* wg[4]; const float* wc[4];      // h-side weights in MFMA fragment order (launch_pack_frag): [Hd x 2Hd], [Hd x Hd]
     const float* att[4];                  // attention rows [N, L] (AUGRU) or NULL (GRU)
     float *R[4], *U[4], *C[4], *H[4], *RH[4];    // out
+    int hard;                             // keras recurrent_activation = hard_sigmoid for r / u (the lstm family's GRUs)
+    int xblk[3];                          // column block of the r / u / c pre-activations in a1 (TF cells 0,1,2; keras [z|r|h]: 1,0,2)
 };
 struct RecurTrainBwd {
     int N, L, S, Hd;
@@ -83,13 +85,21 @@ struct RecurTrainBwd {
     const float* up_last[4]; int64_t ld_up;      // gradient of the final state (row stride ld_up) or NULL
     const float* up_all[4];               // gradient of every state or NULL
     const float* wcT[4]; const float* wgT[4];    // transposed h-side weights in fragment order: [Hd x Hd], [2Hd x Hd]
-    float *dAg[4], *dAc[4];               // out: pre-activation gradients [N * L, 2Hd], [N * L, Hd]
+    // out: pre-activation gradients of the reset / update gates (row stride ld_g) and of the candidate (row stride ld_c), one
+    // row per (sample, step).  TF cells: dr = dAg, du = dAg + Hd, ld_g = 2Hd; dc = dAc, ld_c = Hd.  keras [z|r|h] rows of
+    // width 3Hd: du = dA, dr = dA + Hd, dc = dA + 2Hd, ld_g = ld_c = 3Hd.
+    float *dr[4], *du[4], *dc[4];
+    int64_t ld_g, ld_c;
     float* d_score[4];                    // out (AUGRU): d a_t [N, L] or NULL
+    int hard;                             // hard_sigmoid gates: derivative 0.2 inside (0, 1), 0 at the clamps
 };
 int launch_recur_train_fwd(const RecurTrainFwd& f, hipStream_t st);
 int launch_recur_train_bwd(const RecurTrainBwd& b, hipStream_t st);
 // W rows k_off.. (leading dim ld) -> fragment order; transpose = 1 packs W^T (K = columns of W, N = rows taken)
 int launch_pack_frag(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, hipStream_t st);
+// the same for a K-slice of a taller operand: rows [k_dst, k_dst + K) of a [K_total x N] fragment buffer
+int launch_pack_frag_slice(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, int K_total, int k_dst,
+                           hipStream_t st);
 
 // Power-of-two prescale of a weight tile that goes through the fp16 hi + lo split: s = 1 while the tile sits comfortably inside
 // fp16 (2^-6 <= max |w| < 2^14), else s = 2^k with max |w| * s in [2^13, 2^14) - multiplying by s is exact in fp32, hi = fp16(w s)

@@ -309,6 +309,7 @@ struct RecurArgs {
     // new state, r * h_prev - each [n_rows * L, NH] row-major.
     const float* sv_att[4];
     float *sv_r[4], *sv_u[4], *sv_c[4], *sv_h[4], *sv_rh[4];
+    int sv_blk[3];               // SAVE: column block of the r / u / c pre-activations inside a row of xbase (TF cells 0,1,2; keras GRU 1,0,2)
 };
 
 #ifndef RL4RS_FAST_ACT
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
         for (int r = 0; r < 16; ++r) {
             int voff = AUGRU ? (int)s_xoff[crow(r, half)] + xcol4
                              : s_ids[crow(r, half) * LDT + t] * xld4 + xcol4;
-            dst[r] = buf_load1(rs_x, voff, (AUGRU ? t * xld4 : 0) + block * NH * 4);
+            dst[r] = buf_load1(rs_x, voff, (AUGRU ? t * xld4 : 0) + (SAVE ? a.sv_blk[block] : block) * NH * 4);
         }
     };
     f32x16 xr_, xu_, xc_;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float rg, ug;
-            if (!AUGRU && a.hard_gates) {          // keras recurrent_activation = hard_sigmoid (uniform branch)
+            if ((!AUGRU || SAVE) && a.hard_gates) {          // keras recurrent_activation = hard_sigmoid (uniform branch)
                 rg = fminf(fmaxf(0.2f * (acc_r[r] + xr_[r]) + 0.5f, 0.f), 1.f);
                 ug = fminf(fmaxf(0.2f * (acc_u[r] + xu_[r]) + 0.5f, 0.f), 1.f);
             } else {

@@ -178,6 +178,7 @@ int layer_forward(rl4rs_dientrain* t, int N, int which, const float* const* Xin,
     RecurTrainFwd f;
     memset(&f, 0, sizeof(f));
     f.N = N; f.L = L; f.S = S; f.iota = t->iota;
+    f.hard = 0; f.xblk[0] = 0; f.xblk[1] = 1; f.xblk[2] = 2;
     int rc;
     for (int s = 0; s < S; ++s) {
         const CellSave& cl = which == 0 ? t->gru[s] : t->aug[s];
@@ -219,8 +220,10 @@ int layer_backward(rl4rs_dientrain* t, int N, int which, const float* const* up_
         b.R[s] = cl.R; b.U[s] = cl.Ug; b.C[s] = cl.C; b.H[s] = cl.Hs; b.att[s] = att ? att[s] : nullptr;
         b.up_last[s] = up_last ? up_last[s] : nullptr; b.up_all[s] = up_all ? up_all[s] : nullptr;
         b.wcT[s] = t->pkT_c[s]; b.wgT[s] = t->pkT_g[s];
-        b.dAg[s] = t->dAg[s]; b.dAc[s] = t->dAc[s]; b.d_score[s] = att ? t->d_score[s] : nullptr;
+        b.dr[s] = t->dAg[s]; b.du[s] = t->dAg[s] + Hd; b.dc[s] = t->dAc[s]; b.d_score[s] = att ? t->d_score[s] : nullptr;
+        b.ld_g = 2 * Hd; b.ld_c = Hd;
     }
+    b.hard = 0;
     return launch_recur_train_bwd(b, st);
 }
 

@@ -23,13 +23,16 @@ namespace rl4rs {
 
 // W [*, ld] rows k_off .. k_off + K (transpose = 0: B[k][n] = W[k_off + k][n]; 1: B[k][n] = W[k_off + n][k], N = rows, K = columns)
 // -> MFMA-B fragment order of pack_frag: out[((nt * KB + kb) * 64 + lane) * 4 + i] = B[kb * 8 + (lane >> 5) * 4 + i][nt * 32 + (lane & 31)]
-__global__ void k_pack_frag_dev(const float* __restrict__ w, int64_t ld, int k_off, int K, int N, int transpose, float* __restrict__ out) {
+// (K_total, k_dst: the slice is rows [k_dst, k_dst + K) of a [K_total x N] operand's fragment buffer)
+__global__ void k_pack_frag_dev(const float* __restrict__ w, int64_t ld, int k_off, int K, int N, int transpose, float* __restrict__ out,
+                                int K_total, int k_dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= K * N) return;
     const int i = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
     const int KB = K / 8, kb = rest % KB, nt = rest / KB;
     const int k = kb * 8 + (lane >> 5) * 4 + i, n = nt * 32 + (lane & 31);
-    out[idx] = transpose ? w[(size_t)(k_off + n) * ld + k] : w[(size_t)(k_off + k) * ld + n];
+    const float v = transpose ? w[(size_t)(k_off + n) * ld + k] : w[(size_t)(k_off + k) * ld + n];
+    out[(((size_t)nt * (K_total / 8) + (k_dst / 8 + kb)) * 64 + lane) * 4 + i] = v;
 }
 
 struct RecurBwdArgs {
@@ -40,8 +43,10 @@ struct RecurBwdArgs {
     const float* up_all[4];                        // gradient of every state [n_rows * L, NH] or NULL
     const float* wcT[4];                           // Wc_h^T [NH x NH] in fragment order
     const float* wgT[4];                           // Wg_h^T [2NH x NH] in fragment order
-    float *dAg[4], *dAc[4];                        // out: [n_rows * L, 2NH] / [n_rows * L, NH]
+    float *dr[4], *du[4], *dc[4];                  // out: gate / candidate pre-activation gradients, one row per (row, step)
+    int64_t ld_g, ld_c;                            //      row strides of dr / du and of dc
     float* d_score[4];                             // out (AUGRU): d a_t [n_rows, L] or NULL
+    int hard;                                      // hard_sigmoid gates (keras GRU)
 };
 
 template <int NH>
@@ -94,10 +99,10 @@ __global__ __launch_bounds__(NH * 2) void k_recur_bwd(RecurBwdArgs a) {
             up[r] = (1.0f - at) * u;
             const float dac = dd * (1.0f - up[r]) * (1.0f - c * c);
             const float dup = dd * (hp[r] - c);
-            dagu[r] = dup * (1.0f - at) * u * (1.0f - u);
+            dagu[r] = dup * (1.0f - at) * (a.hard ? ((u > 0.f && u < 1.f) ? 0.2f : 0.f) : u * (1.0f - u));
             red[r] = -dup * u;
             tA[row * LDA + col] = dac;
-            if (row0 + row < a.n_rows) a.dAc[sq][si] = dac;
+            if (row0 + row < a.n_rows) a.dc[sq][((size_t)gr * L + t) * a.ld_c + col] = dac;
         }
         if (aug) {
             // d a_t of a row = sum over ALL hidden columns of -dup u: 32 lanes of a half hold 32 columns of one row -> shuffle sum,
@@ -144,14 +149,14 @@ __global__ __launch_bounds__(NH * 2) void k_recur_bwd(RecurBwdArgs a) {
             const int row = crow(r, half);
             const int gr = min(row0 + row, a.n_rows - 1);
             const float drh = acc[r];
-            const float dagr = drh * hp[r] * rg[r] * (1.0f - rg[r]);
+            const float dagr = drh * hp[r] * (a.hard ? ((rg[r] > 0.f && rg[r] < 1.f) ? 0.2f : 0.f) : rg[r] * (1.0f - rg[r]));
             dhp[r] = d[r] * up[r] + drh * rg[r];
             tG[row * LDG + col] = dagr;
             tG[row * LDG + NH + col] = dagu[r];
             if (row0 + row < a.n_rows) {
-                const size_t gi = ((size_t)gr * L + t) * 2 * NH + col;
-                a.dAg[sq][gi] = dagr;
-                a.dAg[sq][gi + NH] = dagu[r];
+                const size_t gi = ((size_t)gr * L + t) * a.ld_g + col;
+                a.dr[sq][gi] = dagr;
+                a.du[sq][gi] = dagu[r];
             }
         }
         __syncthreads();
@@ -188,7 +193,15 @@ inline size_t recur_bwd_smem(int NH, int L) { return (size_t)(32 * (NH + 4) + 32
 // launchers (declared in common.hpp; dientrain.hpp lives in another translation unit)
 int launch_pack_frag(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, hipStream_t st) {
     if (K % 8 || N % 32) { set_error("pack_frag: K=%d must be a multiple of 8 and N=%d of 32", K, N); return RL4RS_EINVAL; }
-    hipLaunchKernelGGL(k_pack_frag_dev, dim3((K * N + 255) / 256), dim3(256), 0, st, w, ld, k_off, K, N, transpose, out);
+    return launch_pack_frag_slice(w, ld, k_off, K, N, transpose, out, K, 0, st);
+}
+int launch_pack_frag_slice(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, int K_total, int k_dst,
+                           hipStream_t st) {
+    if (K % 8 || N % 32 || K_total % 8 || k_dst % 8 || k_dst + K > K_total) {
+        set_error("pack_frag: K=%d (of %d at %d) must be multiples of 8 and N=%d of 32", K, K_total, k_dst, N);
+        return RL4RS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_pack_frag_dev, dim3((K * N + 255) / 256), dim3(256), 0, st, w, ld, k_off, K, N, transpose, out, K_total, k_dst);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
@@ -212,6 +225,8 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
         a.sv_att[s] = f.att[s];
         a.sv_r[s] = f.R[s]; a.sv_u[s] = f.U[s]; a.sv_c[s] = f.C[s]; a.sv_h[s] = f.H[s]; a.sv_rh[s] = f.RH[s];
     }
+    a.hard_gates = f.hard;
+    for (int b = 0; b < 3; ++b) a.sv_blk[b] = f.xblk[b];
     hipLaunchKernelGGL((k_recur<NH, true, 2, 0, true>), dim3((f.N + 31) / 32, f.S), dim3(NH * 2), smem, st, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
@@ -242,8 +257,9 @@ static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
     for (int s = 0; s < b.S; ++s) {
         a.R[s] = b.R[s]; a.U[s] = b.U[s]; a.C[s] = b.C[s]; a.H[s] = b.H[s]; a.att[s] = b.att[s];
         a.up_last[s] = b.up_last[s]; a.up_all[s] = b.up_all[s]; a.wcT[s] = b.wcT[s]; a.wgT[s] = b.wgT[s];
-        a.dAg[s] = b.dAg[s]; a.dAc[s] = b.dAc[s]; a.d_score[s] = b.d_score[s];
+        a.dr[s] = b.dr[s]; a.du[s] = b.du[s]; a.dc[s] = b.dc[s]; a.d_score[s] = b.d_score[s];
     }
+    a.ld_g = b.ld_g; a.ld_c = b.ld_c; a.hard = b.hard;
     hipLaunchKernelGGL((k_recur_bwd<NH>), dim3((b.N + 31) / 32, b.S), dim3(NH * 2), smem, st, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;

@@ -207,6 +207,8 @@ struct rl4rs_simtrain {
     // lstm: saved forwards of the 1 + seq_num GRUs and BPTT scratch
     GruSave gru[5];
     float *g_dA, *g_dX, *g_hprev, *g_G, *g_Gh, *g_dh, *g_dhp, *g_dhg, *g_drh, *g_zero, *g_uzrT, *g_uhT, *g_tmpw;
+    float *g_pk_g, *g_pk_c;            // recurrent weights in MFMA fragment order (persistent recurrence kernels, recur_train.hpp)
+    int32_t* g_iota;
     std::vector<void*> owned;
 };
 
@@ -241,6 +243,20 @@ int gru_forward(rl4rs_simtrain* t, int N, GruSave& g, hipStream_t st) {
     hipLaunchKernelGGL(k_emb_flatten, dim3((N + 3) / 4), dim3(256), 0, st, g.ids, N, len, H, E, t->params + t->off[g.emb], g.X,
                        (int64_t)len * E, 0);
     if ((rc = launch_gemm_f32(g.X, E, K, 3 * U, b, g.A1, 3 * U, N * len, 3 * U, E, 0, st))) return rc;
+    if (t->g_pk_g && (U == 128 || U == 256) && len <= 64 && (int64_t)N * len * 3 * U * 4 < (int64_t)0x7fffffff) {
+        // ONE persistent launch instead of four per step: the inference recurrence kernel with hard_sigmoid gates, the keras
+        // column order [z | r | h] mapped onto its (reset, update, candidate) roles, and the per-step gates saved for the BPTT
+        RecurTrainFwd f;
+        memset(&f, 0, sizeof(f));
+        f.N = N; f.L = len; f.S = 1; f.Hd = U; f.iota = t->g_iota; f.hard = 1;
+        f.xblk[0] = 1; f.xblk[1] = 0; f.xblk[2] = 2;
+        if ((rc = launch_pack_frag(Rw + U, 3 * U, 0, U, U, 0, t->g_pk_g, st))) return rc;                         // reset columns
+        if ((rc = launch_pack_frag(Rw, 3 * U, 0, U, U, 0, t->g_pk_g + (size_t)U * U, st))) return rc;             // update (z) columns
+        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 0, t->g_pk_c, st))) return rc;
+        f.a1[0] = g.A1; f.wg[0] = t->g_pk_g; f.wc[0] = t->g_pk_c; f.att[0] = nullptr;
+        f.R[0] = g.R; f.U[0] = g.Z; f.C[0] = g.HH; f.H[0] = g.H; f.RH[0] = g.RH;
+        return launch_recur_train_fwd(f, st);
+    }
     const dim3 ew((N * U + 255) / 256), b256(256);
     for (int ts = 0; ts < len; ++ts) {
         const float* hprev = ts == 0 ? t->g_zero : g.H + (size_t)(ts - 1) * U;
@@ -264,6 +280,22 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     float* gb = t->grad + t->off[g.pk + 2];
     int rc;
     const dim3 ew((N * U + 255) / 256), b256(256);
+    const bool persistent = t->g_pk_g && (U == 128 || U == 256) && len <= 64 && (int64_t)N * len * 3 * U * 4 < (int64_t)0x7fffffff;
+    if (persistent) {
+        // BPTT as ONE persistent launch (k_recur_bwd): transposed recurrent weights in fragment order - rows [reset | update] of the
+        // second operand in the order of its [d a_r | d a_z] tile - and the gate gradients written straight into the keras
+        // [z | r | h] columns of dA
+        RecurTrainBwd b;
+        memset(&b, 0, sizeof(b));
+        b.N = N; b.L = len; b.S = 1; b.Hd = U; b.ld_up = ld_up; b.hard = 1;
+        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 1, t->g_pk_c, st))) return rc;                                   // U_h^T
+        if ((rc = launch_pack_frag_slice(Rw + U, 3 * U, 0, U, U, 1, t->g_pk_g, 2 * U, 0, st))) return rc;                       // U_r^T
+        if ((rc = launch_pack_frag_slice(Rw, 3 * U, 0, U, U, 1, t->g_pk_g, 2 * U, U, st))) return rc;                           // U_z^T
+        b.R[0] = g.R; b.U[0] = g.Z; b.C[0] = g.HH; b.H[0] = g.H; b.att[0] = nullptr;
+        b.up_last[0] = up; b.up_all[0] = nullptr; b.wcT[0] = t->g_pk_c; b.wgT[0] = t->g_pk_g;
+        b.du[0] = t->g_dA; b.dr[0] = t->g_dA + U; b.dc[0] = t->g_dA + 2 * U; b.ld_g = 3 * U; b.ld_c = 3 * U;
+        if ((rc = launch_recur_train_bwd(b, st))) return rc;
+    } else {
     hipLaunchKernelGGL(k_transpose, dim3((U * 2 * U + 255) / 256), b256, 0, st, Rw, (int64_t)3 * U, U, 2 * U, t->g_uzrT);        // [2U, U]
     hipLaunchKernelGGL(k_transpose, dim3((U * U + 255) / 256), b256, 0, st, Rw + 2 * U, (int64_t)3 * U, U, U, t->g_uhT);        // [U, U]
     const float* dh_a = nullptr;
@@ -283,6 +315,7 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
         }
         dh_a = t->g_dhp;
         dh_b = t->g_dhg;
+    }
     }
     // parameter gradients over all (row, step) samples
     const int Ns = N * len;
@@ -421,6 +454,14 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
         ST_FAIL(al(&t->g_dhg, B * U)); ST_FAIL(al(&t->g_drh, B * U)); ST_FAIL(al(&t->g_zero, B * U));
         ST_FAIL(al(&t->g_uzrT, 2 * U * U)); ST_FAIL(al(&t->g_uhT, U * U)); ST_FAIL(al(&t->g_tmpw, U * 2 * U));
         ST_HIP(hipMemsetAsync(t->g_zero, 0, B * U * 4, st));
+        ST_FAIL(al(&t->g_pk_g, 2 * U * U)); ST_FAIL(al(&t->g_pk_c, U * U));
+        {
+            float* p; ST_FAIL(al(&p, B)); t->g_iota = reinterpret_cast<int32_t*>(p);
+            std::vector<int32_t> io(B);
+            for (size_t i = 0; i < B; ++i) io[i] = (int32_t)i;
+            ST_HIP(hipMemcpyAsync(t->g_iota, io.data(), B * 4, hipMemcpyHostToDevice, st));
+            ST_HIP(hipStreamSynchronize(st));          // io is a local
+        }
     }
     ST_FAIL(al(&t->loss_rows, B));
     ST_FAIL(al(&t->lr_dummy, 4));
