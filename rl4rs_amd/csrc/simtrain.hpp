@@ -190,6 +190,7 @@ enum { SP_CAT_EMB = 0, SP_SEQ_EMB, SP_DW1, SP_DB1, SP_DW2, SP_DB2, SP_FC_W, SP_F
 // one keras GRU of the lstm family in training mode: everything the BPTT needs is kept from the forward
 struct GruSave {
     float *X, *A1, *H, *Z, *R, *HH, *RH, *AZR;     // [N, len, E | 3U | U | U | U | U | U | 2U]
+    float *pkg, *pkc, *dA;                         // persistent-kernel path: fragment-order recurrent weights, [N, len, 3U] gate gradients
     int len, emb, pk;                              // sequence length, SP_* index of its embedding table, of its kernel
     const int32_t* ids;
 };
@@ -207,8 +208,7 @@ struct rl4rs_simtrain {
     // lstm: saved forwards of the 1 + seq_num GRUs and BPTT scratch
     GruSave gru[5];
     float *g_dA, *g_dX, *g_hprev, *g_G, *g_Gh, *g_dh, *g_dhp, *g_dhg, *g_drh, *g_zero, *g_uzrT, *g_uhT, *g_tmpw;
-    float *g_pk_g, *g_pk_c;            // recurrent weights in MFMA fragment order (persistent recurrence kernels, recur_train.hpp)
-    int32_t* g_iota;
+    int32_t* g_iota;                   // 0, 1, 2, ... (persistent recurrence kernels, recur_train.hpp); NULL: step-by-step form
     std::vector<void*> owned;
 };
 
@@ -233,6 +233,38 @@ int st_back(const TrainCtx& x, hipStream_t st, const float* dY, int ldy, int Nou
     return launch_gemm_f32(dY, ldy, x.wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
 }
 
+static bool gru_persistent(const rl4rs_simtrain* t, int N, int len) {
+    const int U = t->c.hidden_units;
+    return t->g_iota && (U == 128 || U == 256) && len <= 64 && (int64_t)N * len * 3 * U * 4 < (int64_t)0x7fffffff;
+}
+
+// keras GRU forward for several GRUs of the SAME length in ONE persistent launch (grid.y = n): the inference recurrence kernel
+// with hard_sigmoid gates, the keras column order [z | r | h] mapped onto its (reset, update, candidate) roles, and the per-step
+// gates saved for the BPTT (recur_train.hpp)
+int gru_forward_multi(rl4rs_simtrain* t, int N, GruSave* const* gs, int n, hipStream_t st) {
+    const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = gs[0]->len;
+    RecurTrainFwd f;
+    memset(&f, 0, sizeof(f));
+    f.N = N; f.L = len; f.S = n; f.Hd = U; f.iota = t->g_iota; f.hard = 1;
+    f.xblk[0] = 1; f.xblk[1] = 0; f.xblk[2] = 2;
+    int rc;
+    for (int k = 0; k < n; ++k) {
+        GruSave& g = *gs[k];
+        const float* K = t->params + t->off[g.pk];
+        const float* Rw = t->params + t->off[g.pk + 1];
+        const float* b = t->params + t->off[g.pk + 2];
+        hipLaunchKernelGGL(k_emb_flatten, dim3((N + 3) / 4), dim3(256), 0, st, g.ids, N, len, H, E, t->params + t->off[g.emb], g.X,
+                           (int64_t)len * E, 0);
+        if ((rc = launch_gemm_f32(g.X, E, K, 3 * U, b, g.A1, 3 * U, N * len, 3 * U, E, 0, st))) return rc;
+        if ((rc = launch_pack_frag(Rw + U, 3 * U, 0, U, U, 0, g.pkg, st))) return rc;                         // reset columns
+        if ((rc = launch_pack_frag(Rw, 3 * U, 0, U, U, 0, g.pkg + (size_t)U * U, st))) return rc;             // update (z) columns
+        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 0, g.pkc, st))) return rc;
+        f.a1[k] = g.A1; f.wg[k] = g.pkg; f.wc[k] = g.pkc; f.att[k] = nullptr;
+        f.R[k] = g.R; f.U[k] = g.Z; f.C[k] = g.HH; f.H[k] = g.H; f.RH[k] = g.RH;
+    }
+    return launch_recur_train_fwd(f, st);
+}
+
 // keras GRU forward over `len` steps for N rows, keeping gates and states (utils.py:34,91: layers.GRU(units=U))
 int gru_forward(rl4rs_simtrain* t, int N, GruSave& g, hipStream_t st) {
     const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = g.len;
@@ -243,20 +275,6 @@ int gru_forward(rl4rs_simtrain* t, int N, GruSave& g, hipStream_t st) {
     hipLaunchKernelGGL(k_emb_flatten, dim3((N + 3) / 4), dim3(256), 0, st, g.ids, N, len, H, E, t->params + t->off[g.emb], g.X,
                        (int64_t)len * E, 0);
     if ((rc = launch_gemm_f32(g.X, E, K, 3 * U, b, g.A1, 3 * U, N * len, 3 * U, E, 0, st))) return rc;
-    if (t->g_pk_g && (U == 128 || U == 256) && len <= 64 && (int64_t)N * len * 3 * U * 4 < (int64_t)0x7fffffff) {
-        // ONE persistent launch instead of four per step: the inference recurrence kernel with hard_sigmoid gates, the keras
-        // column order [z | r | h] mapped onto its (reset, update, candidate) roles, and the per-step gates saved for the BPTT
-        RecurTrainFwd f;
-        memset(&f, 0, sizeof(f));
-        f.N = N; f.L = len; f.S = 1; f.Hd = U; f.iota = t->g_iota; f.hard = 1;
-        f.xblk[0] = 1; f.xblk[1] = 0; f.xblk[2] = 2;
-        if ((rc = launch_pack_frag(Rw + U, 3 * U, 0, U, U, 0, t->g_pk_g, st))) return rc;                         // reset columns
-        if ((rc = launch_pack_frag(Rw, 3 * U, 0, U, U, 0, t->g_pk_g + (size_t)U * U, st))) return rc;             // update (z) columns
-        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 0, t->g_pk_c, st))) return rc;
-        f.a1[0] = g.A1; f.wg[0] = t->g_pk_g; f.wc[0] = t->g_pk_c; f.att[0] = nullptr;
-        f.R[0] = g.R; f.U[0] = g.Z; f.C[0] = g.HH; f.H[0] = g.H; f.RH[0] = g.RH;
-        return launch_recur_train_fwd(f, st);
-    }
     const dim3 ew((N * U + 255) / 256), b256(256);
     for (int ts = 0; ts < len; ++ts) {
         const float* hprev = ts == 0 ? t->g_zero : g.H + (size_t)(ts - 1) * U;
@@ -271,7 +289,32 @@ int gru_forward(rl4rs_simtrain* t, int N, GruSave& g, hipStream_t st) {
 }
 
 // BPTT of one GRU from the gradient of its final state (`up`, row stride ld_up); accumulates into the embedding gradient
-int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t ld_up, hipStream_t st) {
+// BPTT of several GRUs of the SAME length as ONE persistent launch (k_recur_bwd): transposed recurrent weights in fragment order -
+// rows [reset | update] of the second operand in the order of its [d a_r | d a_z] tile - and the gate gradients written
+// straight into the keras [z | r | h] columns of each GRU's dA
+int gru_backward_launch_multi(rl4rs_simtrain* t, int N, GruSave* const* gs, const float* const* ups, int64_t ld_up, int n, hipStream_t st) {
+    const int U = t->c.hidden_units, len = gs[0]->len;
+    RecurTrainBwd b;
+    memset(&b, 0, sizeof(b));
+    b.N = N; b.L = len; b.S = n; b.Hd = U; b.ld_up = ld_up; b.hard = 1;
+    b.ld_g = 3 * U; b.ld_c = 3 * U;
+    int rc;
+    for (int k = 0; k < n; ++k) {
+        GruSave& g = *gs[k];
+        const float* Rw = t->params + t->off[g.pk + 1];
+        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 1, g.pkc, st))) return rc;                                   // U_h^T
+        if ((rc = launch_pack_frag_slice(Rw + U, 3 * U, 0, U, U, 1, g.pkg, 2 * U, 0, st))) return rc;                       // U_r^T
+        if ((rc = launch_pack_frag_slice(Rw, 3 * U, 0, U, U, 1, g.pkg, 2 * U, U, st))) return rc;                           // U_z^T
+        b.R[k] = g.R; b.U[k] = g.Z; b.C[k] = g.HH; b.H[k] = g.H; b.att[k] = nullptr;
+        b.up_last[k] = ups[k]; b.up_all[k] = nullptr; b.wcT[k] = g.pkc; b.wgT[k] = g.pkg;
+        b.du[k] = g.dA; b.dr[k] = g.dA + U; b.dc[k] = g.dA + 2 * U;
+    }
+    return launch_recur_train_bwd(b, st);
+}
+
+// use_dA != NULL: the recurrence already ran (gru_backward_launch_multi) and left the gate gradients there - only the
+// parameter gradients and the embedding scatter remain
+int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t ld_up, float* use_dA, hipStream_t st) {
     const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = g.len;
     const float* K = t->params + t->off[g.pk];
     const float* Rw = t->params + t->off[g.pk + 1];
@@ -280,22 +323,8 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     float* gb = t->grad + t->off[g.pk + 2];
     int rc;
     const dim3 ew((N * U + 255) / 256), b256(256);
-    const bool persistent = t->g_pk_g && (U == 128 || U == 256) && len <= 64 && (int64_t)N * len * 3 * U * 4 < (int64_t)0x7fffffff;
-    if (persistent) {
-        // BPTT as ONE persistent launch (k_recur_bwd): transposed recurrent weights in fragment order - rows [reset | update] of the
-        // second operand in the order of its [d a_r | d a_z] tile - and the gate gradients written straight into the keras
-        // [z | r | h] columns of dA
-        RecurTrainBwd b;
-        memset(&b, 0, sizeof(b));
-        b.N = N; b.L = len; b.S = 1; b.Hd = U; b.ld_up = ld_up; b.hard = 1;
-        if ((rc = launch_pack_frag(Rw + 2 * U, 3 * U, 0, U, U, 1, t->g_pk_c, st))) return rc;                                   // U_h^T
-        if ((rc = launch_pack_frag_slice(Rw + U, 3 * U, 0, U, U, 1, t->g_pk_g, 2 * U, 0, st))) return rc;                       // U_r^T
-        if ((rc = launch_pack_frag_slice(Rw, 3 * U, 0, U, U, 1, t->g_pk_g, 2 * U, U, st))) return rc;                           // U_z^T
-        b.R[0] = g.R; b.U[0] = g.Z; b.C[0] = g.HH; b.H[0] = g.H; b.att[0] = nullptr;
-        b.up_last[0] = up; b.up_all[0] = nullptr; b.wcT[0] = t->g_pk_c; b.wgT[0] = t->g_pk_g;
-        b.du[0] = t->g_dA; b.dr[0] = t->g_dA + U; b.dc[0] = t->g_dA + 2 * U; b.ld_g = 3 * U; b.ld_c = 3 * U;
-        if ((rc = launch_recur_train_bwd(b, st))) return rc;
-    } else {
+    float* dA = use_dA ? use_dA : t->g_dA;
+    if (!use_dA) {
     hipLaunchKernelGGL(k_transpose, dim3((U * 2 * U + 255) / 256), b256, 0, st, Rw, (int64_t)3 * U, U, 2 * U, t->g_uzrT);        // [2U, U]
     hipLaunchKernelGGL(k_transpose, dim3((U * U + 255) / 256), b256, 0, st, Rw + 2 * U, (int64_t)3 * U, U, U, t->g_uhT);        // [U, U]
     const float* dh_a = nullptr;
@@ -321,13 +350,13 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     const int Ns = N * len;
     hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, t->g_hprev, N, U, len);
     const TrainCtx cx = {t->chunk, t->part, t->wt};
-    st_tn(cx, st, g.X, E, E, t->g_dA, 3 * U, 3 * U, Ns, gK);
-    st_cs(cx, st, t->g_dA, 3 * U, 3 * U, Ns, gb);
-    st_tn(cx, st, t->g_hprev, U, U, t->g_dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
+    st_tn(cx, st, g.X, E, E, dA, 3 * U, 3 * U, Ns, gK);
+    st_cs(cx, st, dA, 3 * U, 3 * U, Ns, gb);
+    st_tn(cx, st, t->g_hprev, U, U, dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
     RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, t->g_tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
-    st_tn(cx, st, g.RH, U, U, t->g_dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
+    st_tn(cx, st, g.RH, U, U, dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
     RL4RS_HIP_TRY(hipMemcpy2DAsync(gR + 2 * U, (size_t)3 * U * 4, t->g_tmpw, (size_t)U * 4, (size_t)U * 4, U, hipMemcpyDeviceToDevice, st));
-    if ((rc = st_back(cx, st, t->g_dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
+    if ((rc = st_back(cx, st, dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
     hipLaunchKernelGGL(k_emb_flatten_bwd, dim3((N + 3) / 4), b256, 0, st, g.ids, N, len, H, E, t->g_dX, (int64_t)len * E,
                        t->grad + t->off[g.emb]);
     RL4RS_LAUNCH_CHECK();
@@ -447,6 +476,7 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
             const size_t n = B * q.len;
             ST_FAIL(al(&q.X, n * E)); ST_FAIL(al(&q.A1, n * 3 * U)); ST_FAIL(al(&q.H, n * U)); ST_FAIL(al(&q.Z, n * U));
             ST_FAIL(al(&q.R, n * U)); ST_FAIL(al(&q.HH, n * U)); ST_FAIL(al(&q.RH, n * U)); ST_FAIL(al(&q.AZR, n * 2 * U));
+            ST_FAIL(al(&q.pkg, 2 * U * U)); ST_FAIL(al(&q.pkc, U * U)); ST_FAIL(al(&q.dA, n * 3 * U));
         }
         const size_t nm = B * maxlen_any;
         ST_FAIL(al(&t->g_dA, nm * 3 * U)); ST_FAIL(al(&t->g_dX, nm * E)); ST_FAIL(al(&t->g_hprev, nm * U));
@@ -454,7 +484,6 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
         ST_FAIL(al(&t->g_dhg, B * U)); ST_FAIL(al(&t->g_drh, B * U)); ST_FAIL(al(&t->g_zero, B * U));
         ST_FAIL(al(&t->g_uzrT, 2 * U * U)); ST_FAIL(al(&t->g_uhT, U * U)); ST_FAIL(al(&t->g_tmpw, U * 2 * U));
         ST_HIP(hipMemsetAsync(t->g_zero, 0, B * U * 4, st));
-        ST_FAIL(al(&t->g_pk_g, 2 * U * U)); ST_FAIL(al(&t->g_pk_c, U * U));
         {
             float* p; ST_FAIL(al(&p, B)); t->g_iota = reinterpret_cast<int32_t*>(p);
             std::vector<int32_t> io(B);
@@ -536,9 +565,18 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         hipLaunchKernelGGL(k_emb_flatten, g4, b256, 0, st, cat, N, Cn, H, E, P + o[SP_CAT_EMB], t->obs, (int64_t)OD, 256 + U);
     } else if (ls) {
         // [GRU finals of the sequences | tower | GRU final of the category embeddings | Flatten(category emb)] -> obs (lstm.py:31-36)
+        for (int g = 0; g <= S; ++g) t->gru[g].ids = g == 0 ? cat : seq[g - 1];
+        const bool pers = gru_persistent(t, N, t->gru[0].len) && gru_persistent(t, N, t->gru[1].len);
+        if (pers) {
+            // persistent recurrence kernels: the category GRU alone (its own length), the sequence GRUs together in ONE launch
+            GruSave* one[1] = {&t->gru[0]};
+            if ((rc = gru_forward_multi(t, N, one, 1, st))) return rc;
+            GruSave* seqs[4];
+            for (int s2 = 0; s2 < S; ++s2) seqs[s2] = &t->gru[1 + s2];
+            if ((rc = gru_forward_multi(t, N, seqs, S, st))) return rc;
+        }
         for (int g = 0; g <= S; ++g) {
-            t->gru[g].ids = g == 0 ? cat : seq[g - 1];
-            if ((rc = gru_forward(t, N, t->gru[g], st))) return rc;
+            if (!pers && (rc = gru_forward(t, N, t->gru[g], st))) return rc;
             const int off = g == 0 ? S * U + U : (g - 1) * U;
             const GruSave& q = t->gru[g];
             RL4RS_HIP_TRY(hipMemcpy2DAsync(t->feat + off, (size_t)FCK * 4, q.H + (size_t)(q.len - 1) * U, (size_t)q.len * U * 4, (size_t)U * 4,
@@ -591,9 +629,19 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         if ((rc = back(t->d_obs, 256, 256, P + o[SP_OBS_W], FCK, t->d_feat, FCK))) return rc;
         RL4RS_HIP_TRY(hipMemsetAsync(G + o[SP_SEQ_EMB], 0, (size_t)H * E * 4, st));
         hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, cat, N, Cn, H, E, t->d_feat + S * U + 2 * U, (int64_t)FCK, G + o[SP_CAT_EMB]);
+        const bool pers = gru_persistent(t, N, t->gru[0].len) && gru_persistent(t, N, t->gru[1].len);
+        if (pers) {
+            GruSave* one[1] = {&t->gru[0]};
+            const float* up0[1] = {t->d_feat + S * U + U};
+            if ((rc = gru_backward_launch_multi(t, N, one, up0, (int64_t)FCK, 1, st))) return rc;
+            GruSave* seqs[4];
+            const float* ups[4];
+            for (int s2 = 0; s2 < S; ++s2) { seqs[s2] = &t->gru[1 + s2]; ups[s2] = t->d_feat + s2 * U; }
+            if ((rc = gru_backward_launch_multi(t, N, seqs, ups, (int64_t)FCK, S, st))) return rc;
+        }
         for (int g = 0; g <= S; ++g) {
             const int off = g == 0 ? S * U + U : (g - 1) * U;
-            if ((rc = gru_backward(t, N, t->gru[g], t->d_feat + off, (int64_t)FCK, st))) return rc;
+            if ((rc = gru_backward(t, N, t->gru[g], t->d_feat + off, (int64_t)FCK, pers ? t->gru[g].dA : (float*)nullptr, st))) return rc;
         }
     } else {
         hipLaunchKernelGGL(k_elu_bwd, ew(N * 256), b256, 0, st, t->d_obs, (int64_t)256, t->obs, (int64_t)256, (const uint8_t*)nullptr, 0.f, N * 256, 256);
