@@ -52,6 +52,21 @@ constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
 #ifndef RL4RS_X_SPREAD
 #define RL4RS_X_SPREAD 0
 #endif
+// where in a step the staged projections of the update gate / the candidate are read into their accumulators (MFMA C-in): right
+// in front of the gate's first item (8 / 24) or some items earlier, so that the LDS round trip is not in front of that item's MFMAs
+// (both accumulators are free from item 0; the staging is per wave and was filled one step ago; must stay below the DMA window)
+#ifndef RL4RS_X_XU_AT
+#define RL4RS_X_XU_AT 8
+#endif
+#ifndef RL4RS_X_XC_AT
+#define RL4RS_X_XC_AT 24
+#endif
+#ifndef RL4RS_X_SPLITPAIR
+#define RL4RS_X_SPLITPAIR 1     // plane_store through split_h16_pair (v_cvt_pk_f16_f32 + v_fma_mix_f32: 2 VALU per element instead of
+#endif                          // ~3; same roundings, bit-identical planes; same-box A/B: 0.8595 -> 0.8503 ms per launch) - 0: the C++ casts
+#ifndef RL4RS_X_AMAX
+#define RL4RS_X_AMAX 0          // 1: track max |h| over the steps for the range check (0: the final state alone decides, see the epilogue)
+#endif
 // which items of a step keep their weight fragments in registers: a contiguous stretch behind the projection issue window
 // (RL4RS_X_SPREAD = 0) or every (48 / NRES)-th item (1: uniform load on the L1 return path)
 // (RL4RS_X_RESMASK: an explicit 48-bit item mask for experiments, 32-row form only, with RL4RS_X_WINDOW = the item the
@@ -224,6 +239,15 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     // four consecutive hidden columns (run q) of this lane's row -> the fp16 hi / lo planes (8-byte LDS writes)
     auto plane_store = [&](char* p_hi, char* p_lo, int m, int q, const float* v) {
         half4_t vh, vl;
+#if RL4RS_X_SPLITPAIR
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            half2_t h2, l2;
+            split_h16_pair(v[j], v[j + 1], h2, l2);        // same roundings: hi = RNE(x), lo = RNE(x - hi) from ONE fp32 value each
+            vh[j] = h2[0]; vh[j + 1] = h2[1];
+            vl[j] = l2[0]; vl[j + 1] = l2[1];
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // the value must be ONE rounded fp32 number for both uses below: left transparent, the compiler contracts the
@@ -235,6 +259,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             vh[j] = h;
             vl[j] = (_Float16)(x - (float)h);
         }
+#endif
         // column 32w + 8q + 4half + j -> k-block 2w + q/2, k-half q%2, element 4half + j
         const int o = m * TILE + (2 * wave + (q >> 1)) * 1024 + (q & 1) * 512 + li * 16 + half * 8;
         *reinterpret_cast<half4_t*>(p_hi + o) = vh;
@@ -262,7 +287,9 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         for (int m = 0; m < MT; ++m) {
             const float cnd = (RL4RS_X_AB & 1) ? acc_c[m][r] : gate_tanh_k(acc_c[m][r], k_c);
             const float hn = __builtin_fmaf(acc_u[m][r], h_own[m][r] - cnd, cnd);       // u h + (1-u) c
+#if RL4RS_X_AMAX
             amax[m] = fmaxf(amax[m], fabsf(hn));
+#endif
             h_own[m][r] = hn;
             quad[m][r & 3] = hn;
             if ((r & 3) == 3) plane_store(hp_hi, hp_lo, m, r >> 2, quad[m]);
@@ -286,18 +313,24 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = gate(i), cur = i & 1;
-            if (i == 8) {
-                RL4RS_XT(1);
+            if (i == 8) RL4RS_XT(1);
+            if (i == RL4RS_X_XU_AT) {
                 if (!(RL4RS_X_AB & (4 | 128))) {                  // x_u(t)   (128: no staging reads, DMA keeps going): staged one step ago
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_u[m], 1, m);
+                }
+            }
+            if (i == RL4RS_X_XC_AT && RL4RS_X_XC_AT != 24) {
+                if (!(RL4RS_X_AB & (4 | 128))) {                  // x_c(t), ahead of the barrier
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) x_read(acc_c[m], 2, m);
                 }
             }
             if (i == 24) {
                 RL4RS_XT(2);
                 if (!(RL4RS_X_AB & 16)) __syncthreads();           // r*h planes complete
                 RL4RS_XT(3);
-                if (!(RL4RS_X_AB & (4 | 128))) {                  // x_c(t)
+                if (RL4RS_X_XC_AT == 24 && !(RL4RS_X_AB & (4 | 128))) {                  // x_c(t)
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_c[m], 2, m);
                 }
@@ -380,7 +413,13 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         if (!(RL4RS_X_AB & 16)) __syncthreads();                   // late half of the new state complete
         RL4RS_XT(7);
     }
-    // ---- poison rows that left the fp16 range (or went NaN) and write the final state (16-byte stores)
+    // ---- poison rows that left the fp16 range (or went NaN) and write the final state (16-byte stores).  The final state alone
+    // decides: a state element beyond the largest finite fp16 number becomes +-inf in the hi plane and -+inf in the lo plane at
+    // the step it appears; from then on its row's accumulators hold inf - inf = NaN or a saturated gate times inf, i.e. the
+    // state stays inf / NaN to the end (nothing maps them back to a finite number: sigmoid / tanh of +-inf give 0 / 1 / +-1 and
+    // the blend multiplies the non-finite h by them or by 0), so |h_final| < 6e4 fails for exactly those rows - no per-step
+    // running maximum needed (16 v_max3 per wave and step).  Rows that pass through [6e4, 65504] and come back were carried
+    // exactly and are not errors.
     uint32_t* s_bad = reinterpret_cast<uint32_t*>(rp_hi);          // the planes are dead now
     if (tid < 32 * MT) s_bad[tid] = 0u;
     __syncthreads();
