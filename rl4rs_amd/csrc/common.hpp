@@ -66,6 +66,11 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
                           const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION, shared by every handle of the process: it is only ever
+// raised (a second handle with a smaller shape must not lower the limit under the first one's launches - ADVICE r2 on k_ppo_pass,
+// applied to every kernel whose LDS size depends on a handle's shape).  Defined in env.hip.
+int raise_dyn_smem(const void* fn, size_t bytes);
+
 // Training-mode recurrences as persistent kernels (recur_train.hpp, compiled into dien.hip; called from dientrain.hpp).
 // Arrays are per sequence input (S <= 4 inputs run in ONE launch, grid.y = S); saved tensors are [N * L, Hd] row-major.
 struct RecurTrainFwd {

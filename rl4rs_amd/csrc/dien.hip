@@ -1713,22 +1713,16 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             reinterpret_cast<const void*>(&k_recur<256, true, AUGRU_U, 15>),
 #endif
         };
+        // (per-function limits, only ever raised: handles with different maxlen share these kernels)
         for (const void* f : augru_variants)
-            RL4RS_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_aug));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_h16_smem(1, NH2, L)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(1)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)augru_x_smem(2)));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_gru));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_x), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)din_x_smem()));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_scores<true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            if ((rc = raise_dyn_smem(f, sm_aug))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), augru_h16_smem(1, NH2, L)))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), augru_x_smem(1)))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), augru_x_smem(2)))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>), sm_gru))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_din_x), din_x_smem()))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_din_scores<true, false>), 96 * 1024))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_din_scores<true, true>), 96 * 1024))) return rc;
     }
     RL4RS_HIP_TRY(hipStreamSynchronize(st));   // host staging (keep) may now be released
     *out = n;
@@ -1764,8 +1758,8 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
             a.wg[0] = n->gru_wg16[s]; a.wc[0] = n->gru_wc16[s];
             const size_t smem16 = (((size_t)4 * 32 * (128 + 8) * 2 + (size_t)32 * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * 8 * 2048;
             if (!n->gru16_attr) {
-                RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_h16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)smem16));
+                int rc16 = raise_dyn_smem(reinterpret_cast<const void*>(&k_gru_h16), smem16);
+                if (rc16) return rc16;
                 n->gru16_attr = true;
             }
             hipLaunchKernelGGL(k_gru_h16, dim3((cnt + 31) / 32, 1), dim3(256), smem16, st, a);

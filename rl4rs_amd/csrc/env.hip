@@ -580,6 +580,22 @@ static int launch_rows(rl4rs_env* e, int R, const int32_t* actions, int cur, int
     return RL4RS_OK;
 }
 
+namespace rl4rs {
+int raise_dyn_smem(const void* fn, size_t bytes) {
+    static std::vector<std::pair<const void*, size_t>> cur;      // a handful of kernels: a linear scan is fine (handles are not thread-safe)
+    for (auto& e : cur)
+        if (e.first == fn) {
+            if (bytes <= e.second) return RL4RS_OK;
+            RL4RS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            e.second = bytes;
+            return RL4RS_OK;
+        }
+    RL4RS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    cur.emplace_back(fn, bytes);
+    return RL4RS_OK;
+}
+}  // namespace rl4rs
+
 extern "C" {
 
 const char* rl4rs_last_error(void) { return g_err.c_str(); }

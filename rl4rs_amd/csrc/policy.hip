@@ -1164,9 +1164,9 @@ size_t tile_smem(const PolDims& d, int mode) {
 template <int MODE>
 int launch_policy_tile(rl4rs_policy* p, const TileArgs& a, hipStream_t st) {
     const size_t smem = tile_smem(p->d, MODE);
-    if (!p->tile_attr[MODE]) {
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_tile<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)smem));
+    if (!p->tile_attr[MODE]) {       // per-function limit, only ever raised (policies of different shapes share the kernel)
+        int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_policy_tile<MODE>), smem);
+        if (rca) return rca;
         p->tile_attr[MODE] = true;
     }
     hipLaunchKernelGGL(k_policy_tile<MODE>, dim3((a.N + 7) / 8), dim3(512), smem, st, a);

@@ -211,8 +211,10 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
     static bool attr = false;
     const size_t smem = (size_t)(2 * 32 * (NH + 4) + 32 * (f.L + 1) + 32) * 4;
     if (!attr) {
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<NH, true, 2, 0, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        // the opt-in belongs to the FUNCTION, not to a call: raised once to the most any admitted shape needs (L = 64), so a
+        // short sequence launched first cannot leave the limit below what a longer one asks for later
+        int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur<NH, true, 2, 0, true>), (size_t)(2 * 32 * (NH + 4) + 32 * 65 + 32) * 4);
+        if (rca) return rca;
         attr = true;
     }
     RecurArgs a;
@@ -247,8 +249,9 @@ template <int NH>
 static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
     static bool attr = false;
     const size_t smem = recur_bwd_smem(NH, b.L);
-    if (!attr) {
-        RL4RS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur_bwd<NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!attr) {          // per function, once, for the longest admitted sequence (see recur_train_fwd_t)
+        int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur_bwd<NH>), recur_bwd_smem(NH, 64));
+        if (rca) return rca;
         attr = true;
     }
     RecurBwdArgs a;

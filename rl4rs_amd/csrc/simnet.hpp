@@ -164,11 +164,7 @@ int rl4rs_simnet_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights* w
             SN_FAIL(sn_prepare_gru(n, n->seq_emb, w->seq_gru_kernel[s], w->seq_gru_recurrent[s], w->seq_gru_bias[s], &n->seq_tab[s],
                                    &n->seq_wg[s], &n->seq_wc[s], keep, st));
         }
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)((2 * 32 * (U + 4) + 32 * (64 + 1) + 32) * 4));
-        if (ea != hipSuccess) {
-            set_error("simnet_create: hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
+        if (raise_dyn_smem(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>), (size_t)(2 * 32 * (U + 4) + 32 * (64 + 1) + 32) * 4) != RL4RS_OK) {
             rl4rs_simnet_destroy(n);
             return RL4RS_EHIP;
         }
