@@ -182,6 +182,9 @@ class LogStore(object):
             'user_cat': torch.zeros((n, 10), dtype=torch.int32, device=device),
         }
         self.exposed_len = np.zeros(n, dtype=np.int64)
+        # host copy of the logged item ids (a few hundred KB): the reference-shaped offline_action hands out python lists of
+        # them, which then need no device round trip
+        self.exposed_host = np.zeros((n, W), dtype=np.int32)
 
     def ensure(self, rows, device):
         """Make sure the given line numbers are parsed and resident on ``device``."""
@@ -200,6 +203,7 @@ class LogStore(object):
             src = torch.from_numpy(getattr(cols, name)).to(device)
             self._dev[name].index_copy_(0, idx, src)
         self.exposed_len[todo] = cols.exposed_len
+        self.exposed_host[todo] = cols.exposed
         self._parsed[todo] = True
 
     def preload(self, device):

@@ -99,6 +99,7 @@ class SlateState(RecState):
             store.ensure(rows, dev)
             log_steps = store.log_steps
             self._exposed_len_min = int(store.exposed_len[rows].min())
+            self._exposed_host = None if self._tensor_mode() else store.exposed_host[rows]
             self._users = None
             self._store_rows = (store, rows)
             # RecDataBase.sample draws the batch WITH replacement from a cache window (base.py:92-100; 4096 envs from
@@ -128,6 +129,7 @@ class SlateState(RecState):
                         user_dense=rc.user_dense, user_cat=rc.user_cat)
             log_steps = rc.log_steps
             self._exposed_len_min = int(rc.exposed_len.min())
+            self._exposed_host = np.ascontiguousarray(rc.exposed, dtype=np.int32)
             self._users = rc.users
             self._feedback_cols = cols['feedback']
         key = ('env', self.is_seq, log_steps, self.batch_size, self.max_steps, self._violation_zeroes_reward())
@@ -269,19 +271,32 @@ class SlateState(RecState):
         if env.cur_steps < self.max_steps and env.cur_steps >= self._exposed_len_min:
             raise IndexError('list index out of range')       # exposed_items[cur_step], slate.py:154-156
         conti = bool(self.config.get("support_conti_env", False))
-        cache = getattr(self, '_offline_cache', None)
-        if (not self._tensor_mode() and cache is not None and cache[0] == self._batch_version and cache[1] == env.cur_steps
-                and cache[2] is not None and env.cur_steps < self.max_steps):
-            out = cache[2]                                  # came back with the last transition record (rl4rs_env_step_record)
-            if not conti and cache[3] is not None and self.batch_size > 1:
-                # the same ids also sit in the device record: a list that remembers it (until somebody changes it)
-                return D.OfflineActionList(out.tolist(), dev=cache[3], tag=(self._batch_version, env.cur_steps))
-        else:
-            out = env.offline_action(conti=conti)
-            if self._tensor_mode():
-                return out
-            out = D.to_host(out)
-        return [row for row in out] if conti else out.tolist()
+        if self._tensor_mode():
+            return env.offline_action(conti=conti)
+        nxt = getattr(self, '_next_offline', None)
+        if nxt is not None and nxt[0] == (self._batch_version, env.cur_steps):
+            return nxt[1]                                   # built while the last transition's kernels ran (SlateRecEnv._step)
+        return self._offline_from_host(env.cur_steps, conti, None)
+
+    def _offline_from_host(self, cur, conti, dev_ids):
+        """The logged action of step ``cur`` in the reference's shape (slate.py:152-161) from the HOST copy of the logged item
+        ids: a python list of ids, or of action-embedding rows for a continuous-action env.  ``dev_ids``: device tensor holding
+        the same ids (part of the last transition record), remembered by the list so that handing it back to ``step`` uploads
+        nothing."""
+        env = self._live()
+        ex = getattr(self, '_exposed_host', None)
+        if ex is None:                                      # (defensive: no host copy)
+            out = D.to_host(env.offline_action(conti=conti))
+            return [row for row in out] if conti else out.tolist()
+        ids = ex[:, cur] if (cur < self.max_steps and cur < ex.shape[1]) else np.zeros(self.batch_size, dtype=np.int32)
+        if conti:
+            if ids.min() < 0 or ids.max() >= self.action_size:      # the device kernel flags this and plays item 0: let it
+                out = D.to_host(env.offline_action(conti=True))
+                return [row for row in out]
+            return [row for row in self._catalog.action_emb[ids]]
+        if dev_ids is not None and self.batch_size > 1:
+            return D.OfflineActionList(ids.tolist(), dev=dev_ids, tag=(self._batch_version, cur))
+        return ids.tolist()
 
     @property
     def offline_reward(self):
@@ -562,11 +577,18 @@ class SlateRecEnv(RecSimBase):
                 want.append('click_p')
             built = {}
 
+            cur_after = env.cur_steps + 1
+
             def in_the_gpu_shadow(rec):
-                # python objects that only need the (still empty) views: built while the kernels run
+                # host work that needs no result of this transition, done while its kernels run: the python objects around the
+                # (still empty) views, and the NEXT step's logged-action list (from the host copy of the log; the device copy
+                # of the same ids is part of the record)
                 if masked:
                     built['obs'] = [{"action_mask": m, "obs": o} for m, o in zip(rec.mask, rec.obs)]
                 built['done'] = [1 if last else 0] * self.batch_size
+                if cur_after < self.max_steps and cur_after < samples._exposed_len_min:
+                    samples._next_offline = ((samples._batch_version, cur_after),
+                                             samples._offline_from_host(cur_after, conti, None if conti else stepper.offline_action_view()))
 
             if (isinstance(action, D.OfflineActionList) and action._dev is not None
                     and action._tag == (samples._batch_version, env.cur_steps)):
@@ -577,8 +599,6 @@ class SlateRecEnv(RecSimBase):
                                  "(numpy would raise at rl4rs/env/slate.py:199)")
             import torch
             samples.last_actions = torch.from_numpy(r.chosen)
-            samples._offline_cache = (samples._batch_version, env.cur_steps, r.offline_action,
-                                      None if conti else stepper.offline_action_view())
             due = self._reward_due(samples)
             samples._range_seen = getattr(samples, '_range_seen', 0) | int(r.status[1])      # the record read-and-cleared the flag
             if due and samples._range_seen:
@@ -594,7 +614,7 @@ class SlateRecEnv(RecSimBase):
             samples._seq1_version += 1
             self._encoded_seq1 = samples._seq1_version
         self._last_obs = None
-        return obs, reward, [1 if last else 0] * self.batch_size, samples.info
+        return obs, reward, built['done'] if not samples._tensor_mode() else [1 if last else 0] * self.batch_size, samples.info
 
     # -- reward --------------------------------------------------------------------------------
     def _reward_due(self, samples):
