@@ -183,14 +183,14 @@ def run_scenario(name, state_cls, FeatureUtil, cfg, records, seq, conti, rs, mas
 
 
 def compact(g, min_bytes=200000, head_rows=8):
-    """Large float feature arrays of a big-batch scenario are committed as a digest: '<key>__sha1' (sha1 of the C-order bytes),
+    """Large float feature-row arrays (dense_*, c_dense_*) of a big-batch scenario are committed as a digest: '<key>__sha1' (sha1 of the C-order bytes),
     '<key>__shape', '<key>__dtype' and the first rows '<key>__head' - bit-exact comparison needs no more than that, and the
     fixture stays small.  tests/helpers.py::golden_equal understands both forms."""
     import hashlib
     out = {}
     for k, v in g.items():
         v = np.ascontiguousarray(v)
-        if v.dtype.kind == 'f' and v.nbytes >= min_bytes:
+        if v.dtype.kind == 'f' and v.nbytes >= min_bytes and (k.startswith('dense_') or k.startswith('c_dense_')):
             out[k + '__sha1'] = np.frombuffer(hashlib.sha1(v.tobytes()).digest(), dtype=np.uint8).copy()
             out[k + '__shape'] = np.asarray(v.shape, dtype=np.int64)
             out[k + '__dtype'] = np.array(str(v.dtype))
@@ -247,6 +247,15 @@ def main():
     g = run_scenario('slate256_discrete', SlateState, FeatureUtil, cfg, rec_c, False, False, np.random.RandomState(13), 'support_rllib_mask')
     cfg['iteminfo_file'] = 'catalog_synth.csv'
     emit('slate256_discrete', compact(g), cfg, False, False, 'support_rllib_mask', 'catalog_synth.csv', 'records_slate256.txt')
+
+    # ---------------- SeqSlateRecEnv-v0 at batch 64, 36 steps (4 pages), mask mode: the paging quirks (special-mask re-poisoning
+    # across pages, page-0-only special check of get_violation, literal 9 of offline_reward) on a batch that fills two row tiles
+    rec_d = synth.make_records(64, pages=4, seed=4000, illegal_frac=0.3, special_ids=sp)
+    synth.write_records(os.path.join(HERE, 'records_seq64.txt'), rec_d)
+    cfg = base_config(iteminfo_file=cat_path, batch_size=64, max_steps=36)
+    g = run_scenario('seq36_b64_discrete', SeqSlateState, FeatureUtil, cfg, rec_d, True, False, np.random.RandomState(17), 'support_rllib_mask')
+    cfg['iteminfo_file'] = 'catalog_synth.csv'
+    emit('seq36_b64_discrete', compact(g, min_bytes=60000), cfg, True, False, 'support_rllib_mask', 'catalog_synth.csv', 'records_seq64.txt')
 
     # ---------------- real data known answers (tutorial.ipynb cell 4 record + dataset/item_info.csv)
     # RL4RS dataset (c) fuxiAIlab, CC BY-SA 4.0 (reference LICENSE); one record and the public catalogue.
