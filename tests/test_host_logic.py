@@ -235,3 +235,50 @@ def test_lazy_stats_is_a_mapping_that_resolves_once_and_pickles_as_a_dict():
     assert FakeTrainer.calls == 1                       # one resolution serves every access
     back = pickle.loads(pickle.dumps(st))
     assert type(back) is dict and back == {'policy_loss': 1.5, 'kl': 0.25, 'iteration': 7} and st == back
+
+
+def test_offline_action_list_is_a_list_that_forgets_its_device_copy_when_changed():
+    """rl4rs_amd.device.OfflineActionList: what offline_action hands out in the reference-shaped modes - a plain list to every
+    consumer (equality, json, numpy, pickle / deepcopy give plain lists), carrying a reference to the device copy of the same
+    ids that ANY in-place change drops (a modified list must be converted and uploaded like any other)."""
+    import copy
+    import json
+    import pickle
+    from rl4rs_amd.device import OfflineActionList
+    dev = object()
+    a = OfflineActionList([3, 1, 2], dev=dev, tag=(1, 0))
+    assert isinstance(a, list) and a == [3, 1, 2] and a._dev is dev and a._tag == (1, 0)
+    assert json.dumps(a) == '[3, 1, 2]' and np.asarray(a).tolist() == [3, 1, 2]
+    assert type(pickle.loads(pickle.dumps(a))) is list and type(copy.deepcopy(a)) is list
+    b = a + [4]                                       # new objects are plain lists, the original keeps its reference
+    assert type(b) is list and a._dev is dev
+    assert a[1:] == [1, 2] and a._dev is dev          # reading does not drop it
+    for change in (lambda x: x.__setitem__(0, 9), lambda x: x.append(1), lambda x: x.extend([1]), lambda x: x.insert(0, 1),
+                   lambda x: x.pop(), lambda x: x.remove(1), lambda x: x.reverse(), lambda x: x.sort(), lambda x: x.clear(),
+                   lambda x: x.__iadd__([5]), lambda x: x.__imul__(2), lambda x: x.__delitem__(0),
+                   lambda x: x.__setitem__(slice(0, 1), [7])):
+        c = OfflineActionList([3, 1, 2], dev=dev, tag=(1, 0))
+        change(c)
+        assert c._dev is None, change
+
+
+def test_scorer_kernel_option_names():
+    """config['scorer_kernels'] parsing (names of rl4rs_dien_cfg.kernel_opts bits) - no GPU needed."""
+    from rl4rs_amd.device import parse_dien_opts
+    from rl4rs_amd import _lib
+    assert parse_dien_opts(None) == () and parse_dien_opts('') == ()
+    assert parse_dien_opts(' augru_h16 , no_din16,augru_h16') == ('augru_h16', 'no_din16')
+    assert parse_dien_opts(['DIN_V1']) == ('din_v1',)
+    with pytest.raises(ValueError, match='scorer_kernels'):
+        parse_dien_opts('augru_rows48')
+    bits = [_lib.DIEN_OPTS[k] for k in _lib.DIEN_OPTS]
+    assert sorted(bits) == [1 << i for i in range(len(bits))]          # one distinct bit each, contiguous from bit 0
+    # the header's enum and the binding agree (names and values)
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'rl4rs_hip.h')).read()
+    for name, bit in _lib.DIEN_OPTS.items():
+        m = re.search(r'RL4RS_DIEN_OPT_%s = 1 << (\d+)' % name.upper(), hdr)
+        assert m and (1 << int(m.group(1))) == bit, name
+    for name, val in _lib.STEP_WANT.items():
+        m = re.search(r'RL4RS_STEP_WANT_%s = (\d+)' % name.upper(), hdr)
+        assert m and int(m.group(1)) == val, name
