@@ -464,6 +464,18 @@ int rl4rs_stepper_record_layout(rl4rs_stepper* s, uint32_t want, int32_t conti, 
 /* action_kind: 0 = int32 item ids [B]; 1 / 2 = float32 / float64 action embeddings [B, action_emb_size] (masked K-NN first) */
 int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
                           void* stream);
+/* The same transition, and the record's host part brought home by the library: `record_host` = host_bytes of (pinned) host
+ * memory, filled when `stream` has drained - ONE wait on `stream` by the caller.  The int64 mask (the bulk of a
+ * support_rllib_mask record, B * action_size * 8 bytes, and a function of the act alone) leaves on a copy stream of the
+ * stepper as soon as the act is done, beside the scorer's kernels; the rest follows as one prefix copy after the last kernel. */
+int rl4rs_env_step_record_host(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
+                               void* record_host, void* stream);
+/* The record of the state the env is IN, without a transition - what RecSimBase.sample returns right after a reset
+ * (base.py:172-175: obs_fn(samples.state)): obs / obs_d3rl / mask_i64 / mask_bits / offline_action (the logged action of the
+ * CURRENT step) / status in the same layout (`conti` selects the offline_action form); reward, done and chosen are left alone.
+ * The caller has encoded the batch's sequences (rl4rs_dien_encode).  record_host may be NULL (no copies). */
+int rl4rs_env_observe_record_host(rl4rs_stepper* s, int32_t conti, uint32_t want, void* record_dev, void* record_host,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size

@@ -191,6 +191,8 @@ SIGNATURES = {
     'rl4rs_dien_status_word': (_I, [_P, C.POINTER(_P)]),
     'rl4rs_stepper_record_layout': (_I, [_P, C.c_uint32, _I32, C.POINTER(StepRecord)]),
     'rl4rs_env_step_record': (_I, [_P, _P, _I32, C.c_uint32, _P, _P]),
+    'rl4rs_env_step_record_host': (_I, [_P, _P, _I32, C.c_uint32, _P, _P, _P]),
+    'rl4rs_env_observe_record_host': (_I, [_P, _I32, C.c_uint32, _P, _P, _P]),
     'rl4rs_env_set_option': (_I, [_P, _I32, _I32]),
     'rl4rs_policy_set_option': (_I, [_P, _I32, _I32]),
     'rl4rs_env_get_cfg': (_I, [_P, _P]),

@@ -22,6 +22,8 @@ struct rl4rs_stepper {
     float* probs;              // [B * (n_complete - 1)] click probabilities of the complete-state rows
     float* p_last;             // [B] probability of the state row just scored (= the last complete-state row)
     const float* dense; const int32_t* cat; const int32_t* seq1; const float* c_dense; const int32_t* c_cat;
+    hipStream_t copy_stream;   // rl4rs_env_step_record_host: early device-to-host copies run here, beside the scorer's kernels
+    hipEvent_t ev_ready, ev_copied;
 };
 
 namespace {
@@ -153,6 +155,9 @@ int rl4rs_stepper_destroy(rl4rs_stepper* s) {
     if (!s) return RL4RS_OK;
     if (s->probs) (void)hipFree(s->probs);
     if (s->p_last) (void)hipFree(s->p_last);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
     return RL4RS_OK;
 }
@@ -197,10 +202,12 @@ int rl4rs_stepper_record_layout(rl4rs_stepper* s, uint32_t want, int32_t conti, 
     L->chosen = take(B * 4);
     const bool d3rl = (want & RL4RS_STEP_WANT_D3RL_OBS) != 0;
     if (d3rl) L->obs_d3rl = take(B * (OD + ncols + 1) * 8); else L->obs = take(B * OD * 4);
-    if (want & RL4RS_STEP_WANT_MASK_I64) L->mask_i64 = take(B * A * 8);
     if (want & RL4RS_STEP_WANT_MASK_BITS) L->mask_bits = take(B * W * 4);
     if (want & RL4RS_STEP_WANT_CLICK_P) L->click_p = take(B * s->n_complete * 4);
     if (want & RL4RS_STEP_WANT_OFFLINE_ACTION) L->offline_action = take(conti ? B * s->cfg.action_emb_size * 8 : B * 4);
+    // the int64 mask is by far the largest part (B * A * 8 bytes) and depends on the act alone: last of the host part, so that
+    // rl4rs_env_step_record_host can send it home on its own while the scorer runs and bring the rest back as one prefix
+    if (want & RL4RS_STEP_WANT_MASK_I64) L->mask_i64 = take(B * A * 8);
     L->host_bytes = off;
     if (d3rl) L->obs = take(B * OD * 4);                           // float32 activations: device-side scratch only in this mode
     L->total_bytes = off;
@@ -209,9 +216,13 @@ int rl4rs_stepper_record_layout(rl4rs_stepper* s, uint32_t want, int32_t conti, 
     return RL4RS_OK;
 }
 
-int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev, void* stream) {
-    RL4RS_REQUIRE(s && actions_dev && record_dev, "env_step_record: null argument");
+// `observe`: no transition - the record of the state the env is in (after a reset: what RecSimBase.sample returns, base.py:172-175);
+// reward / done / chosen are then left alone and `actions_dev` is unused.
+static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
+                       void* record_host, void* stream) {
+    RL4RS_REQUIRE(s && (observe || actions_dev) && record_dev, "env_step_record: null argument");
     RL4RS_REQUIRE(action_kind >= 0 && action_kind <= 2, "env_step_record: action_kind must be 0 (int32 ids), 1 (float32) or 2 (float64 embeddings)");
+    RL4RS_REQUIRE(!(observe && (want & RL4RS_STEP_WANT_CLICK_P)), "env_observe_record: click_p belongs to a reward step");
     rl4rs_step_record L;
     int rc = rl4rs_stepper_record_layout(s, want, action_kind != 0, &L);
     if (rc) return rc;
@@ -220,18 +231,42 @@ int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t act
     const int B = s->cfg.batch_size;
     float* obs = reinterpret_cast<float*>(R + L.obs);
     int32_t* chosen = reinterpret_cast<int32_t*>(R + L.chosen);
-    const int cur = rl4rs_env_cur_steps(s->env);
-    if (action_kind == 0) {
+    const int cur = rl4rs_env_cur_steps(s->env) - (observe ? 1 : 0);      // `cur + 1` below = the step counter the record describes
+    if (observe) {
+        rc = RL4RS_OK;
+    } else if (action_kind == 0) {
         RL4RS_HIP_TRY(hipMemcpyAsync(chosen, actions_dev, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
         rc = rl4rs_env_act_discrete(s->env, reinterpret_cast<const int32_t*>(actions_dev), stream);
     } else {
         rc = rl4rs_env_act_conti(s->env, actions_dev, action_kind == 2 ? 1 : 0, chosen, stream);
     }
     if (rc) return rc;
-    const int reward_step = rl4rs_env_is_reward_step(s->env);
-    if ((rc = after_act(s, cur, obs, reinterpret_cast<double*>(R + L.reward), reinterpret_cast<uint8_t*>(R + L.done),
-                        L.mask_bits >= 0 ? reinterpret_cast<uint32_t*>(R + L.mask_bits) : nullptr, stream))) return rc;
+    const int reward_step = observe ? 0 : rl4rs_env_is_reward_step(s->env);
+    // the observation-side mask is a function of the env state the act just left (slate.py:90-97); nothing below changes that state
     if (L.mask_i64 >= 0 && (rc = rl4rs_env_obs_mask(s->env, R + L.mask_i64, 2, stream))) return rc;
+    char* H = reinterpret_cast<char*>(record_host);
+    int64_t prefix = L.host_bytes;
+    bool early = false;
+    if (H && L.mask_i64 >= 0) {
+        if (!s->copy_stream) {
+            RL4RS_HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+            RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+            RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
+        }
+        RL4RS_HIP_TRY(hipEventRecord(s->ev_ready, st));
+        RL4RS_HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_ready, 0));
+        RL4RS_HIP_TRY(hipMemcpyAsync(H + L.mask_i64, R + L.mask_i64, (size_t)(L.host_bytes - L.mask_i64), hipMemcpyDeviceToHost, s->copy_stream));
+        RL4RS_HIP_TRY(hipEventRecord(s->ev_copied, s->copy_stream));
+        prefix = L.mask_i64;
+        early = true;
+    }
+    if (observe) {
+        if ((rc = scorer_forward(s, B, 1, s->dense, s->cat, obs, nullptr, stream))) return rc;
+        if (L.mask_bits >= 0 && (rc = rl4rs_env_obs_mask(s->env, R + L.mask_bits, 4, stream))) return rc;
+    } else if ((rc = after_act(s, cur, obs, reinterpret_cast<double*>(R + L.reward), reinterpret_cast<uint8_t*>(R + L.done),
+                               L.mask_bits >= 0 ? reinterpret_cast<uint32_t*>(R + L.mask_bits) : nullptr, stream))) {
+        return rc;
+    }
     if (L.obs_d3rl >= 0) {
         // masked_actions: all of prev_actions (slate.py:100-104) or the current page's columns (seqslate.py:18-23), POST-act step counter
         const int cur_after = cur + 1, T = s->cfg.max_steps, P = s->cfg.page_items;
@@ -265,7 +300,25 @@ int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t act
         hipLaunchKernelGGL(k_record_status, dim3(1), dim3(64), 0, st, reinterpret_cast<const int32_t*>(ep), rf, reinterpret_cast<int32_t*>(R + L.status));
         RL4RS_LAUNCH_CHECK();
     }
+    if (H) {
+        RL4RS_HIP_TRY(hipMemcpyAsync(H, R, (size_t)prefix, hipMemcpyDeviceToHost, st));
+        if (early) RL4RS_HIP_TRY(hipStreamWaitEvent(st, s->ev_copied, 0));     // one wait on `stream` covers both copies
+    }
     return RL4RS_OK;
+}
+
+int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev, void* stream) {
+    return step_record(s, false, actions_dev, action_kind, want, record_dev, nullptr, stream);
+}
+
+int rl4rs_env_step_record_host(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
+                               void* record_host, void* stream) {
+    RL4RS_REQUIRE(record_host, "env_step_record_host: null host block");
+    return step_record(s, false, actions_dev, action_kind, want, record_dev, record_host, stream);
+}
+
+int rl4rs_env_observe_record_host(rl4rs_stepper* s, int32_t conti, uint32_t want, void* record_dev, void* record_host, void* stream) {
+    return step_record(s, true, nullptr, conti ? 2 : 0, want, record_dev, record_host, stream);
 }
 
 }  // extern "C"

@@ -395,7 +395,8 @@ class DeviceStepper(object):
         return cache[key]
 
     def step_record(self, actions, conti=False, want=(), shadow=None):
-        """rl4rs_env_step_record + the copy of the record's host part into a fresh pinned block -> ``StepResult`` of numpy
+        """rl4rs_env_step_record_host (the transition + its record's host part copied into a fresh pinned block: the int64
+        mask of the rllib mode beside the scorer's kernels, the rest after the last one) -> ``StepResult`` of numpy
         views (obs float32 [B, obs_dim], or float64 [B, obs_dim + cols + 1] when 'd3rl_obs' is wanted; reward float64 [B];
         done uint8 [B]; chosen int32 [B]; mask int64 [B, A]; mask_bits uint32 [B, W]; click_p float32 [B, n]; offline_action
         int32 [B] / float64 [B, E]; status int32 [2]).  ``want``: names from rl4rs_amd._lib.STEP_WANT.
@@ -406,7 +407,9 @@ class DeviceStepper(object):
         for name in want:
             bits |= _lib.STEP_WANT[name]
         L, rec = self._layout(bits, conti)
-        if conti:
+        if actions is None:
+            a = None                                        # observe_record: no transition
+        elif conti:
             a = actions
             if not (isinstance(a, torch.Tensor) and a.is_cuda):
                 a = np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a)
@@ -421,10 +424,12 @@ class DeviceStepper(object):
             assert a.numel() == self.B, (a.shape, self.B)
             kind = 0
         self._last_record = (L, rec)
-        check(self.lib.rl4rs_env_step_record(self.h, _ptr(a), kind, bits, _ptr(rec), _stream()))
         nb = int(L.host_bytes)
         host = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
-        host.copy_(rec[:nb], non_blocking=True)
+        if a is None:
+            check(self.lib.rl4rs_env_observe_record_host(self.h, 1 if conti else 0, bits, _ptr(rec), host.data_ptr(), _stream()))
+        else:
+            check(self.lib.rl4rs_env_step_record_host(self.h, _ptr(a), kind, bits, _ptr(rec), host.data_ptr(), _stream()))
         raw = host.numpy()
         B = self.B
 
@@ -449,6 +454,11 @@ class DeviceStepper(object):
             shadow(r)
         wait_stream()
         return r
+
+    def observe_record(self, conti=False, want=(), shadow=None):
+        """rl4rs_env_observe_record_host: the record of the state the env is in (no transition; what a reset returns) in the
+        same form as ``step_record``; reward / done / chosen of the result are meaningless."""
+        return self.step_record(None, conti=conti, want=want, shadow=shadow)
 
 
 class StepResult(object):

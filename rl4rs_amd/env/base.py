@@ -14,6 +14,7 @@ What differs, by design: the log file is parsed ONCE into columnar tensors resid
 machine run on the GPU through librl4rs_hip.so.  There is no CPU execution path.
 """
 from abc import ABC, abstractmethod
+from operator import itemgetter
 
 import numpy as np
 
@@ -151,12 +152,27 @@ class LogStore(object):
         self._parsed = np.zeros(self.n, dtype=bool)
         self._dev = None
         self._min_len = None
+        self._stripped = None
+        self._all_parsed = False
         # prefix count of blank lines (a line whose rstrip() is empty reads as EOF for the reference's loop)
         self._blank_prefix = np.concatenate([[0], np.cumsum([0 if l.rstrip() else 1 for l in self.lines])])
 
     def nonblank_run(self, start, num):
         """True when lines [start, start + num) hold no blank line."""
         return int(self._blank_prefix[start + num] - self._blank_prefix[start]) == 0
+
+    def nonblank_len(self, start):
+        """Length of the run of non-blank lines that starts at ``start`` (0 at a blank line or at the end of the file)."""
+        if start >= self.n:
+            return 0
+        return int(np.searchsorted(self._blank_prefix, self._blank_prefix[start], side='right')) - 1 - start
+
+    @property
+    def stripped(self):
+        """``line.rstrip()`` of every line (what ``fp.readline().rstrip()`` yields), built once: a cache window is a slice."""
+        if self._stripped is None:
+            self._stripped = [l.rstrip() for l in self.lines]
+        return self._stripped
 
     def _ensure_width(self, rows):
         if self.log_steps is None:
@@ -188,6 +204,8 @@ class LogStore(object):
 
     def ensure(self, rows, device):
         """Make sure the given line numbers are parsed and resident on ``device``."""
+        if self._all_parsed:
+            return
         import torch
         from ..data import parse_records_native
         rows = np.unique(np.asarray(rows, dtype=np.int64))
@@ -209,6 +227,7 @@ class LogStore(object):
     def preload(self, device):
         rows = [i for i, l in enumerate(self.lines) if l.strip()]
         self.ensure(rows, device)
+        self._all_parsed = True          # blank lines are never handed to a state (they read as EOF, sample_cache wraps there)
 
     def gather(self, rows, device):
         self.ensure(rows, device)
@@ -235,6 +254,7 @@ class RecDataBase(object):
         self.config = config
         self.sample_list = []
         self.sample_rows = []
+        self._rows_arr = None
         self.state_cls = state_cls
         self.state_kwargs = {}
         self.is_eval = config.get('is_eval', False)
@@ -256,22 +276,25 @@ class RecDataBase(object):
 
     def sample_cache(self, f, num):
         """base.py:82-90: on a blank/EOF read, seek to the start, skip one line, take the next."""
-        lines = self.store.lines
-        c = self._cursor
-        if c + num <= self.store.n and self.store.nonblank_run(c, num):
-            # fast path (no blank line and no EOF inside the window): the reference's loop degenerates to a slice
-            self.sample_list.extend([l.rstrip() for l in lines[c:c + num]])
-            self.sample_rows.extend(range(c, c + num))
-            self._cursor = c + num
-            return
-        for _ in range(num):
-            tmp, row = self._readline()
+        stripped = self.store.stripped
+        while num > 0:
+            # a run without a blank line and without EOF: the reference's loop degenerates to a slice
+            run = min(num, self.store.nonblank_len(self._cursor))
+            if run > 0:
+                c = self._cursor
+                self.sample_list.extend(stripped[c:c + run])
+                self.sample_rows.extend(range(c, c + run))
+                self._cursor = c + run
+                num -= run
+                continue
+            tmp, row = self._readline()                 # blank or EOF: wrap, skip one line, take the next whatever it is
             if len(tmp) < 1:
                 self._cursor = 0
                 self._readline()
                 tmp, row = self._readline()
             self.sample_list.append(tmp)
             self.sample_rows.append(row)
+            num -= 1
 
     def sample(self, batch_size):
         if self.is_eval:
@@ -281,13 +304,18 @@ class RecDataBase(object):
         else:
             # np.random.choice(self.sample_list, batch_size) draws randint(0, len, size) from the global RNG
             pick = np.random.choice(len(self.sample_list), batch_size)
-        rows = [self.sample_rows[i] for i in pick]
-        records = RecordBatch([self.sample_list[i] for i in pick], rows=rows, store=self.store)
+        if self._rows_arr is None or len(self._rows_arr) != len(self.sample_rows):
+            self._rows_arr = np.asarray(self.sample_rows, dtype=np.int64)
+        rows = self._rows_arr[pick]
+        picked = pick.tolist()
+        strings = list(itemgetter(*picked)(self.sample_list)) if len(picked) > 1 else [self.sample_list[i] for i in picked]
+        records = RecordBatch(strings, rows=rows, store=self.store)
         return self.state_cls(self.config, records, **self.state_kwargs)
 
     def reset(self, reset_file=False):
         self.sample_list = []
         self.sample_rows = []
+        self._rows_arr = None
         if reset_file:
             self._cursor = 0
         self.sample_cache(None, self.cache_size)

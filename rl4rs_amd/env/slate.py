@@ -69,7 +69,7 @@ class SlateState(RecState):
         self.action_emb_size = self.config.get("action_emb_size", 32)
         self.max_steps = config['max_steps']
         self.page_items = config.get("page_items", 9)
-        self.infos = [{} for _ in range(self.batch_size)]
+        self._infos = None              # the per-env info dicts (slate.py:50) are made on first use: `infos` below
         onehot = config.get('support_onehot_action', False)
         # the reference always takes the last 32 dims (get_iteminfo_from_file default, slate.py:21,29); config's
         # action_emb_size only shapes the action space
@@ -246,6 +246,16 @@ class SlateState(RecState):
         if self._users is None:
             self._users = [x.split('@')[1] for x in self.records]
         return self._users
+
+    @property
+    def infos(self):
+        if self._infos is None:
+            self._infos = [{} for _ in range(self.batch_size)]
+        return self._infos
+
+    @infos.setter
+    def infos(self, value):
+        self._infos = value
 
     @property
     def info(self):
@@ -547,6 +557,53 @@ class SlateRecEnv(RecSimBase):
             self._stepper_key = key
         return env, net, self._stepper
 
+    def _mask_dicts(self, rec):
+        """The support_rllib_mask observation (slate.py:262-266): a list of B ``{"action_mask", "obs"}`` dicts over row views of the
+        record's pinned block.  Called while the transition's kernels run, so it also takes the costs that would otherwise
+        fall between two steps, with the GPU idle: the previous list (4096 dicts + 8192 row views at the bench size) is
+        kept alive until here, so that it is torn down now and not when the caller rebinds its variable; the cycle
+        collector is paused for the build (thousands of container allocations would trigger it several times, and dicts of
+        arrays cannot form cycles)."""
+        import gc
+        self._obs_keepalive = None
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            out = [{"action_mask": m, "obs": o} for m, o in zip(rec.mask, rec.obs)]
+        finally:
+            if was_on:
+                gc.enable()
+        self._obs_keepalive = out
+        return out
+
+    def sample(self, batch_size):
+        """base.py:172-175: ``samples = recData.sample(B); obs = obs_fn(samples.state)``.  In the reference's host-returning
+        modes the observation of the fresh batch comes back the way a transition's does (``_step`` below): ONE library call
+        (rl4rs_env_observe_record_host) whose record - obs, the int64 mask or the float64 d3rl rows, the first logged action -
+        is in pinned memory after one wait, the python objects around it built while the scorer runs."""
+        samples = self._recData.sample(batch_size)
+        if samples._tensor_mode() or not self._fused_ok(samples):
+            return samples, self.obs_fn(samples.state)
+        env, net, stepper = self._stepper_for(samples)
+        conti = bool(self.config.get("support_conti_env", False))
+        masked = self.config.get("support_rllib_mask", False)
+        d3rl = (not masked) and self.config.get("support_d3rl_mask", False)
+        want = ['offline_action'] + (['mask_i64'] if masked else []) + (['d3rl_obs'] if d3rl else [])
+        built = {}
+
+        def in_the_gpu_shadow(rec):
+            if masked:
+                built['obs'] = self._mask_dicts(rec)
+            samples.infos                                   # the per-env info dicts
+            if env.cur_steps < self.max_steps and env.cur_steps < samples._exposed_len_min:
+                samples._next_offline = ((samples._batch_version, env.cur_steps),
+                                         samples._offline_from_host(env.cur_steps, conti, None if conti else stepper.offline_action_view()))
+
+        r = stepper.observe_record(conti=conti, want=want, shadow=in_the_gpu_shadow)
+        samples._range_seen = getattr(samples, '_range_seen', 0) | int(r.status[1])
+        self._last_obs = None
+        return samples, (built['obs'] if masked else r.obs)
+
     def _step(self, samples, action, **kwargs):
         """base.py:157-170.  The whole transition is ONE library call whenever this package's own act / obs_fn / forward are in
         charge: rl4rs_env_step_discrete / _conti in zero-copy mode (device tensors in and out, no host round trip),
@@ -584,7 +641,7 @@ class SlateRecEnv(RecSimBase):
                 # (still empty) views, and the NEXT step's logged-action list (from the host copy of the log; the device copy
                 # of the same ids is part of the record)
                 if masked:
-                    built['obs'] = [{"action_mask": m, "obs": o} for m, o in zip(rec.mask, rec.obs)]
+                    built['obs'] = self._mask_dicts(rec)
                 built['done'] = [1 if last else 0] * self.batch_size
                 if cur_after < self.max_steps and cur_after < samples._exposed_len_min:
                     samples._next_offline = ((samples._batch_version, cur_after),

@@ -65,7 +65,7 @@ def test_recdatabase_cache_wrap_and_rng(tmp_path):
     st = db.sample(3)
     np.random.seed(42)
     assert list(st.records) == list(np.random.choice(lines[:5], 3))
-    assert st.records.rows == [lines.index(x) for x in st.records]
+    assert list(st.records.rows) == [lines.index(x) for x in st.records]
     # eval mode: the first B cached lines, cache_size must equal B (base.py:93-96)
     ev = RecDataBase(dict(cfg, is_eval=True), _CaptureState)
     ev.reset()
@@ -282,3 +282,48 @@ def test_scorer_kernel_option_names():
     for name, val in _lib.STEP_WANT.items():
         m = re.search(r'RL4RS_STEP_WANT_%s = (\d+)' % name.upper(), hdr)
         assert m and int(m.group(1)) == val, name
+
+
+def test_cache_window_with_blank_lines_matches_the_line_by_line_loop(tmp_path):
+    """base.py:82-90 read line by line (readline().rstrip(); on an empty read: seek(0), skip one line, take the next) against
+    the bulk form RecDataBase.sample_cache uses (slices of the blank-free runs), on files with blank lines in odd places."""
+    from rl4rs_amd.env.base import RecDataBase
+    rng = np.random.RandomState(5)
+    for trial in range(30):
+        n = int(rng.randint(3, 40))
+        lines = ['rec%d  ' % i if rng.rand() > 0.15 else ('' if rng.rand() > 0.5 else '   ') for i in range(n)]
+        lines[1] = 'rec1'                                  # the line taken after a wrap
+        text = '\n'.join(lines) + ('\n' if rng.rand() > 0.3 else '')
+        p = tmp_path / ('log%d.csv' % trial)
+        p.write_text(text)
+        file_lines = text.split('\n')
+
+        class Loop(object):                                # the reference's loop over a file object
+            def __init__(self):
+                self.c = 0
+
+            def readline(self):
+                if self.c >= len(file_lines):
+                    return ''
+                self.c += 1
+                return file_lines[self.c - 1].rstrip()
+
+            def window(self, num):
+                out = []
+                for _ in range(num):
+                    tmp = self.readline()
+                    if len(tmp) < 1:
+                        self.c = 0
+                        self.readline()
+                        tmp = self.readline()
+                    out.append(tmp)
+                return out
+
+        cache = int(rng.randint(1, 25))
+        db = RecDataBase({'sample_file': str(p), 'maxlen': 64, 'cache_size': cache, 'is_eval': False}, _CaptureState)
+        ref = Loop()
+        for _ in range(6):
+            db.reset()
+            want = ref.window(cache)
+            assert db.sample_list == want, (trial, lines, cache)
+            assert [file_lines[r].rstrip() if r >= 0 else '' for r in db.sample_rows] == want
