@@ -473,6 +473,10 @@ def test_reference_shaped_step_is_one_record_and_bit_identical(tmp_path, kind):
         out = []
         for ep in range(2):
             out.append(env.reset())
+            if fused and B > 1 and not cfg.get('support_conti_env'):
+                # the reset came back through rl4rs_env_observe_record_host: the first logged action is already on the device
+                first = env.offline_action
+                assert type(first).__name__ == 'OfflineActionList' and first._dev is not None
             for t in range(T):
                 a = env.offline_action
                 obs, reward, done, info = env.step(a)
