@@ -213,6 +213,14 @@ struct LossArgs {
 // A2C / PPO loss of one sample from its masked logits / value in s_out and their log-sum-exp: writes d loss / d [logits |
 // value] into s_d (LDS) and dOut (global, may be NULL), returns {pi_loss, vf_loss, entropy, kl}.  Shared by the FC mask policy
 // and the raw-state policy.
+// Store of a word ANOTHER workgroup reads later in the same launch (k_ppo_pass): write-through to the device's coherence point
+// (global_store ... sc1), so the producer needs no L2 write-back fence before it arrives at the grid barrier - the guide's
+// publish recipe R1 (write-through payload, drain, flag; consumer: one agent acquire, plain loads).
+__device__ __forceinline__ void store_wt(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool WT = false>
 __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossArgs& L, const float* s_out, float lse, int n, int lane,
                                                   float* s_d, float* __restrict__ dOut) {
     const int act = L.actions[n];
@@ -317,7 +325,9 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
             g = g_v;
         }
         s_d[a] = g;
-        if (dOut) dOut[(size_t)n * d.AE + a] = g;
+        if (dOut) {
+            if (WT) store_wt(dOut + (size_t)n * d.AE + a, g); else dOut[(size_t)n * d.AE + a] = g;
+        }
     }
     return make_float4(pi_loss, vf_loss, ent, kl);
 }
@@ -537,13 +547,23 @@ struct PassArgs {
 // then plain loads.
 // Returns false once any workgroup has given up (bar[1] != 0): the caller then stops touching the parameters, so a pass whose
 // workgroups were not co-resident leaves them at the last consistent minibatch instead of running racy updates.
+#ifndef RL4RS_PASS_WT
+#define RL4RS_PASS_WT 1      // 1: everything another workgroup reads is stored write-through (store_wt) and the barrier has no release
+#endif                       //    fence; 0: plain stores + lane-0 agent release (L2 write-back) before the arrival
+#if RL4RS_PASS_WT
+#define PUB(ptr, val) store_wt(&(ptr), (val))
+#else
+#define PUB(ptr, val) ((ptr) = (val))
+#endif
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen) {
     __shared__ unsigned s_dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
     if (threadIdx.x == 0) {
+#if !RL4RS_PASS_WT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     unsigned gen = 0;
     for (int i = blockIdx.x * 512 + tid; i < HID * AE; i += gridDim.x * 512) {
         const int j = i / AE, c = i - j * AE;
-        a.w2t[(size_t)c * HID + j] = W2[i];
+        PUB(a.w2t[(size_t)c * HID + j], W2[i]);
     }
     if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
     for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
@@ -658,7 +678,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             for (int q = 0; q < parts; ++q) s += s_d[(size_t)(t * parts + q) * 1024 + r * 32 + c];
             const float h = tanhf(s);
             s_h[r * SH + j] = h;
-            a.H[(size_t)(r0 + r) * HID + j] = h;
+            PUB(a.H[(size_t)(r0 + r) * HID + j], h);
         }
         __syncthreads();
         RL4RS_PT(2);
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 float se = 0.f;
                 for (int c = lane; c < d.A; c += 64) se += expf(so[c] - mx);
                 const float lse = mx + logf(wave_sum(se));
-                const float4 tm = policy_row_loss(d, L, so, lse, row, lane, s_d + row * SA, a.dOut + (size_t)r0 * AE);
+                const float4 tm = policy_row_loss<RL4RS_PASS_WT != 0>(d, L, so, lse, row, lane, s_d + row * SA, a.dOut + (size_t)r0 * AE);
                 if (lane == 0) a.terms[lo + r0 + row] = tm;       // per-sample loss terms of the whole pass (KL mean -> kl_coeff rule)
                 if (row == 0) RL4RS_PT(11);
             }
@@ -741,7 +761,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             float s = 0.f;
             for (int q = 0; q < parts; ++q) s += s_out[(size_t)(t * parts + q) * 1024 + r * 32 + c];
             const float h = s_h[r * SH + j];
-            a.dHpre[(size_t)(r0 + r) * HID + j] = s * (1.f - h * h);
+            PUB(a.dHpre[(size_t)(r0 + r) * HID + j], s * (1.f - h * h));
         }
         RL4RS_PT(5);
         if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
@@ -839,10 +859,10 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                             a.am[idx[c]] = mi;
                             a.av[idx[c]] = vi;
                             const float pn = pp[c] - lr_t * mi / (sqrtf(vi) + a.eps);
-                            a.prm[idx[c]] = pn;
+                            PUB(a.prm[idx[c]], pn);
                             if (!first) {
                                 const int r = 4 * q + c;
-                                a.w2t[(size_t)j * HID + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = pn;
+                                PUB(a.w2t[(size_t)j * HID + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], pn);
                             }
                         }
                     }
@@ -851,7 +871,13 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                     for (int qq = 0; qq < 4; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
                     const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
                     a.grad[idx] = sum;
-                    if (a.apply) adam_elem(a.prm + idx, a.am + idx, a.av + idx, sum, lr_t, a.b1, a.b2, a.eps);
+                    if (a.apply) {
+                        const float mi = a.b1 * a.am[idx] + (1.f - a.b1) * sum;
+                        const float vi = a.b2 * a.av[idx] + (1.f - a.b2) * sum * sum;
+                        a.am[idx] = mi;
+                        a.av[idx] = vi;
+                        PUB(a.prm[idx], a.prm[idx] - lr_t * mi / (sqrtf(vi) + a.eps));
+                    }
                 }
                 __syncthreads();                                          // s_part is rewritten by the next trip
             }
