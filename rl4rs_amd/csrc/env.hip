@@ -128,6 +128,10 @@ __device__ __forceinline__ void stage_items(const EnvDev& e, float* s_item) {
     }
 }
 
+#ifndef RL4RS_ROWS_PER_ENV
+#define RL4RS_ROWS_PER_ENV 1     // complete rows: 1 = one wave per env writes all its rows, 0 = one wave per row (A/B builds)
+#endif
+
 // mode 0: un-acted state rows (reset);  mode 1: act(actions) then state rows;  mode 2: complete rows.
 // One wave assembles one row; waves are independent (each keeps its env's prev_actions row in a wave-private
 // LDS slot, ordered by wave-level fences only), so after the one-time catalogue staging there is no
@@ -149,6 +153,29 @@ __global__ __launch_bounds__(1024) void k_env_rows(EnvDev e, const int32_t* __re
     const float* s_item = USE_LDS ? s_item_lds : e.item_vec;
     const int R = (MODE == 2) ? e.B * n_complete : e.B;
     const int total_waves = gridDim.x * nw;
+    if (MODE == 2 && RL4RS_ROWS_PER_ENV) {
+        // complete rows: one wave writes ALL n_complete rows of its env - prev_actions and the user columns are fetched once,
+        // then the wave only issues stores (a row per wave paid one dependent global round trip per 1.8 KB row)
+        for (int b = blockIdx.x * nw + wave; b < e.B; b += total_waves) {
+            for (int j = lane; j < e.T; j += 64) s_prev[j] = e.prev[(size_t)b * e.T + j];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int jj = 0; jj < n_complete; ++jj) {
+                const int j = j_base + jj;
+                const size_t r = (size_t)b * n_complete + jj;
+                int page_init = 0, npage = e.T, seq_id = 1;
+                if (e.is_seq) {
+                    page_init = j / e.P * e.P;
+                    npage = min(e.P, e.T - page_init);
+                    seq_id = j / e.P + 1;
+                }
+                build_row(e, s_item, s_prev, b, page_init, npage, seq_id, s_prev[j], e.c_dense + r * e.Dn, e.c_cat + r * e.Cn, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // s_prev is rewritten for the next env
+        }
+        return;
+    }
     for (int r = blockIdx.x * nw + wave; r < R; r += total_waves) {
         const int b = (MODE == 2) ? r / n_complete : r;
         int a = 0;
@@ -561,6 +588,11 @@ static RowsLaunch rows_launch(const rl4rs_env* e, int R, int mode) {
     int waves = 16;
     if (R < 256 * 16) waves = 4;                 // small batches: more, smaller workgroups
     int grid = (R + waves - 1) / waves;
+    if (mode == 2 && RL4RS_ROWS_PER_ENV) {       // one wave per env
+        const int B = e->cfg.batch_size;
+        waves = B < 256 * 16 ? 4 : 16;
+        grid = (B + waves - 1) / waves;
+    }
     const int cap = L.lds ? 256 * (waves == 16 ? 2 : 3) : 256 * 8;   // LDS staging: amortise the 45 KB copy
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
