@@ -591,3 +591,46 @@ def test_configs0_batch_256_replay_against_reference_vectors(flag):
     viol = g['violation_end']
     r = np.asarray(reward, dtype=np.float64)
     assert (r[viol == 0] == 0).all() and (r[viol == 1] > 0).all()
+
+
+def test_record_entry_points_validate_and_agree(tmp_path):
+    """rl4rs_env_step_record_host / rl4rs_env_observe_record_host at the C ABI: bad arguments come back as error codes with a
+    message (never a crash), the record a NULL host block leaves on the device equals what the host-copying form brings home,
+    and the int64 mask - copied on the stepper's own stream beside the scorer - is the mask the composed path reports."""
+    import ctypes as C
+    import torch
+    from rl4rs_amd import _lib, device as D
+    cfg, records, w = _setup(tmp_path, False, 24, 9, support_rllib_mask=True)
+    env = _make(cfg, False)
+    env.reset()
+    sim, samples = env.sim, env.samples
+    _, _, stepper = sim._stepper_for(samples)
+    lib = _lib.load()
+    want = _lib.STEP_WANT['mask_i64'] | _lib.STEP_WANT['offline_action']
+    L, rec = stepper._layout(want, False)
+    host = torch.empty(int(L.host_bytes), dtype=torch.uint8, pin_memory=True)
+    stream = D._stream()
+    acts = torch.zeros(24, dtype=torch.int32, device='cuda')
+    # error paths
+    assert lib.rl4rs_env_step_record_host(stepper.h, acts.data_ptr(), 0, want, rec.data_ptr(), None, stream) != 0
+    assert b'host' in lib.rl4rs_last_error()
+    assert lib.rl4rs_env_observe_record_host(stepper.h, 0, want | _lib.STEP_WANT['click_p'], rec.data_ptr(), host.data_ptr(), stream) != 0
+    assert b'click_p' in lib.rl4rs_last_error()
+    bad = _lib.StepRecord()
+    assert lib.rl4rs_stepper_record_layout(stepper.h, 1 << 9, 0, C.byref(bad)) != 0
+    assert lib.rl4rs_env_step_record_host(stepper.h, acts.data_ptr(), 7, want, rec.data_ptr(), host.data_ptr(), stream) != 0
+    # the failed calls changed nothing: observe twice, once with and once without the host copies
+    _lib.check(lib.rl4rs_env_observe_record_host(stepper.h, 0, want, rec.data_ptr(), host.data_ptr(), stream))
+    torch.cuda.synchronize()
+    first = host.clone()
+    _lib.check(lib.rl4rs_env_observe_record_host(stepper.h, 0, want, rec.data_ptr(), None, stream))
+    torch.cuda.synchronize()
+    dev = rec[:int(L.host_bytes)].cpu()
+    lo, hi = int(L.obs), int(L.obs) + 24 * 256 * 4
+    assert torch.equal(dev[lo:hi], first[lo:hi])
+    mlo = int(L.mask_i64)
+    assert torch.equal(dev[mlo:mlo + 24 * 284 * 8], first[mlo:mlo + 24 * 284 * 8])
+    mask = first[mlo:mlo + 24 * 284 * 8].numpy().view(np.int64).reshape(24, 284)
+    assert np.array_equal(mask, samples._obs_mask())
+    obs = first[lo:hi].numpy().view(np.float32).reshape(24, 256)
+    assert np.array_equal(obs, np.stack([o['obs'] for o in env.state]))
