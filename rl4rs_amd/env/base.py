@@ -153,6 +153,7 @@ class LogStore(object):
         self._dev = None
         self._min_len = None
         self._stripped = None
+        self._stripped_arr = None
         self._all_parsed = False
         # prefix count of blank lines (a line whose rstrip() is empty reads as EOF for the reference's loop)
         self._blank_prefix = np.concatenate([[0], np.cumsum([0 if l.rstrip() else 1 for l in self.lines])])
@@ -166,6 +167,15 @@ class LogStore(object):
         if start >= self.n:
             return 0
         return int(np.searchsorted(self._blank_prefix, self._blank_prefix[start], side='right')) - 1 - start
+
+    @property
+    def stripped_array(self):
+        """The same lines as an object ndarray (built once): a sampled batch's record strings are one fancy-index gather."""
+        if self._stripped_arr is None:
+            arr = np.empty(self.n, dtype=object)
+            arr[:] = self.stripped
+            self._stripped_arr = arr
+        return self._stripped_arr
 
     @property
     def stripped(self):
@@ -307,8 +317,11 @@ class RecDataBase(object):
         if self._rows_arr is None or len(self._rows_arr) != len(self.sample_rows):
             self._rows_arr = np.asarray(self.sample_rows, dtype=np.int64)
         rows = self._rows_arr[pick]
-        picked = pick.tolist()
-        strings = list(itemgetter(*picked)(self.sample_list)) if len(picked) > 1 else [self.sample_list[i] for i in picked]
+        if len(rows) > 1 and rows.min() >= 0:
+            strings = self.store.stripped_array[rows].tolist()      # one gather from the object array of all stripped lines
+        else:
+            picked = pick.tolist()
+            strings = list(itemgetter(*picked)(self.sample_list)) if len(picked) > 1 else [self.sample_list[i] for i in picked]
         records = RecordBatch(strings, rows=rows, store=self.store)
         return self.state_cls(self.config, records, **self.state_kwargs)
 

@@ -59,6 +59,18 @@ class StateRows(object):
         return seq, dense, cat
 
 
+def _unique_lines(rows, n):
+    """np.unique(rows, return_inverse=True) for line numbers in [0, n): a presence table instead of a sort (the batch is drawn
+    from a window of a few thousand lines, base.py:92-100) -> (sorted distinct lines, index of every row's line in them)."""
+    if n > 4 * len(rows) + 65536 or rows.min() < 0:
+        return np.unique(rows, return_inverse=True)
+    present = np.zeros(n, dtype=bool)
+    present[rows] = True
+    uniq = np.flatnonzero(present)
+    slot = np.cumsum(present, dtype=np.int64) - 1
+    return uniq, slot[rows]
+
+
 class SlateState(RecState):
     is_seq = False
 
@@ -99,13 +111,13 @@ class SlateState(RecState):
             store.ensure(rows, dev)
             log_steps = store.log_steps
             self._exposed_len_min = int(store.exposed_len[rows].min())
-            self._exposed_host = None if self._tensor_mode() else store.exposed_host[rows]
+            self._exposed_host = None            # host copy of the logged ids of these rows: gathered on first use (_offline_from_host)
             self._users = None
             self._store_rows = (store, rows)
             # RecDataBase.sample draws the batch WITH replacement from a cache window (base.py:92-100; 4096 envs from
             # 2048 lines at the bench config), so many envs share one user history: keep the distinct histories and
             # the env -> history map, the scorer encodes each distinct sequence once
-            uniq, inv = np.unique(rows, return_inverse=True)
+            uniq, inv = _unique_lines(rows, store.n)
             dedup = len(uniq) < len(rows)
             # ONE pinned block, one host-to-device copy: [line of every env | distinct lines | env -> history slot | envs sorted
             # by slot]; ONE gather launch (rl4rs_env_load_lines) instead of a dozen index_select / copy / memset launches
@@ -117,7 +129,7 @@ class SlateState(RecState):
                 packed[B:B + U] = uniq
                 packed[B + U:2 * B + U] = inv
                 # envs sorted by their history's slot: the scorer processes duplicates next to each other (L2 locality)
-                packed[2 * B + U:] = np.argsort(inv, kind='stable')
+                packed[2 * B + U:] = np.argsort(inv.astype(np.uint16) if U <= 65536 else inv, kind='stable')   # 16-bit keys: radix sort
             pk = h2d_async(packed, dev)
             fused = (store._dev, store.n, pk[:B], pk[B:B + U] if dedup else None)
             if dedup:
@@ -295,6 +307,9 @@ class SlateState(RecState):
         nothing."""
         env = self._live()
         ex = getattr(self, '_exposed_host', None)
+        if ex is None and not self._tensor_mode() and getattr(self, '_store_rows', None) is not None:
+            store, rows = self._store_rows
+            ex = self._exposed_host = store.exposed_host[rows]
         if ex is None:                                      # (defensive: no host copy)
             out = D.to_host(env.offline_action(conti=conti))
             return [row for row in out] if conti else out.tolist()
