@@ -467,7 +467,8 @@ int rl4rs_env_step_record(rl4rs_stepper* s, const void* actions_dev, int32_t act
 /* The same transition, and the record's host part brought home by the library: `record_host` = host_bytes of (pinned) host
  * memory, filled when `stream` has drained - ONE wait on `stream` by the caller.  The int64 mask (the bulk of a
  * support_rllib_mask record, B * action_size * 8 bytes, and a function of the act alone) leaves on a copy stream of the
- * stepper as soon as the act is done, beside the scorer's kernels; the rest follows as one prefix copy after the last kernel. */
+ * stepper as soon as the act is done, beside the scorer's kernels; on a reward step the observation follows it as soon as the
+ * observation forward is done, beside the reward forward; the rest is copied on `stream` after the last kernel. */
 int rl4rs_env_step_record_host(rl4rs_stepper* s, const void* actions_dev, int32_t action_kind, uint32_t want, void* record_dev,
                                void* record_host, void* stream);
 /* The record of the state the env is IN, without a transition - what RecSimBase.sample returns right after a reset

@@ -39,6 +39,15 @@ int scorer_encode(rl4rs_stepper* s, int q, const int32_t* ids, int n, void* stre
     return s->dien ? rl4rs_dien_encode(s->dien, q, ids, n, 0, stream) : rl4rs_simnet_encode(s->simnet, q, ids, n, 0, stream);
 }
 
+int ensure_copy_stream(rl4rs_stepper* s) {
+    if (!s->copy_stream) {
+        RL4RS_HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+        RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
+    }
+    return RL4RS_OK;
+}
+
 // the constant outputs of a transition in one launch: done flags, and the zero reward of a step on which none is due
 __global__ void k_step_tail(uint8_t* done, uint8_t v, double* zero_reward, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,8 +57,13 @@ __global__ void k_step_tail(uint8_t* done, uint8_t v, double* zero_reward, int n
     }
 }
 
-// everything after the act: observation, reward (when due), done, packed obs-side mask
-int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint8_t* done, uint32_t* mask_bits, void* stream) {
+// everything after the act: observation, reward (when due), done, packed obs-side mask.  `on_obs` runs right after the
+// observation forward has been enqueued (the record form sends the observation home from there on a reward step, beside the
+// reward forward).
+struct NoHook { int operator()() const { return RL4RS_OK; } };
+template <typename Hook = NoHook>
+int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint8_t* done, uint32_t* mask_bits, void* stream,
+              Hook on_obs = Hook()) {
     hipStream_t st = (hipStream_t)stream;
     rl4rs_env* e = s->env;
     const int B = s->cfg.batch_size;
@@ -60,6 +74,7 @@ int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint
             if ((rc = scorer_encode(s, q, s->seq1, B, stream))) return rc;
     }
     if ((rc = scorer_forward(s, B, 1, s->dense, s->cat, obs, nullptr, stream))) return rc;
+    if ((rc = on_obs())) return rc;
     double* zero_reward = nullptr;
     if (reward) {
         if (rl4rs_env_is_reward_step(e) == 1) {
@@ -248,11 +263,7 @@ static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, 
     int64_t prefix = L.host_bytes;
     bool early = false;
     if (H && L.mask_i64 >= 0) {
-        if (!s->copy_stream) {
-            RL4RS_HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-            RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
-            RL4RS_HIP_TRY(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
-        }
+        if ((rc = ensure_copy_stream(s))) return rc;
         RL4RS_HIP_TRY(hipEventRecord(s->ev_ready, st));
         RL4RS_HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_ready, 0));
         RL4RS_HIP_TRY(hipMemcpyAsync(H + L.mask_i64, R + L.mask_i64, (size_t)(L.host_bytes - L.mask_i64), hipMemcpyDeviceToHost, s->copy_stream));
@@ -260,27 +271,48 @@ static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, 
         prefix = L.mask_i64;
         early = true;
     }
+    // the observation the caller gets: float32 activations, or the float64 row of the d3rlpy mode assembled from them
+    const int64_t obs_off = L.obs_d3rl >= 0 ? L.obs_d3rl : L.obs;
+    const int64_t obs_bytes = L.obs_d3rl >= 0 ? (int64_t)B * L.d3rl_cols * 8 : (int64_t)B * L.obs_dim * 4;
+    bool obs_sent = false;
+    auto finish_obs = [&]() -> int {
+        if (L.obs_d3rl >= 0) {
+            // masked_actions: all of prev_actions (slate.py:100-104) or the current page's columns (seqslate.py:18-23), POST-act step counter
+            const int cur_after = cur + 1, T = s->cfg.max_steps, P = s->cfg.page_items;
+            int c0 = 0, ncols = T;
+            if (s->cfg.is_seq) {
+                const int page_init = cur_after / P * P, page_end = (page_init + P - 1 < T - 1) ? page_init + P - 1 : T - 1;
+                c0 = page_end + 1 - P; ncols = P;
+            }
+            void* pp; int64_t nb;
+            int rc2 = rl4rs_env_buffer(s->env, RL4RS_BUF_PREV_ACTIONS, &pp, &nb);
+            if (rc2) return rc2;
+            const int64_t total = (int64_t)B * L.d3rl_cols;
+            hipLaunchKernelGGL(k_record_d3rl, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, L.obs_dim,
+                               reinterpret_cast<const int32_t*>(pp), T, c0, ncols, cur_after, reinterpret_cast<double*>(R + L.obs_d3rl), B);
+            RL4RS_LAUNCH_CHECK();
+        }
+        if (H && reward_step == 1) {
+            // a reward step: 4 - 9 MB of observation would otherwise wait for the whole reward forward and then cross PCIe
+            // with the GPU idle; it leaves now, on the copy stream, beside the reward forward
+            int rc2 = ensure_copy_stream(s);
+            if (rc2) return rc2;
+            RL4RS_HIP_TRY(hipEventRecord(s->ev_ready, st));
+            RL4RS_HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_ready, 0));
+            RL4RS_HIP_TRY(hipMemcpyAsync(H + obs_off, R + obs_off, (size_t)obs_bytes, hipMemcpyDeviceToHost, s->copy_stream));
+            RL4RS_HIP_TRY(hipEventRecord(s->ev_copied, s->copy_stream));
+            obs_sent = true;
+            early = true;
+        }
+        return RL4RS_OK;
+    };
     if (observe) {
         if ((rc = scorer_forward(s, B, 1, s->dense, s->cat, obs, nullptr, stream))) return rc;
+        if ((rc = finish_obs())) return rc;
         if (L.mask_bits >= 0 && (rc = rl4rs_env_obs_mask(s->env, R + L.mask_bits, 4, stream))) return rc;
     } else if ((rc = after_act(s, cur, obs, reinterpret_cast<double*>(R + L.reward), reinterpret_cast<uint8_t*>(R + L.done),
-                               L.mask_bits >= 0 ? reinterpret_cast<uint32_t*>(R + L.mask_bits) : nullptr, stream))) {
+                               L.mask_bits >= 0 ? reinterpret_cast<uint32_t*>(R + L.mask_bits) : nullptr, stream, finish_obs))) {
         return rc;
-    }
-    if (L.obs_d3rl >= 0) {
-        // masked_actions: all of prev_actions (slate.py:100-104) or the current page's columns (seqslate.py:18-23), POST-act step counter
-        const int cur_after = cur + 1, T = s->cfg.max_steps, P = s->cfg.page_items;
-        int c0 = 0, ncols = T;
-        if (s->cfg.is_seq) {
-            const int page_init = cur_after / P * P, page_end = (page_init + P - 1 < T - 1) ? page_init + P - 1 : T - 1;
-            c0 = page_end + 1 - P; ncols = P;
-        }
-        void* pp; int64_t nb;
-        if ((rc = rl4rs_env_buffer(s->env, RL4RS_BUF_PREV_ACTIONS, &pp, &nb))) return rc;
-        const int64_t total = (int64_t)B * L.d3rl_cols;
-        hipLaunchKernelGGL(k_record_d3rl, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, L.obs_dim,
-                           reinterpret_cast<const int32_t*>(pp), T, c0, ncols, cur_after, reinterpret_cast<double*>(R + L.obs_d3rl), B);
-        RL4RS_LAUNCH_CHECK();
     }
     if (L.click_p >= 0 && reward_step == 1) {
         const int m = s->n_complete - 1;
@@ -301,8 +333,14 @@ static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, 
         RL4RS_LAUNCH_CHECK();
     }
     if (H) {
-        RL4RS_HIP_TRY(hipMemcpyAsync(H, R, (size_t)prefix, hipMemcpyDeviceToHost, st));
-        if (early) RL4RS_HIP_TRY(hipStreamWaitEvent(st, s->ev_copied, 0));     // one wait on `stream` covers both copies
+        if (obs_sent) {     // the prefix around the observation that is already on its way
+            RL4RS_HIP_TRY(hipMemcpyAsync(H, R, (size_t)obs_off, hipMemcpyDeviceToHost, st));
+            const int64_t tail = obs_off + ((obs_bytes + 63) & ~(int64_t)63);
+            if (prefix > tail) RL4RS_HIP_TRY(hipMemcpyAsync(H + tail, R + tail, (size_t)(prefix - tail), hipMemcpyDeviceToHost, st));
+        } else {
+            RL4RS_HIP_TRY(hipMemcpyAsync(H, R, (size_t)prefix, hipMemcpyDeviceToHost, st));
+        }
+        if (early) RL4RS_HIP_TRY(hipStreamWaitEvent(st, s->ev_copied, 0));     // one wait on `stream` covers every copy (the copy stream is in order)
     }
     return RL4RS_OK;
 }

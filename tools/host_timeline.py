@@ -1,4 +1,4 @@
-"""Host timeline of the reference-shaped API per episode-batch (bench workload, no return_tensors): python tools/host_timeline.py [plain|rllib]
+"""Host timeline of the reference-shaped API per episode-batch (bench workload, no return_tensors): python tools/host_timeline.py [plain|rllib] [episodes]
 -> ms per episode-batch spent in reset, in the library call + launches, in the work done while the kernels run, in the wait."""
 import sys, time, os, tempfile, argparse
 sys.path.insert(0, os.getcwd())
@@ -34,13 +34,19 @@ def step_record(self, actions, conti=False, want=(), shadow=None):
     return r
 D.DeviceStepper.step_record = step_record
 
-for ep in range(6):
+EPISODES = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+per_episode = []
+for ep in range(EPISODES + 2):
     if ep == 2:
         acc.clear(); torch.cuda.synchronize(); T0 = time.perf_counter()
+    te = time.perf_counter()
     t0 = time.perf_counter(); env.reset(); tick('reset', t0)
     for _ in range(T):
         t0 = time.perf_counter(); act = env.offline_action; tick('offline_action', t0)
         t0 = time.perf_counter(); env.step(act); tick('step_total', t0)
+    per_episode.append(round((time.perf_counter() - te) * 1e3, 2))
 torch.cuda.synchronize()
-tot = (time.perf_counter() - T0) / 4 * 1e3
-print(mode, 'episode ms', round(tot, 2), {k: round(v / 4 * 1e3, 2) for k, v in acc.items()})
+tot = (time.perf_counter() - T0) / EPISODES * 1e3
+print(mode, 'episode ms', round(tot, 2), {k: round(v / EPISODES * 1e3, 2) for k, v in acc.items()})
+if EPISODES > 4:
+    print('per episode:', per_episode[2:])
