@@ -575,12 +575,15 @@ class SlateRecEnv(RecSimBase):
     def _mask_dicts(self, rec):
         """The support_rllib_mask observation (slate.py:262-266): a list of B ``{"action_mask", "obs"}`` dicts over row views of the
         record's pinned block.  Called while the transition's kernels run, so it also takes the costs that would otherwise
-        fall between two steps, with the GPU idle: the previous list (4096 dicts + 8192 row views at the bench size) is
-        kept alive until here, so that it is torn down now and not when the caller rebinds its variable; the cycle
-        collector is paused for the build (thousands of container allocations would trigger it several times, and dicts of
-        arrays cannot form cycles)."""
+        fall between two steps, with the GPU idle: the lists of the last TWO calls (4096 dicts + 8192 row views each at the
+        bench size) are kept alive, and the older one is dropped here - a loop that holds ``obs`` until the next step has
+        returned (``obs, r, d, info = env.step(a)``) would otherwise tear it down when it rebinds its variable, between two
+        steps; this way the 12 k objects go while the kernels run.  The cycle collector is paused for the build (thousands
+        of container allocations would trigger it several times, and dicts of arrays cannot form cycles)."""
         import gc
-        self._obs_keepalive = None
+        keep = self.__dict__.setdefault('_obs_keep', [])
+        while len(keep) >= 2:
+            keep.pop(0)
         was_on = gc.isenabled()
         gc.disable()
         try:
@@ -588,7 +591,7 @@ class SlateRecEnv(RecSimBase):
         finally:
             if was_on:
                 gc.enable()
-        self._obs_keepalive = out
+        keep.append(out)
         return out
 
     def sample(self, batch_size):
