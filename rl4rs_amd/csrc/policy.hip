@@ -555,7 +555,11 @@ struct PassArgs {
 #else
 #define PUB(ptr, val) ((ptr) = (val))
 #endif
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen) {
+// `mid` runs on every thread between the arrival and the poll: the place to REQUEST data that does not depend on what the
+// other workgroups publish (the next minibatch's observations and loss inputs) - the loads fly while the barrier waits.
+struct NoMid { __device__ void operator()() const {} };
+template <typename Mid = NoMid>
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen, Mid mid = Mid()) {
     __shared__ unsigned s_dead;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -566,6 +570,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host,
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mid();
+    if (threadIdx.x == 0) {
         const unsigned target = gen * nwg;
         // bounded wait (~seconds): if the workgroups are not all resident (a tool that serialises workgroups, a shared GPU)
         // the pass gives up instead of hanging the device - bar[1] is raised and rl4rs_policy_ppo_epoch reports it
@@ -618,40 +625,78 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         const int j = i / AE, c = i - j * AE;
         PUB(a.w2t[(size_t)c * HID + j], W2[i]);
     }
-    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
+    // The inputs of a minibatch that no workgroup writes (observation rows, old logits, mask words, per-sample scalars) are
+    // requested INSIDE the grid barrier in front of it, between this workgroup's arrival and its poll, and go to LDS from
+    // registers afterwards: their HBM round trip (2.1 us of the 33 per minibatch when it followed the barrier) runs while the
+    // barrier waits.  Only when they fit a few registers per thread (8 rows per workgroup: 4 + 5 + 1 + 5).
+    constexpr int PF_OBS = 4, PF_OLD = 5;
+    const bool can_pf = R * OD <= 512 * PF_OBS && R * d.A <= 512 * PF_OLD && R * d.W <= 512 && R <= 512;
+    float pf_obs[PF_OBS], pf_old[PF_OLD], pf_sc[5];
+    uint32_t pf_mask = 0;
+    int pf_act = 0;
+    auto prefetch = [&](int mbn) {
+        if (!can_pf || mbn >= a.mb_end) return;
+        const size_t ln = (size_t)mbn * MB;
+#pragma unroll
+        for (int u = 0; u < PF_OBS; ++u) pf_obs[u] = a.obs[(ln + r0) * OD + min(tid + 512 * u, R * OD - 1)];
+#pragma unroll
+        for (int u = 0; u < PF_OLD; ++u) pf_old[u] = a.L.old_logits[(ln + r0) * d.A + min(tid + 512 * u, R * d.A - 1)];
+        if (a.mask) pf_mask = a.mask[(ln + r0) * d.W + min(tid, R * d.W - 1)];
+        const int tr = min(tid, R - 1);
+        pf_act = a.L.actions[ln + r0 + tr];
+        pf_sc[0] = a.L.adv[ln + r0 + tr]; pf_sc[1] = a.L.ret[ln + r0 + tr];
+        pf_sc[2] = a.L.old_logp[ln + r0 + tr]; pf_sc[3] = a.L.old_value[ln + r0 + tr];
+    };
+    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { prefetch(a.mb_begin); })) return;
     for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
         const size_t lo = (size_t)mb * MB;
         // ------------------------------------------------------------------ phase A
         RL4RS_PT(0);
-        for (int i0 = tid; i0 < R * OD; i0 += 512 * 16) {               // 16 loads in flight per thread and trip
-            float x[16];
+        if (can_pf) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = a.obs[(lo + r0) * OD + min(i0 + 512 * u, R * OD - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = i0 + 512 * u;
-                if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = x[u];
+            for (int u = 0; u < PF_OBS; ++u) {
+                const int i = tid + 512 * u;
+                if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = pf_obs[u];
             }
-        }
-        // the row-loss inputs do not depend on the parameters: staged here, in one round trip with the observations
-        for (int i0 = tid; i0 < R * d.A; i0 += 512 * 16) {
-            float x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = a.L.old_logits[(lo + r0) * d.A + min(i0 + 512 * u, R * d.A - 1)];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < PF_OLD; ++u)
+                if (tid + 512 * u < R * d.A) s_old[tid + 512 * u] = pf_old[u];
+            if (a.mask && tid < R * d.W) s_mask[tid] = pf_mask;
+            if (tid < R) {
+                reinterpret_cast<int32_t*>(s_sc)[tid] = pf_act;
+                s_sc[32 + tid] = pf_sc[0]; s_sc[64 + tid] = pf_sc[1]; s_sc[96 + tid] = pf_sc[2]; s_sc[128 + tid] = pf_sc[3];
+            }
+        } else {
+            for (int i0 = tid; i0 < R * OD; i0 += 512 * 16) {               // 16 loads in flight per thread and trip
+                float x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (i0 + 512 * u < R * d.A) s_old[i0 + 512 * u] = x[u];
-        }
-        if (a.mask)
-            for (int i = tid; i < R * d.W; i += 512) s_mask[i] = a.mask[(lo + r0) * d.W + i];
-        if (tid < R) {
-            reinterpret_cast<int32_t*>(s_sc)[tid] = a.L.actions[lo + r0 + tid];
-            s_sc[32 + tid] = a.L.adv[lo + r0 + tid];
-            s_sc[64 + tid] = a.L.ret[lo + r0 + tid];
-            s_sc[96 + tid] = a.L.old_logp[lo + r0 + tid];
-            s_sc[128 + tid] = a.L.old_value[lo + r0 + tid];
+                for (int u = 0; u < 16; ++u) x[u] = a.obs[(lo + r0) * OD + min(i0 + 512 * u, R * OD - 1)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + 512 * u;
+                    if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = x[u];
+                }
+            }
+            // the row-loss inputs do not depend on the parameters: staged here, in one round trip with the observations
+            for (int i0 = tid; i0 < R * d.A; i0 += 512 * 16) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = a.L.old_logits[(lo + r0) * d.A + min(i0 + 512 * u, R * d.A - 1)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (i0 + 512 * u < R * d.A) s_old[i0 + 512 * u] = x[u];
+            }
+            if (a.mask)
+                for (int i = tid; i < R * d.W; i += 512) s_mask[i] = a.mask[(lo + r0) * d.W + i];
+            if (tid < R) {
+                reinterpret_cast<int32_t*>(s_sc)[tid] = a.L.actions[lo + r0 + tid];
+                s_sc[32 + tid] = a.L.adv[lo + r0 + tid];
+                s_sc[64 + tid] = a.L.ret[lo + r0 + tid];
+                s_sc[96 + tid] = a.L.old_logp[lo + r0 + tid];
+                s_sc[128 + tid] = a.L.old_value[lo + r0 + tid];
+            }
         }
         __syncthreads();
         RL4RS_PT(1);
@@ -883,7 +928,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             }
         }
         RL4RS_PT(7);
-        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
+        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { prefetch(mb + 1); })) return;
         RL4RS_PT(8);
     }
 }
