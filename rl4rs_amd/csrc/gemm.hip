@@ -497,6 +497,140 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// k_gemm_h16_wres: the same fp16x2 GEMM for a SHORT K and MANY rows (the scorer's cache projections: K = 128, N = 832, one call
+// per encode, M = distinct histories x maxlen ~ 10^5), WEIGHTS RESIDENT.  k_gemm_h16 tiles that shape as (M / 64) x 7
+// short-lived workgroups: 0.27 ms per call.  What the way here measured (rocprofv3, 113 000 x 832 x 128, one GPU box):
+//   one workgroup per 32 rows and all columns, C staged in LDS and written as one contiguous piece      264 us
+//     - without the C stores 254: the 377 MB output stream is NOT the cost (staging + a stream of C alone: 75 us)
+//     - without the column-tile loop 75: the loop waits for weight fragments - every 32-row block pulls the whole 426 KB
+//       weight set through L2 -> L1 again (1.5 GB per call)
+//   the same with four workgroups per CU (fragments single-buffered, half a tile of lookahead)             187 us  (8 TB/s of L2)
+//   operands trade places - a wave keeps ONE column tile's fragments for the whole launch (below)          134 us
+//   rows requested two blocks ahead / one barrier per 64 rows                                              128 / 122 us
+//   C through a buffer descriptor with scalar row offsets                                                    84 - 98 us
+// The last step is the general lesson: per 32 x 32 tile the epilogue `if (row < M) C[row * ldc + col] = ...` is a compare, an exec
+// mask, a 64-bit address and a store per element - ~400 VALU issue slots next to 24 MFMAs; with four waves on a SIMD that
+// was 6 us of VALU per 64-row block against 3 us of matrix pipe.
+// Form: a wave keeps its column tile's fragments (all k-blocks, both planes: 64 registers); a workgroup of 13 waves covers 416
+// columns; the workgroups of a column group walk the 64-row blocks of A - staged and split into the fp16 planes once per
+// (block, column group), double-buffered in LDS, the next block's rows requested before this block's MFMAs, ONE barrier per
+// block.  Weight traffic: 426 KB per workgroup per launch.  Per output element the MFMA sequence is that of k_gemm_h16
+// (k-blocks in order, hi*hi, lo*hi, hi*lo): bit-identical results (tests/test_gpu_gemm.py compares the two paths).
+constexpr int WRES_WAVES = 13;
+template <int KB>
+__global__ __launch_bounds__(WRES_WAVES * 64) void k_gemm_h16_wres(const float* __restrict__ A, int64_t lda, const char* __restrict__ Wp,
+                                                                   const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                                                                   int M, int N, int act) {
+    // a row block = SUB sub-blocks of 32 rows: one barrier per 64 rows (with 32 an iteration was 4.6 us for 1.1 us of MFMAs)
+    constexpr int SUB = 2, BM = 32 * SUB, SLAB = 32 * 16 + 16, PLANE = 2 * KB * SLAB, K = KB * 16, CHUNKS = 32 * K / 8;
+    static_assert(CHUNKS <= WRES_WAVES * 64, "one chunk per thread and sub-block");
+    __shared__ __attribute__((aligned(16))) char s_pl[2][SUB][2][PLANE];    // [buffer][sub-block][hi / lo]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, li = lane & 31;
+    const int NT = (N + 31) / 32;
+    const int nt = blockIdx.y * WRES_WAVES + wave;
+    const bool tile_ok = nt < NT;
+    const int col = nt * 32 + li;
+    const int nrb = (M + BM - 1) / BM;
+    // this wave's column tile: all k-blocks, both planes, for the whole launch
+    ghalf8_t bh[KB], bl[KB];
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wp + (size_t)(tile_ok ? nt : 0) * KB * 2048), 0, KB * 2048, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            bh[j] = gbuf_load_h8(rs_w, lane * 16, j * 2048);
+            bl[j] = gbuf_load_h8(rs_w, lane * 16 + 1024, j * 2048);
+        }
+    }
+    const bool col_ok = tile_ok && col < N;
+    const float inv_s = reinterpret_cast<const float*>(Wp)[(size_t)NT * KB * 512 + (col_ok ? col : 0)];
+    const float bv = (bias && col_ok) ? bias[col] : 0.f;
+    const int ldc4 = (int)ldc * 4;
+    const int c_voff = col_ok ? (4 * half * (int)ldc + col) * 4 : 0x7ffffff0;      // this lane's element of row 4 * half; other rows: + scalar
+    // A staging: thread c < CHUNKS owns chunk c (8 consecutive k of one row) of every 32-row sub-block
+    const bool stager = tid < CHUNKS;
+    const int cr = tid / (K / 8), ckc = tid % (K / 8);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((((int64_t)M - 1) * lda + K) * 4), 0x00020000);
+    auto request = [&](int rb, float4 (&v)[SUB][2]) {       // rows >= M read as zero (past the descriptor's end)
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const int64_t row = (int64_t)rb * BM + u * 32 + cr;
+            const int voff = (int)((row * lda + ckc * 8) * 4);
+            v[u][0] = gbuf_load4(rs_a, row < M ? voff : 0x7ffffff0, 0);
+            v[u][1] = gbuf_load4(rs_a, row < M ? voff + 16 : 0x7ffffff0, 0);
+        }
+    };
+    auto stage = [&](int buf, const float4 (&v)[SUB][2]) {
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {
+            const float x[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+            ghalf8_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 h = (_Float16)x[e];
+                hi[e] = h;
+                lo[e] = (_Float16)(x[e] - (float)h);
+            }
+            const int off = ckc * SLAB + cr * 16;            // slab (kb, k-half) = chunk index within the row
+            *reinterpret_cast<ghalf8_t*>(&s_pl[buf][u][0][off]) = hi;
+            *reinterpret_cast<ghalf8_t*>(&s_pl[buf][u][1][off]) = lo;
+        }
+    };
+    float4 pf[SUB][2];
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) pf[u][0] = pf[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int G = gridDim.x;
+    int rb = blockIdx.x;
+    if (rb < nrb && stager) { request(rb, pf); stage(0, pf); }
+    int buf = 0;
+    for (; rb < nrb; rb += G, buf ^= 1) {
+        const bool more = rb + G < nrb;
+        if (more && stager) request(rb + G, pf);             // the next block's rows fly under this block's MFMAs
+        __syncthreads();                                     // planes[buf] complete; everybody is done with planes[buf ^ 1]
+        if (tile_ok) {
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int off = (j * 2 + half) * SLAB + li * 16;
+                    const ghalf8_t ah = *reinterpret_cast<const ghalf8_t*>(&s_pl[buf][u][0][off]);
+                    const ghalf8_t al = *reinterpret_cast<const ghalf8_t*>(&s_pl[buf][u][1][off]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc, 0, 0, 0);
+                }
+                // C through a buffer descriptor over the sub-block's valid rows: rows >= M and columns >= N (their lanes carry
+                // an out-of-range offset) are dropped by the hardware, the row part of the address is a scalar - one
+                // instruction per element instead of a compare, an exec mask and a 64-bit address (the epilogue's VALU was
+                // the kernel's bound: ~400 instructions per wave and sub-block next to 24 MFMAs)
+                const int m0 = rb * BM + u * 32;
+                if (m0 < M) {
+                    const int rows_here = min(32, M - m0);
+                    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+                        C + (size_t)m0 * ldc, 0, (int)((((int64_t)rows_here - 1) * ldc + N) * 4), 0x00020000);
+                    if (act == ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r] * inv_s + bv), rs_c, c_voff,
+                                                                  ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[r] * inv_s + bv, act)), rs_c, c_voff,
+                                                                  ((r & 3) + 8 * (r >> 2)) * ldc4, 0);
+                    }
+                }
+            }
+        }
+        if (more && stager) stage(buf ^ 1, pf);
+    }
+}
+
 // host: split W [K,N] into fp16 hi / lo and pack it into B-fragment order for k_gemm_h16 (K padded to 16, N to 32);
 // returned as floats (NT * KB16 * 512)
 // Every COLUMN j is stored multiplied by its own power of two s_j (pow2_prescale: max_k |w[k][j]| s_j in [2^13, 2^14), exact), so
@@ -552,6 +686,16 @@ int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const f
     return launch_gemm_h16_impl(a, lda, wp1, bias1, nullptr, 0, M, N1, K1, act1, st, nullptr, 0, ch);
 }
 
+static int device_cus() {
+    static int cus = 0;                     // one device per process (one process per GPU)
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
                                 int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, G16Chain chain) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
@@ -559,6 +703,17 @@ static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, 
     const int ny = ((N + 31) / 32 + 3) / 4;
     const char* wp = reinterpret_cast<const char*>(wp16);
     const bool vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+#ifndef RL4RS_G16_NO_ROWS
+    // short K, many rows, wide C (the cache projections): weights resident in registers, the workgroups walk the rows
+    if (K == 128 && vec && !addend && !chain.wp2 && N >= 256 && M >= 8192 && (int64_t)M * lda * 4 < (int64_t)0x7fffff00) {
+        const int groups = ((N + 31) / 32 + WRES_WAVES - 1) / WRES_WAVES;
+        int workers = device_cus() / groups;
+        if (workers < 1) workers = 1;
+        hipLaunchKernelGGL((k_gemm_h16_wres<8>), dim3(workers, groups), dim3(WRES_WAVES * 64), 0, st, a, lda, wp, bias, c, ldc, M, N, act);
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
+#endif
     const bool small = (int64_t)((M + 63) / 64) * ny < 512;       // small problems: 32-row tiles so that the grid covers the CUs
     const dim3 grid(small ? (M + 31) / 32 : (M + 63) / 64, ny);
 #define RL4RS_G16_LAUNCH(WM_, VEC_) hipLaunchKernelGGL((k_gemm_h16<WM_, VEC_>), grid, dim3(256), 0, st, a, lda, wp, KB, bias, c, ldc, M, N, K, act, addend, ldadd, chain)

@@ -36,7 +36,8 @@ def test_gemm_f32(M, N, K, act):
 
 
 @pytest.mark.parametrize('M,N,K,act', [(1, 2, 3, 0), (33, 65, 17, 1), (64, 64, 64, 0), (300, 284, 70, 3), (4096, 128, 432, 1),
-                                       (4096, 256, 768, 0), (32768, 256, 768, 0), (5000, 832, 128, 0), (77, 2, 256, 2)])
+                                       (4096, 256, 768, 0), (32768, 256, 768, 0), (5000, 832, 128, 0), (77, 2, 256, 2),
+                                       (9001, 832, 128, 0), (8300, 300, 128, 1)])      # K = 128, many rows: k_gemm_h16_wres
 def test_gemm_h16(M, N, K, act):
     """fp16x2 GEMM (the scorer's GEMMs in scorer_mode fp16x2) vs fp64: same bar as the exact-fp32 kernel, on operands that
     exercise the split: large and tiny magnitudes next to each other, strided A, row / column / k tails."""
