@@ -475,25 +475,49 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
         const int col2 = wave * 32 + li;
         if (tile2_ok && col2 < chain.n2) {
             const float bv2 = chain.bias2 ? chain.bias2[col2] : 0.f;
+            const __amdgpu_buffer_rsrc_t rs_c2 = __builtin_amdgcn_make_buffer_rsrc(chain.c2 + (size_t)m0 * chain.ldc2, 0,
+                                                                                   (int)((((int64_t)rows_here - 1) * chain.ldc2 + chain.n2) * 4), 0x00020000);
+            const int l24 = (int)chain.ldc2 * 4, v2 = (4 * half * (int)chain.ldc2 + col2) * 4;
 #pragma unroll
             for (int w = 0; w < WM; ++w)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < M) chain.c2[(size_t)row * chain.ldc2 + col2] = apply_act(acc2[w][r] * inv_s2 + bv2, chain.act2);
-                }
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc2[w][r] * inv_s2 + bv2, chain.act2)), rs_c2, v2,
+                                                          (32 * w + (r & 3) + 8 * (r >> 2)) * l24, 0);
         }
         return;
     }
     if (tile_ok && col < N) {
+        // C (and the addend) through buffer descriptors over this workgroup's valid rows: rows >= M are dropped (read as zero) by
+        // the hardware and the row part of an address is a scalar - one instruction per element instead of a compare, an exec
+        // mask and a 64-bit address (see k_gemm_h16_wres: that VALU work was comparable to the tile's MFMA time)
         const float bv = bias ? bias[col] : 0.f;
+        const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)m0 * ldc, 0, (int)((((int64_t)rows_here - 1) * ldc + N) * 4), 0x00020000);
+        const int ldc4 = (int)ldc * 4, c_voff = (4 * half * (int)ldc + col) * 4;
+        if (addend) {
+            const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(addend + (size_t)m0 * ldadd), 0,
+                                                                                  (int)((((int64_t)rows_here - 1) * ldadd + N) * 4), 0x00020000);
+            const int ldd4 = (int)ldadd * 4, d_voff = (4 * half * (int)ldadd + col) * 4;
+            float add[WM][16];
 #pragma unroll
-        for (int w = 0; w < WM; ++w)
+            for (int w = 0; w < WM; ++w)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) C[(size_t)row * ldc + col] = apply_act(acc[w][r] * inv_s + bv + (addend ? addend[(size_t)row * ldadd + col] : 0.f), act);
-            }
+                for (int r = 0; r < 16; ++r)
+                    add[w][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, d_voff, (32 * w + (r & 3) + 8 * (r >> 2)) * ldd4, 0));
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[w][r] * inv_s + bv + add[w][r], act)), rs_c, c_voff,
+                                                          (32 * w + (r & 3) + 8 * (r >> 2)) * ldc4, 0);
+        } else {
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[w][r] * inv_s + bv + 0.f, act)), rs_c, c_voff,
+                                                          (32 * w + (r & 3) + 8 * (r >> 2)) * ldc4, 0);
+        }
     }
 }
 
