@@ -721,6 +721,73 @@ int rl4rs_qloss_dqn(rl4rs_qnet* net, int32_t N, const float* q_t_dev, const int3
                     const float* imitator_next_logits_dev, float action_flexibility, float gamma, float cql_alpha,
                     float* dq_dev, float* rows_scratch_dev, float* loss2_dev, int32_t* best_next_action_dev, void* stream);
 
+/* Continuous-action offline-RL learners: what script/batchrl_trainer.py:61-73 ('BCQ-conti', d3rlpy.algos.BCQ) and :91-107
+ * ('CQL-conti', d3rlpy.algos.CQL) train on the continuous dataset of data_generate_rl4rs_a_conti (:220-270, actions = 32-d item
+ * embeddings), BASELINE configs[4].  Both leave the custom encoder factory commented out, so every network is d3rlpy's default
+ * VectorEncoderWithAction([256, 256], relu) on cat([x, action]) + one Linear head = an "amlp":
+ *     h1 = relu([x | a] W1 + b1);  h2 = relu(h1 W2 + b2);  out = head_act(h2 W3 + b3)      (act_dim = 0: plain VectorEncoder)
+ * head_act: the activation codes of rl4rs_gemm_f32 (0 none, 3 tanh ...).
+ * Flat float32 parameter / gradient layout, matrices stored [in, out]:
+ *     [ W1 (obs_dim + act_dim) x hidden1 (observation rows first, like torch.cat([x, action])) | b1 | W2 | b2 | W3 | b3 ]
+ * forward: obs_dev [N / rep, obs_dim] - row r is the observation of rows r*rep .. r*rep + rep - 1 of act_dev [N, act_dim]
+ * (rep sampled actions per observation: the observation side of the first layer is computed once per observation);
+ * out_dev [N, out_dim].  The activations stay in the handle: backward must follow the forward of the SAME rows, takes the
+ * gradient wrt the head's PRE-activation output (the loss entry points below fold the head activation in), writes every
+ * parameter gradient into the handle when want_param_grad, and the gradient wrt act_dev into dact_dev when that is not NULL.
+ * N <= max_rows for forward, N <= max_grad_rows for backward.  adam_step is torch.optim.Adam; soft_update is d3rlpy's
+ * soft_sync  targ = (1 - tau) * targ + tau * src. */
+typedef struct rl4rs_amlp rl4rs_amlp;
+typedef struct rl4rs_amlp_cfg {
+    int32_t obs_dim;
+    int32_t act_dim;
+    int32_t hidden1;
+    int32_t hidden2;
+    int32_t out_dim;
+    int32_t head_act;
+    int32_t max_rows;
+    int32_t max_grad_rows;
+} rl4rs_amlp_cfg;
+int rl4rs_amlp_create(const rl4rs_amlp_cfg* cfg, const float* params_host, void* stream, rl4rs_amlp** out);
+int rl4rs_amlp_destroy(rl4rs_amlp* net);
+int rl4rs_amlp_params(rl4rs_amlp* net, float** params_dev, float** grad_dev, int64_t* count);
+int rl4rs_amlp_copy_params(rl4rs_amlp* dst, const rl4rs_amlp* src, void* stream);
+int rl4rs_amlp_soft_update(rl4rs_amlp* targ, const rl4rs_amlp* src, float tau, void* stream);
+int rl4rs_amlp_forward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev, float* out_dev,
+                       void* stream);
+int rl4rs_amlp_backward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev,
+                        const float* dout_dev, float* dact_dev, int32_t want_param_grad, void* stream);
+int rl4rs_amlp_adam_step(rl4rs_amlp* net, float lr, float beta1, float beta2, float eps, void* stream);
+/* d3rlpy ConditionalVAE (the BCQ imitator).  enc_out_dev [N, 2L] = [mu | logstd] (the encoder amlp's two Linear heads side by
+ * side); sample: z = mu + exp(clamp(logstd, min, max)) * eps (Normal.rsample with the caller's noise).
+ * loss (compute_error): decoded_dev [N, E] = tanh output of the decoder amlp on (x, z); loss2_dev = {mean_n sum_e (y - a)^2,
+ * mean_n sum_l KL(N(mu, sigma) || N(0, 1))} - the loss is loss2[0] / E + beta * loss2[1] / L; d_dec_pre_dev = gradient of the
+ * mse term wrt the decoder's pre-tanh output.  rows_scratch_dev: [N, 2] float32.
+ * encoder_grad: d_enc_out_dev [N, 2L] from dz_dev (the decoder's action-input gradient) and the beta-weighted KL term. */
+int rl4rs_cvae_sample(int32_t N, int32_t L, const float* enc_out_dev, const float* eps_dev, float min_logstd, float max_logstd,
+                      float* z_dev, void* stream);
+int rl4rs_cvae_loss(int32_t N, int32_t E, int32_t L, const float* decoded_dev, const float* actions_dev, const float* enc_out_dev,
+                    float min_logstd, float max_logstd, float* d_dec_pre_dev, float* rows_scratch_dev, float* loss2_dev,
+                    void* stream);
+int rl4rs_cvae_encoder_grad(int32_t N, int32_t L, const float* enc_out_dev, const float* eps_dev, const float* dz_dev, float beta,
+                            float min_logstd, float max_logstd, float* d_enc_out_dev, void* stream);
+/* d3rlpy DeterministicResidualPolicy: out = clamp(action + scale * tanh_out, -1, 1) with tanh_out_dev [N, E] the tanh head
+ * of the policy amlp on (x, action); residual_grad: gradient wrt the policy head's pre-tanh output given d_out_dev. */
+int rl4rs_residual_action(int32_t N, int32_t E, const float* action_dev, const float* tanh_out_dev, float scale, float* out_dev,
+                          void* stream);
+int rl4rs_residual_grad(int32_t N, int32_t E, const float* action_dev, const float* tanh_out_dev, float scale,
+                        const float* d_out_dev, float* d_pre_dev, void* stream);
+/* BCQ target (d3rlpy compute_max_with_n_actions): per row b the value max_j [(1 - lam) max(q1, q2) + lam min(q1, q2)] over its n
+ * sampled actions (q*_dev [B * n]); y_dev [B] = rewards + gamma * value * (1 - terminals), or the bare value when rewards_dev
+ * is NULL; best_dev [B] (optional) = the first maximising j.  q2_dev NULL: the value is q1 (the greedy pick of predict). */
+int rl4rs_bcq_target(int32_t B, int32_t n, const float* q1_dev, const float* q2_dev, float lam, const float* rewards_dev,
+                     const float* terminals_dev, float gamma, float* y_dev, int32_t* best_dev, void* stream);
+/* out_dev [B, E] = rows_dev [b * n + best_dev[b], :] */
+int rl4rs_pick_rows(int32_t B, int32_t n, int32_t E, const float* rows_dev, const int32_t* best_dev, float* out_dev, void* stream);
+/* Twin ContinuousMeanQFunction error: loss2_dev = {mean (q1 - y)^2, mean (q2 - y)^2} (the critic loss is their sum),
+ * dq*_dev = 2 (q* - y) / N. */
+int rl4rs_critic_mse(int32_t N, const float* q1_dev, const float* q2_dev, const float* y_dev, float* dq1_dev, float* dq2_dev,
+                     float* loss2_dev, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh, 4 ReLU. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

@@ -76,6 +76,10 @@ class QNetCfg(C.Structure):
                                          'max_rows')]
 
 
+class AmlpCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('obs_dim', 'act_dim', 'hidden1', 'hidden2', 'out_dim', 'head_act', 'max_rows', 'max_grad_rows')]
+
+
 class RawPolicyCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num', 'category_hash_size',
@@ -217,6 +221,22 @@ SIGNATURES = {
     'rl4rs_q_best_action': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P]),
     'rl4rs_qloss_imitation': (_I, [_P, _I32, _P, _P, C.c_float, _P, _P, _P, _P]),
     'rl4rs_qloss_dqn': (_I, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
+    'rl4rs_amlp_create': (_I, [_P, _FP, _P, _P]),
+    'rl4rs_amlp_destroy': (_I, [_P]),
+    'rl4rs_amlp_params': (_I, [_P, _P, _P, _P]),
+    'rl4rs_amlp_copy_params': (_I, [_P, _P, _P]),
+    'rl4rs_amlp_soft_update': (_I, [_P, _P, C.c_float, _P]),
+    'rl4rs_amlp_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P]),
+    'rl4rs_amlp_backward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _I32, _P]),
+    'rl4rs_amlp_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    'rl4rs_cvae_sample': (_I, [_I32, _I32, _P, _P, C.c_float, C.c_float, _P, _P]),
+    'rl4rs_cvae_loss': (_I, [_I32, _I32, _I32, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
+    'rl4rs_cvae_encoder_grad': (_I, [_I32, _I32, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
+    'rl4rs_residual_action': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P]),
+    'rl4rs_residual_grad': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P, _P]),
+    'rl4rs_bcq_target': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _P]),
+    'rl4rs_pick_rows': (_I, [_I32, _I32, _I32, _P, _P, _P, _P]),
+    'rl4rs_critic_mse': (_I, [_I32, _P, _P, _P, _P, _P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_h16_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),

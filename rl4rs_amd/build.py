@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'librl4rs_hip.so')
 SOURCES = ['env.hip', 'gemm.hip', 'dien.hip', 'policy.hip', 'records.hip', 'step.hip']
-HEADERS = ['common.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
+HEADERS = ['common.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
 
 
 def _stale():

@@ -49,9 +49,14 @@ inline int dev_alloc(T** p, size_t n) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Launches of the generic fp32 MFMA GEMM (gemm.hip); ldw = leading dim of W [K,N].
+// activation codes of the GEMM epilogues (the `act` argument of rl4rs_gemm_f32 in include/rl4rs_hip.h)
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_RELU = 4 };
+
+// Launches of the generic fp32 MFMA GEMM (gemm.hip); ldw = leading dim of W [K,N].  Optional addend: row (m / add_div) of a
+// row-major [ceil(M / add_div), ldadd] array is added before the activation.
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
-                    float* c, int64_t ldc, int M, int N, int K, int act, hipStream_t st);
+                    float* c, int64_t ldc, int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr,
+                    int64_t ldadd = 0, int add_div = 1);
 
 // GEMM against a weight matrix pre-packed by pack_gemm_weight (gemm.hip); C = act(A W + bias + addend) with an optional
 // row-major addend [M, ldadd]

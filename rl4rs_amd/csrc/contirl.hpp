@@ -1,0 +1,433 @@
+// Continuous-action offline-RL learners (BASELINE configs[4]: "Continuous-action SlateRecEnv + K-NN item search, BCQ offline
+// RL"): what the reference trains with d3rlpy.algos.BCQ ('BCQ-conti', script/batchrl_trainer.py:61-73) and d3rlpy.algos.CQL
+// ('CQL-conti', :91-107) on the dataset whose actions are the 32-d item embeddings (data_generate_rl4rs_a_conti, :220-270); the
+// learned policy's embedding is what the env's K-NN resolves (rl4rs/env/slate.py:180-198).  Both scripts leave the custom encoder
+// factory commented out, so every network is d3rlpy's default:
+//
+//   amlp ("action MLP")   VectorEncoderWithAction(hidden_units=[256, 256], relu) on cat([x, action]) + one nn.Linear head
+//       h1 = relu([x | a] W1 + b1);  h2 = relu(h1 W2 + b2);  out = act(h2 W3 + b3)         (act_dim = 0: plain VectorEncoder)
+//   BCQ    ConditionalVAE   encoder amlp(x, action) -> [mu | logstd] (the two Linear heads side by side), decoder
+//                           amlp(x, latent) -> tanh -> action;  loss = mse(decode(x, rsample), a) + beta * KL(N(mu, sigma) || N(0,1))
+//          DeterministicResidualPolicy   a' = clamp(a + scale * tanh(amlp(x, a)), -1, 1),  scale = action_flexibility (0.05)
+//          twin ContinuousMeanQFunction  amlp(x, a) -> 1;  loss = sum_c mean (Q_c(s, a) - y)^2
+//          target  y = r + gamma * (1 - terminal) * max_n [(1 - lam) max_c + lam min_c] Q_targ_c(s', pi_targ(s', decode(s', z_n))),
+//                  z_n = clamp(randn, -0.5, 0.5), n = 100 sampled actions per next observation, lam = 0.75
+//          actor   -mean Q_1(s, pi(s, decode(s, z)));  soft target updates tau = 0.005
+//   CQL    SquashedNormalPolicy amlp(x) -> [mu | logstd];  SAC actor / temperature losses;  twin critics with the conservative
+//          term alpha * (w * (logsumexp_{3n} [Q(s, a_j) - log p_j] - Q(s, a)) - threshold), learned log alpha
+// d3rlpy 0.91 is absent from this image (environment.yml:146): the algorithms are restated as published, PARITY UNPINNED, and
+// checked against torch float64 autograd of the same restatement in tests/test_gpu_offline_conti.py.
+//
+// MI355X notes.  The heavy part of a BCQ update is the target: 4 forward networks over batch * 100 = 25 600 rows.  The observation
+// (266 of the 298 first-layer inputs) is the SAME for the 100 sampled actions of a row, so the first layer is split: the
+// observation side x W1[:D] + b1 is one GEMM over the 256 distinct rows, and the per-sample GEMM has K = act_dim only with that
+// projection as a row-shared addend (k_gemm_f32's add_div) - 89 % of the first layer's FLOPs and all of the repeated-observation
+// traffic (d3rlpy materialises the [25600, 266] expand) never happen.  Everything is exact fp32 on v_mfma_f32_32x32x2_f32;
+// sample-axis reductions use the fixed-order helpers of simtrain.hpp, so an update is bit-reproducible given its noise.
+#pragma once
+
+namespace rl4rs {
+
+// out[n] = dot(h[n, :H], w) + b : the one-output head of a critic (one wave per row)
+__global__ __launch_bounds__(256) void k_amlp_head1(const float* __restrict__ h, int N, int H, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += h[(size_t)n * H + k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0) out[n] = s + b[0];
+}
+
+// dproj[r, c] = sum_{i < rep} d[(r * rep + i), c]   (fixed order)
+__global__ void k_group_sum(const float* __restrict__ d, int R, int rep, int cols, float* __restrict__ dproj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * cols) return;
+    const int r = i / cols, c = i - r * cols;
+    float s = 0.f;
+    for (int k = 0; k < rep; ++k) s += d[((size_t)r * rep + k) * cols + c];
+    dproj[i] = s;
+}
+
+// targ = (1 - tau) * targ + tau * src        (d3rlpy soft_sync)
+__global__ void k_soft_update(float* __restrict__ targ, const float* __restrict__ src, int64_t n, float tau) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) targ[i] = targ[i] * (1.0f - tau) + tau * src[i];
+}
+
+// ConditionalVAE.encode(...).rsample():  z = mu + exp(clamp(logstd, lo, hi)) * eps,   enc = [mu | logstd] per row
+__global__ void k_cvae_sample(int N, int L, const float* __restrict__ enc, const float* __restrict__ eps, float lo, float hi,
+                              float* __restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * L) return;
+    const int n = i / L, l = i - n * L;
+    const float mu = enc[(size_t)n * 2 * L + l], ls = fminf(fmaxf(enc[(size_t)n * 2 * L + L + l], lo), hi);
+    z[i] = mu + expf(ls) * eps[i];
+}
+
+// ConditionalVAE.compute_error: one wave per row.  y = decoder output (tanh already applied by the head);
+// rows[n] = {sum_e (y - a)^2, sum_l KL(N(mu, sigma) || N(0, 1))};  d_dec = d mse / d (pre-tanh decoder output)
+__global__ __launch_bounds__(256) void k_cvae_loss(int N, int E, int L, const float* __restrict__ y, const float* __restrict__ a,
+                                                   const float* __restrict__ enc, float lo, float hi, float* __restrict__ d_dec,
+                                                   float2* __restrict__ rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float se = 0.f, kl = 0.f;
+    const float sc = 2.0f / ((float)N * (float)E);
+    for (int e = lane; e < E; e += 64) {
+        const float yy = y[(size_t)n * E + e], d = yy - a[(size_t)n * E + e];
+        se += d * d;
+        d_dec[(size_t)n * E + e] = sc * d * (1.0f - yy * yy);
+    }
+    for (int l = lane; l < L; l += 64) {
+        const float mu = enc[(size_t)n * 2 * L + l], ls = fminf(fmaxf(enc[(size_t)n * 2 * L + L + l], lo), hi);
+        const float var = expf(2.0f * ls);
+        kl += 0.5f * (var + mu * mu - 1.0f) - ls;        // torch kl_divergence(Normal, Normal) with q = N(0, 1)
+    }
+    se = wave_sum(se);
+    kl = wave_sum(kl);
+    if (lane == 0) rows[n] = make_float2(se, kl);
+}
+
+// gradient wrt [mu | logstd] given dz (the decoder's input gradient):  mse path through z = mu + sigma eps, plus beta * mean KL
+__global__ void k_cvae_enc_grad(int N, int L, const float* __restrict__ enc, const float* __restrict__ eps,
+                                const float* __restrict__ dz, float beta, float lo, float hi, float* __restrict__ d_enc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * L) return;
+    const int n = i / L, l = i - n * L;
+    const float mu = enc[(size_t)n * 2 * L + l], raw = enc[(size_t)n * 2 * L + L + l];
+    const float ls = fminf(fmaxf(raw, lo), hi);
+    const float sig = expf(ls), k = beta / ((float)N * (float)L);
+    d_enc[(size_t)n * 2 * L + l] = dz[i] + k * mu;
+    // torch.clamp passes the gradient where lo <= x <= hi
+    d_enc[(size_t)n * 2 * L + L + l] = (raw >= lo && raw <= hi) ? dz[i] * eps[i] * sig + k * (sig * sig - 1.0f) : 0.f;
+}
+
+// DeterministicResidualPolicy.forward: out = clamp(a + scale * t, -1, 1),  t = tanh(fc(h)) (applied by the head)
+__global__ void k_residual_action(int n, const float* __restrict__ a, const float* __restrict__ t, float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fminf(fmaxf(a[i] + scale * t[i], -1.0f), 1.0f);
+}
+
+// d (pre-tanh head output) = d_out * [|a + scale t| inside the clamp] * scale * (1 - t^2)
+__global__ void k_residual_grad(int n, const float* __restrict__ a, const float* __restrict__ t, float scale,
+                                const float* __restrict__ d_out, float* __restrict__ d_pre) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = a[i] + scale * t[i];
+    d_pre[i] = (v >= -1.0f && v <= 1.0f) ? d_out[i] * scale * (1.0f - t[i] * t[i]) : 0.f;
+}
+
+// compute_max_with_n_actions: per row b, v_j = (1 - lam) max(q1, q2) + lam min(q1, q2) over its n sampled actions; value = max_j
+// (first maximum), y = r + gamma * value * (1 - terminal) when rewards are given.  q2 NULL: v_j = q1 (the greedy pick of predict).
+__global__ __launch_bounds__(256) void k_bcq_target(int B, int n, const float* __restrict__ q1, const float* __restrict__ q2, float lam,
+                                                    const float* __restrict__ rewards, const float* __restrict__ terminals, float gamma,
+                                                    float* __restrict__ y, int32_t* __restrict__ best) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float bv = 0.f;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const float a = q1[(size_t)b * n + j];
+        float v = a;
+        if (q2) {
+            const float c = q2[(size_t)b * n + j];
+            v = (1.0f - lam) * fmaxf(a, c) + lam * fminf(a, c);
+        }
+        if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oj = __shfl_xor(bj, off);
+        if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+    }
+    if (lane == 0) {
+        if (y) y[b] = rewards ? rewards[b] + gamma * bv * (1.0f - terminals[b]) : bv;
+        if (best) best[b] = bj;
+    }
+}
+
+// out[b, :] = actions[b * n + best[b], :]
+__global__ void k_pick_rows(int B, int n, int E, const float* __restrict__ actions, const int32_t* __restrict__ best, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * E) return;
+    const int b = i / E, e = i - b * E;
+    out[i] = actions[((size_t)b * n + best[b]) * E + e];
+}
+
+// EnsembleContinuousQFunction.compute_error (mean Q functions): loss = sum_c mean_n (q_c - y)^2;  dq_c = 2 (q_c - y) / N
+// single block, fixed order; loss2 = {mean (q1 - y)^2, mean (q2 - y)^2}
+__global__ __launch_bounds__(256) void k_critic_mse(int N, const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ y,
+                                                    float* __restrict__ dq1, float* __restrict__ dq2, float* __restrict__ loss2) {
+    __shared__ float2 sm[256];
+    float2 s = make_float2(0.f, 0.f);
+    const float k = 2.0f / (float)N;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float d1 = q1[n] - y[n], d2 = q2[n] - y[n];
+        s.x += d1 * d1;
+        s.y += d2 * d2;
+        dq1[n] = k * d1;
+        dq2[n] = k * d2;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sm[threadIdx.x].x += sm[threadIdx.x + o].x; sm[threadIdx.x].y += sm[threadIdx.x + o].y; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss2[0] = sm[0].x / (float)N; loss2[1] = sm[0].y / (float)N; }
+}
+
+}  // namespace rl4rs
+
+enum { AP_W1 = 0, AP_B1, AP_W2, AP_B2, AP_W3, AP_B3, AP_COUNT };
+
+struct rl4rs_amlp {
+    rl4rs_amlp_cfg c;
+    int64_t n_params, off[AP_COUNT], size[AP_COUNT];
+    TrainCtx cx;
+    float *params, *grad, *adam_m, *adam_v;
+    float *proj, *h1, *h2;              // forward: [max_rows, hidden1] observation-side projection (one row per DISTINCT observation), activations
+    float *d_h1, *d_h2, *d_proj;        // backward scratch, [max_grad_rows, ...]
+    int last_n, last_rep;               // rows of the last forward (the backward must match)
+    int64_t adam_t;
+    std::vector<void*> owned;
+};
+
+extern "C" {
+
+int rl4rs_amlp_destroy(rl4rs_amlp* p) {
+    if (!p) return RL4RS_OK;
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+    return RL4RS_OK;
+}
+
+int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* stream, rl4rs_amlp** out) {
+    RL4RS_REQUIRE(c && params_host && out, "amlp_create: null argument");
+    RL4RS_REQUIRE(c->obs_dim > 0 && c->act_dim >= 0 && c->hidden1 > 0 && c->hidden2 > 0 && c->out_dim > 0 && c->max_rows > 0 &&
+                  c->max_grad_rows >= 0 && c->max_grad_rows <= c->max_rows && c->head_act >= 0 && c->head_act <= 4, "amlp_create: bad sizes");
+    if (rl4rs_device_count() <= 0) {
+        set_error("no HIP device visible: librl4rs_hip has no CPU fallback");
+        return RL4RS_EHIP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t D = c->obs_dim, E = c->act_dim, H1 = c->hidden1, H2 = c->hidden2, K = c->out_dim;
+    rl4rs_amlp* p = new rl4rs_amlp();
+    p->c = *c;
+    p->adam_t = 0;
+    p->last_n = p->last_rep = 0;
+    const int64_t sizes[AP_COUNT] = {(D + E) * H1, H1, H1 * H2, H2, H2 * K, K};
+    int64_t o = 0;
+    for (int i = 0; i < AP_COUNT; ++i) { p->off[i] = o; p->size[i] = sizes[i]; o += sizes[i]; }
+    p->n_params = o;
+    int rc;
+    auto al = [&](float** dst, size_t n) {
+        int r = dev_alloc(dst, n);
+        if (r == RL4RS_OK) p->owned.push_back(*dst);
+        return r;
+    };
+#define AM_FAIL(expr) do { if ((rc = (expr)) != RL4RS_OK) { rl4rs_amlp_destroy(p); return rc; } } while (0)
+#define AM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e_)); \
+        rl4rs_amlp_destroy(p); return RL4RS_EHIP; } } while (0)
+    AM_FAIL(al(&p->params, p->n_params)); AM_FAIL(al(&p->grad, p->n_params));
+    AM_FAIL(al(&p->adam_m, p->n_params)); AM_FAIL(al(&p->adam_v, p->n_params));
+    AM_HIP(hipMemcpyAsync(p->params, params_host, (size_t)p->n_params * 4, hipMemcpyHostToDevice, st));
+    AM_HIP(hipMemsetAsync(p->grad, 0, (size_t)p->n_params * 4, st));
+    AM_HIP(hipMemsetAsync(p->adam_m, 0, (size_t)p->n_params * 4, st));
+    AM_HIP(hipMemsetAsync(p->adam_v, 0, (size_t)p->n_params * 4, st));
+    const size_t B = c->max_rows, G = c->max_grad_rows;
+    AM_FAIL(al(&p->proj, B * H1)); AM_FAIL(al(&p->h1, B * H1)); AM_FAIL(al(&p->h2, B * H2));
+    if (G > 0) {
+        AM_FAIL(al(&p->d_h1, G * H1)); AM_FAIL(al(&p->d_h2, G * H2)); AM_FAIL(al(&p->d_proj, G * H1));
+        int64_t wmax = 0;
+        for (int i = 0; i < AP_COUNT; ++i) if (sizes[i] > wmax) wmax = sizes[i];
+        p->cx.chunk = 128;
+        AM_FAIL(al(&p->cx.wt, wmax));
+        AM_FAIL(al(&p->cx.part, (size_t)((G + 127) / 128) * wmax));
+    }
+    AM_HIP(hipStreamSynchronize(st));
+#undef AM_HIP
+#undef AM_FAIL
+    *out = p;
+    return RL4RS_OK;
+}
+
+int rl4rs_amlp_params(rl4rs_amlp* p, float** params_dev, float** grad_dev, int64_t* count) {
+    RL4RS_REQUIRE(p, "amlp_params: null handle");
+    if (params_dev) *params_dev = p->params;
+    if (grad_dev) *grad_dev = p->grad;
+    if (count) *count = p->n_params;
+    return RL4RS_OK;
+}
+
+int rl4rs_amlp_copy_params(rl4rs_amlp* dst, const rl4rs_amlp* src, void* stream) {
+    RL4RS_REQUIRE(dst && src && dst->n_params == src->n_params, "amlp_copy_params: handles differ");
+    RL4RS_HIP_TRY(hipMemcpyAsync(dst->params, src->params, (size_t)src->n_params * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RL4RS_OK;
+}
+
+int rl4rs_amlp_soft_update(rl4rs_amlp* targ, const rl4rs_amlp* src, float tau, void* stream) {
+    RL4RS_REQUIRE(targ && src && targ->n_params == src->n_params, "amlp_soft_update: handles differ");
+    hipLaunchKernelGGL(k_soft_update, dim3((unsigned)((src->n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, targ->params,
+                       src->params, src->n_params, tau);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// obs [N / rep, obs_dim] (row r is the observation of rows r*rep .. r*rep + rep - 1), act [N, act_dim], out [N, out_dim]
+int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, const float* act, float* out, void* stream) {
+    RL4RS_REQUIRE(p && obs && out && N > 0 && rep > 0 && N <= p->c.max_rows && N % rep == 0 && (act || p->c.act_dim == 0) &&
+                  (p->c.act_dim > 0 || rep == 1), "amlp_forward: bad argument (N=%d, rep=%d, max_rows=%d)", N, rep, p ? p->c.max_rows : -1);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = p->c.obs_dim, E = p->c.act_dim, H1 = p->c.hidden1, H2 = p->c.hidden2, K = p->c.out_dim, R = N / rep;
+    const float* P = p->params;
+    const int64_t* o = p->off;
+    int rc;
+    if (E == 0) {
+        if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->h1, H1, N, H1, D, ACT_RELU, st))) return rc;
+    } else {
+        if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st))) return rc;
+        if ((rc = launch_gemm_f32(act, E, P + o[AP_W1] + (size_t)D * H1, H1, nullptr, p->h1, H1, N, H1, E, ACT_RELU, st, p->proj, H1, rep)))
+            return rc;
+    }
+    if ((rc = launch_gemm_f32(p->h1, H1, P + o[AP_W2], H2, P + o[AP_B2], p->h2, H2, N, H2, H1, ACT_RELU, st))) return rc;
+    if (K == 1 && p->c.head_act == ACT_NONE) {
+        hipLaunchKernelGGL(k_amlp_head1, dim3((N + 3) / 4), dim3(256), 0, st, p->h2, N, H2, P + o[AP_W3], P + o[AP_B3], out);
+        RL4RS_LAUNCH_CHECK();
+    } else if ((rc = launch_gemm_f32(p->h2, H2, P + o[AP_W3], K, P + o[AP_B3], out, K, N, K, H2, p->c.head_act, st))) {
+        return rc;
+    }
+    p->last_n = N;
+    p->last_rep = rep;
+    return RL4RS_OK;
+}
+
+// dout [N, out_dim] = gradient wrt the head's PRE-activation output (the loss kernels fold the head activation's derivative in).
+// want_param_grad: write the gradient of every parameter into the handle's flat gradient buffer; dact (optional) [N, act_dim]
+// receives the gradient wrt the action input.  Must follow rl4rs_amlp_forward of the SAME rows.
+int rl4rs_amlp_backward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, const float* act, const float* dout, float* dact,
+                        int32_t want_param_grad, void* stream) {
+    RL4RS_REQUIRE(p && obs && dout && N > 0 && rep > 0 && N % rep == 0 && (act || p->c.act_dim == 0), "amlp_backward: bad argument");
+    RL4RS_REQUIRE(N <= p->c.max_grad_rows, "amlp_backward: N=%d exceeds max_grad_rows=%d", N, p->c.max_grad_rows);
+    RL4RS_REQUIRE(N == p->last_n && rep == p->last_rep, "amlp_backward: does not follow the forward of the same rows (forward N=%d rep=%d)",
+                  p->last_n, p->last_rep);
+    RL4RS_REQUIRE(!dact || p->c.act_dim > 0, "amlp_backward: no action input to differentiate");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = p->c.obs_dim, E = p->c.act_dim, H1 = p->c.hidden1, H2 = p->c.hidden2, K = p->c.out_dim, R = N / rep;
+    const float* P = p->params;
+    float* G = p->grad;
+    const int64_t* o = p->off;
+    auto ew = [](int n) { return dim3((n + 255) / 256); };
+    const dim3 b256(256);
+    int rc;
+    if (want_param_grad) {
+        st_tn(p->cx, st, p->h2, H2, H2, dout, K, K, N, G + o[AP_W3]);
+        st_cs(p->cx, st, dout, K, K, N, G + o[AP_B3]);
+    }
+    if ((rc = st_back(p->cx, st, dout, K, K, P + o[AP_W3], K, H2, p->d_h2, H2, N))) return rc;
+    hipLaunchKernelGGL(k_relu_bwd, ew(N * H2), b256, 0, st, p->d_h2, (int64_t)H2, p->h2, (int64_t)H2, N * H2, H2);
+    if (want_param_grad) {
+        st_tn(p->cx, st, p->h1, H1, H1, p->d_h2, H2, H2, N, G + o[AP_W2]);
+        st_cs(p->cx, st, p->d_h2, H2, H2, N, G + o[AP_B2]);
+    }
+    if ((rc = st_back(p->cx, st, p->d_h2, H2, H2, P + o[AP_W2], H2, H1, p->d_h1, H1, N))) return rc;
+    hipLaunchKernelGGL(k_relu_bwd, ew(N * H1), b256, 0, st, p->d_h1, (int64_t)H1, p->h1, (int64_t)H1, N * H1, H1);
+    if (want_param_grad) {
+        const float* dp = p->d_h1;
+        if (rep > 1) {
+            hipLaunchKernelGGL(k_group_sum, ew(R * H1), b256, 0, st, p->d_h1, R, rep, H1, p->d_proj);
+            dp = p->d_proj;
+        }
+        st_tn(p->cx, st, obs, D, D, dp, H1, H1, R, G + o[AP_W1]);
+        st_cs(p->cx, st, dp, H1, H1, R, G + o[AP_B1]);
+        if (E > 0) st_tn(p->cx, st, act, E, E, p->d_h1, H1, H1, N, G + o[AP_W1] + (size_t)D * H1);
+    }
+    if (dact && (rc = st_back(p->cx, st, p->d_h1, H1, H1, P + o[AP_W1] + (size_t)D * H1, H1, E, dact, E, N))) return rc;
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// torch.optim.Adam (see rl4rs_qnet_adam_step)
+int rl4rs_amlp_adam_step(rl4rs_amlp* p, float lr, float beta1, float beta2, float eps, void* stream) {
+    RL4RS_REQUIRE(p, "amlp_adam_step: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    p->adam_t += 1;
+    const double t = (double)p->adam_t;
+    const double c2 = sqrt(1.0 - pow((double)beta2, t));
+    const float lr_t = (float)(lr * c2 / (1.0 - pow((double)beta1, t)));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((p->n_params + 255) / 256)), dim3(256), 0, st, p->params, p->grad, p->adam_m, p->adam_v,
+                       (int)p->n_params, lr_t, beta1, beta2, (float)(eps * c2), (const float*)nullptr, 0.f);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_cvae_sample(int32_t N, int32_t L, const float* enc_out, const float* eps, float min_logstd, float max_logstd, float* z,
+                      void* stream) {
+    RL4RS_REQUIRE(enc_out && eps && z && N > 0 && L > 0, "cvae_sample: bad argument");
+    hipLaunchKernelGGL(k_cvae_sample, dim3((N * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, L, enc_out, eps, min_logstd, max_logstd, z);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_cvae_loss(int32_t N, int32_t E, int32_t L, const float* decoded, const float* actions, const float* enc_out, float min_logstd,
+                    float max_logstd, float* d_dec_pre, float* rows_scratch, float* loss2, void* stream) {
+    RL4RS_REQUIRE(decoded && actions && enc_out && d_dec_pre && rows_scratch && loss2 && N > 0 && E > 0 && L > 0, "cvae_loss: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    float2* rows = reinterpret_cast<float2*>(rows_scratch);
+    hipLaunchKernelGGL(k_cvae_loss, dim3((N + 3) / 4), dim3(256), 0, st, N, E, L, decoded, actions, enc_out, min_logstd, max_logstd, d_dec_pre, rows);
+    hipLaunchKernelGGL(k_q_mean2, dim3(1), dim3(256), 0, st, rows, N, loss2);     // {sum_e se / N, sum_l kl / N}: the caller divides by E, L
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_cvae_encoder_grad(int32_t N, int32_t L, const float* enc_out, const float* eps, const float* dz, float beta, float min_logstd,
+                            float max_logstd, float* d_enc_out, void* stream) {
+    RL4RS_REQUIRE(enc_out && eps && dz && d_enc_out && N > 0 && L > 0, "cvae_encoder_grad: bad argument");
+    hipLaunchKernelGGL(k_cvae_enc_grad, dim3((N * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, L, enc_out, eps, dz, beta, min_logstd,
+                       max_logstd, d_enc_out);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_residual_action(int32_t N, int32_t E, const float* action, const float* tanh_out, float scale, float* out, void* stream) {
+    RL4RS_REQUIRE(action && tanh_out && out && N > 0 && E > 0, "residual_action: bad argument");
+    hipLaunchKernelGGL(k_residual_action, dim3((N * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, N * E, action, tanh_out, scale, out);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_residual_grad(int32_t N, int32_t E, const float* action, const float* tanh_out, float scale, const float* d_out, float* d_pre,
+                        void* stream) {
+    RL4RS_REQUIRE(action && tanh_out && d_out && d_pre && N > 0 && E > 0, "residual_grad: bad argument");
+    hipLaunchKernelGGL(k_residual_grad, dim3((N * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, N * E, action, tanh_out, scale, d_out, d_pre);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_bcq_target(int32_t B, int32_t n, const float* q1, const float* q2, float lam, const float* rewards, const float* terminals,
+                     float gamma, float* y, int32_t* best, void* stream) {
+    RL4RS_REQUIRE(q1 && B > 0 && n > 0 && (y || best) && (!rewards || terminals), "bcq_target: bad argument");
+    hipLaunchKernelGGL(k_bcq_target, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, n, q1, q2, lam, rewards, terminals, gamma, y, best);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_pick_rows(int32_t B, int32_t n, int32_t E, const float* rows, const int32_t* best, float* out, void* stream) {
+    RL4RS_REQUIRE(rows && best && out && B > 0 && n > 0 && E > 0, "pick_rows: bad argument");
+    hipLaunchKernelGGL(k_pick_rows, dim3((B * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n, E, rows, best, out);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_critic_mse(int32_t N, const float* q1, const float* q2, const float* y, float* dq1, float* dq2, float* loss2, void* stream) {
+    RL4RS_REQUIRE(q1 && q2 && y && dq1 && dq2 && loss2 && N > 0, "critic_mse: bad argument");
+    hipLaunchKernelGGL(k_critic_mse, dim3(1), dim3(256), 0, (hipStream_t)stream, N, q1, q2, y, dq1, dq2, loss2);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+}  // extern "C"

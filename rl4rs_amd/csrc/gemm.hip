@@ -20,8 +20,6 @@ namespace rl4rs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_RELU = 4 };
-
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case ACT_ELU: return x > 0.f ? x : expm1f(x);
@@ -37,7 +35,8 @@ constexpr int GBM = 128, GBN = 64, GBK = 32, GLD = GBK + 4;
 __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, int64_t lda,
                                                   const float* __restrict__ W, int64_t ldw,
                                                   const float* __restrict__ bias, float* __restrict__ C,
-                                                  int64_t ldc, int M, int N, int K, int act) {
+                                                  int64_t ldc, int M, int N, int K, int act,
+                                                  const float* __restrict__ addend, int64_t ldadd, int add_div) {
     __shared__ __attribute__((aligned(16))) float As[2][GBM][GLD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -121,8 +120,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
             int row = (r & 3) + 8 * (r >> 2) + 4 * half;
             int g0 = m0 + wm * 64 + row;
             int g1 = g0 + 32;
-            if (g0 < M) C[(size_t)g0 * ldc + col] = apply_act(acc0[r] + bv, act);
-            if (g1 < M) C[(size_t)g1 * ldc + col] = apply_act(acc1[r] + bv, act);
+            // optional addend row g / add_div: a term shared by add_div consecutive rows (contirl.hpp: the observation side of a
+            // first layer whose observation is repeated for add_div sampled actions)
+            if (g0 < M) C[(size_t)g0 * ldc + col] = apply_act(acc0[r] + bv + (addend ? addend[(size_t)(g0 / add_div) * ldadd + col] : 0.f), act);
+            if (g1 < M) C[(size_t)g1 * ldc + col] = apply_act(acc1[r] + bv + (addend ? addend[(size_t)(g1 / add_div) * ldadd + col] : 0.f), act);
         }
     }
 }
@@ -784,14 +785,14 @@ int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float
 }
 
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* c,
-                    int64_t ldc, int M, int N, int K, int act, hipStream_t st) {
+                    int64_t ldc, int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, int add_div) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
     dim3 grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN);
     if (grid.y > 65535u) {
         set_error("gemm: N=%d too large", N);
         return RL4RS_EINVAL;
     }
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act, addend, ldadd, add_div > 0 ? add_div : 1);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

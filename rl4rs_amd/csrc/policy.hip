@@ -1752,3 +1752,4 @@ int rl4rs_policy_set_option(rl4rs_policy* p, int32_t which, int32_t value) {
 #include "dientrain.hpp"
 #include "rawtrain.hpp"
 #include "qlearn.hpp"
+#include "contirl.hpp"

@@ -1492,3 +1492,198 @@ class DeviceQNet(object):
         out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
         check(self.lib.rl4rs_q_best_action(q.shape[0], self.A, _ptr(q), _ptr(imitator_logits), action_flexibility, _ptr(out), _stream()))
         return out
+
+
+class DeviceAMLP(object):
+    """rl4rs_amlp handle: d3rlpy's default continuous-control network - ``VectorEncoderWithAction([256, 256], relu)`` on
+    ``cat([x, action])`` (``act_dim = 0``: plain ``VectorEncoder``) + one Linear head - with forward, backward (parameter and
+    action-input gradients) and torch-style Adam on the device.  ``params``: dict of float32 arrays stored [in, out]:
+    fc1_w [obs_dim + act_dim, hidden1] (observation rows first), fc1_b, fc2_w, fc2_b, head_w, head_b.
+    ``head_act``: 'none' or 'tanh'.  The building block of the continuous BCQ / CQL learners (``offline_rl.BCQ`` / ``CQL``)."""
+
+    HEAD_ACTS = {'none': 0, 'elu': 1, 'sigmoid': 2, 'tanh': 3, 'relu': 4}
+
+    def __init__(self, obs_dim, act_dim, out_dim, params, hidden1=256, hidden2=256, head_act='none', max_rows=256, max_grad_rows=None,
+                 device=None):
+        _lib.require_device()
+        self.lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.D, self.E, self.K, self.H1, self.H2 = int(obs_dim), int(act_dim), int(out_dim), int(hidden1), int(hidden2)
+        self.max_rows = int(max_rows)
+        self.max_grad_rows = self.max_rows if max_grad_rows is None else int(max_grad_rows)
+        self.shapes = [('fc1_w', (self.D + self.E, self.H1)), ('fc1_b', (self.H1,)), ('fc2_w', (self.H1, self.H2)), ('fc2_b', (self.H2,)),
+                       ('head_w', (self.H2, self.K)), ('head_b', (self.K,))]
+        flat = []
+        for name, shape in self.shapes:
+            arr = np.ascontiguousarray(params[name], dtype=np.float32)
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError('amlp parameter %r has shape %r, expected %r' % (name, tuple(arr.shape), tuple(shape)))
+            flat.append(arr.reshape(-1))
+        flat = np.ascontiguousarray(np.concatenate(flat))
+        cfg = _lib.AmlpCfg(self.D, self.E, self.H1, self.H2, self.K, self.HEAD_ACTS[head_act], self.max_rows, self.max_grad_rows)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.rl4rs_amlp_create(C.byref(cfg), flat.ctypes.data_as(_lib._FP), _stream(), C.byref(h)))
+        self.h = h
+        self.n_params = int(flat.size)
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.rl4rs_amlp_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _buffers(self):
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.rl4rs_amlp_params(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        return p, g, n.value
+
+    def _flat(self, which):
+        p, g, n = self._buffers()
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(out), p if which == 'params' else g, n * 4, _stream()))
+        return out
+
+    def _split(self, flat):
+        out, o = {}, 0
+        for name, shape in self.shapes:
+            k = int(np.prod(shape))
+            out[name] = flat[o:o + k].reshape(shape)
+            o += k
+        return out
+
+    def weights(self):
+        return self._split(self._flat('params'))
+
+    def gradients(self):
+        return self._split(self._flat('grad'))
+
+    def flat_gradient(self):
+        return self._flat('grad')
+
+    def flat_params(self):
+        return self._flat('params')
+
+    def set_flat_gradient(self, flat):
+        _, g, n = self._buffers()
+        assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
+        check(self.lib.rl4rs_copy_d2d(g, _ptr(flat), n * 4, _stream()))
+
+    def set_flat_params(self, flat):
+        p, _, n = self._buffers()
+        assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
+        check(self.lib.rl4rs_copy_d2d(p, _ptr(flat), n * 4, _stream()))
+
+    def copy_from(self, other):
+        check(self.lib.rl4rs_amlp_copy_params(self.h, other.h, _stream()))
+
+    def soft_update_from(self, other, tau):
+        check(self.lib.rl4rs_amlp_soft_update(self.h, other.h, tau, _stream()))
+
+    def check_status(self):
+        pass
+
+    def _rows(self, obs, act, rep):
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.D
+        n = obs.shape[0] * rep
+        if self.E:
+            assert act.is_cuda and act.dtype == torch.float32 and act.is_contiguous() and tuple(act.shape) == (n, self.E), \
+                (tuple(act.shape), n, self.E)
+        return n
+
+    def forward(self, obs, act=None, rep=1, out=None):
+        """out [N, out_dim] for obs [N / rep, obs_dim] (each observation shared by ``rep`` consecutive action rows) and act
+        [N, act_dim].  Keeps the activations for ``backward``."""
+        n = self._rows(obs, act, rep)
+        if out is None:
+            out = torch.empty((n, self.K), dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_amlp_forward(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))
+        return out
+
+    def backward(self, obs, act, dout, rep=1, want_dact=False, want_param_grad=True):
+        """Given the gradient wrt the head's PRE-activation output: parameter gradients into the handle, returns the gradient
+        wrt ``act`` when ``want_dact``."""
+        n = self._rows(obs, act, rep)
+        assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous() and dout.numel() == n * self.K
+        dact = torch.empty((n, self.E), dtype=torch.float32, device=self.device) if want_dact else None
+        check(self.lib.rl4rs_amlp_backward(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(dout), _ptr(dact), 1 if want_param_grad else 0,
+                                           _stream()))
+        return dact
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        check(self.lib.rl4rs_amlp_adam_step(self.h, lr, beta1, beta2, eps, _stream()))
+
+
+def cvae_sample(enc_out, eps, min_logstd=-20.0, max_logstd=2.0):
+    """z = mu + exp(clamp(logstd)) * eps for enc_out [N, 2L] = [mu | logstd]."""
+    lib = _lib.load()
+    N, L = eps.shape
+    z = torch.empty_like(eps)
+    check(lib.rl4rs_cvae_sample(N, L, _ptr(enc_out), _ptr(eps), min_logstd, max_logstd, _ptr(z), _stream()))
+    return z
+
+
+def cvae_loss(decoded, actions, enc_out, min_logstd=-20.0, max_logstd=2.0):
+    """(loss2 = [mean_n sum_e (y - a)^2, mean_n sum_l KL], gradient of the mse term wrt the decoder's pre-tanh output)."""
+    lib = _lib.load()
+    N, E = decoded.shape
+    L = enc_out.shape[1] // 2
+    d = torch.empty_like(decoded)
+    rows = torch.empty((N, 2), dtype=torch.float32, device=decoded.device)
+    loss2 = torch.empty(2, dtype=torch.float32, device=decoded.device)
+    check(lib.rl4rs_cvae_loss(N, E, L, _ptr(decoded), _ptr(actions), _ptr(enc_out), min_logstd, max_logstd, _ptr(d), _ptr(rows), _ptr(loss2),
+                              _stream()))
+    return loss2, d
+
+
+def cvae_encoder_grad(enc_out, eps, dz, beta, min_logstd=-20.0, max_logstd=2.0):
+    lib = _lib.load()
+    N, L = eps.shape
+    d = torch.empty_like(enc_out)
+    check(lib.rl4rs_cvae_encoder_grad(N, L, _ptr(enc_out), _ptr(eps), _ptr(dz), beta, min_logstd, max_logstd, _ptr(d), _stream()))
+    return d
+
+
+def residual_action(action, tanh_out, scale):
+    lib = _lib.load()
+    N, E = action.shape
+    out = torch.empty_like(action)
+    check(lib.rl4rs_residual_action(N, E, _ptr(action), _ptr(tanh_out), scale, _ptr(out), _stream()))
+    return out
+
+
+def residual_grad(action, tanh_out, scale, d_out):
+    lib = _lib.load()
+    N, E = action.shape
+    d = torch.empty_like(action)
+    check(lib.rl4rs_residual_grad(N, E, _ptr(action), _ptr(tanh_out), scale, _ptr(d_out), _ptr(d), _stream()))
+    return d
+
+
+def bcq_target(q1, q2, n, lam, rewards=None, terminals=None, gamma=0.99, want_best=False):
+    """(y [B], best [B] or None): max over the n sampled actions of the lam-weighted twin value (q2 None: of q1)."""
+    lib = _lib.load()
+    B = q1.numel() // n
+    y = torch.empty(B, dtype=torch.float32, device=q1.device)
+    best = torch.empty(B, dtype=torch.int32, device=q1.device) if want_best else None
+    check(lib.rl4rs_bcq_target(B, n, _ptr(q1), _ptr(q2), lam, _ptr(rewards), _ptr(terminals), gamma, _ptr(y), _ptr(best), _stream()))
+    return y, best
+
+
+def pick_rows(rows, best, n):
+    lib = _lib.load()
+    B, E = best.numel(), rows.shape[1]
+    out = torch.empty((B, E), dtype=torch.float32, device=rows.device)
+    check(lib.rl4rs_pick_rows(B, n, E, _ptr(rows), _ptr(best), _ptr(out), _stream()))
+    return out
+
+
+def critic_mse(q1, q2, y):
+    """(loss2 = [mean (q1 - y)^2, mean (q2 - y)^2], dq1, dq2)."""
+    lib = _lib.load()
+    N = y.numel()
+    dq1, dq2 = torch.empty_like(q1), torch.empty_like(q2)
+    loss2 = torch.empty(2, dtype=torch.float32, device=y.device)
+    check(lib.rl4rs_critic_mse(N, _ptr(q1), _ptr(q2), _ptr(y), _ptr(dq1), _ptr(dq2), _ptr(loss2), _stream()))
+    return loss2, dq1, dq2

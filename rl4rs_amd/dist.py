@@ -68,6 +68,14 @@ def world_size():
     return 1
 
 
+def rank():
+    """Rank in the initialised process group (0 when torch.distributed is not in use)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return 0
+
+
 def _needs_host_staging(t):
     """gloo moves host memory: a CUDA tensor goes through a pinned host copy (2 ranks on ONE GPU in the GPU tests, CPU
     tests); RCCL ("nccl") works on device memory directly."""

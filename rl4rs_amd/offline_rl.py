@@ -12,6 +12,12 @@ through ``librl4rs_hip`` (``rl4rs_qnet_*``, ``rl4rs_qloss_*``); this module is t
   beta 0.5, Adam lr 6.25e-5, hard target sync every ``target_update_interval`` (8000) updates.
 * ``DiscreteCQL`` - DoubleDQN + ``alpha * (logsumexp Q - Q[a])`` (alpha 1.0) on d3rlpy's default two-layer encoder, as the
   script leaves the custom factory commented out for CQL.
+* ``BCQ`` - the CONTINUOUS-action learner of ``'BCQ-conti'`` (script/batchrl_trainer.py:61-73, ``d3rlpy.algos.BCQ(batch_size=256)``
+  on default encoders): what BASELINE configs[4] is quoted on.  Trains on the dataset ``generate_offline_dataset`` emits for
+  ``support_conti_env`` (actions = 32-d item embeddings, :220-270): conditional-VAE imitator, residual perturbation actor, twin
+  critics with the lam-weighted min/max target over 100 sampled actions, soft target updates; ``predict`` returns the embedding
+  the env's K-NN resolves (``env.step(policy.predict(obs))``, batchrl_trainer.py:398-399 with ``predict_with_mask`` ->
+  ``predict`` for continuous envs, rl4rs/policy/policy_model.py:17-19).
 
 d3rlpy is absent from this image (parity unpinned): the hyper-parameter defaults above are d3rlpy 0.91's as published;
 every gradient is checked against torch autograd of the restated model in ``tests/test_gpu_offline_rl.py``.  With
@@ -22,15 +28,20 @@ import numpy as np
 import torch
 
 from . import device as D
+from . import device as D_
 from . import dist as rdist
 
 
-def transitions_from_mdp(observations, actions, rewards, terminals):
+def transitions_from_mdp(observations, actions, rewards, terminals, discrete_action=True):
     """(obs, act, next_reward, next_obs, terminal) tensors from MDPDataset-style arrays (rows in time order, an episode
     ends at ``terminals == 1``).  Row t of an episode gives the transition (o_t, a_t, r_{t+1}, o_{t+1}, 0); the terminal
-    row gives (o_T, a_T, 0, zeros, 1); a trailing episode without terminal flag drops its last row."""
+    row gives (o_T, a_T, 0, zeros, 1); a trailing episode without terminal flag drops its last row.
+    ``discrete_action=False`` (``MDPDataset(..., discrete_action=False)``, batchrl_trainer.py:266): actions stay float [N, E]."""
     obs = torch.as_tensor(observations, dtype=torch.float32)
-    act = torch.as_tensor(actions).reshape(obs.shape[0], -1)[:, 0].to(torch.int32)
+    if discrete_action:
+        act = torch.as_tensor(actions).reshape(obs.shape[0], -1)[:, 0].to(torch.int32)
+    else:
+        act = torch.as_tensor(actions, dtype=torch.float32).reshape(obs.shape[0], -1)
     rew = torch.as_tensor(rewards, dtype=torch.float32).reshape(-1)
     ter = torch.as_tensor(terminals, dtype=torch.float32).reshape(-1)
     n = obs.shape[0]
@@ -219,3 +230,207 @@ class DiscreteCQL(_QLearner):
 
     def predict(self, obs):
         return self.q.best_action(self.q.forward(obs))
+
+
+def init_amlp_params(obs_dim, act_dim, out_dim, hidden1=256, hidden2=256, seed=0, heads=1):
+    """torch's default Linear initialiser (U(+-1/sqrt(fan_in)) for weight and bias), stored [in, out]; ``heads`` Linear layers
+    of ``out_dim // heads`` outputs side by side (the mu / logstd pair of a ConditionalVAE or a SquashedNormalPolicy)."""
+    rs = np.random.RandomState(seed)
+
+    def linear(fan_in, fan_out):
+        k = 1.0 / np.sqrt(fan_in)
+        return (rs.uniform(-k, k, size=(fan_in, fan_out)).astype(np.float32), rs.uniform(-k, k, size=(fan_out,)).astype(np.float32))
+
+    p = {}
+    p['fc1_w'], p['fc1_b'] = linear(obs_dim + act_dim, hidden1)
+    p['fc2_w'], p['fc2_b'] = linear(hidden1, hidden2)
+    hw = [linear(hidden2, out_dim // heads) for _ in range(heads)]
+    p['head_w'] = np.ascontiguousarray(np.concatenate([w for w, _ in hw], axis=1))
+    p['head_b'] = np.ascontiguousarray(np.concatenate([b for _, b in hw]))
+    return p
+
+
+def _allreduce_group(nets):
+    """Data parallel: ONE mean all-reduce for the flat gradients of a group of networks that are stepped together."""
+    if rdist.world_size() <= 1:
+        return
+    flats = [net.flat_gradient() for net in nets]
+    g = torch.cat(flats)
+    rdist.allreduce_mean_(g)
+    o = 0
+    for net, f in zip(nets, flats):
+        net.set_flat_gradient(g[o:o + f.numel()].contiguous())
+        o += f.numel()
+
+
+class BCQ(object):
+    """d3rlpy.algos.BCQ(batch_size=256) as 'BCQ-conti' instantiates it (script/batchrl_trainer.py:61-73): default
+    ``VectorEncoderWithAction([256, 256])`` everywhere, Adam 1e-3 for actor / critic / imitator, gamma 0.99, tau 0.005, two
+    critics, lam 0.75, 100 sampled actions, action_flexibility 0.05, latent_size 32, beta 0.5, update_actor_interval 1,
+    rl_start_step 0 (d3rlpy 0.91 defaults; d3rlpy is absent here - PARITY UNPINNED).
+
+    One ``update`` = d3rlpy's ``BCQ._update``: imitator step, critic step, actor step, soft target updates.  All network
+    arithmetic runs through ``librl4rs_hip`` (``rl4rs_amlp_*`` and the cvae / residual / bcq_target / critic_mse entry points);
+    torch supplies device memory and the Gaussian noise.  ``noise`` (tests): dict with ``eps`` [B, L], ``z_target`` [B * n, L]
+    and ``z_actor`` [B, L] replacing the three ``torch.randn`` draws (the latter two before clamping to +-0.5).
+    With ``torch.distributed`` initialised each rank trains on its own minibatches; the flat gradients of the networks of a
+    phase are mean-all-reduced together before Adam (3 collectives per update; the phases depend on each other)."""
+
+    def __init__(self, config, obs_dim, action_size=None, batch_size=256, actor_learning_rate=1e-3, critic_learning_rate=1e-3,
+                 imitator_learning_rate=1e-3, gamma=0.99, tau=0.005, update_actor_interval=1, lam=0.75, n_action_samples=100,
+                 action_flexibility=0.05, rl_start_step=0, latent_size=32, beta=0.5, predict_rows=512, seed=0, device=None):
+        self.config = config
+        self.D = int(obs_dim)
+        self.E = int(action_size if action_size is not None else config['action_emb_size'])
+        self.L = int(latent_size)
+        self.batch_size = int(batch_size)
+        self.n = int(n_action_samples)
+        self.actor_lr, self.critic_lr, self.imitator_lr = float(actor_learning_rate), float(critic_learning_rate), float(imitator_learning_rate)
+        self.gamma, self.tau, self.lam = float(gamma), float(tau), float(lam)
+        self.update_actor_interval, self.rl_start_step = int(update_actor_interval), int(rl_start_step)
+        self.scale, self.beta = float(action_flexibility), float(beta)
+        self.predict_rows = max(int(predict_rows), 1)
+        self.seed = int(seed)
+        self.total_step = 0
+        B, n, D, E, L = self.batch_size, self.n, self.D, self.E, self.L
+        big = max(B, self.predict_rows) * n
+
+        def net(act_dim, out_dim, seed_off, max_rows, grad_rows, head_act='none', heads=1):
+            return D_.DeviceAMLP(D, act_dim, out_dim, init_amlp_params(D, act_dim, out_dim, seed=seed + seed_off, heads=heads),
+                                 head_act=head_act, max_rows=max_rows, max_grad_rows=grad_rows, device=device)
+
+        self.imit_enc = net(E, 2 * L, 0, B, B, heads=2)                 # ConditionalVAE._encoder_encoder + _mu | _logstd
+        self.imit_dec = net(L, E, 1, big, B, head_act='tanh')           # ConditionalVAE._decoder_encoder + _fc, tanh
+        self.policy = net(E, E, 2, big, B, head_act='tanh')             # DeterministicResidualPolicy
+        self.policy_targ = net(E, E, 2, B * n, 0, head_act='tanh')
+        self.q1 = net(E, 1, 3, big, B)                                  # ContinuousMeanQFunction x 2
+        self.q2 = net(E, 1, 4, big, B)
+        self.q1_targ = net(E, 1, 3, B * n, 0)
+        self.q2_targ = net(E, 1, 4, B * n, 0)
+        self.policy_targ.copy_from(self.policy)
+        self.q1_targ.copy_from(self.q1)
+        self.q2_targ.copy_from(self.q2)
+        self.nets = [self.imit_enc, self.imit_dec, self.policy, self.policy_targ, self.q1, self.q2, self.q1_targ, self.q2_targ]
+        self.device = self.q1.device
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self.seed + 1000003 * rdist.rank())
+        self._minus_inv_b = None
+
+    def _randn(self, rows, noise, key):
+        if noise is not None and key in noise:
+            return noise[key].to(device=self.device, dtype=torch.float32).contiguous()
+        return torch.randn((rows, self.L), generator=self._gen, device=self.device, dtype=torch.float32)
+
+    def _sample_actions(self, obs, z, policy, rep):
+        """imitator.decode(x, clip(z)) -> policy residual: [rows, E] actions for ``rep`` latents per observation."""
+        sampled = self.imit_dec.forward(obs, z, rep=rep)
+        t = policy.forward(obs, sampled, rep=rep)
+        return sampled, t, D_.residual_action(sampled, t, self.scale)
+
+    def update(self, obs, act, rew, nxt, ter, noise=None):
+        B, n = obs.shape[0], self.n
+        metrics = {}
+        # --- imitator (BCQImpl.update_imitator: ConditionalVAE.compute_error) ---
+        eps = self._randn(B, noise, 'eps')
+        enc_out = self.imit_enc.forward(obs, act)
+        z = D_.cvae_sample(enc_out, eps)
+        y = self.imit_dec.forward(obs, z)
+        loss2, d_dec = D_.cvae_loss(y, act, enc_out)
+        dz = self.imit_dec.backward(obs, z, d_dec, want_dact=True)
+        d_enc = D_.cvae_encoder_grad(enc_out, eps, dz, self.beta)
+        self.imit_enc.backward(obs, act, d_enc)
+        _allreduce_group([self.imit_enc, self.imit_dec])
+        self.imit_enc.adam_step(self.imitator_lr)
+        self.imit_dec.adam_step(self.imitator_lr)
+        metrics['imitator_loss'] = loss2[0] / self.E + self.beta * loss2[1] / self.L
+        if self.total_step >= self.rl_start_step:
+            # --- critic (DDPGBaseImpl.update_critic with BCQImpl.compute_target) ---
+            zt = self._randn(B * n, noise, 'z_target').clamp(-0.5, 0.5)
+            _, _, a_next = self._sample_actions(nxt, zt, self.policy_targ, n)
+            q1n = self.q1_targ.forward(nxt, a_next, rep=n)
+            q2n = self.q2_targ.forward(nxt, a_next, rep=n)
+            yq, _ = D_.bcq_target(q1n, q2n, n, self.lam, rew, ter, self.gamma)
+            q1v = self.q1.forward(obs, act)
+            q2v = self.q2.forward(obs, act)
+            closs2, dq1, dq2 = D_.critic_mse(q1v, q2v, yq)
+            self.q1.backward(obs, act, dq1)
+            self.q2.backward(obs, act, dq2)
+            _allreduce_group([self.q1, self.q2])
+            self.q1.adam_step(self.critic_lr)
+            self.q2.adam_step(self.critic_lr)
+            metrics['critic_loss'] = closs2[0] + closs2[1]
+            if self.total_step % self.update_actor_interval == 0:
+                # --- actor (BCQImpl.compute_actor_loss: -Q_1(s, pi(s, decode(s, z))).mean()) ---
+                za = self._randn(B, noise, 'z_actor').clamp(-0.5, 0.5)
+                sampled, t, a_pi = self._sample_actions(obs, za, self.policy, 1)
+                qv = self.q1.forward(obs, a_pi)
+                if self._minus_inv_b is None or self._minus_inv_b.numel() != B:
+                    self._minus_inv_b = torch.full((B, 1), -1.0 / B, dtype=torch.float32, device=self.device)
+                da = self.q1.backward(obs, a_pi, self._minus_inv_b, want_dact=True, want_param_grad=False)
+                d_pre = D_.residual_grad(sampled, t, self.scale, da)
+                self.policy.backward(obs, sampled, d_pre)
+                _allreduce_group([self.policy])
+                self.policy.adam_step(self.actor_lr)
+                metrics['actor_loss'] = -qv.mean()
+                self.policy_targ.soft_update_from(self.policy, self.tau)
+                self.q1_targ.soft_update_from(self.q1, self.tau)
+                self.q2_targ.soft_update_from(self.q2, self.tau)
+        self.total_step += 1
+        return metrics
+
+    def fit(self, transitions, n_steps, shuffle_seed=None):
+        """``n_steps`` updates over ``transitions`` (``transitions_from_mdp(..., discrete_action=False)``), epoch-wise random
+        permutation like d3rlpy's ``fit``; returns dict of per-step loss lists."""
+        obs, act, rew, nxt, ter = [t.to(self.device) for t in transitions]
+        n = obs.shape[0]
+        assert n >= self.batch_size, 'dataset smaller than one minibatch'
+        assert act.dim() == 2 and act.shape[1] == self.E and act.dtype == torch.float32, 'BCQ needs continuous actions [N, %d]' % self.E
+        rs = np.random.RandomState(self.seed if shuffle_seed is None else shuffle_seed)
+        hist, perm, pos = [], None, n
+        for _ in range(n_steps):
+            if pos + self.batch_size > n:
+                perm = torch.from_numpy(rs.permutation(n)).to(obs.device)
+                pos = 0
+            idx = perm[pos:pos + self.batch_size]
+            pos += self.batch_size
+            hist.append(self.update(obs[idx].contiguous(), act[idx].contiguous(), rew[idx].contiguous(), nxt[idx].contiguous(),
+                                    ter[idx].contiguous()))
+        out = {}
+        for k in ('imitator_loss', 'critic_loss', 'actor_loss'):
+            vals = [h[k] for h in hist if k in h]
+            out[k] = [float(x) for x in torch.stack(vals).cpu()] if vals else []
+        return out
+
+    def predict(self, obs, noise=None):
+        """BCQImpl._predict_best_action: 100 sampled actions per observation, the one the FIRST critic values highest.
+        obs [B, D] (device tensor or array) -> actions [B, E] on the device: the embedding the env's K-NN resolves."""
+        obs = D_._dev_tensor(obs, torch.float32, self.device)
+        out = torch.empty((obs.shape[0], self.E), dtype=torch.float32, device=self.device)
+        n = self.n
+        for lo in range(0, obs.shape[0], self.predict_rows):
+            x = obs[lo:lo + self.predict_rows].contiguous()
+            b = x.shape[0]
+            if noise is not None:
+                z = noise[lo * n:(lo + b) * n].to(device=self.device, dtype=torch.float32)
+            else:
+                z = torch.randn((b * n, self.L), generator=self._gen, device=self.device, dtype=torch.float32)
+            _, _, a = self._sample_actions(x, z.clamp(-0.5, 0.5).contiguous(), self.policy, n)
+            q = self.q1.forward(x, a, rep=n)
+            _, best = D_.bcq_target(q, None, n, 0.0, want_best=True)
+            out[lo:lo + b] = D_.pick_rows(a, best, n)
+        return out
+
+    def predict_value(self, obs, actions):
+        """AlgoBase.predict_value: the mean of the critics' values of (obs, action)."""
+        obs = D_._dev_tensor(obs, torch.float32, self.device)
+        actions = D_._dev_tensor(actions, torch.float32, self.device)
+        out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
+        rows = max(self.batch_size, self.predict_rows) * self.n
+        for lo in range(0, obs.shape[0], rows):
+            x, a = obs[lo:lo + rows].contiguous(), actions[lo:lo + rows].contiguous()
+            out[lo:lo + x.shape[0]] = 0.5 * (self.q1.forward(x, a)[:, 0] + self.q2.forward(x, a)[:, 0])
+        return out
+
+    def close(self):
+        for net in self.nets:
+            net.close()

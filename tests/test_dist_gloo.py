@@ -111,6 +111,38 @@ def test_offline_learner_update_is_data_parallel():
         assert g == mean and p == [-0.5 * x for x in mean] and steps == 1
 
 
+def _group_worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from rl4rs_amd import dist as D
+    from rl4rs_amd.offline_rl import _allreduce_group
+    D.init('gloo')
+    nets = [_StubNet(torch.arange(4, dtype=torch.float32) * (rank + 1)), _StubNet(torch.ones(3) * (10 * rank))]
+    _allreduce_group(nets)
+    D.barrier()
+    out.put((rank, D.rank(), nets[0].g.tolist(), nets[1].g.tolist()))
+
+
+def test_continuous_learner_groups_its_gradient_allreduce():
+    """offline_rl._allreduce_group (continuous BCQ / CQL): the flat gradients of the networks stepped together (the two halves
+    of the VAE, the twin critics) travel as ONE mean all-reduce and come back split per network."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, drank, g0, g1 in res:
+        assert rank == drank
+        assert g0 == [1.5 * k for k in range(4)] and g1 == [5.0] * 3
+
+
 def _rows_worker(rank, world, port, out):
     import torch
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
