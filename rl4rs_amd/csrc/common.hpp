@@ -58,6 +58,15 @@ int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, co
                     float* c, int64_t ldc, int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr,
                     int64_t ldadd = 0, int add_div = 1);
 
+// Small-M form (one 32 x 32 tile per workgroup, K split over its four waves; launch_gemm_f32 picks it by itself when the big
+// tiling would leave most CUs idle) with an optional SECOND operand pair: C = act(A W + A2 W2 + bias + addend).
+int launch_gemm_small(const float* a, int64_t lda, const float* w, int64_t ldw, int K, const float* a2, int64_t lda2, const float* w2,
+                      int64_t ldw2, int K2, const float* bias, float* c, int64_t ldc, int M, int N, int act, hipStream_t st,
+                      const float* addend = nullptr, int64_t ldadd = 0, int add_div = 1);
+// dX [M, Kin] = dY [M, Nout] W[Kin, Nout]^T, zeroed where relu_of [M, Kin] (optional: the layer's forward output) is not > 0
+int launch_gemm_nt(const float* dy, int64_t ldy, const float* w, int64_t ldw, float* dx, int64_t ldx, int M, int Kin, int Nout,
+                   hipStream_t st, const float* relu_of = nullptr, int64_t ldr = 0);
+
 // GEMM against a weight matrix pre-packed by pack_gemm_weight (gemm.hip); C = act(A W + bias + addend) with an optional
 // row-major addend [M, ldadd]
 int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float* bias, float* c, int64_t ldc,

@@ -247,7 +247,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
         for (int i = 0; i < AP_COUNT; ++i) if (sizes[i] > wmax) wmax = sizes[i];
         p->cx.chunk = 128;
         AM_FAIL(al(&p->cx.wt, wmax));
-        AM_FAIL(al(&p->cx.part, (size_t)((G + 127) / 128) * wmax));
+        AM_FAIL(al(&p->cx.part, (size_t)((G + 127) / 128) * (wmax + std::max(H1, std::max(H2, K)))));
     }
     AM_HIP(hipStreamSynchronize(st));
 #undef AM_HIP
@@ -289,6 +289,10 @@ int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, 
     int rc;
     if (E == 0) {
         if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->h1, H1, N, H1, D, ACT_RELU, st))) return rc;
+    } else if (rep == 1 && N <= 4096) {
+        // cat([x, a]) W1 as two operand pairs of one launch
+        if ((rc = launch_gemm_small(obs, D, P + o[AP_W1], H1, D, act, E, P + o[AP_W1] + (size_t)D * H1, H1, E, P + o[AP_B1], p->h1, H1, N, H1,
+                                    ACT_RELU, st))) return rc;
     } else {
         if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st))) return rc;
         if ((rc = launch_gemm_f32(act, E, P + o[AP_W1] + (size_t)D * H1, H1, nullptr, p->h1, H1, N, H1, E, ACT_RELU, st, p->proj, H1, rep)))
@@ -324,29 +328,22 @@ int rl4rs_amlp_backward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs,
     auto ew = [](int n) { return dim3((n + 255) / 256); };
     const dim3 b256(256);
     int rc;
-    if (want_param_grad) {
-        st_tn(p->cx, st, p->h2, H2, H2, dout, K, K, N, G + o[AP_W3]);
-        st_cs(p->cx, st, dout, K, K, N, G + o[AP_B3]);
-    }
-    if ((rc = st_back(p->cx, st, dout, K, K, P + o[AP_W3], K, H2, p->d_h2, H2, N))) return rc;
-    hipLaunchKernelGGL(k_relu_bwd, ew(N * H2), b256, 0, st, p->d_h2, (int64_t)H2, p->h2, (int64_t)H2, N * H2, H2);
-    if (want_param_grad) {
-        st_tn(p->cx, st, p->h1, H1, H1, p->d_h2, H2, H2, N, G + o[AP_W2]);
-        st_cs(p->cx, st, p->d_h2, H2, H2, N, G + o[AP_B2]);
-    }
-    if ((rc = st_back(p->cx, st, p->d_h2, H2, H2, P + o[AP_W2], H2, H1, p->d_h1, H1, N))) return rc;
-    hipLaunchKernelGGL(k_relu_bwd, ew(N * H1), b256, 0, st, p->d_h1, (int64_t)H1, p->h1, (int64_t)H1, N * H1, H1);
+    // per layer: ONE launch for the weight + bias gradient (k_gemm_tn with the column sums folded in) and ONE for the input
+    // gradient (k_gemm_nt: no transposed weight copy, the ReLU derivative of the layer below in its epilogue)
+    if (want_param_grad) st_tn_cs(p->cx, st, p->h2, H2, H2, dout, K, K, N, G + o[AP_W3], G + o[AP_B3]);
+    if ((rc = launch_gemm_nt(dout, K, P + o[AP_W3], K, p->d_h2, H2, N, H2, K, st, p->h2, H2))) return rc;
+    if (want_param_grad) st_tn_cs(p->cx, st, p->h1, H1, H1, p->d_h2, H2, H2, N, G + o[AP_W2], G + o[AP_B2]);
+    if ((rc = launch_gemm_nt(p->d_h2, H2, P + o[AP_W2], H2, p->d_h1, H1, N, H1, H2, st, p->h1, H1))) return rc;
     if (want_param_grad) {
         const float* dp = p->d_h1;
         if (rep > 1) {
             hipLaunchKernelGGL(k_group_sum, ew(R * H1), b256, 0, st, p->d_h1, R, rep, H1, p->d_proj);
             dp = p->d_proj;
         }
-        st_tn(p->cx, st, obs, D, D, dp, H1, H1, R, G + o[AP_W1]);
-        st_cs(p->cx, st, dp, H1, H1, R, G + o[AP_B1]);
+        st_tn_cs(p->cx, st, obs, D, D, dp, H1, H1, R, G + o[AP_W1], G + o[AP_B1]);
         if (E > 0) st_tn(p->cx, st, act, E, E, p->d_h1, H1, H1, N, G + o[AP_W1] + (size_t)D * H1);
     }
-    if (dact && (rc = st_back(p->cx, st, p->d_h1, H1, H1, P + o[AP_W1] + (size_t)D * H1, H1, E, dact, E, N))) return rc;
+    if (dact && (rc = launch_gemm_nt(p->d_h1, H1, P + o[AP_W1] + (size_t)D * H1, H1, dact, E, N, E, H1, st))) return rc;
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

@@ -129,6 +129,135 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// Small-M forms of the same fp32 GEMM for the training paths (minibatches of 256 rows: policy / offline-RL / simulator
+// training).  With 128 x 64 block tiles a 256 x 256 output is 8 workgroups on a 256-CU chip and one launch took ~32 us
+// (profiles/r04a_bcq_kernel_stats.md: 37 such launches = half of a continuous-BCQ update).  Here a workgroup owns ONE 32 x 32
+// output tile and its four waves split K (interleaved 8-wide k-blocks), so the same output is 64 workgroups x 4 waves and each
+// wave runs K / 8 MFMAs; the partial tiles meet in LDS.  Operands come straight from global memory (they are L2-resident
+// and read once per tile): A as one 16-byte load per lane per k-block (the k order inside an 8-block is permuted like
+// k_gemm_f32's), B as four coalesced dwords (NN) or one 16-byte load (NT).
+//   k_gemm_small  C[M,N] = act(A[M,K] W[K,N] (+ A2[M,K2] W2[K2,N]) + bias + addend[row / add_div])     two operand pairs: the
+//                 first layer of an action-conditioned MLP on cat([x, a]) without materialising the concatenation
+//   k_gemm_nt     C[M,Kin] = dY[M,Nout] W[Kin,Nout]^T (* [relu_of > 0])      the input gradient of a Linear layer without the
+//                 transposed weight copy, with the ReLU derivative of the layer below folded into the epilogue
+__device__ __forceinline__ float4 ld4_guard(const float* __restrict__ p, bool row_ok, int left, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok && left > 0) {
+        if (vec && left >= 4) {
+            v = *reinterpret_cast<const float4*>(p);
+        } else {
+            v.x = p[0];
+            if (left > 1) v.y = p[1];
+            if (left > 2) v.z = p[2];
+            if (left > 3) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+// split-K partial tiles -> one tile; thread (wave w, lane l) finishes accumulator registers 4w .. 4w+3 of lane l
+#define SMALL_REDUCE_PROLOGUE()                                                            \
+    __shared__ float red[4][16][64];                                                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];           \
+    __syncthreads();
+
+__global__ __launch_bounds__(256) void k_gemm_small(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw, int K,
+                                                    const float* __restrict__ A2, int64_t lda2, const float* __restrict__ W2, int64_t ldw2, int K2,
+                                                    const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int M, int N, int act,
+                                                    const float* __restrict__ addend, int64_t ldadd, int add_div) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int row = m0 + li, col = n0 + li;
+    const bool row_ok = row < M, col_ok = col < N;
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    auto run = [&](const float* __restrict__ a, int64_t la, const float* __restrict__ w, int64_t lw, int k_len) {
+        const bool vec = ((la & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+        const int nkb = (k_len + 7) / 8;
+        const float* arow = a + (size_t)(row_ok ? row : 0) * la;
+        for (int kb = wave; kb < nkb; kb += 8) {           // two k-blocks per trip: 2 + 8 loads in flight before the 8 MFMAs
+            float4 av[2];
+            float bv[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = (kb + 4 * u) * 8 + half * 4;
+                av[u] = ld4_guard(arow + k, row_ok, k_len - k, vec);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[u][i] = (col_ok && k + i < k_len) ? w[(size_t)(k + i) * lw + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u][3], acc, 0, 0, 0);
+            }
+        }
+    };
+    run(A, lda, W, ldw, K);
+    if (A2) run(A2, lda2, W2, ldw2, K2);
+    SMALL_REDUCE_PROLOGUE()
+    if (col_ok) {
+        const float bvl = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
+            const int g = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (g < M) {
+                float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane] + bvl;
+                if (addend) v += addend[(size_t)(g / add_div) * ldadd + col];
+                C[(size_t)g * ldc + col] = apply_act(v, act);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dY, int64_t ldy, const float* __restrict__ W, int64_t ldw,
+                                                 float* __restrict__ dX, int64_t ldx, int M, int Kin, int Nout,
+                                                 const float* __restrict__ relu_of, int64_t ldr) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int row = m0 + li, col = n0 + li;
+    const bool row_ok = row < M, col_ok = col < Kin;
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool vec_a = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0);
+    const bool vec_b = ((ldw & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    const float* arow = dY + (size_t)(row_ok ? row : 0) * ldy;
+    const float* brow = W + (size_t)(col_ok ? col : 0) * ldw;
+    const int nkb = (Nout + 7) / 8;
+    for (int kb = wave; kb < nkb; kb += 8) {
+        float4 av[2], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = (kb + 4 * u) * 8 + half * 4;
+            av[u] = ld4_guard(arow + k, row_ok, Nout - k, vec_a);
+            bv[u] = ld4_guard(brow + k, col_ok, Nout - k, vec_b);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+    }
+    SMALL_REDUCE_PROLOGUE()
+    if (col_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
+            const int g = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (g < M) {
+                float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+                if (relu_of && !(relu_of[(size_t)g * ldr + col] > 0.f)) v = 0.f;
+                dX[(size_t)g * ldx + col] = v;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Same GEMM with the weight matrix PRE-PACKED into MFMA B-fragment order (done once when a model is
 // loaded): Wp[ntile][kb][lane] is the float4 {W[kb*8 + (lane>>5)*4 + i][ntile*32 + (lane&31)], i=0..3},
 // K zero-padded to a multiple of 8, N to a multiple of 32.  One 16-byte load feeds four MFMAs; the next
@@ -784,6 +913,36 @@ int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float
     return RL4RS_OK;
 }
 
+constexpr unsigned SMALL_GEMM_MAX_BIG_BLOCKS = 96;
+
+int launch_gemm_small(const float* a, int64_t lda, const float* w, int64_t ldw, int K, const float* a2, int64_t lda2, const float* w2,
+                      int64_t ldw2, int K2, const float* bias, float* c, int64_t ldc, int M, int N, int act, hipStream_t st,
+                      const float* addend, int64_t ldadd, int add_div) {
+    if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
+    dim3 grid((M + 31) / 32, (N + 31) / 32);
+    if (grid.y > 65535u) {
+        set_error("gemm: N=%d too large", N);
+        return RL4RS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_gemm_small, grid, dim3(256), 0, st, a, lda, w, ldw, K, a2, lda2, w2, ldw2, K2, bias, c, ldc, M, N, act, addend,
+                       ldadd, add_div > 0 ? add_div : 1);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int launch_gemm_nt(const float* dy, int64_t ldy, const float* w, int64_t ldw, float* dx, int64_t ldx, int M, int Kin, int Nout,
+                   hipStream_t st, const float* relu_of, int64_t ldr) {
+    if (M <= 0 || Kin <= 0 || Nout <= 0) return RL4RS_OK;
+    dim3 grid((M + 31) / 32, (Kin + 31) / 32);
+    if (grid.y > 65535u) {
+        set_error("gemm_nt: Kin=%d too large", Kin);
+        return RL4RS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, dy, ldy, w, ldw, dx, ldx, M, Kin, Nout, relu_of, ldr);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias, float* c,
                     int64_t ldc, int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, int add_div) {
     if (M <= 0 || N <= 0 || K <= 0) return RL4RS_OK;
@@ -792,6 +951,8 @@ int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, co
         set_error("gemm: N=%d too large", N);
         return RL4RS_EINVAL;
     }
+    if (grid.x * grid.y < SMALL_GEMM_MAX_BIG_BLOCKS)       // the 128 x 64 tiling would leave most of the 256 CUs idle
+        return launch_gemm_small(a, lda, w, ldw, K, nullptr, 0, nullptr, 0, 0, bias, c, ldc, M, N, act, st, addend, ldadd, add_div);
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act, addend, ldadd, add_div > 0 ? add_div : 1);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;

@@ -377,9 +377,11 @@ __global__ __launch_bounds__(256) void k_policy_train(PolDims d, const float* __
 // C_part[z][M][Nc] = sum over samples n in chunk z of A[n][m] * B[n][j]   ("A^T B" over the sample axis).
 // One wave = one 32x32 tile; lane (i, half) feeds A[n = n0 + 2s + half][m0 + i] and B[..][j0 + i]: both are
 // 128-byte coalesced reads of row-major sample-major matrices, no transpose needed.
+// bias_part (optional): the column sums of B over the chunk (the bias gradient of the same Linear layer) from the waves of the
+// first tile row, which hold every B value of their 32 columns anyway: bias_part[z][Nc].
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, int M,
                                                  const float* __restrict__ B, int ldb, int Nc, int Ns, int chunk,
-                                                 float* __restrict__ part) {
+                                                 float* __restrict__ part, float* __restrict__ bias_part) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, li = lane & 31;
     const int tiles_n = (Nc + 31) / 32;
@@ -392,6 +394,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool want_cs = bias_part != nullptr && tm == 0;
+    float cs = 0.f;
     // 8 sample pairs per trip: the 16 loads are issued together, then the 8 MFMAs (same accumulation order as a plain
     // loop; one load per MFMA made every step pay a full memory latency)
     for (int n = n_lo; n < n_hi; n += 16) {
@@ -405,6 +409,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (n + 2 * u < n_hi) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        if (want_cs) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cs += b[u];
+        }
+    }
+    if (want_cs) {
+        cs += __shfl_xor(cs, 32);
+        if (half == 0 && j_ok) bias_part[(size_t)z * Nc + j] = cs;
     }
     float* out = part + (size_t)z * M * Nc;
     for (int r = 0; r < 16; ++r) {
@@ -1327,7 +1339,7 @@ int rl4rs_policy_loss_grad(rl4rs_policy* p, int32_t algo, int32_t N, const float
     auto tn = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst) {
         int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
         // one chunk (PPO minibatches): the partial IS the result, no reduction pass
-        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, N, p->chunk, nz == 1 ? dst : p->part);
+        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, N, p->chunk, nz == 1 ? dst : p->part, (float*)nullptr);
         if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, p->part, M * Nc, nz, dst);
     };
     auto cs = [&](const float* X, int ld, int Nc, float* dst) {

@@ -219,7 +219,7 @@ struct TrainCtx { int chunk; float* part; float* wt; };
 void st_tn(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
     const int nz = (Ns + x.chunk - 1) / x.chunk;
     const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
-    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, x.chunk, nz == 1 ? dst : x.part);
+    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, x.chunk, nz == 1 ? dst : x.part, (float*)nullptr);
     if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, x.part, M * Nc, nz, dst);
 }
 void st_cs(const TrainCtx& x, hipStream_t st, const float* X, int ld, int Nc, int Ns, float* dst) {
@@ -227,8 +227,23 @@ void st_cs(const TrainCtx& x, hipStream_t st, const float* X, int ld, int Nc, in
     hipLaunchKernelGGL(k_colsum, dim3((Nc + 63) / 64, nz), dim3(64), 0, st, X, ld, Nc, Ns, x.chunk, nz == 1 ? dst : x.part);
     if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, x.part, Nc, nz, dst);
 }
+// weight AND bias gradient of one Linear layer in one launch: dW [M, Nc] = A^T B, db [Nc] = column sums of B.  x.part must hold
+// nz * (M * Nc + Nc) floats when Ns > x.chunk.
+void st_tn_cs(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dW, float* db) {
+    const int nz = (Ns + x.chunk - 1) / x.chunk;
+    const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
+    float* bpart = x.part + (size_t)nz * M * Nc;
+    hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, x.chunk, nz == 1 ? dW : x.part,
+                       nz == 1 ? db : bpart);
+    if (nz > 1) {
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), dim3(256), 0, st, x.part, M * Nc, nz, dW);
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((Nc + 255) / 256), dim3(256), 0, st, bpart, Nc, nz, db);
+    }
+}
 int st_back(const TrainCtx& x, hipStream_t st, const float* dY, int ldy, int Nout, const float* W, int ldw, int Kin, float* dX, int ldx,
             int Ns) {      // dX [Ns, Kin] = dY [Ns, Nout] W^T,  W [Kin, Nout] with leading dimension ldw
+    if ((int64_t)((Ns + 127) / 128) * ((Kin + 63) / 64) < 512)        // minibatch-sized: no transposed weight copy, 32 x 32 tiles
+        return launch_gemm_nt(dY, ldy, W, ldw, dX, ldx, Ns, Kin, Nout, st);
     hipLaunchKernelGGL(k_transpose, dim3((Kin * Nout + 255) / 256), dim3(256), 0, st, W, (int64_t)ldw, Kin, Nout, x.wt);
     return launch_gemm_f32(dY, ldy, x.wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
 }
@@ -597,7 +612,7 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
     const int nz = (N + t->chunk - 1) / t->chunk;
     auto tn = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst) {      // dst = A^T B over samples
         int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
-        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), b256, 0, st, A, lda, M, B, ldb, Nc, N, t->chunk, nz == 1 ? dst : t->part);
+        hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), b256, 0, st, A, lda, M, B, ldb, Nc, N, t->chunk, nz == 1 ? dst : t->part, (float*)nullptr);
         if (nz > 1) hipLaunchKernelGGL(k_reduce_chunks, dim3((M * Nc + 255) / 256), b256, 0, st, t->part, M * Nc, nz, dst);
     };
     auto cs = [&](const float* X, int ld, int Nc, float* dst) {
