@@ -56,6 +56,10 @@ def make_config(args, workdir, rank):
         cfg['no_row_order'] = True            # A/B: without the slot-sorted processing order of the scorer
     if getattr(args, 'conti', False):
         cfg["support_conti_env"] = True       # configs[4]: continuous 32-d actions resolved by the masked K-NN
+    if getattr(args, 'train', 'none') == 'bcq':
+        # configs[4]: the continuous env in the d3rlpy observation mode (obs | previous actions | cur_step, batchrl_train.py:25-27)
+        cfg["support_conti_env"] = True
+        cfg["support_d3rl_mask"] = True
     return cfg, records
 
 
@@ -202,6 +206,37 @@ def cpu_baseline(cfg, records, seq, sample_batch, faithful_batch=64):
     return out
 
 
+class BcqWorkload(object):
+    """BASELINE configs[4] on one rank: the continuous-action env + K-NN with the BCQ learner of 'BCQ-conti'
+    (script/batchrl_trainer.py:61-73).  Set-up (untimed): the rank's logged-policy dataset is generated on the device
+    (data_generate_rl4rs_a_conti, :220-270).  One step = ``updates`` learner updates of 256 transitions (data parallel: the
+    flat gradients of each phase all-reduced over the ranks) + one episode-batch of the learned policy driving the env:
+    ``predict`` (100 sampled actions per env, the first critic's pick) -> ``env.step`` (masked K-NN over the catalogue,
+    scorer, reward) - the `evaluate` loop of batchrl_trainer.py:377-411."""
+
+    def __init__(self, env, cfg, rank, updates=16, epochs=2):
+        import torch
+        from rl4rs_amd.offline import generate_offline_dataset
+        from rl4rs_amd.offline_rl import BCQ, transitions_from_mdp
+        self.env, self.cfg, self.updates = env, cfg, int(updates)
+        data = generate_offline_dataset(env, epochs=epochs, shuffle=False)
+        self.tr = transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=False)
+        self.bcq = BCQ(cfg, self.tr[0].shape[1], batch_size=256, seed=7)       # the same initial replica on every rank
+        self.bcq._gen.manual_seed(1000 + rank)                                  # its own noise / minibatch stream
+        self.rank = rank
+        self.calls = 0
+        self.last_losses = None
+
+    def step(self):
+        T = self.cfg['max_steps']
+        self.last_losses = self.bcq.fit(self.tr, self.updates, shuffle_seed=1000 + self.rank + 7919 * self.calls, to_host=False)
+        self.calls += 1
+        obs = self.env.reset()
+        for _ in range(T):
+            obs, reward, done, info = self.env.step(self.bcq.predict(obs))
+        return reward
+
+
 def episode_host(env, T):
     """The same loop through the reference-shaped API (config without return_tensors): lists / ndarrays / dicts come back to
     the host every step (obs [B, 256] float32, the int64 action mask in rllib-mask mode, rewards as a python list), and the
@@ -238,6 +273,10 @@ def extra_leg(args, workdir, rank, name, steps=3):
         a.env, a.horizon = 'seq', 32
     elif name == 'seq_t32_ppo':
         a.env, a.horizon, train = 'seq', 32, 'PPO'
+    elif name == 'seq_t32_a2c':
+        a.env, a.horizon, train = 'seq', 32, 'A2C'            # configs[3]'s per-GPU shard (modelfree_train.py:42-44,248-304)
+    elif name == 'bcq_conti':
+        a.train = 'bcq'
     elif name == 'conti':
         a.conti = True
     elif name == 'all_distinct':
@@ -258,6 +297,8 @@ def extra_leg(args, workdir, rank, name, steps=3):
     env.seed(1000 + rank)
     env.sim._recData.store.preload(torch.device('cuda', torch.cuda.current_device()))
     B, T = cfg['batch_size'], cfg['max_steps']
+    if name == 'bcq_conti':
+        return bcq_leg(env, cfg, rank)
     if train:
         from rl4rs_amd.train import Trainer
         tr = Trainer(env, algo=train, seed=1000 + rank)
@@ -274,7 +315,8 @@ def extra_leg(args, workdir, rank, name, steps=3):
     out = {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "workload": "%s B=%d T=%d%s%s" % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T,
                                              ', continuous actions -> masked K-NN' if a.conti else '',
-                                             ', PPO rollout + update (configs[2])' if train else ', offline_action replay')}
+                                             ', %s rollout + update (configs[%d])' % (train, 2 if train == 'PPO' else 3) if train
+                                             else ', offline_action replay')}
     if compat:
         out["workload"] += (" through the REFERENCE-SHAPED API (no return_tensors%s): one rl4rs_env_step_record call + one pinned "
                             "device-to-host copy per step; PCIe-inclusive, python list / dict construction included"
@@ -294,6 +336,39 @@ def extra_leg(args, workdir, rank, name, steps=3):
         out["dtype"] = "f32"
         out["roofline"] = {"bound": "mfma", "kernel": net.augru_kernel, "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
+    return out
+
+
+def bcq_leg(env, cfg, rank, update_steps=200, rollouts=3):
+    """configs[4] on one GPU, its two halves timed separately: learner updates/s (256 transitions each, 100 sampled actions per
+    target row) and the policy -> K-NN rollout's env-steps/s."""
+    import torch
+    wl = BcqWorkload(env, cfg, rank)
+    B, T = cfg['batch_size'], cfg['max_steps']
+    wl.bcq.fit(wl.tr, 10, to_host=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hist = wl.bcq.fit(wl.tr, update_steps, to_host=False)
+    torch.cuda.synchronize()
+    dt_u = time.perf_counter() - t0
+    wl.updates = 0
+    wl.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rollouts):
+        wl.step()
+    torch.cuda.synchronize()
+    dt_r = time.perf_counter() - t0
+    out = {"value": B * T * rollouts / dt_r, "unit": "env-steps/s", "ms_per_step": dt_r / rollouts * 1e3, "steps": rollouts,
+           "workload": "SlateRecEnv-v0 B=%d T=%d, continuous actions: BCQ policy predict (100 sampled 32-d actions per env, first critic's "
+                       "pick) -> masked K-NN -> scorer (configs[4] evaluation rollout)" % (B, T),
+           "learner": {"updates_per_s": update_steps / dt_u, "transitions_per_s": update_steps * 256 / dt_u, "ms_per_update": dt_u / update_steps * 1e3,
+                       "updates": update_steps,
+                       "what": "d3rlpy.algos.BCQ(batch_size=256) restated on the device: conditional-VAE imitator, residual actor, twin "
+                               "critics, lam-weighted target over 100 sampled actions per row (25 600-row forward through 4 networks), soft "
+                               "target updates; dataset = %d transitions generated on the device" % wl.tr[0].shape[0],
+                       "last_losses": dict((k, float(v[-1])) for k, v in hist.items() if len(v))}}
+    wl.bcq.close()
     return out
 
 
@@ -320,9 +395,11 @@ def main():
     ap.add_argument('--scorer', choices=['auto', 'fp32', 'fp16x2'], default='auto',
                     help='arithmetic of the AUGRU recurrence (config scorer_precision); auto = fp16x2 operand split, '
                          'fp32 accumulate, same measured error as the exact fp32 MFMA kernel')
-    ap.add_argument('--train', choices=['none', 'a2c', 'ppo'], default='none',
+    ap.add_argument('--train', choices=['none', 'a2c', 'ppo', 'bcq'], default='none',
                     help='none: offline_action replay (BASELINE configs[1]); a2c/ppo: policy rollout + update with the '
-                         'flat-gradient all-reduce over RCCL (configs[2]/[3])')
+                         'flat-gradient all-reduce over RCCL (configs[2]/[3]); bcq: continuous-action env, a step = --bcq-updates '
+                         'BCQ updates (gradient all-reduce) + one policy -> K-NN episode-batch (configs[4])')
+    ap.add_argument('--bcq-updates', type=int, default=16, help='--train bcq: learner updates per step')
     ap.add_argument('--minibatch', type=int, default=256,
                     help='--train ppo: SGD minibatch per rank (RLlib: 256).  With N > 1 every minibatch costs one gradient '
                          'all-reduce (synchronous SGD over N x minibatch samples): 512 / 1024 halve / quarter the collectives '
@@ -354,10 +431,15 @@ def main():
     env.sim._recData.store.preload(torch.device('cuda', local_rank))
     B, T = args.batch, args.horizon
     trainer = None
-    if args.train != 'none':
+    if args.train == 'bcq':
+        trainer = BcqWorkload(env, cfg, rank, updates=args.bcq_updates)
+        run_step = trainer.step
+    elif args.train != 'none':
         from rl4rs_amd.train import Trainer
         trainer = Trainer(env, algo=args.train.upper(), seed=1000 + rank, minibatch=args.minibatch)
-    run_step = (lambda: trainer.train_iteration()) if trainer else (lambda: episode(env, T))
+        run_step = trainer.train_iteration
+    else:
+        run_step = lambda: episode(env, T)
     for _ in range(args.warmup):
         run_step()
     net = env.sim.model.device_net
@@ -370,13 +452,21 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
+    torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0            # this rank's own clock up to ITS last step (before the closing barrier)
     rdist.barrier()
     elapsed = rdist.max_over_ranks(time.perf_counter() - t0, device='cuda')
+    # what the collective layer actually saw: the number of ranks that took part (an all-reduced count - equals --gpus only
+    # if every rank joined the same process group) and every rank's own env-steps/s
+    ranks_seen = int(round(rdist.sum_over_ranks(1.0, device='cuda')))
+    per_rank = rdist.gather_floats(B * T * args.steps / my_elapsed, device='cuda')
     prof = net.profile()
     net.set_profiling(0)
     breakdown, breakdown_steps = None, 3
     # the per-kernel breakdown pass is rank 0's - except that a train step with world > 1 contains collectives (the gradient
     # all-reduce), so then every rank has to take the same steps (only rank 0 records events)
+    if args.train == 'bcq' and rank == 0:
+        out_bcq = {"updates_per_step": args.bcq_updates, "last_losses": dict((k, float(v[-1])) for k, v in (trainer.last_losses or {}).items() if len(v))}
     if rank == 0 or (trainer is not None and world > 1):
         if rank == 0:
             net.set_profiling(1)
@@ -450,6 +540,8 @@ def main():
             "value": env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "per_rank_env_steps_per_s": [round(v, 1) for v in per_rank],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -462,7 +554,9 @@ def main():
                                    "%s simulator scorer, offline_action replay"
                                    % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T, cfg.get('algo', 'dien').upper() if is_dien else cfg['algo']),
                        "step": "one episode-batch = reset + %d env.step incl. reward forward" % T +
-                               ("" if not trainer else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()) +
+                               ("" if not trainer or args.train == 'bcq' else " with %s policy sampling + update (gradient all-reduce)" % args.train.upper()) +
+                               ("" if args.train != 'bcq' else " driven by the BCQ policy (predict: 100 sampled actions per env), after %d BCQ "
+                                "updates of 256 transitions (3 gradient all-reduces each)" % args.bcq_updates) +
                                ("" if not args.conti else "; continuous actions -> masked K-NN over the catalogue"),
                        "parallelism": "independent env batches per GPU (no data-path collective)"},
             # dien: the AUGRU recurrence; the GEMM-only families (dnn / widedeep / lstm) have no dominant matrix kernel,
@@ -481,10 +575,12 @@ def main():
         default_run = world == 1 and is_dien and not trainer and not seq and not args.conti
         if default_run and not args.no_extra_legs:
             out["extra"] = dict((name, extra_leg(args, workdir, rank, name))
-                                for name in ('seq_t32', 'seq_t32_ppo', 'conti', 'all_distinct', 'compat_numpy', 'compat_rllib_mask',
-                                             'compat_d3rl_mask'))
+                                for name in ('seq_t32', 'seq_t32_ppo', 'seq_t32_a2c', 'conti', 'bcq_conti', 'all_distinct', 'compat_numpy',
+                                             'compat_rllib_mask', 'compat_d3rl_mask'))
         if default_run and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg:
             out["exact_fp32_scorer"] = extra_leg(args, workdir, rank, 'fp32')
+        if args.train == 'bcq':
+            out["bcq"] = out_bcq
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, records, seq, args.cpu_batch)
         print(json.dumps(out))

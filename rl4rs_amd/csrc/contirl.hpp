@@ -245,9 +245,9 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
         AM_FAIL(al(&p->d_h1, G * H1)); AM_FAIL(al(&p->d_h2, G * H2)); AM_FAIL(al(&p->d_proj, G * H1));
         int64_t wmax = 0;
         for (int i = 0; i < AP_COUNT; ++i) if (sizes[i] > wmax) wmax = sizes[i];
-        p->cx.chunk = 128;
+        p->cx.chunk = 256;
         AM_FAIL(al(&p->cx.wt, wmax));
-        AM_FAIL(al(&p->cx.part, (size_t)((G + 127) / 128) * (wmax + std::max(H1, std::max(H2, K)))));
+        AM_FAIL(al(&p->cx.part, (size_t)((G + 255) / 256) * (wmax + std::max(H1, std::max(H2, K)))));
     }
     AM_HIP(hipStreamSynchronize(st));
 #undef AM_HIP

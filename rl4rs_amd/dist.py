@@ -60,6 +60,20 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_floats(value, device=None):
+    """Every rank's python float, in rank order, on every rank (bench.py: per-rank rates beside the max-over-ranks time)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    W = dist.get_world_size()
+    dev = None if dist.get_backend() == 'gloo' else device
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(W)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def world_size():
     """Size of the initialised process group (1 when torch.distributed is not in use)."""
     import torch.distributed as dist

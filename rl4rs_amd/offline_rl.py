@@ -378,9 +378,10 @@ class BCQ(object):
         self.total_step += 1
         return metrics
 
-    def fit(self, transitions, n_steps, shuffle_seed=None):
+    def fit(self, transitions, n_steps, shuffle_seed=None, to_host=True):
         """``n_steps`` updates over ``transitions`` (``transitions_from_mdp(..., discrete_action=False)``), epoch-wise random
-        permutation like d3rlpy's ``fit``; returns dict of per-step loss lists."""
+        permutation like d3rlpy's ``fit``; returns dict of per-step loss lists (``to_host=False``: of stacked device tensors,
+        nothing waits for the GPU)."""
         obs, act, rew, nxt, ter = [t.to(self.device) for t in transitions]
         n = obs.shape[0]
         assert n >= self.batch_size, 'dataset smaller than one minibatch'
@@ -398,7 +399,12 @@ class BCQ(object):
         out = {}
         for k in ('imitator_loss', 'critic_loss', 'actor_loss'):
             vals = [h[k] for h in hist if k in h]
-            out[k] = [float(x) for x in torch.stack(vals).cpu()] if vals else []
+            if not vals:
+                out[k] = []
+            elif to_host:
+                out[k] = [float(x) for x in torch.stack(vals).cpu()]
+            else:
+                out[k] = torch.stack(vals)
         return out
 
     def predict(self, obs, noise=None):

@@ -24,7 +24,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize('leg', [[], ['--train', 'a2c'], ['--train', 'ppo'], ['--env', 'seq', '--horizon', '18'], ['--conti'],
-                                 ['--train', 'ppo', '--minibatch', '512']])
+                                 ['--train', 'ppo', '--minibatch', '512'], ['--env', 'seq', '--train', 'a2c'],
+                                 ['--train', 'bcq', '--bcq-updates', '2']])
 def test_bench_two_ranks_over_gloo(leg):
     env = dict(os.environ, RL4RS_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -37,3 +38,8 @@ def test_bench_two_ranks_over_gloo(leg):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['value'] > 0 and rec['scaling'] == 'weak'
     assert rec['unit'] == 'env-steps/s' and rec['roofline'] is not None
+    # what the collective layer saw: both ranks joined the one process group, and each reports its own rate
+    assert rec['ranks_seen'] == 2 and len(rec['per_rank_env_steps_per_s']) == 2 and min(rec['per_rank_env_steps_per_s']) > 0
+    assert rec['value'] <= sum(rec['per_rank_env_steps_per_s']) * 1.001
+    if leg[:2] == ['--train', 'bcq']:
+        assert rec['bcq']['updates_per_step'] == 2 and all(v == v for v in rec['bcq']['last_losses'].values())
