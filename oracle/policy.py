@@ -187,6 +187,21 @@ def update_kl_coeff(kl_coeff, sampled_kl, kl_target):
     return kl_coeff
 
 
+def a2c_train_call(state, batch, lr, mask_fn, od=256, hid=64, A=284, vf_coeff=0.5, ent_coeff=0.01, grad_clip=10.0):
+    """One A2C train call (script/modelfree_train.py:248-304: RLlib A2C, ONE gradient over the whole rollout batch, summed
+    losses, tf.clip_by_global_norm(40 -> the script's grad_clip 10), AdamOptimizer).  state = (flat, m, v, t) float64; batch =
+    dict of numpy arrays obs, act, mask, adv, ret.  -> (state, sums [pi, vf, ent, 0], gradient norm before clipping, clipped
+    gradient)."""
+    flat, m, v, t = state
+    mask = mask_fn(batch['mask']) if batch.get('mask') is not None else None
+    g, s = loss_and_grad(0, flat, batch['obs'], mask, batch['act'], batch['adv'], batch['ret'], vf_coeff=vf_coeff, ent_coeff=ent_coeff,
+                         od=od, hid=hid, A=A)
+    norm = float(np.sqrt((g * g).sum()))
+    if grad_clip and norm > grad_clip:
+        g = g * (grad_clip / norm)
+    return adam_update(flat, m, v, t, g, lr), s, norm, g
+
+
 def ppo_train_call(state, batch, minibatch, lr, kl_coeff, kl_target, mask_fn, od=256, hid=64, A=284, vf_coeff=0.5, clip=0.3,
                    vf_clip=500.0):
     """One PPO train call on an already shuffled batch.  state = (flat, m, v, t) float64; batch = dict of numpy arrays

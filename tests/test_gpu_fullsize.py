@@ -92,21 +92,17 @@ def _full_cfg(d, B, T, recs, **extra):
     return cfg
 
 
-def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
-    """BASELINE configs[2]: SeqSlateRecEnv-v0, B=4096, 32-step horizon (pages of 9: rewards after steps 9, 18, 27; the last 5
-    steps never pay, seqslate.py:138).  Integer state of the WHOLE batch bit-exact vs the oracle at every step, observations
-    and page rewards of a 512-env subset vs the fp64 DIEN oracle, then one PPO train call of the on-device loop on the same env
-    (script/modelfree_train.py:42-44,179-247)."""
+def _seqslate_full_episode(tmp_path, T, every_first_page_step=True):
+    """SeqSlateRecEnv-v0 at B=4096: one offline_action episode with the integer state of the WHOLE batch bit-exact vs the oracle
+    at every step, observations and page rewards of a 512-env subset vs the fp64 DIEN oracle (at every page boundary, the
+    step before it and the end; on the first page at every step when asked).  Returns (env, number of reward steps)."""
     import torch
     import rl4rs_amd
     from rl4rs_amd import synth
-    from rl4rs_amd.nets.dien import init_dien_weights
     from rl4rs_amd.env.seqslate import SeqSlateRecEnv, SeqSlateState
-    from rl4rs_amd.train import Trainer
     from oracle.state import OracleState
-    from oracle.dien import OracleDien
     from oracle.env import reward_from_probs, is_reward_step
-    B, T = 4096, 32
+    B = 4096
     d = str(tmp_path)
     text = synth.make_catalog_text(seed=1234)
     synth.write_text(os.path.join(d, 'c.csv'), text)
@@ -134,10 +130,11 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
         assert np.array_equal(a.cpu().numpy(), np.asarray(st.offline_action))
         obs, reward, done, info = env.step(a)
         st.act(a.cpu().numpy())
-        # observations against the fp64 scorer on the first page, at every page boundary and at the end (each costs NPICK
-        # fp64 DIEN rows on the host); masks and integer state at EVERY step
-        check_obs(obs, t < 10 or t % 9 in (0, 8) or t == T - 1)
-        assert np.array_equal(env.samples.prev_actions, st.prev_actions) if t % 8 == 7 or t == T - 1 else True
+        # observations against the fp64 scorer at every page boundary, the step before it and the end (each costs NPICK fp64
+        # DIEN rows on the host); masks at EVERY step, the whole integer state at every page boundary
+        check_obs(obs, (every_first_page_step and t < 10) or t % 9 in (0, 8) or t == T - 1)
+        if t % 9 == 8 or t == T - 1:
+            assert np.array_equal(env.samples.prev_actions, st.prev_actions)
         r = reward.cpu().numpy()
         if is_reward_step(st):
             n_reward_steps += 1
@@ -153,8 +150,20 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
         else:
             assert (r == 0).all()
         assert done == [1 if t == T - 1 else 0] * B
-    assert n_reward_steps == 3
     assert np.array_equal(env.samples.get_violation(), st.get_violation())
+    return env, n_reward_steps
+
+
+def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
+    """BASELINE configs[2]: SeqSlateRecEnv-v0, B=4096, 32-step horizon (pages of 9: rewards after steps 9, 18, 27; the last 5
+    steps never pay, seqslate.py:138).  Integer state of the WHOLE batch bit-exact vs the oracle, observations
+    and page rewards of a 512-env subset vs the fp64 DIEN oracle, then one PPO train call of the on-device loop on the same env
+    (script/modelfree_train.py:42-44,179-247)."""
+    import torch
+    from rl4rs_amd.train import Trainer
+    B, T = 4096, 32
+    env, n_reward_steps = _seqslate_full_episode(tmp_path, T)
+    assert n_reward_steps == 3
     # ---- one PPO train call over this env (rollout of 131 072 samples, 512 minibatches of 256 in the persistent pass)
     tr = Trainer(env, algo='PPO', seed=11, init_seed=3)
     p0 = tr.params().clone()
@@ -167,6 +176,61 @@ def test_full_size_seqslate_t32_episode_then_ppo_iteration(tmp_path):
     assert env.samples.get_violation().all()
     acts = tr.buf['act'].view(T, B).cpu().numpy()
     assert (acts >= 1).all() and (acts < 284).all()
+    tr.close()
+
+
+@pytest.mark.parametrize('T', [36, 32])
+def test_full_size_seqslate_a2c(tmp_path, T):
+    """BASELINE configs[3]'s per-GPU shard at full size: SeqSlateRecEnv-v0, B=4096, the parity horizon T=36 (4 pages, 4 reward
+    steps: script/modelfree_train.py:43, simulator_eval.py:20) and the bench horizon T=32, followed by A2C train calls of the
+    on-device loop (modelfree_train.py:248-304: one summed-loss gradient over the whole 147 456 / 131 072-sample rollout,
+    global-norm clip 10, Adam 1e-4) tracked against the float64 restatement (oracle/policy.py a2c_train_call), teacher-forced
+    on the device's own rollouts."""
+    import torch
+    from rl4rs_amd.train import Trainer
+    from oracle import policy as OP
+    B = 4096
+    env, n_reward_steps = _seqslate_full_episode(tmp_path, T, every_first_page_step=False)
+    assert n_reward_steps == T // 9
+    tr = Trainer(env, algo='A2C', seed=11, init_seed=3, keep_last_batch=True)
+    assert tr.R == 1 and tr.buf['obs'].shape[0] == B * T
+    flat = tr.params().cpu().numpy().astype(np.float64)
+    state = (flat, np.zeros_like(flat), np.zeros_like(flat), 0)
+
+    def unpack(bits):
+        b = bits.view(np.uint32)
+        return ((b[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(b.shape[0], -1)[:, :284].astype(np.float64)
+
+    for it in range(2):
+        out = tr.train_iteration()
+        lb = tr.last_batch
+        batch = dict((k, lb[k].cpu().numpy()) for k in ('obs', 'act', 'mask', 'adv', 'ret'))
+        # the rollout itself: every sampled action legal for its slot, a reward only at the page boundaries
+        acts = batch['act'].reshape(T, B)
+        assert (acts >= 1).all() and (acts < 284).all()
+        rew = tr.buf['rew'].view(T, B).cpu().numpy()
+        pay = np.array([(t + 1) % 9 == 0 for t in range(T)])
+        assert (rew[~pay] == 0).all() and (rew[pay] > 0).any()
+        assert env.samples.get_violation().all()             # the masked policy never violates the slate rules
+        # returns with gamma = 1: ret[t] = sum of the rewards from t on
+        ret = batch['ret'].reshape(T, B)
+        assert np.allclose(ret, np.cumsum(rew[::-1], axis=0)[::-1], rtol=1e-6, atol=1e-4)
+        state, sums, norm, g = OP.a2c_train_call(state, batch, 1e-4, unpack)
+        got = tr.params().cpu().numpy()
+        assert norm > 10.0                                    # summed losses over 1e5 samples: the clip is active
+        # the gradient itself (before the clip) against float64 autograd over the whole rollout batch
+        g_ref = g * max(norm / 10.0, 1.0)
+        g_dev = tr.grad.cpu().numpy().astype(np.float64)
+        assert np.abs(g_dev - g_ref).max() < 2e-3 * np.abs(g_ref).max(), (it, np.abs(g_dev - g_ref).max(), np.abs(g_ref).max())
+        # Adam's first steps move a weight by ~lr * sign(g): an entry whose gradient is a rounding-level residue of the 1e5-term
+        # sums may step the other way in fp32; every entry whose fp32 gradient is good to 1 % must land on the float64 weight
+        solid = np.abs(g_dev - g_ref) <= 0.01 * np.abs(g_ref)
+        assert solid.mean() > 0.9, solid.mean()
+        assert np.abs(got - state[0])[solid].max() < 5e-6, (it, np.abs(got - state[0])[solid].max())
+        assert np.abs(got - state[0]).max() <= 2.2e-4 * (it + 1)
+        N = B * T
+        assert np.allclose([out['policy_loss'] / N, out['vf_loss'] / N, out['entropy'] / N], sums[:3] / N, rtol=2e-3, atol=1e-4), (out, sums)
+        assert out['episode_reward_mean'] > 0
     tr.close()
 
 
