@@ -1,0 +1,86 @@
+"""``rl4rs.policy.policy_model`` (reference: rl4rs/policy/policy_model.py:8-92) over the device learners: the masked greedy action
+of the discrete learners equals the numpy restatement of the reference rule applied to the same scores (integer: bit-exact), the
+continuous learner's ``predict_with_mask`` is its ``predict``, numpy in -> numpy out / device tensor in -> device tensor out."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+A, P, OBS = 284, 9, 256
+D = OBS + P + 1
+
+
+def _setup(tmp_path):
+    from rl4rs_amd import synth
+    from rl4rs_amd.data import CatalogTables
+    path = os.path.join(str(tmp_path), 'item_info.csv')
+    synth.write_text(path, synth.make_catalog_text(seed=21))
+    tab = CatalogTables(path, A, 32)
+    cfg = {"maxlen": 64, "batch_size": 2048, "action_size": A, "dense_feature_num": 432, "category_feature_num": 21, "max_steps": 9,
+           "page_items": P, "action_emb_size": 32, "iteminfo_file": path, "location_mask": tab.location_mask,
+           "special_items": tab.special_items}
+    rs = np.random.RandomState(3)
+    n = 700                                       # not a multiple of the learners' minibatch: exercises the chunking
+    x = np.zeros((n, D), np.float32)
+    x[:, :OBS] = rs.randn(n, OBS)
+    loc = np.asarray(tab.location_mask)
+    for i in range(n):
+        cur = rs.randint(0, 10)
+        for j in range(min(cur, 9)):
+            x[i, OBS + j] = rs.choice(np.nonzero(loc[j // 3])[0])
+        x[i, -1] = cur
+    return cfg, tab, x
+
+
+@pytest.mark.parametrize('algo', ['BC', 'BCQ', 'CQL'])
+def test_discrete_learners_predict_with_mask(tmp_path, algo):
+    import torch
+    from rl4rs.policy.policy_model import policy_model
+    from rl4rs_amd import offline_rl as R
+    from oracle.policy import predict_with_mask
+    cfg, tab, x = _setup(tmp_path)
+    model = {'BC': R.DiscreteBC, 'BCQ': R.DiscreteBCQ, 'CQL': R.DiscreteCQL}[algo](cfg, D, batch_size=256, seed=5)
+    pm = policy_model(model, config=cfg)
+    probs = pm.action_probs(x)
+    assert isinstance(probs, np.ndarray) and probs.shape == (x.shape[0], A)
+    if algo != 'BC':
+        assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-5)
+    got = pm.predict_with_mask(x)
+    assert isinstance(got, np.ndarray) and got.dtype == np.int64
+    ref = predict_with_mask(probs.astype(np.float64), x, tab.location_mask, tab.special_items)
+    assert np.array_equal(got, ref)
+    # the chosen item is legal for the slot the observation tail names and was not chosen before
+    loc = np.asarray(tab.location_mask)
+    layer = (x[:, -1].astype(int) % 9) // 3
+    assert (loc[layer, got] == 1).all()
+    assert not (x[:, OBS:OBS + P].astype(int) == got[:, None]).any()
+    # device tensors stay on the device
+    got_t = pm.predict_with_mask(torch.from_numpy(x).cuda())
+    assert got_t.is_cuda and np.array_equal(got_t.cpu().numpy(), ref)
+    a = pm.predict(x)
+    assert a.shape == (x.shape[0],)
+    if algo != 'BC':
+        q = pm.predict_q(x, a)
+        assert q.shape == (x.shape[0],) and np.isfinite(q).all()
+    model.close()
+
+
+def test_continuous_learner_predict_with_mask_is_predict(tmp_path):
+    import torch
+    from rl4rs.policy.policy_model import policy_model
+    from rl4rs_amd.offline_rl import BCQ
+    cfg, tab, x = _setup(tmp_path)
+    cfg = dict(cfg, support_conti_env=True)
+    model = BCQ(cfg, D, batch_size=64, n_action_samples=10, predict_rows=256, seed=2)
+    pm = policy_model(model, config=cfg)
+    model._gen.manual_seed(9)
+    a = pm.predict_with_mask(x)
+    model._gen.manual_seed(9)
+    b = model.predict(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert isinstance(a, np.ndarray) and a.shape == (x.shape[0], 32) and np.array_equal(a, b)
+    assert (np.abs(a) <= 1).all()
+    q = pm.predict_q(x, a)
+    assert q.shape == (x.shape[0],) and np.isfinite(q).all()
+    model.close()
