@@ -84,6 +84,7 @@ int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const f
 // raised (a second handle with a smaller shape must not lower the limit under the first one's launches - ADVICE r2 on k_ppo_pass,
 // applied to every kernel whose LDS size depends on a handle's shape).  Defined in env.hip.
 int raise_dyn_smem(const void* fn, size_t bytes);
+int current_device();
 
 // Training-mode recurrences as persistent kernels (recur_train.hpp, compiled into dien.hip; called from dientrain.hpp).
 // Arrays are per sequence input (S <= 4 inputs run in ONE launch, grid.y = S); saved tensors are [N * L, Hd] row-major.

@@ -12,6 +12,7 @@
 // Bound: HBM writes.  Algorithmic bytes per built row = Dn*4 + Cn*4 written + UD*4 + UC*4 + 36 read
 // = 2016 B at the reference config.
 #include <cstdlib>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -603,6 +604,7 @@ static RowsLaunch rows_launch(const rl4rs_env* e, int R, int mode) {
 }
 template <int MODE>
 static int launch_rows(rl4rs_env* e, int R, const int32_t* actions, int cur, int n_complete, int j_base, hipStream_t st) {
+    if (MODE == 1) e->state_fresh = false;      // an act writes prev_actions / the masks: the next reset must clear them again
     RowsLaunch L = rows_launch(e, R, MODE);
     if (L.lds)
         hipLaunchKernelGGL((k_env_rows<MODE, true>), dim3(L.grid), dim3(L.threads), L.smem, st, e->d, actions, cur, n_complete, j_base);
@@ -613,17 +615,28 @@ static int launch_rows(rl4rs_env* e, int R, const int32_t* actions, int cur, int
 }
 
 namespace rl4rs {
+// The attribute is a property of (device, function): the cache is keyed by both and guarded, so handles created on a second
+// device or from another thread of the process still opt in (a process normally drives one device).
+int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
 int raise_dyn_smem(const void* fn, size_t bytes) {
-    static std::vector<std::pair<const void*, size_t>> cur;      // a handful of kernels: a linear scan is fine (handles are not thread-safe)
+    struct Entry { int dev; const void* fn; size_t bytes; };
+    static std::vector<Entry> cur;              // a handful of kernels: a linear scan is fine
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = current_device();
     for (auto& e : cur)
-        if (e.first == fn) {
-            if (bytes <= e.second) return RL4RS_OK;
+        if (e.dev == dev && e.fn == fn) {
+            if (bytes <= e.bytes) return RL4RS_OK;
             RL4RS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            e.second = bytes;
+            e.bytes = bytes;
             return RL4RS_OK;
         }
     RL4RS_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    cur.emplace_back(fn, bytes);
+    cur.push_back(Entry{dev, fn, bytes});
     return RL4RS_OK;
 }
 }  // namespace rl4rs

@@ -841,13 +841,12 @@ int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const f
 }
 
 static int device_cus() {
-    static int cus = 0;                     // one device per process (one process per GPU)
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
+    static int cus[64] = {0};               // per device ordinal; a benign race: every thread computes the same value
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0)
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return cus[dev];
 }
 
 static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,

@@ -13,6 +13,7 @@
 // into fixed chunks and summed in a fixed order => bit-reproducible gradients).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -1543,13 +1544,19 @@ int pass_rows_per_wg(const rl4rs_policy* p) {
 // shapes cannot undercut each other.  Residency is still computed per handle with that handle's real LDS size.
 constexpr size_t PASS_SMEM_MAX = (size_t)160 * 1024 - 64;
 bool pass_opt_in() {
-    static const bool ok = [] {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
-            (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
-            return false;
-        }
-        return true;
-    }();
+    // once per DEVICE (the attribute is per device and function), guarded: see raise_dyn_smem
+    static std::mutex mu;
+    static std::vector<std::pair<int, bool>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = current_device();
+    for (auto& e : done)
+        if (e.first == dev) return e.second;
+    bool ok = true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
+        (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
+        ok = false;
+    }
+    done.emplace_back(dev, ok);
     return ok;
 }
 

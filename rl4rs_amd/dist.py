@@ -127,6 +127,22 @@ def broadcast_(t, src=0):
     return t
 
 
+LAST_ROWS_PATH = None          # 'sparse' / 'dense': which exchange the last allreduce_rows_mean_ call of this process took (tests)
+
+
+def calibrate_row_cap(ids, table_rows, headroom=4, floor=1024):
+    """A static distinct-row bound for ``allreduce_rows_mean_`` measured ONCE on a trainer's first minibatch and agreed across the
+    ranks: ``headroom`` x the largest distinct-id count any rank saw, rounded up to a multiple of ``floor``, at most the number
+    of id slots / table rows.  (One host read of a device scalar + one MAX all-reduce, at start-up only; the id-slot count
+    itself - 256 x 64 x 2 = 32768 for the raw-state policy's sequence table - made every W >= 2 fall back to the dense 51 MB
+    all-reduce)  A later minibatch with more distinct rows than the cap turns the exchanged rows into NaN (loud)."""
+    import torch
+    distinct = int(torch.unique(ids.reshape(-1)).numel())
+    most = int(round(max_over_ranks(float(distinct), device=ids.device if ids.is_cuda else None)))
+    cap = ((headroom * max(most, 1) + floor - 1) // floor) * floor
+    return int(min(cap, ids.numel(), table_rows))
+
+
 def allreduce_rows_mean_(table_grad, ids, cap=None):
     """Mean all-reduce of a SPARSE-ROW gradient: ``table_grad`` [H, E] is zero outside the rows named by ``ids`` (int64, in
     [0, H), duplicates allowed) that this rank's minibatch touched (embedding tables of the raw-state policy: 2 x 100000 x 128
@@ -150,8 +166,11 @@ def allreduce_rows_mean_(table_grad, ids, cap=None):
     ids = ids.reshape(-1)
     n = int(ids.numel())
     cap = min(H, n if cap is None else int(cap))
+    global LAST_ROWS_PATH
     if n == 0 or cap * W * 2 > H:
+        LAST_ROWS_PATH = 'dense'
         return allreduce_mean_(table_grad.view(-1)).view(H, E)
+    LAST_ROWS_PATH = 'sparse'
     dev = table_grad.device
     srt, _ = ids.to(device=dev, dtype=torch.int64).sort()
     first = torch.ones(n, dtype=torch.bool, device=dev)

@@ -297,7 +297,14 @@ class SlateState(RecState):
             return env.offline_action(conti=conti)
         nxt = getattr(self, '_next_offline', None)
         if nxt is not None and nxt[0] == (self._batch_version, env.cur_steps):
-            return nxt[1]                                   # built while the last transition's kernels ran (SlateRecEnv._step)
+            # built while the last transition's kernels ran (SlateRecEnv._step).  Handed out ONCE: the reference builds a fresh
+            # list on every access (slate.py:150-161), so a caller that mutates what it got must not see its own edits on the
+            # next read - later reads of the same step rebuild the list (remembering the same device copy of the ids)
+            lst = nxt[1]
+            if lst is None:
+                return self._offline_from_host(env.cur_steps, conti, None if conti else nxt[2])
+            self._next_offline = (nxt[0], None, getattr(lst, '_dev', None))
+            return lst
         return self._offline_from_host(env.cur_steps, conti, None)
 
     def _offline_from_host(self, cur, conti, dev_ids):
@@ -594,6 +601,16 @@ class SlateRecEnv(RecSimBase):
         keep.append(out)
         return out
 
+    def _copied_obs(self, rec, masked):
+        """config['copy_outputs']: the observation as PAGEABLE copies.  By default every array a reference-shaped step returns
+        is a view into ONE page-locked block per step (13 MB at B=4096 in the rllib-mask mode): a caller that keeps a single
+        row - a replay buffer appending ``obs[i]`` - keeps the whole block alive, and thousands of kept steps pin gigabytes of
+        host memory.  Keep the default for the act -> step loop; set ``copy_outputs`` when observations are stored."""
+        if not masked:
+            return np.array(rec.obs)
+        m, o = np.array(rec.mask), np.array(rec.obs)
+        return [{"action_mask": mi, "obs": oi} for mi, oi in zip(m, o)]
+
     def sample(self, batch_size):
         """base.py:172-175: ``samples = recData.sample(B); obs = obs_fn(samples.state)``.  In the reference's host-returning
         modes the observation of the fresh batch comes back the way a transition's does (``_step`` below): ONE library call
@@ -620,6 +637,8 @@ class SlateRecEnv(RecSimBase):
         r = stepper.observe_record(conti=conti, want=want, shadow=in_the_gpu_shadow)
         samples._range_seen = getattr(samples, '_range_seen', 0) | int(r.status[1])
         self._last_obs = None
+        if self.config.get('copy_outputs', False):
+            return samples, self._copied_obs(r, masked)
         return samples, (built['obs'] if masked else r.obs)
 
     def _step(self, samples, action, **kwargs):
@@ -681,9 +700,12 @@ class SlateRecEnv(RecSimBase):
                     "fp16x2 scorer: a recurrent state left the fp16 range (|h| >= 6e4 or NaN); the affected forwards are "
                     "invalid - use config['scorer_precision'] = 'fp32' for this model")
             if fetch and due:
+                click_p = np.array(r.click_p)               # a small pageable copy: info dicts outlive the step's pinned block
                 for i in range(self.batch_size):
-                    samples.info[i].update({'click_p': r.click_p[i]})
+                    samples.info[i].update({'click_p': click_p[i]})
             obs = built['obs'] if masked else r.obs
+            if self.config.get('copy_outputs', False):
+                obs = self._copied_obs(r, masked)
             reward = r.reward.tolist() if due else [0] * self.batch_size
         if first_of_page:                                   # the library re-encoded the second sequence input
             samples._seq1_version += 1

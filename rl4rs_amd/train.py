@@ -186,6 +186,7 @@ class RawStateTrainer(_DeferredStats):
                         val=torch.empty(N, dtype=torch.float32, device=dev), rew=torch.empty(N, dtype=torch.float64, device=dev),
                         logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
         self._grad = None
+        self._row_caps = None            # static distinct-row bounds of the sparse table exchange (dist.calibrate_row_cap)
         if rdist.world_size() > 1:
             rdist.broadcast_(self.policy.flat_view('params'), src=0)      # replicas start identical (Adam state is zero)
             self._grad = self.policy.flat_view('grad')
@@ -233,8 +234,11 @@ class RawStateTrainer(_DeferredStats):
         # ids clamped the way the kernels clamp them; allreduce_rows_mean_ finds the distinct rows itself with fixed-shape
         # device ops (torch.unique would drain the queue once per minibatch)
         flat = [cat.reshape(-1).to(torch.int64), torch.cat([q.reshape(-1) for q in seqs]).to(torch.int64)]
-        for (off, H, E), i in zip(tables, flat):
-            rdist.allreduce_rows_mean_(g[off:off + H * E].view(H, E), i.clamp(0, H - 1))
+        if self._row_caps is None:
+            # static distinct-row bounds, measured on the first minibatch and agreed across the ranks (start-up only)
+            self._row_caps = [rdist.calibrate_row_cap(i.clamp(0, H - 1), H) for (off, H, E), i in zip(tables, flat)]
+        for (off, H, E), i, cap in zip(tables, flat, self._row_caps):
+            rdist.allreduce_rows_mean_(g[off:off + H * E].view(H, E), i.clamp(0, H - 1), cap=cap)
         tail = tables[-1][0] + tables[-1][1] * tables[-1][2]
         rdist.allreduce_mean_(g[tail:])
 

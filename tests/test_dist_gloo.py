@@ -176,6 +176,23 @@ def _rows_worker(rank, world, port, out):
     big_ids = torch.arange(rank, 16, 2)
     big[big_ids] = float(rank + 1)
     D.allreduce_rows_mean_(big, big_ids)
+    assert D.LAST_ROWS_PATH == 'dense'
+    # the bench shape of the raw-state policy's SEQUENCE table: 256 x 64 x 2 = 32768 id slots naming at most 283
+    # distinct item ids of a 100000-row table.  With the slot count as the bound every W >= 2 took the dense 51 MB all-reduce;
+    # the calibrated bound keeps it on the sparse exchange
+    Hs, n_slots = 100000, 256 * 64 * 2
+    seq_ids = torch.randint(1, 284, (n_slots,), generator=g)
+    seq_tab = torch.zeros(Hs, 4)
+    seq_tab[torch.unique(seq_ids)] = float(rank + 1)
+    cap = D.calibrate_row_cap(seq_ids, Hs)
+    assert cap == 2048 and cap * 2 * 2 <= Hs
+    D.allreduce_rows_mean_(seq_tab, seq_ids, cap=cap)
+    assert D.LAST_ROWS_PATH == 'sparse'
+    touched = torch.zeros(Hs, dtype=torch.bool)
+    touched[1:284] = True
+    assert (seq_tab[~touched] == 0).all() and not torch.isnan(seq_tab).any() and (seq_tab[touched] > 0).all()
+    D.allreduce_rows_mean_(torch.zeros(Hs, 4), seq_ids)          # without the hint: the id-slot count -> dense fallback
+    assert D.LAST_ROWS_PATH == 'dense'
     b = torch.full((5,), float(rank))
     D.broadcast_(b, src=1)
     D.barrier()

@@ -348,8 +348,8 @@ def test_fused_step_is_bit_identical(tmp_path, kind):
     if kind == 'slate_widedeep':                  # the family whose observation is wider than 256 (256 + U + Cn * E)
         cfg['algo'] = 'widedeep'
 
-    def run(fused):
-        c = dict(cfg, no_fused_step=not fused)
+    def run(fused, copies=False):
+        c = dict(cfg, no_fused_step=not fused, copy_outputs=copies)
         if seq:
             env = rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=SeqSlateRecEnv(c, state_cls=SeqSlateState))
         else:
@@ -463,8 +463,8 @@ def test_reference_shaped_step_is_one_record_and_bit_identical(tmp_path, kind):
     if kind == 'widedeep':
         cfg['algo'] = 'widedeep'
 
-    def run(fused):
-        c = dict(cfg, no_fused_step=not fused)
+    def run(fused, copies=False):
+        c = dict(cfg, no_fused_step=not fused, copy_outputs=copies)
         if seq:
             env = rl4rs_amd.make('SeqSlateRecEnv-v0', recsim=SeqSlateRecEnv(c, state_cls=SeqSlateState))
         else:
@@ -477,9 +477,24 @@ def test_reference_shaped_step_is_one_record_and_bit_identical(tmp_path, kind):
                 # the reset came back through rl4rs_env_observe_record_host: the first logged action is already on the device
                 first = env.offline_action
                 assert type(first).__name__ == 'OfflineActionList' and first._dev is not None
+                # every access hands out a FRESH list like the reference (slate.py:150-161): editing one does not leak into the
+                # next read, which still remembers the device copy of the ids
+                again = env.offline_action
+                assert again is not first and again == first and again._dev is not None
+                first[0] = -7
+                assert env.offline_action[0] == again[0] != -7
             for t in range(T):
                 a = env.offline_action
                 obs, reward, done, info = env.step(a)
+                if copies and fused:
+                    # config['copy_outputs']: pageable arrays that own their memory (not views of the step's pinned block)
+                    arrs = [obs] if isinstance(obs, np.ndarray) else ([obs[0]['obs'], obs[0]['action_mask']] if isinstance(obs, list) else
+                                                                     [obs['obs'], obs['action_mask']])
+                    for arr in arrs:
+                        root = arr
+                        while isinstance(getattr(root, 'base', None), np.ndarray):
+                            root = root.base
+                        assert root.flags.owndata and root.nbytes <= max(a_.nbytes for a_ in arrs) * B
                 info_copy = [dict((k, np.array(v)) for k, v in i.items()) for i in (info if isinstance(info, list) else [info])]
                 out.append((a, obs, reward, done, info_copy, np.asarray(env.samples.last_actions.cpu().numpy())))
             out.append((env.samples.prev_actions, env.samples.get_violation(), env.offline_reward))
@@ -490,6 +505,10 @@ def test_reference_shaped_step_is_one_record_and_bit_identical(tmp_path, kind):
     assert len(a) == len(b)
     for i, (x, y) in enumerate(zip(a, b)):
         assert _deep_equal(x, y), (kind, i)
+    if kind in ('plain', 'rllib_mask', 'd3rl_mask', 'one_env'):
+        c = run(True, copies=True)
+        for i, (x, y) in enumerate(zip(a, c)):
+            assert _deep_equal(x, y), (kind, 'copy_outputs', i)
     steps = [x for x in a if isinstance(x, tuple) and len(x) == 6]
     assert any(np.sum(np.abs(np.asarray(s[2], dtype=np.float64))) > 0 for s in steps)            # rewards were paid
     if 'fetch' in kind:
