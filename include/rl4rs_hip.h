@@ -349,6 +349,9 @@ int rl4rs_dien_set_row_order(rl4rs_dien* net, const int32_t* order_dev, int32_t 
 int rl4rs_dien_set_profiling(rl4rs_dien* net, int enable);
 int rl4rs_dien_kernel_count(void);
 const char* rl4rs_dien_kernel_name(int which);
+/* The kernel(s) THIS handle launches for class `which`, named as a rocprofv3 kernel trace shows them (they depend on the
+ * scorer mode and the handle's kernel_opts; rl4rs_dien_kernel_name is the static class name).  NUL-terminated into buf[cap]. */
+int rl4rs_dien_kernel_label(rl4rs_dien* net, int which, char* buf, int32_t cap);
 int rl4rs_dien_profile_read(rl4rs_dien* net, int which, double* ms_total, int64_t* launches);
 int rl4rs_dien_profile_reset(rl4rs_dien* net);
 

@@ -152,6 +152,7 @@ SIGNATURES = {
     'rl4rs_dien_set_profiling': (_I, [_P, _I]),
     'rl4rs_dien_kernel_count': (_I, []),
     'rl4rs_dien_kernel_name': (C.c_char_p, [_I]),
+    'rl4rs_dien_kernel_label': (_I, [_P, _I, C.c_char_p, _I32]),
     'rl4rs_dien_profile_read': (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(_I64)]),
     'rl4rs_dien_profile_reset': (_I, [_P]),
     'rl4rs_policy_param_count': (_I, [_I32, _I32, _I32]),

@@ -2006,6 +2006,38 @@ int rl4rs_dien_status_word(rl4rs_dien* n, int32_t** word_dev) {
     return RL4RS_OK;
 }
 int rl4rs_dien_kernel_count(void) { return KID_COUNT; }
+// The kernels THIS handle launches for kernel class `which` (they depend on the scorer mode and the handle's options), as they
+// appear in a rocprofv3 kernel trace - the static class names of rl4rs_dien_kernel_name are those of the fp32 build.
+int rl4rs_dien_kernel_label(rl4rs_dien* n, int which, char* buf, int32_t cap) {
+    RL4RS_REQUIRE(n && buf && cap > 0 && which >= 0 && which < KID_COUNT, "dien_kernel_label: bad argument");
+    const char* gemm = n->gemm16 ? "k_gemm_h16" : "k_gemm_pk";
+    const bool din_x = n->fp16x2 && n->din16 && n->h1f[0];
+    std::string s;
+    switch (which) {
+        case KID_CAT: s = "k_cat_attn"; break;
+        case KID_DENSE:
+            s = (n->gemm16 && n->dense_chain && n->U <= 128 && n->U % 16 == 0) ? "k_gemm_h16<chain>(dense tower, both layers)"
+                                                                                : std::string(gemm) + " x2 (dense tower)";
+            break;
+        case KID_DIN:
+            s = std::string(din_x ? "k_din_x" : (n->fp16x2 && n->din16 ? "k_din_scores<h16>" : "k_din_scores")) + " + " + gemm + "(q-side term)";
+            break;
+        case KID_AUGRU:
+            s = !n->fp16x2 ? "k_recur<256,augru>" : (n->augru_x ? "k_augru_x" : "k_augru_h16");
+            break;
+        case KID_HEAD:
+            s = std::string(gemm) + "(simulator_obs)" + ((n->ptab && !n->tsum) ? " + k_head_finish" : "");
+            break;
+        case KID_PROB: s = "k_head_prob"; break;
+        case KID_GRU1:
+            s = n->gru16 ? "k_gru_h16" : "k_recur<128,gru>";
+            if (n->h1f[0]) s += " + k_h1_frag";
+            break;
+        case KID_PROJ: s = n->gemm16 ? "k_gemm_h16 / k_gemm_h16_wres(seq projections)" : "k_gemm_pk(seq projections)"; break;
+    }
+    snprintf(buf, (size_t)cap, "%s", s.c_str());
+    return RL4RS_OK;
+}
 const char* rl4rs_dien_kernel_name(int which) {
     return (which >= 0 && which < KID_COUNT) ? kKernelNames[which] : "";
 }
