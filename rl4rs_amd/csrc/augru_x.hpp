@@ -55,6 +55,9 @@ constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
 // where in a step the staged projections of the update gate / the candidate are read into their accumulators (MFMA C-in): right
 // in front of the gate's first item (8 / 24) or some items earlier, so that the LDS round trip is not in front of that item's MFMAs
 // (both accumulators are free from item 0; the staging is per wave and was filled one step ago; must stay below the DMA window)
+#ifndef RL4RS_X_LATE_UPD_SHADOW
+#define RL4RS_X_LATE_UPD_SHADOW 0   // 1: the late waves also compute their update gate in the shadow of their first C items (like the early
+#endif                              // waves) instead of as a VALU-only stretch in front of them (round 4 A/B)
 #ifndef RL4RS_X_XU_AT
 #define RL4RS_X_XU_AT 8
 #endif
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) x_read(acc_c[m], 2, m);
                 }
-                if (!early) {
+                if (!early && !RL4RS_X_LATE_UPD_SHADOW) {
                     // late role: the whole update gate first (VALU only) - its partner on the SIMD is already in its C items
 #pragma unroll
                     for (int r = 0; r < 16; ++r) update_gate(r);
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
             // ---- epilogue work in this item's MFMA shadow
             if (i >= 8 && i < 24) {
                 reset_gate(i - 8);
-            } else if (early && i >= 24 && i < 32) {
+            } else if ((early || RL4RS_X_LATE_UPD_SHADOW) && i >= 24 && i < 32) {
                 update_gate(2 * (i - 24));
                 update_gate(2 * (i - 24) + 1);
             } else if (!early && i >= 40) {

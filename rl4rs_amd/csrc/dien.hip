@@ -265,6 +265,180 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_cat_attn2: the same category branch for the default shape (E = 128, Cn <= 24) with HALF the LDS per row.
+// k_cat_attn keeps a [Cn, E + 4] fp32 image of the row's embedding block in LDS (11.2 KB for Cn = 21): 4-row workgroups of
+// 44.8 KB fit three to a CU = 12 rows in flight per CU, but an obs-sized launch at B = 4096 has 16 rows per CU, so it ran
+// as one full round plus a one-third-full second round of the same dependent chain (ids -> gathers -> LDS -> Gram MFMAs ->
+// softmax -> pooled row), and the reward-sized launch had 12 chains per CU in flight where the register file allows 16+.
+// Here the image holds one 64-column half of the block at a time (5.8 KB per row): the Gram matrix S = E E^T is accumulated
+// over the two halves (the k order of an MFMA sum is free), and the pooled row comes from the gathered registers (lane e
+// still holds E[j][e], E[j][e + 64] of every row j) instead of re-reading the image.  22.9 KB per workgroup: seven fit a CU,
+// the register file (<= 128 VGPRs) allows 16 waves = 16 rows: an obs-sized launch is ONE round.  Bit-identical arithmetic to
+// k_cat_attn except the pooled row (register FMAs in the same j order: identical too).
+__global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict__ cat, int R, int Cn, int H,
+                                                      const float* __restrict__ cat_emb, const float* __restrict__ seq_emb,
+                                                      float* __restrict__ allf, int ldf, int off_c, float* __restrict__ q, int write_flat,
+                                                      int h16, const float* __restrict__ ptab, const float* __restrict__ obs_b,
+                                                      float* __restrict__ tsum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 128, HK = 64, LE = HK + 4, MAXC = 24, TCH = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, li = lane & 31;
+    float* sE = reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * LE + 32);
+    float* sW = sE + Cn * LE;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const int32_t* crowp = cat + (size_t)row * Cn;
+    float* frow = allf + (size_t)row * ldf + off_c;
+    const int myid = (lane < Cn) ? min(max(crowp[lane], 0), H - 1) : 0;
+    const int nq = min(10, Cn);
+    // register budget (<= 128 for four waves per SIMD): the query rows are requested first and folded into two sums as soon as
+    // they are there (they return in request order, ahead of the 48 category-row requests behind them); the head-table rows
+    // come in six chunks of 4, each requested one stage ahead of where it is summed
+    float qv0[10], qv1[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        const float* src = seq_emb + (size_t)__builtin_amdgcn_readlane(myid, max(Cn - 10 + u, 0)) * E;      // wave-uniform: scalar base
+        qv0[u] = src[lane];
+        qv1[u] = src[lane + 64];
+    }
+    float v0[MAXC], v1[MAXC];
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+        const float* src = cat_emb + (size_t)__builtin_amdgcn_readlane(myid, min(u, Cn - 1)) * E;
+        v0[u] = src[lane];
+        v1[u] = src[lane + 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 10; ++u)
+        if (u >= 10 - nq) { q0 += qv0[u]; q1 += qv1[u]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool do_t = tsum != nullptr;
+    float4 tacc = make_float4(0.f, 0.f, 0.f, 0.f), tv[TCH];
+    auto t_request = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < TCH; ++u) {
+            const int j = min(c * TCH + u, Cn - 1);
+            tv[u] = reinterpret_cast<const float4*>(ptab + ((size_t)j * H + __builtin_amdgcn_readlane(myid, j)) * OBS_DIM)[lane];
+        }
+    };
+    auto t_add = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < TCH; ++u)
+            if (c * TCH + u < Cn) { tacc.x += tv[u].x; tacc.y += tv[u].y; tacc.z += tv[u].z; tacc.w += tv[u].w; }
+    };
+    // stage c: sum chunk c - 1, request chunk c (same summation order as k_cat_attn: bias, then rows 0, 1, 2, ...)
+#define CAT2_T_STAGE(c) do { if (do_t) { if ((c) > 0) t_add((c) - 1); if ((c) * TCH < Cn && (c) * TCH < MAXC) t_request(c); } } while (0)
+    if (do_t) tacc = reinterpret_cast<const float4*>(obs_b)[lane];
+    CAT2_T_STAGE(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool row_ok = li < Cn;
+    const float* er32 = sE + (row_ok ? li : 0) * LE + half * 4;
+    const float* er16 = sE + (row_ok ? li : 0) * LE + half * 8;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph) {                                   // every lane has finished reading the first half
+            CAT2_T_STAGE(1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u)
+            if (u < Cn) {
+                sE[u * LE + lane] = ph ? v1[u] : v0[u];
+                if (write_flat) frow[E + u * E + ph * 64 + lane] = ph ? v1[u] : v0[u];       // Flatten()(category_emb)
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (h16) {
+#pragma unroll
+            for (int kb = 0; kb < HK / 16; ++kb) {
+                float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+                if (row_ok) { f0 = *reinterpret_cast<const float4*>(er16 + kb * 16); f1 = *reinterpret_cast<const float4*>(er16 + kb * 16 + 4); }
+                const float x[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                half8_t fh, fl;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    half2_t h2, l2;
+                    split_h16_pair(x[e], x[e + 1], h2, l2);
+                    fh[e] = h2[0]; fh[e + 1] = h2[1];
+                    fl[e] = l2[0]; fl[e + 1] = l2[1];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, fh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fl, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < HK / 8; ++kb) {
+                float4 f = row_ok ? *reinterpret_cast<const float4*>(er32 + kb * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, f.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, f.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, f.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, f.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    // (the second half of the block stays in the LDS image: the pooled row reads its columns 64..127 from there, columns
+    // 0..63 from the registers - the v1 registers are free from here on)
+    CAT2_T_STAGE(2);
+    float m = -3.4e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (crow(r, half) < Cn) m = fmaxf(m, acc[r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float z = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float ev = (crow(r, half) < Cn) ? expf(acc[r] - m) : 0.f;
+        acc[r] = ev;
+        z += ev;
+    }
+    z += __shfl_xor(z, 32);
+    CAT2_T_STAGE(3);
+    const float inv = row_ok ? 1.f / z : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] * inv;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (li == 0) sW[crow(r, half)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    CAT2_T_STAGE(4);
+    {
+        const float invc = 1.f / (float)Cn;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j)
+            if (j < Cn) {
+                const float w = sW[j];
+                s0 = fmaf(w, v0[j], s0);
+                s1 = fmaf(w, sE[j * LE + lane], s1);
+            }
+        frow[lane] = s0 * invc;
+        frow[lane + 64] = s1 * invc;
+    }
+    CAT2_T_STAGE(5);
+    const float invq = 1.f / (float)nq;
+    q[(size_t)row * E + lane] = q0 * invq;
+    q[(size_t)row * E + lane + 64] = q1 * invq;
+    if (do_t) {
+        t_add(5);
+        reinterpret_cast<float4*>(tsum + (size_t)row * OBS_DIM)[lane] = tacc;
+    }
+#undef CAT2_T_STAGE
+}
+
+// -------------------------------------------------------------------------------------------------
 // Recurrent kernel: GRU (NH = E, first layer, writes every state) or AUGRU (NH = 2E, writes the final state).
 //   gates  [r|u] = sigmoid(xg_t + h @ Wg)      Wg packed [2*NW tiles][NH/8][64 lanes][4]
 //   cand   c     = tanh(xc_t + (r*h) @ Wc)     Wc packed [NW tiles][NH/8][64][4]
@@ -1313,6 +1487,7 @@ struct rl4rs_dien {
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
+    bool cat_v2;           // category branch through k_cat_attn2 (half-K LDS image) when the shape allows (RL4RS_DIEN_OPT_CAT_V1: first form)
     bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
     bool din16;            // fp16x2 mode: the DIN layer-1 operands (q*h1 bounded by the embedding table, W1d) fit fp16 too
@@ -1488,6 +1663,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->din_x = !(opts & RL4RS_DIEN_OPT_DIN_V1);
     n->gemm16 = false;
     n->cat16 = false;
+    n->cat_v2 = !(opts & RL4RS_DIEN_OPT_CAT_V1);
     n->dense_chain = !(opts & RL4RS_DIEN_OPT_NO_DENSE_CHAIN);
     n->gru16 = false;
     n->gru16_attr = false;
@@ -1795,10 +1971,17 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     int rc;
     {
         Prof p(n, KID_CAT, st);
-        size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
-        hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
-                           n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
-                           n->ptab, n->obs_b, n->tsum);
+        if (n->cat_v2 && E == 128 && Cn <= 24) {
+            size_t smem = (size_t)4 * (Cn * (64 + 4) + 32) * 4;
+            hipLaunchKernelGGL(k_cat_attn2, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, n->H, n->cat_emb,
+                               n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
+                               n->ptab, n->obs_b, n->tsum);
+        } else {
+            size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
+            hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
+                               n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
+                               n->ptab, n->obs_b, n->tsum);
+        }
         RL4RS_LAUNCH_CHECK();
     }
     {
@@ -2014,7 +2197,7 @@ int rl4rs_dien_kernel_label(rl4rs_dien* n, int which, char* buf, int32_t cap) {
     const bool din_x = n->fp16x2 && n->din16 && n->h1f[0];
     std::string s;
     switch (which) {
-        case KID_CAT: s = "k_cat_attn"; break;
+        case KID_CAT: s = (n->cat_v2 && n->E == 128 && n->Cn <= 24) ? "k_cat_attn2" : "k_cat_attn"; break;
         case KID_DENSE:
             s = (n->gemm16 && n->dense_chain && n->U <= 128 && n->U % 16 == 0) ? "k_gemm_h16<chain>(dense tower, both layers)"
                                                                                 : std::string(gemm) + " x2 (dense tower)";

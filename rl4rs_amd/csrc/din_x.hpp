@@ -22,6 +22,10 @@
 //     32 lines of which it uses a quarter each; the rows of a reward group (same slot) hit in L1, no LDS tile needed.
 #pragma once
 
+#ifndef RL4RS_DINX_AB
+#define RL4RS_DINX_AB 0         // timing ablations of k_din_x (results are WRONG when non-zero): 1 all rows on cache slot 0, 2 no layer-1 sigmoids
+#endif
+
 namespace rl4rs {
 
 // h1 [slot, L, E = 128] -> fragment order [slot][NT][8][64][8]; steps >= L of the last tile are zero
@@ -80,7 +84,11 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
         const int g = idx / grp;
         const int gs = a.order ? a.order[g] : g;
         const int row = gs * grp + (idx - g * grp);
+#if RL4RS_DINX_AB & 1       // timing ablation (results WRONG): every row reads cache slot 0 - the cache traffic becomes L1 / L2 hits
+        const int slot = 0 * a.slots[(size_t)sq * a.slots_stride + gs];
+#else
         const int slot = a.slots[(size_t)sq * a.slots_stride + gs];
+#endif
         __builtin_amdgcn_wave_barrier();
         // the row's q and q-side term are requested here and staged in LDS inside the first tile, behind that tile's own
         // requests: one memory round trip at the start of a row instead of two
@@ -175,7 +183,11 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         half2_t h2, l2;
+#if RL4RS_DINX_AB & 2       // timing ablation (results WRONG): no layer-1 sigmoids
+                        split_h16_pair(acc[m][kb2 * 8 + e], acc[m][kb2 * 8 + e + 1], h2, l2);
+#else
                         split_h16_pair(gate_sigmoid(acc[m][kb2 * 8 + e]), gate_sigmoid(acc[m][kb2 * 8 + e + 1]), h2, l2);
+#endif
                         bh2[e] = h2[0]; bh2[e + 1] = h2[1];
                         bl2[e] = l2[0]; bl2[e + 1] = l2[1];
                     }
