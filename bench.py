@@ -413,6 +413,19 @@ def bcq_leg(env, cfg, rank, update_steps=200, rollouts=3):
                                "critics, lam-weighted target over 100 sampled actions per row (25 600-row forward through 4 networks), soft "
                                "target updates; dataset = %d transitions generated on the device" % wl.tr[0].shape[0],
                        "last_losses": dict((k, float(v[-1])) for k, v in hist.items() if len(v))}}
+    # the other continuous learner the reference offers for this config ('CQL-conti', batchrl_trainer.py:91-107): updates/s only
+    from rl4rs_amd.offline_rl import CQL, StandardRewardScaler
+    cql = CQL(cfg, wl.tr[0].shape[1], batch_size=256, gamma=1.0, reward_scaler=StandardRewardScaler(wl.tr[2]), seed=7)
+    cql.fit(wl.tr, 10, to_host=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cql.fit(wl.tr, update_steps, to_host=False)
+    torch.cuda.synchronize()
+    dt_c = time.perf_counter() - t0
+    out["learner_cql"] = {"updates_per_s": update_steps / dt_c, "transitions_per_s": update_steps * 256 / dt_c, "ms_per_update": dt_c / update_steps * 1e3,
+                          "what": "d3rlpy.algos.CQL(batch_size=256, gamma=1, reward_scaler='standard') restated on the device: squashed-Gaussian "
+                                  "actor, learned temperature and alpha, twin critics with the conservative term over 31 rows per transition"}
+    cql.close()
     wl.bcq.close()
     return out
 

@@ -794,6 +794,30 @@ int rl4rs_pick_rows(int32_t B, int32_t n, int32_t E, const float* rows_dev, cons
 int rl4rs_critic_mse(int32_t N, const float* q1_dev, const float* q2_dev, const float* y_dev, float* dq1_dev, float* dq2_dev,
                      float* loss2_dev, void* stream);
 
+/* Continuous CQL (d3rlpy.algos.CQL = SAC + the conservative critic term; 'CQL-conti', script/batchrl_trainer.py:91-107).
+ * squashed_sample: d3rlpy SquashedNormalPolicy.sample(_n)_with_log_prob.  head_dev [N / rep, 2A] = [mu | logstd] (the policy
+ * amlp's two Linear heads side by side, act_dim = 0), eps_dev [N, A] the caller's Gaussian noise (NULL: the deterministic
+ * best_action a = tanh(mu), no log-prob).  u = mu + exp(clamp(logstd)) * eps, a = tanh(u), logp = sum_e [Normal log-prob of u
+ * - 2 (log 2 - u - softplus(-2u))].  Sample i of observation r is written to destination row r * out_rep + out_off + i % rep of
+ * act_out_dev [.., A] and logp_out_dev (so several sample groups of an observation can sit side by side).
+ * sac_actor_grad: gradient of mean_b [exp(log_temp) * logp_b - Qmin(s_b, a_b)] wrt the head, given g_act_dev [B, A] = gradient
+ * of -mean Qmin wrt the action (the critics' rl4rs_amlp_backward dact, 1 / B included); log_temp_dev: device scalar.
+ * twin_min: qmin = min(q1, q2) and (optional) the selector dq_c = -1/B on the smaller critic (q1 on ties).
+ * cql_critic_loss: rows laid out [B][m], column 0 = the dataset action, columns 1..m-1 = sampled actions with importance
+ * offsets offs_dev (log-prob of a policy sample, A * log 0.5 of a uniform one):
+ *   sums6_dev = {sum_b (q1[b,0] - y_b)^2, same for q2, sum_b logsumexp_j (q1[b,j] - offs[b,j]), same for q2, sum_b q1[b,0], sum_b q2[b,0]}
+ *   dq_c[b,0] = 2 (q_c[b,0] - y_b) / B - aw / (2B),  dq_c[b,j>0] = aw / (2B) * softmax_j,  aw = *alpha_w_dev (clipped alpha *
+ *   conservative weight, device scalar).  y_dev NULL: sums only (the alpha update).  rows_scratch_dev: [B, 6] float32. */
+int rl4rs_squashed_sample(int32_t N, int32_t rep, int32_t A, const float* head_dev, const float* eps_dev, float min_logstd,
+                          float max_logstd, int32_t out_rep, int32_t out_off, float* act_out_dev, float* logp_out_dev, void* stream);
+int rl4rs_sac_actor_grad(int32_t B, int32_t A, const float* head_dev, const float* eps_dev, const float* act_dev,
+                         const float* g_act_dev, const float* log_temp_dev, float min_logstd, float max_logstd, float* d_head_dev,
+                         void* stream);
+int rl4rs_twin_min(int32_t B, const float* q1_dev, const float* q2_dev, float* qmin_dev, float* dq1_dev, float* dq2_dev, void* stream);
+int rl4rs_cql_critic_loss(int32_t B, int32_t m, const float* q1_dev, const float* q2_dev, const float* offs_dev, const float* y_dev,
+                          const float* alpha_w_dev, float* dq1_dev, float* dq2_dev, float* rows_scratch_dev, float* sums6_dev,
+                          void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh, 4 ReLU. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

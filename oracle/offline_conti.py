@@ -104,3 +104,68 @@ def predict_best_action(dec, policy, q1, obs, z, n, scale):
 
 def soft_sync(targ, src, tau):
     return dict((k, (1.0 - tau) * targ[k] + tau * src[k]) for k in targ)
+
+
+# ---- continuous CQL (d3rlpy.algos.CQL = SAC + conservative critic loss), d3rlpy 0.91 as published; PARITY UNPINNED --------------
+#   d3rlpy/models/torch/policies.py   SquashedNormalPolicy: Normal(mu, exp(clamp(logstd, -20, 2))), _squash_action:
+#                                     tanh(u), log_prob = sum(dist.log_prob(u) - 2 (log 2 - u - softplus(-2u)))
+#   d3rlpy/algos/torch/sac_impl.py    actor (exp(log_temp) * logp - min_c Q_c(s, a)).mean(); temp -(exp(log_temp) * (logp - A)).mean()
+#   d3rlpy/algos/torch/cql_impl.py    conservative loss over [pi(s) samples | pi(s') samples | uniform], deterministic target
+
+def squashed_sample(policy, obs, eps, min_logstd=-20.0, max_logstd=2.0):
+    """(tanh(u), log-prob [rows]) for eps [rows, A]; rows = n_obs * rep with the observation of row i = i // rep."""
+    head = policy(_t(obs))
+    A = head.shape[1] // 2
+    eps = _t(eps)
+    rep = eps.shape[0] // head.shape[0]
+    mu = head[:, :A].repeat_interleave(rep, dim=0)
+    logstd = head[:, A:].clamp(min_logstd, max_logstd).repeat_interleave(rep, dim=0)
+    dist = torch.distributions.Normal(mu, logstd.exp())
+    u = mu + logstd.exp() * eps
+    jacob = 2.0 * (np.log(2.0) - u - torch.nn.functional.softplus(-2.0 * u))
+    return torch.tanh(u), (dist.log_prob(u) - jacob).sum(dim=1)
+
+
+def best_action(policy, obs):
+    head = policy(_t(obs))
+    return torch.tanh(head[:, :head.shape[1] // 2])
+
+
+def temp_loss(policy, log_temp, obs, eps):
+    with torch.no_grad():
+        _, logp = squashed_sample(policy, obs, eps)
+        targ = logp - eps.shape[1]
+    return -(log_temp.exp() * targ).mean()
+
+
+def conservative_loss(policy, qs, log_alpha, obs, act, nxt, eps_t, eps_tp1, uniform, n, weight, threshold):
+    """CQLImpl._compute_conservative_loss: clipped_alpha * (weight * (logsumexp.mean - data.mean) - threshold)"""
+    obs, act = _t(obs), _t(act)
+    B, A = act.shape
+    with torch.no_grad():
+        a_t, lp_t = squashed_sample(policy, obs, eps_t)
+        a_tp1, lp_tp1 = squashed_sample(policy, nxt, eps_tp1)
+    rep = obs.repeat_interleave(n, dim=0)
+    uni = _t(uniform).reshape(B * n, A)
+    vals = []
+    for q in qs:
+        v = torch.cat([(q(rep, a_t)[:, 0] - lp_t).reshape(B, n), (q(rep, a_tp1)[:, 0] - lp_tp1).reshape(B, n),
+                       (q(rep, uni)[:, 0] - np.log(0.5 ** A)).reshape(B, n)], dim=1)
+        vals.append(v)
+    lse = torch.stack([torch.logsumexp(v, dim=1) for v in vals])               # [critics, B]
+    data = torch.stack([q(obs, act)[:, 0] for q in qs])
+    scaled = weight * (lse.mean(dim=0).mean() - data.mean(dim=0).mean())
+    return log_alpha.exp().clamp(0, 1e6) * (scaled - threshold)
+
+
+def cql_target(policy, q_targs, nxt, rewards, terminals, gamma):
+    with torch.no_grad():
+        a = best_action(policy, nxt)
+        v = torch.stack([q(_t(nxt), a)[:, 0] for q in q_targs]).min(dim=0).values
+        return _t(rewards) + gamma * v * (1.0 - _t(terminals))
+
+
+def sac_actor_loss(policy, qs, log_temp, obs, eps):
+    a, logp = squashed_sample(policy, obs, eps)
+    qmin = torch.stack([q(_t(obs), a)[:, 0] for q in qs]).min(dim=0).values
+    return (log_temp.detach().exp() * logp - qmin).mean()

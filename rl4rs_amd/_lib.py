@@ -238,6 +238,10 @@ SIGNATURES = {
     'rl4rs_bcq_target': (_I, [_I32, _I32, _P, _P, C.c_float, _P, _P, C.c_float, _P, _P, _P]),
     'rl4rs_pick_rows': (_I, [_I32, _I32, _I32, _P, _P, _P, _P]),
     'rl4rs_critic_mse': (_I, [_I32, _P, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_squashed_sample': (_I, [_I32, _I32, _I32, _P, _P, C.c_float, C.c_float, _I32, _I32, _P, _P, _P]),
+    'rl4rs_sac_actor_grad': (_I, [_I32, _I32, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P]),
+    'rl4rs_twin_min': (_I, [_I32, _P, _P, _P, _P, _P, _P]),
+    'rl4rs_cql_critic_loss': (_I, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'rl4rs_gemm_f32_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_h16_packed': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),
     'rl4rs_gemm_f32': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I, _P]),

@@ -181,6 +181,127 @@ __global__ __launch_bounds__(256) void k_critic_mse(int N, const float* __restri
     if (threadIdx.x == 0) { loss2[0] = sm[0].x / (float)N; loss2[1] = sm[0].y / (float)N; }
 }
 
+
+// ---- continuous CQL (d3rlpy.algos.CQL = SAC + conservative critic loss) -------------------------------------------------------
+// SquashedNormalPolicy.sample(_n)_with_log_prob: head [R, 2A] = [mu | logstd] of R = N / rep observations, eps [N, A]:
+//   u = mu + exp(clamp(logstd, lo, hi)) * eps,  a = tanh(u),
+//   logp = sum_e [ Normal(mu, sigma).log_prob(u) - 2 (log 2 - u - softplus(-2 u)) ]            (d3rlpy _squash_action)
+// eps NULL: the deterministic best_action a = tanh(mu) (no log-prob).  Sample i of observation r lands in destination row
+// r * out_rep + out_off + i % rep of act_out [.., A] / logp_out: the caller lays several sample groups of one observation side
+// by side (the [data | pi(s) | pi(s') | uniform] rows of the conservative loss).  One wave per sample row.
+__global__ __launch_bounds__(256) void k_squashed_sample(int N, int rep, int A, const float* __restrict__ head, const float* __restrict__ eps,
+                                                         float lo, float hi, int out_rep, int out_off, float* __restrict__ act_out,
+                                                         float* __restrict__ logp_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int r = i / rep;
+    const size_t dst = (size_t)r * out_rep + out_off + (i - r * rep);
+    float lp = 0.f;
+    for (int e = lane; e < A; e += 64) {
+        const float mu = head[(size_t)r * 2 * A + e];
+        float u = mu;
+        if (eps) {
+            const float ls = fminf(fmaxf(head[(size_t)r * 2 * A + A + e], lo), hi);
+            const float ep = eps[(size_t)i * A + e];
+            u = mu + expf(ls) * ep;
+            const float m2u = -2.0f * u;
+            const float softplus = fmaxf(m2u, 0.f) + log1pf(expf(-fabsf(m2u)));
+            lp += -0.5f * ep * ep - ls - 0.9189385332046727f - 2.0f * (0.6931471805599453f - u - softplus);
+        }
+        act_out[dst * A + e] = tanhf(u);
+    }
+    if (eps && logp_out) {
+        lp = wave_sum(lp);
+        if (lane == 0) logp_out[dst] = lp;
+    }
+}
+
+// SAC actor loss  mean_b [ T * logp_b - Qmin(s_b, a_b) ]  back to the policy head [mu | logstd]:  g_a [B, A] = gradient of
+// -mean Qmin wrt the action (from the critics' backward, 1 / B included), T = exp(log_temp).
+//   dL/du = T * 2 a / B + g_a (1 - a^2)     (d logp / du = 2 tanh(u): the Normal log-prob of an rsample does not move with mu)
+//   dL/dmu = dL/du;   dL/dlogstd = [lo <= raw <= hi] (dL/du * sigma * eps - T / B)
+__global__ void k_sac_actor_grad(int B, int A, const float* __restrict__ head, const float* __restrict__ eps, const float* __restrict__ act,
+                                 const float* __restrict__ g_a, const float* __restrict__ log_temp, float lo, float hi,
+                                 float* __restrict__ d_head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * A) return;
+    const int b = i / A, e = i - b * A;
+    const float T = expf(log_temp[0]), inv_b = 1.0f / (float)B;
+    const float a = act[i], raw = head[(size_t)b * 2 * A + A + e];
+    const float ls = fminf(fmaxf(raw, lo), hi);
+    const float du = T * 2.0f * a * inv_b + g_a[i] * (1.0f - a * a);
+    d_head[(size_t)b * 2 * A + e] = du;
+    d_head[(size_t)b * 2 * A + A + e] = (raw >= lo && raw <= hi) ? du * expf(ls) * eps[i] - T * inv_b : 0.f;
+}
+
+// twin-critic minimum and the gradient selector of -mean_b min(q1, q2): dq_c = -1/B on the smaller one (q1 on ties)
+__global__ void k_twin_min(int B, const float* __restrict__ q1, const float* __restrict__ q2, float* __restrict__ qmin,
+                           float* __restrict__ dq1, float* __restrict__ dq2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const bool first = q1[i] <= q2[i];
+    qmin[i] = first ? q1[i] : q2[i];
+    if (dq1) {
+        dq1[i] = first ? -1.0f / (float)B : 0.f;
+        dq2[i] = first ? 0.f : -1.0f / (float)B;
+    }
+}
+
+// CQL critic loss over rows laid out [B][m]: column 0 = the dataset action (TD + the -Q(s, a) term), columns 1 .. m-1 = the
+// sampled actions of the conservative term with their importance offsets offs (log-prob of a policy sample, log 0.5^A of a
+// uniform one).  One wave per observation.  y NULL: values only (the alpha update).
+//   sums[0..1] = sum_b (q_c[b,0] - y_b)^2,  sums[2..3] = sum_b logsumexp_j (q_c[b,j] - offs[b,j]),  sums[4..5] = sum_b q_c[b,0]
+//   dq_c[b,0] = 2 (q_c[b,0] - y_b) / B - aw / (2 B),   dq_c[b,j] = aw / (2 B) * softmax_j(...),   aw = clipped alpha * weight
+__global__ __launch_bounds__(256) void k_cql_rows(int B, int m, const float* __restrict__ q1, const float* __restrict__ q2,
+                                                  const float* __restrict__ offs, const float* __restrict__ y, const float* __restrict__ aw_dev,
+                                                  float* __restrict__ dq1, float* __restrict__ dq2, float* __restrict__ rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float aw = aw_dev ? aw_dev[0] : 0.f;
+    const float k = aw / (2.0f * (float)B);
+    float out[6];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* q = (c == 0 ? q1 : q2) + (size_t)b * m;
+        float* dq = (c == 0 ? dq1 : dq2);
+        float mx = -3.4028235e38f;
+        for (int j = 1 + lane; j < m; j += 64) mx = fmaxf(mx, q[j] - offs[(size_t)b * m + j]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int j = 1 + lane; j < m; j += 64) se += expf(q[j] - offs[(size_t)b * m + j] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        const float d0 = q[0] - (y ? y[b] : 0.f);
+        out[c] = d0 * d0;
+        out[2 + c] = lse;
+        out[4 + c] = q[0];
+        if (y && dq) {
+            for (int j = 1 + lane; j < m; j += 64) dq[(size_t)b * m + j] = k * expf(q[j] - offs[(size_t)b * m + j] - lse);
+            if (lane == 0) dq[(size_t)b * m] = 2.0f * d0 / (float)B - k;
+        }
+    }
+    if (lane == 0)
+        for (int c = 0; c < 6; ++c) rows[(size_t)b * 6 + c] = out[c];
+}
+
+// sums[c] = sum_b rows[b][c], c < 6 (single block, fixed order)
+__global__ __launch_bounds__(256) void k_sum6(const float* __restrict__ rows, int B, float* __restrict__ sums) {
+    __shared__ float sm[6][256];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += 256)
+        for (int c = 0; c < 6; ++c) s[c] += rows[(size_t)b * 6 + c];
+    for (int c = 0; c < 6; ++c) sm[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int c = 0; c < 6; ++c) sm[c][threadIdx.x] += sm[c][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) sums[threadIdx.x] = sm[threadIdx.x][0];
+}
+
 }  // namespace rl4rs
 
 enum { AP_W1 = 0, AP_B1, AP_W2, AP_B2, AP_W3, AP_B3, AP_COUNT };
@@ -423,6 +544,42 @@ int rl4rs_pick_rows(int32_t B, int32_t n, int32_t E, const float* rows, const in
 int rl4rs_critic_mse(int32_t N, const float* q1, const float* q2, const float* y, float* dq1, float* dq2, float* loss2, void* stream) {
     RL4RS_REQUIRE(q1 && q2 && y && dq1 && dq2 && loss2 && N > 0, "critic_mse: bad argument");
     hipLaunchKernelGGL(k_critic_mse, dim3(1), dim3(256), 0, (hipStream_t)stream, N, q1, q2, y, dq1, dq2, loss2);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_squashed_sample(int32_t N, int32_t rep, int32_t A, const float* head, const float* eps, float min_logstd, float max_logstd,
+                          int32_t out_rep, int32_t out_off, float* act_out, float* logp_out, void* stream) {
+    RL4RS_REQUIRE(head && act_out && N > 0 && rep > 0 && N % rep == 0 && A > 0 && out_rep >= rep && out_off >= 0 && out_off + rep <= out_rep,
+                  "squashed_sample: bad argument");
+    hipLaunchKernelGGL(k_squashed_sample, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, rep, A, head, eps, min_logstd, max_logstd,
+                       out_rep, out_off, act_out, logp_out);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_sac_actor_grad(int32_t B, int32_t A, const float* head, const float* eps, const float* act, const float* g_act, const float* log_temp,
+                         float min_logstd, float max_logstd, float* d_head, void* stream) {
+    RL4RS_REQUIRE(head && eps && act && g_act && log_temp && d_head && B > 0 && A > 0, "sac_actor_grad: bad argument");
+    hipLaunchKernelGGL(k_sac_actor_grad, dim3((B * A + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, A, head, eps, act, g_act, log_temp,
+                       min_logstd, max_logstd, d_head);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_twin_min(int32_t B, const float* q1, const float* q2, float* qmin, float* dq1, float* dq2, void* stream) {
+    RL4RS_REQUIRE(q1 && q2 && qmin && B > 0 && (!dq1 == !dq2), "twin_min: bad argument");
+    hipLaunchKernelGGL(k_twin_min, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, q1, q2, qmin, dq1, dq2);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+int rl4rs_cql_critic_loss(int32_t B, int32_t m, const float* q1, const float* q2, const float* offs, const float* y, const float* alpha_w,
+                          float* dq1, float* dq2, float* rows_scratch, float* sums6, void* stream) {
+    RL4RS_REQUIRE(q1 && q2 && offs && rows_scratch && sums6 && B > 0 && m > 1 && (!y || (dq1 && dq2 && alpha_w)), "cql_critic_loss: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cql_rows, dim3((B + 3) / 4), dim3(256), 0, st, B, m, q1, q2, offs, y, alpha_w, dq1, dq2, rows_scratch);
+    hipLaunchKernelGGL(k_sum6, dim3(1), dim3(256), 0, st, rows_scratch, B, sums6);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

@@ -1693,3 +1693,56 @@ def critic_mse(q1, q2, y):
     loss2 = torch.empty(2, dtype=torch.float32, device=y.device)
     check(lib.rl4rs_critic_mse(N, _ptr(q1), _ptr(q2), _ptr(y), _ptr(dq1), _ptr(dq2), _ptr(loss2), _stream()))
     return loss2, dq1, dq2
+
+
+def squashed_sample(head, eps, rep=1, act_out=None, logp_out=None, out_rep=None, out_off=0, min_logstd=-20.0, max_logstd=2.0):
+    """d3rlpy SquashedNormalPolicy sampling from head [R, 2A] = [mu | logstd]: (actions, log-probs).  ``eps`` [R * rep, A] Gaussian
+    noise, or None for the deterministic best_action tanh(mu).  ``act_out`` [rows, A] / ``logp_out`` [rows] with ``out_rep`` /
+    ``out_off``: write sample i of observation r to row r * out_rep + out_off + i % rep of caller-owned buffers."""
+    lib = _lib.load()
+    R, A = head.shape[0], head.shape[1] // 2
+    N = R * rep
+    if out_rep is None:
+        out_rep = rep
+    if act_out is None:
+        act_out = torch.empty((R * out_rep, A), dtype=torch.float32, device=head.device)
+    if logp_out is None and eps is not None:
+        logp_out = torch.empty(R * out_rep, dtype=torch.float32, device=head.device)
+    if eps is not None:
+        assert eps.is_contiguous() and eps.dtype == torch.float32 and eps.numel() == N * A
+    check(lib.rl4rs_squashed_sample(N, rep, A, _ptr(head), _ptr(eps), min_logstd, max_logstd, out_rep, out_off, _ptr(act_out), _ptr(logp_out),
+                                    _stream()))
+    return act_out, logp_out
+
+
+def sac_actor_grad(head, eps, act, g_act, log_temp, min_logstd=-20.0, max_logstd=2.0):
+    lib = _lib.load()
+    B, A = act.shape
+    d = torch.empty_like(head)
+    check(lib.rl4rs_sac_actor_grad(B, A, _ptr(head), _ptr(eps), _ptr(act), _ptr(g_act), _ptr(log_temp), min_logstd, max_logstd, _ptr(d), _stream()))
+    return d
+
+
+def twin_min(q1, q2, want_grad=False):
+    """(min(q1, q2), dq1, dq2): the selector of -mean min (None without ``want_grad``)."""
+    lib = _lib.load()
+    B = q1.numel()
+    qmin = torch.empty(B, dtype=torch.float32, device=q1.device)
+    dq1 = torch.empty_like(q1) if want_grad else None
+    dq2 = torch.empty_like(q2) if want_grad else None
+    check(lib.rl4rs_twin_min(B, _ptr(q1), _ptr(q2), _ptr(qmin), _ptr(dq1), _ptr(dq2), _stream()))
+    return qmin, dq1, dq2
+
+
+def cql_critic_loss(q1, q2, offs, m, y=None, alpha_w=None):
+    """(sums6, dq1, dq2) of the continuous CQL critic loss over rows [B][m] (column 0 = dataset action): see
+    rl4rs_cql_critic_loss.  ``y`` None: sums only."""
+    lib = _lib.load()
+    B = q1.numel() // m
+    dq1 = torch.empty_like(q1) if y is not None else None
+    dq2 = torch.empty_like(q2) if y is not None else None
+    rows = torch.empty((B, 6), dtype=torch.float32, device=q1.device)
+    sums = torch.empty(6, dtype=torch.float32, device=q1.device)
+    check(lib.rl4rs_cql_critic_loss(B, m, _ptr(q1), _ptr(q2), _ptr(offs), _ptr(y), _ptr(alpha_w), _ptr(dq1), _ptr(dq2), _ptr(rows), _ptr(sums),
+                                    _stream()))
+    return sums, dq1, dq2

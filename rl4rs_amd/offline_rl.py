@@ -18,6 +18,10 @@ through ``librl4rs_hip`` (``rl4rs_qnet_*``, ``rl4rs_qloss_*``); this module is t
   critics with the lam-weighted min/max target over 100 sampled actions, soft target updates; ``predict`` returns the embedding
   the env's K-NN resolves (``env.step(policy.predict(obs))``, batchrl_trainer.py:398-399 with ``predict_with_mask`` ->
   ``predict`` for continuous envs, rl4rs/policy/policy_model.py:17-19).
+* ``CQL`` - the continuous-action learner of ``'CQL-conti'`` (script/batchrl_trainer.py:91-107, ``d3rlpy.algos.CQL(batch_size=256,
+  gamma=1.0, reward_scaler='standard')``; the ``alpha=`` keyword the script passes is not a parameter of the continuous CQL and
+  is swallowed by d3rlpy's ``**kwargs``): SAC (squashed-Gaussian actor, learned temperature) with the conservative critic term
+  over 10 policy samples at s, 10 at s' and 10 uniform actions per row, learned log-alpha with threshold 10, weight 5.
 
 d3rlpy is absent from this image (parity unpinned): the hyper-parameter defaults above are d3rlpy 0.91's as published;
 every gradient is checked against torch autograd of the restated model in ``tests/test_gpu_offline_rl.py``.  With
@@ -385,7 +389,8 @@ class BCQ(object):
         obs, act, rew, nxt, ter = [t.to(self.device) for t in transitions]
         n = obs.shape[0]
         assert n >= self.batch_size, 'dataset smaller than one minibatch'
-        assert act.dim() == 2 and act.shape[1] == self.E and act.dtype == torch.float32, 'BCQ needs continuous actions [N, %d]' % self.E
+        E = getattr(self, 'E', None) or self.A
+        assert act.dim() == 2 and act.shape[1] == E and act.dtype == torch.float32, 'continuous actions [N, %d] needed' % E
         rs = np.random.RandomState(self.seed if shuffle_seed is None else shuffle_seed)
         hist, perm, pos = [], None, n
         for _ in range(n_steps):
@@ -397,7 +402,7 @@ class BCQ(object):
             hist.append(self.update(obs[idx].contiguous(), act[idx].contiguous(), rew[idx].contiguous(), nxt[idx].contiguous(),
                                     ter[idx].contiguous()))
         out = {}
-        for k in ('imitator_loss', 'critic_loss', 'actor_loss'):
+        for k in self._LOSS_KEYS:
             vals = [h[k] for h in hist if k in h]
             if not vals:
                 out[k] = []
@@ -406,6 +411,8 @@ class BCQ(object):
             else:
                 out[k] = torch.stack(vals)
         return out
+
+    _LOSS_KEYS = ('imitator_loss', 'critic_loss', 'actor_loss')
 
     def predict(self, obs, noise=None):
         """BCQImpl._predict_best_action: 100 sampled actions per observation, the one the FIRST critic values highest.
@@ -432,6 +439,202 @@ class BCQ(object):
         actions = D_._dev_tensor(actions, torch.float32, self.device)
         out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
         rows = max(self.batch_size, self.predict_rows) * self.n
+        for lo in range(0, obs.shape[0], rows):
+            x, a = obs[lo:lo + rows].contiguous(), actions[lo:lo + rows].contiguous()
+            out[lo:lo + x.shape[0]] = 0.5 * (self.q1.forward(x, a)[:, 0] + self.q2.forward(x, a)[:, 0])
+        return out
+
+    def close(self):
+        for net in self.nets:
+            net.close()
+
+
+class StandardRewardScaler(object):
+    """d3rlpy 0.91 ``reward_scaler='standard'``: (r - mean) / (std + 1e-3) with the statistics of the dataset's rewards."""
+
+    def __init__(self, rewards, eps=1e-3):
+        r = torch.as_tensor(rewards, dtype=torch.float64)
+        self.mean, self.std, self.eps = float(r.mean()), float(r.std(unbiased=False)), float(eps)
+
+    def transform(self, r):
+        return ((r - self.mean) / (self.std + self.eps)).to(torch.float32)
+
+
+class _ScalarParam(object):
+    """One learned scalar (SAC's log-temperature, CQL's log-alpha) with torch-style Adam, kept on the device: a handful of
+    one-element tensor ops per update (plumbing; no network arithmetic)."""
+
+    def __init__(self, value, device):
+        self.p = torch.full((1,), float(value), dtype=torch.float32, device=device)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.t = 0
+
+    def adam_step(self, grad, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        if rdist.world_size() > 1:
+            grad = rdist.allreduce_mean_(grad.clone())
+        self.t += 1
+        self.m.mul_(beta1).add_(grad, alpha=1.0 - beta1)
+        self.v.mul_(beta2).addcmul_(grad, grad, value=1.0 - beta2)
+        denom = (self.v / (1.0 - beta2 ** self.t)).sqrt_().add_(eps)
+        self.p.addcdiv_(self.m, denom, value=-lr / (1.0 - beta1 ** self.t))
+
+
+class CQL(object):
+    """d3rlpy.algos.CQL (continuous) as 'CQL-conti' instantiates it (script/batchrl_trainer.py:91-107): default encoders,
+    actor lr 1e-4, critic lr 3e-4, temperature / alpha lr 1e-4, tau 0.005, two critics, initial temperature 1, initial alpha 1,
+    alpha threshold 10, conservative weight 5, 10 action samples, deterministic (non-soft) backup; the script sets gamma = 1 and
+    ``reward_scaler='standard'`` (pass ``gamma=1.0`` and ``reward_scaler=StandardRewardScaler(dataset rewards)``).
+    d3rlpy 0.91 defaults as published; PARITY UNPINNED.
+
+    One ``update`` = d3rlpy's ``CQL._update``: temperature step, alpha step, critic step (TD on the min of the target critics at
+    tanh(mu(s')) + the conservative term), actor step, soft critic-target update.  Network arithmetic through ``librl4rs_hip``
+    (``rl4rs_amlp_*``, ``rl4rs_squashed_sample``, ``rl4rs_cql_critic_loss``, ``rl4rs_sac_actor_grad``, ``rl4rs_twin_min``); torch
+    supplies device memory, the noise and the two learned scalars' Adam.  The 1 + 3n rows of an observation (dataset action | n
+    samples of pi(s) | n of pi(s') | n uniform) go through each critic as ONE forward / backward with the observation side of
+    the first layer computed once per observation (rep = 31).  ``noise`` (tests): dict with ``eps_temp`` [B, A], ``alpha`` and
+    ``critic`` = (eps_t [B*n, A], eps_tp1 [B*n, A], uniform [B, n, A]), ``eps_actor`` [B, A]."""
+
+    def __init__(self, config, obs_dim, action_size=None, batch_size=256, actor_learning_rate=1e-4, critic_learning_rate=3e-4,
+                 temp_learning_rate=1e-4, alpha_learning_rate=1e-4, gamma=0.99, tau=0.005, initial_temperature=1.0, initial_alpha=1.0,
+                 alpha_threshold=10.0, conservative_weight=5.0, n_action_samples=10, reward_scaler=None, predict_rows=4096, seed=0,
+                 device=None):
+        self.config = config
+        self.D = int(obs_dim)
+        self.A = int(action_size if action_size is not None else config['action_emb_size'])
+        self.batch_size, self.n = int(batch_size), int(n_action_samples)
+        self.m = 1 + 3 * self.n
+        self.actor_lr, self.critic_lr = float(actor_learning_rate), float(critic_learning_rate)
+        self.temp_lr, self.alpha_lr = float(temp_learning_rate), float(alpha_learning_rate)
+        self.gamma, self.tau = float(gamma), float(tau)
+        self.alpha_threshold, self.conservative_weight = float(alpha_threshold), float(conservative_weight)
+        self.reward_scaler = reward_scaler
+        self.predict_rows = max(int(predict_rows), 1)
+        self.seed = int(seed)
+        self.total_step = 0
+        B, D, A, m = self.batch_size, self.D, self.A, self.m
+        rows = max(B * m, self.predict_rows)
+
+        def net(act_dim, out_dim, seed_off, max_rows, grad_rows, heads=1):
+            return D_.DeviceAMLP(D, act_dim, out_dim, init_amlp_params(D, act_dim, out_dim, seed=seed + seed_off, heads=heads),
+                                 max_rows=max_rows, max_grad_rows=grad_rows, device=device)
+
+        self.policy = net(0, 2 * A, 0, max(B, self.predict_rows), B, heads=2)        # SquashedNormalPolicy: encoder + _mu | _logstd
+        self.q1 = net(A, 1, 1, rows, B * m)
+        self.q2 = net(A, 1, 2, rows, B * m)
+        self.q1_targ = net(A, 1, 1, B, 0)
+        self.q2_targ = net(A, 1, 2, B, 0)
+        self.q1_targ.copy_from(self.q1)
+        self.q2_targ.copy_from(self.q2)
+        self.nets = [self.policy, self.q1, self.q2, self.q1_targ, self.q2_targ]
+        self.device = self.q1.device
+        self.log_temp = _ScalarParam(np.log(initial_temperature), self.device)
+        self.log_alpha = _ScalarParam(np.log(initial_alpha), self.device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self.seed + 1000003 * rdist.rank())
+        self._acts = torch.zeros((B, m, A), dtype=torch.float32, device=self.device)
+        self._offs = torch.zeros((B, m), dtype=torch.float32, device=self.device)
+        self._offs[:, 1 + 2 * self.n:] = float(A * np.log(0.5))                       # log of the uniform density on [-1, 1]^A
+
+    def _randn(self, shape, given):
+        if given is not None:
+            return given.to(device=self.device, dtype=torch.float32).contiguous()
+        return torch.randn(shape, generator=self._gen, device=self.device, dtype=torch.float32)
+
+    def _conservative_rows(self, head_obs, head_nxt, act, given):
+        """[B, m, A] actions and [B, m] importance offsets of the conservative term: column 0 the dataset action, then n samples of
+        pi(. | s), n of pi(. | s'), n uniform on [-1, 1]^A (CQLImpl._compute_policy_is_values / _compute_random_is_values)."""
+        B, n, A = act.shape[0], self.n, self.A
+        acts, offs = self._acts[:B], self._offs[:B]
+        acts[:, 0] = act
+        e_t, e_tp1, uni = given if given is not None else (None, None, None)
+        flat_a, flat_o = acts.view(B * self.m, A), offs.view(B * self.m)
+        D_.squashed_sample(head_obs, self._randn((B * n, A), e_t), rep=n, act_out=flat_a, logp_out=flat_o, out_rep=self.m, out_off=1)
+        D_.squashed_sample(head_nxt, self._randn((B * n, A), e_tp1), rep=n, act_out=flat_a, logp_out=flat_o, out_rep=self.m, out_off=1 + n)
+        if uni is not None:
+            acts[:, 1 + 2 * n:] = uni.to(device=self.device, dtype=torch.float32)
+        else:
+            acts[:, 1 + 2 * n:].uniform_(-1.0, 1.0, generator=self._gen)
+        return flat_a, flat_o
+
+    def _conservative_value(self, sums, B):
+        """conservative_weight * (mean_c mean_b logsumexp - mean_c mean_b Q(s, a))"""
+        return self.conservative_weight * ((sums[2] + sums[3]) - (sums[4] + sums[5])) / (2.0 * B)
+
+    def update(self, obs, act, rew, nxt, ter, noise=None):
+        noise = noise or {}
+        B, A, m = obs.shape[0], self.A, self.m
+        if self.reward_scaler is not None:
+            rew = self.reward_scaler.transform(rew)
+        metrics = {}
+        # the policy does not change until the actor step: its heads on s' and s are computed once (s last: the handle keeps the
+        # activations of s for the actor's backward)
+        head_nxt = self.policy.forward(nxt)
+        head_obs = self.policy.forward(obs)
+        # --- temperature (SACImpl.update_temp): -(exp(log_temp) * (logp - A)).mean(), gradient wrt log_temp
+        if self.temp_lr > 0:
+            _, logp = D_.squashed_sample(head_obs, self._randn((B, A), noise.get('eps_temp')))
+            targ = (logp - A).mean()
+            temp = self.log_temp.p.exp()
+            metrics['temp_loss'] = -(temp * targ)[0]
+            self.log_temp.adam_step(-(temp * targ), self.temp_lr)
+        # --- alpha (CQLImpl.update_alpha): -conservative loss, gradient wrt log_alpha
+        if self.alpha_lr > 0:
+            fa, fo = self._conservative_rows(head_obs, head_nxt, act, noise.get('alpha'))
+            sums, _, _ = D_.cql_critic_loss(self.q1.forward(obs, fa, rep=m), self.q2.forward(obs, fa, rep=m), fo, m)
+            gap = self._conservative_value(sums, B) - self.alpha_threshold
+            ea = self.log_alpha.p.exp()
+            metrics['alpha_loss'] = -(ea.clamp(0.0, 1e6) * gap)[0]
+            self.log_alpha.adam_step(torch.where(ea <= 1e6, -(ea * gap), torch.zeros_like(ea)), self.alpha_lr)
+        # --- critic (DDPGBaseImpl.update_critic with CQLImpl.compute_critic_loss / _compute_deterministic_target)
+        a_next, _ = D_.squashed_sample(head_nxt, None)
+        yq, _ = D_.bcq_target(self.q1_targ.forward(nxt, a_next), self.q2_targ.forward(nxt, a_next), 1, 1.0, rew, ter, self.gamma)
+        fa, fo = self._conservative_rows(head_obs, head_nxt, act, noise.get('critic'))
+        clipped_alpha = self.log_alpha.p.exp().clamp(0.0, 1e6)
+        aw = (clipped_alpha * self.conservative_weight).contiguous()
+        q1v = self.q1.forward(obs, fa, rep=m)
+        q2v = self.q2.forward(obs, fa, rep=m)
+        sums, dq1, dq2 = D_.cql_critic_loss(q1v, q2v, fo, m, y=yq, alpha_w=aw)
+        self.q1.backward(obs, fa, dq1, rep=m)
+        self.q2.backward(obs, fa, dq2, rep=m)
+        _allreduce_group([self.q1, self.q2])
+        self.q1.adam_step(self.critic_lr)
+        self.q2.adam_step(self.critic_lr)
+        metrics['critic_loss'] = (sums[0] + sums[1]) / B + (clipped_alpha * (self._conservative_value(sums, B) - self.alpha_threshold))[0]
+        # --- actor (SACImpl.compute_actor_loss): (exp(log_temp) * logp - min_c Q_c(s, a)).mean()
+        eps = self._randn((B, A), noise.get('eps_actor'))
+        a_pi, logp = D_.squashed_sample(head_obs, eps)
+        qmin, dq1, dq2 = D_.twin_min(self.q1.forward(obs, a_pi), self.q2.forward(obs, a_pi), want_grad=True)
+        g_a = self.q1.backward(obs, a_pi, dq1.view(B, 1), want_dact=True, want_param_grad=False)
+        g_a += self.q2.backward(obs, a_pi, dq2.view(B, 1), want_dact=True, want_param_grad=False)
+        d_head = D_.sac_actor_grad(head_obs, eps, a_pi, g_a, self.log_temp.p)
+        self.policy.backward(obs, None, d_head)
+        _allreduce_group([self.policy])
+        self.policy.adam_step(self.actor_lr)
+        metrics['actor_loss'] = (self.log_temp.p.exp() * logp - qmin).mean()
+        self.q1_targ.soft_update_from(self.q1, self.tau)
+        self.q2_targ.soft_update_from(self.q2, self.tau)
+        self.total_step += 1
+        return metrics
+
+    fit = BCQ.fit
+    _LOSS_KEYS = ('critic_loss', 'actor_loss', 'temp_loss', 'alpha_loss')
+
+    def predict(self, obs):
+        """SquashedNormalPolicy.best_action: tanh(mu(s)) - the embedding the env's K-NN resolves."""
+        obs = D_._dev_tensor(obs, torch.float32, self.device)
+        out = torch.empty((obs.shape[0], self.A), dtype=torch.float32, device=self.device)
+        rows = self.policy.max_rows
+        for lo in range(0, obs.shape[0], rows):
+            x = obs[lo:lo + rows].contiguous()
+            D_.squashed_sample(self.policy.forward(x), None, act_out=out[lo:lo + x.shape[0]])
+        return out
+
+    def predict_value(self, obs, actions):
+        obs = D_._dev_tensor(obs, torch.float32, self.device)
+        actions = D_._dev_tensor(actions, torch.float32, self.device)
+        out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
+        rows = self.q1.max_rows
         for lo in range(0, obs.shape[0], rows):
             x, a = obs[lo:lo + rows].contiguous(), actions[lo:lo + rows].contiguous()
             out[lo:lo + x.shape[0]] = 0.5 * (self.q1.forward(x, a)[:, 0] + self.q2.forward(x, a)[:, 0])
