@@ -212,6 +212,19 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
     }
 }
 
+
+// Round 4, measured and dropped - "k_din_x2": both 32-step tiles of a row in one wave (one W1d fragment read feeding two tiles,
+// twelve MFMAs per k-block on four accumulators, next k-block's fragments / split operands requested and built a k-block
+// ahead, 172 registers = two waves per SIMD).  Bit-identical scores, but 1.15 ms per episode-batch against 0.925 ms for this
+// kernel (same box): what bounds the DIN scores is VALU issue, not the LDS / cache waits the wave-level counters suggested
+// (SQ_ACTIVE_INST_VALU = 42 k cycles per SIMD and obs-sized launch against 30.7 k cycles of MFMA; timing ablations: all rows on
+// one cache slot -9 %, no layer-1 sigmoids -4 %), and eight waves per CU overlap the two pipes worse than sixteen.
+// A finding worth keeping from that attempt: split_h16_pair is INLINE ASM, invisible to the compiler's MFMA hazard recogniser.
+// With double-buffered operands the register allocator gave a just-dead MFMA B-operand register to the next asm conversion
+// issued right behind that MFMA, and the 8-pass v_mfma_f32_32x32x16_f16 was still reading it: wrong scores in 4-lane groups
+// (tests/test_gpu_dien.py::test_dien_rowwise_matches_oracle caught it).  In this kernel every asm definition sits behind an LDS
+// or cache wait; keep it that way, or write the split with compiler-visible conversions where a definition can follow an MFMA.
+
 inline size_t din_x_smem() { return 40960 + 48 * 4 + (size_t)8 * (128 + ATT_H1) * 4; }
 
 }  // namespace rl4rs

@@ -113,6 +113,21 @@ def allreduce_mean_(flat):
     return flat
 
 
+def allreduce_sum_(t):
+    """In-place SUM all-reduce of a (small) device tensor, enqueued like any other collective: nothing is read on the host
+    (PPO's KL statistic of a data-parallel train call: every rank later derives the same kl_coeff from the same sum)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if _needs_host_staging(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def broadcast_(t, src=0):
     """In-place broadcast of rank ``src``'s tensor (initial parameters / optimiser state of a data-parallel trainer)."""
     import torch.distributed as dist
