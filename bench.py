@@ -23,15 +23,17 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per AUGRU launch of the default workload, from the PMC passes (profiles/r02*_pmc.md).  fp16x2 (k_augru_x): raw
-# FETCH_SIZE 359 MB per obs-sized / 386 MB per reward-sized launch, x the factor calibrated on this kernel's own LDS-DMA
-# stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for the 64-row form),
-# + WRITE_SIZE 8.4 / 65.6 MB: (10 x 622 + 838) / 11.  fp32 (k_recur): round-1 figure, dword-per-lane loads, uncalibrated.
-TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 3.48e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
-TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (332 MB) + 1 reward-sized (506 MB) launches of an episode-batch; "
+# HBM bytes per AUGRU launch of the default workload, from the round's PMC passes (profiles/r04f_pmc.md, arithmetic in its header).
+# fp16x2 (k_augru_x): raw FETCH_SIZE 185.0 MB per obs-sized / 214.3 MB per reward-sized launch, x the factor calibrated on this
+# kernel's own LDS-DMA stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for
+# the 64-row form), + WRITE_SIZE 8.2 / 65.5 MB: (10 x 324.6 + 494.1) / 11.  fp32 (k_recur): not re-measured since round 1.
+TRAFFIC_SOURCE_FILE = 'profiles/r04f_pmc.md'
+TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 3.40e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
+TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (324.6 MB) + 1 reward-sized (494.1 MB) launches of an episode-batch; "
                 "rocprofv3 FETCH_SIZE x the factor calibrated on this kernel's stream (profiles/r02_fetch_calibration.md) + WRITE_SIZE, "
-                "arithmetic in profiles/r02c_pmc.md; algorithmic bytes = 1746 distinct histories x 64 steps x 768 f32 = 343 MB read + "
-                "8.4 / 67 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
+                "arithmetic in the header of profiles/r04f_pmc.md; algorithmic bytes = 1746 distinct histories x 64 steps x 768 f32 = "
+                "343 MB read + 8.4 / 67 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
+GATHER_TRAFFIC_B = 6.48e7           # k_env_rows<2>: WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch (profiles/r04f_pmc.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
@@ -575,7 +577,7 @@ def main():
                 # CALIBRATED on this kernel's own access pattern, + WRITE_SIZE): launch-weighted mean of the 10 obs-sized
                 # and the 1 reward-sized launch of an episode-batch
                 roofline["traffic"] = TRAFFIC_B_PER_LAUNCH[net.scorer_mode]
-                roofline["traffic_source"] = "constant from the PMC passes under profiles/ (not re-measured in this run): " + TRAFFIC_NOTE
+                roofline["traffic_source"] = "constant from the PMC passes of " + TRAFFIC_SOURCE_FILE + " (not re-measured in this run): " + TRAFFIC_NOTE
         # per-kernel breakdown of ONE episode-batch (separate pass, event pairs around every kernel class)
         kernels = dict((k, {"ms": round(v[0] / breakdown_steps, 3), "launches": int(v[1] // breakdown_steps)}) for k, v in breakdown.items())
         kernel_sum = sum(v["ms"] for v in kernels.values())
@@ -612,10 +614,10 @@ def main():
                               "what": "one launch behind a whole episode-batch (event pair around the single launch, mean of 5); "
                                       "the headline figure above is 50 back-to-back launches onto the same buffers"}}
         if not seq and B == 4096 and T == 9:
-            # rocprofv3 WRITE_SIZE 65.9 MB + FETCH_SIZE 1.2 MB per launch of this exact shape (profiles/r02e_pmc.md) against
-            # 66.8 MB of algorithmic writes + 7.5 MB of (L2-resident) reads: no wasted traffic
-            gather["traffic"] = 6.71e7
-            gather["traffic_source"] = "constant from profiles/r02e_pmc.md (WRITE_SIZE + FETCH_SIZE per launch), not re-measured in this run" 
+            # rocprofv3 WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch of this exact shape against 66.8 MB of algorithmic
+            # writes + 7.5 MB of (L2-resident) reads: no wasted traffic
+            gather["traffic"] = GATHER_TRAFFIC_B
+            gather["traffic_source"] = "constant from " + TRAFFIC_SOURCE_FILE + " (WRITE_SIZE + FETCH_SIZE per launch), not re-measured in this run"
         out = {
             "metric": "env-steps/s (batch=%d, %d-slot slate)" % (B, 9),
             "value": env_steps / elapsed,
