@@ -596,7 +596,7 @@ def main():
         # data, not the previous gather's output) - one launch between two events, averaged over 5 episodes
         situ = []
         for _ in range(5):
-            episode(env, T) if not trainer else run_step()
+            episode(env, T)         # (never run_step here: this block is rank 0's alone, a train step would enter a collective)
             ev0.record()
             samples._env.build_complete()
             ev1.record()

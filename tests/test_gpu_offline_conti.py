@@ -182,7 +182,7 @@ def test_target_critic_and_actor_gradients():
     bcq.q2.backward(xd, ad, dq2)
     want = O.critic_loss([orc['q1'], orc['q2']], x, a, want_y)
     want.backward()
-    assert abs(float(loss2.sum()) - float(want)) < 1e-3 * max(1.0, abs(float(want)))
+    assert abs(float(loss2.sum()) - float(want.detach())) < 1e-3 * max(1.0, abs(float(want.detach())))
     for k in ('q1', 'q2'):
         g, gw = getattr(bcq, k).gradients(), orc[k].grads()
         for pk in gw:
