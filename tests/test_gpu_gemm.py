@@ -33,6 +33,10 @@ def test_gemm_f32(M, N, K, act):
     c2 = gemm_f32(wide[:, 4:4 + K], w, None, 0)
     ref2 = wide[:, 4:4 + K].double() @ w.double()
     assert (c2.double() - ref2).abs().max().item() < 2e-5
+    # rows that are not 16-byte aligned (the scalar-load path of the small-M form, the per-element path of the big one)
+    c3 = gemm_f32(wide[:, 3:3 + K], w, None, 0)
+    ref3 = wide[:, 3:3 + K].double() @ w.double()
+    assert (c3.double() - ref3).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize('M,N,K,act', [(1, 2, 3, 0), (33, 65, 17, 1), (64, 64, 64, 0), (300, 284, 70, 3), (4096, 128, 432, 1),

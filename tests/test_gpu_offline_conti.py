@@ -80,6 +80,40 @@ def test_amlp_forward_and_gradients(act_dim, out_dim, head_act, rep):
     assert torch.equal(before, dev.flat_gradient())
 
 
+@pytest.mark.parametrize('obs_dim,act_dim,h1,h2,out_dim,R,rep', [(37, 5, 48, 40, 3, 17, 3), (266, 32, 256, 256, 1, 300, 31), (10, 0, 33, 65, 7, 70, 1),
+                                                                 (266, 32, 256, 256, 32, 5000, 1)])
+def test_amlp_odd_shapes_and_many_rows(obs_dim, act_dim, h1, h2, out_dim, R, rep):
+    """the small-M GEMM forms behind the amlp (k_gemm_small with one or two operand pairs, k_gemm_nt, k_gemm_tn + bias sums) on
+    widths that are multiples of nothing (scalar-load paths, k / row / column tails), on the 31-rows-per-observation layout of
+    the CQL critic pass (chunked sample-axis reductions: 9300 rows), and above the row count where the big-tile GEMM takes over"""
+    import torch
+    from oracle.offline_conti import OracleAMLP
+    from rl4rs_amd import device as Dv
+    from rl4rs_amd.offline_rl import init_amlp_params
+    p = init_amlp_params(obs_dim, act_dim, out_dim, hidden1=h1, hidden2=h2, seed=7)
+    N = R * rep
+    dev = Dv.DeviceAMLP(obs_dim, act_dim, out_dim, p, hidden1=h1, hidden2=h2, max_rows=N)
+    orc = OracleAMLP(p)
+    rs = np.random.RandomState(3)
+    x = rs.randn(R, obs_dim).astype(np.float32)
+    a = rs.randn(N, act_dim).astype(np.float32) if act_dim else None
+    xd = torch.from_numpy(x).cuda()
+    ad = torch.from_numpy(a).cuda() if act_dim else None
+    out = dev.forward(xd, ad, rep=rep)
+    at = torch.tensor(a, dtype=torch.float64, requires_grad=True) if act_dim else None
+    want = orc(np.repeat(x, rep, axis=0), at)
+    assert np.abs(out.cpu().numpy() - want.detach().numpy()).max() < 2e-4 * max(1.0, float(want.detach().abs().max()))
+    w = (rs.randn(N, out_dim) / N).astype(np.float32)
+    (want * torch.from_numpy(w).double()).sum().backward()
+    dact = dev.backward(xd, ad, torch.from_numpy(w).cuda(), rep=rep, want_dact=bool(act_dim))
+    g, gw = dev.gradients(), orc.grads()
+    for k in gw:
+        _close(g[k].cpu().numpy(), gw[k], 2e-3, 'grad %s' % k)
+    if act_dim:
+        _close(dact.cpu().numpy(), at.grad.numpy(), 2e-3, 'dact')
+    dev.close()
+
+
 def test_backward_must_follow_the_forward_of_the_same_rows():
     import torch
     from rl4rs_amd._lib import Rl4rsHipError
@@ -196,7 +230,7 @@ def test_target_critic_and_actor_gradients():
         v.zero_grad()
     want = O.actor_loss(orc['imit_dec'], orc['policy'], orc['q1'], x, za, bcq.scale)
     want.backward()
-    assert abs(float(-qv.mean()) - float(want)) < 2e-4 * max(1.0, abs(float(want)))
+    assert abs(float(-qv.mean()) - float(want.detach())) < 2e-4 * max(1.0, abs(float(want.detach())))
     g, gw = bcq.policy.gradients(), orc['policy'].grads()
     for pk in gw:
         _close(g[pk].cpu().numpy(), gw[pk], 2e-3, 'actor grad %s' % pk)
