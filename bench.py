@@ -268,7 +268,8 @@ class BcqWorkload(object):
         self.env, self.cfg, self.updates = env, cfg, int(updates)
         data = generate_offline_dataset(env, epochs=epochs, shuffle=False)
         self.tr = transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=False)
-        self.bcq = BCQ(cfg, self.tr[0].shape[1], batch_size=256, seed=7)       # the same initial replica on every rank
+        # predict_rows = the env batch: one pass of 100 x B sampled rows per step (h1 / h2 scratch: 3 x B x 100 x 256 floats per network)
+        self.bcq = BCQ(cfg, self.tr[0].shape[1], batch_size=256, seed=7, predict_rows=cfg['batch_size'])       # the same initial replica on every rank
         self.bcq._gen.manual_seed(1000 + rank)                                  # its own noise / minibatch stream
         self.rank = rank
         self.calls = 0
