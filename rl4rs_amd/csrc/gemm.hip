@@ -258,6 +258,137 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dY, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// Large form of the same GEMM (round 4): 128 x 128 block tiles, BOTH operands staged in LDS, 2 x 2 accumulator tiles per wave.
+// k_gemm_f32 fetches its B fragments from global memory right in front of their MFMAs (four dword loads per eight MFMAs, an
+// L1 / L2 round trip in every k-block): 0.31 - 0.34 of the fp32 MFMA peak on the 25 600 / 409 600-row x 256 x 256 forwards of
+// the continuous learners (tools/gemm_rate.py).  Here a wave owns a 64 x 64 output tile: per 8-wide k-block two ds_read_b128
+// (A, the k order inside the block permuted as in k_gemm_f32) and eight conflict-free ds_read_b32 (B, staged untransposed
+// [k][n], row stride 132) feed sixteen MFMAs; the next k-tile's global loads are in flight while the current one is multiplied.
+// 70.6 KB of LDS per workgroup: two workgroups per CU.
+constexpr int TBM = 128, TBN = 128, TBK = 32, TLDA = TBK + 4, TLDB = TBN + 4;
+constexpr size_t T128_SMEM = (size_t)2 * (TBM * TLDA + TBK * TLDB) * 4;
+
+__global__ __launch_bounds__(256, 2) void k_gemm_f32_t128(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                          int act, const float* __restrict__ addend, int64_t ldadd, int add_div) {
+    extern __shared__ __attribute__((aligned(16))) float t128_sm[];
+    float* As = t128_sm;                                  // [2][TBM][TLDA]
+    float* Bs = t128_sm + 2 * TBM * TLDA;                 // [2][TBK][TLDB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * TBN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging loads are UNCONDITIONAL 16-byte loads from clamped addresses (the launcher takes this kernel only for 16-byte
+    // aligned operands with K and N multiples of 4): out-of-range k / n chunks are zeroed by a select afterwards, out-of-range
+    // rows are never stored.  (Guarded loads compile to a branch per load and a wait behind each: the tile's eight requests
+    // then go out one memory round trip at a time.)
+    float4 sa[4], sb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = tid + p * 256;
+            {   // A: 128 rows x 8 four-float chunks
+                const int r = c >> 3, kq = (c & 7) << 2, gr = min(m0 + r, M - 1), gk = kt * TBK + kq;
+                sa[p] = *reinterpret_cast<const float4*>(A + (size_t)gr * lda + min(gk, K - 4));
+            }
+            {   // B: 32 k-rows x 32 four-float chunks
+                const int kr = c >> 5, nq = (c & 31) << 2, gk = kt * TBK + kr, gn = n0 + nq;
+                sb[p] = *reinterpret_cast<const float4*>(W + (size_t)min(gk, K - 1) * ldw + min(gn, N - 4));
+            }
+        }
+    };
+    // (the zeroing of out-of-range chunks happens HERE, behind the multiplication of the current tile: a select right behind the
+    // loads makes the wave wait for them before it starts multiplying)
+    auto store_tile = [&](int buf, int kt) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = tid + p * 256;
+            const bool a_ok = kt * TBK + ((c & 7) << 2) < K;
+            const bool b_ok = kt * TBK + (c >> 5) < K && n0 + ((c & 31) << 2) < N;
+            // (component-wise selects: a select of the whole float4 sends the staging arrays through scratch memory)
+            const float4 va = make_float4(a_ok ? sa[p].x : 0.f, a_ok ? sa[p].y : 0.f, a_ok ? sa[p].z : 0.f, a_ok ? sa[p].w : 0.f);
+            const float4 vb = make_float4(b_ok ? sb[p].x : 0.f, b_ok ? sb[p].y : 0.f, b_ok ? sb[p].z : 0.f, b_ok ? sb[p].w : 0.f);
+            *reinterpret_cast<float4*>(&As[(buf * TBM + (c >> 3)) * TLDA + ((c & 7) << 2)]) = va;
+            *reinterpret_cast<float4*>(&Bs[(buf * TBK + (c >> 5)) * TLDB + ((c & 31) << 2)]) = vb;
+        }
+    };
+    const int nkt = (K + TBK - 1) / TBK;
+    load_tile(0);
+    store_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const float* a_base = As + (cur * TBM + wm * 64 + li) * TLDA + half * 4;
+        const float* b_base = Bs + (cur * TBK + half * 4) * TLDB + wn * 64 + li;
+        // operands of k-block kb + 1 are read while k-block kb is multiplied (two register sets; the schedule is pinned: left
+        // alone the compiler reads each B pair into one register pair right in front of its four MFMAs, an LDS round trip in
+        // front of every group)
+        float4 a0[2], a1[2];
+        float b0[2][4], b1[2][4];
+        auto lds_read = [&](int s_, int kb) {
+            a0[s_] = *reinterpret_cast<const float4*>(a_base + kb * 8);
+            a1[s_] = *reinterpret_cast<const float4*>(a_base + 32 * TLDA + kb * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                b0[s_][i] = b_base[(kb * 8 + i) * TLDB];
+                b1[s_][i] = b_base[(kb * 8 + i) * TLDB + 32];
+            }
+        };
+        lds_read(0, 0);
+#pragma unroll
+        for (int kb = 0; kb < TBK / 8; ++kb) {
+            const int c_ = kb & 1;
+            if (kb + 1 < TBK / 8) lds_read(c_ ^ 1, kb + 1);
+            const float av0[4] = {a0[c_].x, a0[c_].y, a0[c_].z, a0[c_].w}, av1[4] = {a1[c_].x, a1[c_].y, a1[c_].z, a1[c_].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], b0[c_][i], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], b1[c_][i], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[i], b0[c_][i], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[i], b1[c_][i], acc[1][1], 0, 0, 0);
+            }
+            // this k-block: its LDS reads (of the NEXT block's operands) first, then the sixteen MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1, kt + 1);
+        __syncthreads();
+    }
+    // C (and the row-shared addend) through a buffer descriptor over this workgroup's valid rows: rows >= M fall outside the
+    // descriptor and are dropped by the hardware, the row part of an address is a scalar offset - one instruction per element
+    // instead of a compare, an exec mask and a 64-bit address (the lesson of k_gemm_h16_wres)
+    const int rows_here = min(TBM, M - m0);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)m0 * ldc, 0, (int)((((int64_t)rows_here - 1) * ldc + N) * 4), 0x00020000);
+    const int ldc4 = (int)ldc * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + li;
+        const bool col_ok = col < N;
+        const float bv = (bias && col_ok) ? bias[col] : 0.f;
+        // a column beyond N gets an offset outside the descriptor: its stores are dropped like the rows beyond M
+        const int c_voff = col_ok ? (4 * half * (int)ldc + col) * 4 : 0x7ffffff0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);           // local row without the half part
+                float v = acc[i][j][r] + bv;
+                if (addend) {
+                    const int g = min(m0 + lr + 4 * half, M - 1);
+                    v += col_ok ? addend[(size_t)(g / add_div) * ldadd + col] : 0.f;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(v, act)), rs_c, c_voff, lr * ldc4, 0);
+            }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Same GEMM with the weight matrix PRE-PACKED into MFMA B-fragment order (done once when a model is
 // loaded): Wp[ntile][kb][lane] is the float4 {W[kb*8 + (lane>>5)*4 + i][ntile*32 + (lane&31)], i=0..3},
 // K zero-padded to a multiple of 8, N to a multiple of 32.  One 16-byte load feeds four MFMAs; the next
@@ -950,8 +1081,19 @@ int launch_gemm_f32(const float* a, int64_t lda, const float* w, int64_t ldw, co
         set_error("gemm: N=%d too large", N);
         return RL4RS_EINVAL;
     }
-    if (grid.x * grid.y < SMALL_GEMM_MAX_BIG_BLOCKS)       // the 128 x 64 tiling would leave most of the 256 CUs idle
+    if (grid.x * grid.y < SMALL_GEMM_MAX_BIG_BLOCKS || N <= 32)       // the 128 x 64 tiling would leave most of the 256 CUs idle (or half of every tile: N <= 32)
         return launch_gemm_small(a, lda, w, ldw, K, nullptr, 0, nullptr, 0, 0, bias, c, ldc, M, N, act, st, addend, ldadd, add_div);
+    if (M >= 2048 && N >= 96 && K >= 32 && (K & 3) == 0 && (N & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 && (int64_t)TBM * ldc * 4 < 0x7fff0000) {
+        // many rows x a wide output: both operands through LDS
+        int rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_gemm_f32_t128), T128_SMEM);
+        if (rc) return rc;
+        dim3 g2((M + TBM - 1) / TBM, (N + TBN - 1) / TBN);
+        hipLaunchKernelGGL(k_gemm_f32_t128, g2, dim3(256), T128_SMEM, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act, addend, ldadd,
+                           add_div > 0 ? add_div : 1);
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, a, lda, w, ldw, bias, c, ldc, M, N, K, act, addend, ldadd, add_div > 0 ? add_div : 1);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
