@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ A, i
 //                 first layer of an action-conditioned MLP on cat([x, a]) without materialising the concatenation
 //   k_gemm_nt     C[M,Kin] = dY[M,Nout] W[Kin,Nout]^T (* [relu_of > 0])      the input gradient of a Linear layer without the
 //                 transposed weight copy, with the ReLU derivative of the layer below folded into the epilogue
+#ifndef RL4RS_SMALL_U
+#define RL4RS_SMALL_U 4       // k-blocks of a wave's K slice whose operand loads are in flight together (2: 8.6 us, 4: see DESIGN 9)
+#endif
+constexpr int SMALL_U = RL4RS_SMALL_U;
 __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ p, bool row_ok, int left, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row_ok && left > 0) {
@@ -175,18 +179,18 @@ __global__ __launch_bounds__(256) void k_gemm_small(const float* __restrict__ A,
         const bool vec = ((la & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
         const int nkb = (k_len + 7) / 8;
         const float* arow = a + (size_t)(row_ok ? row : 0) * la;
-        for (int kb = wave; kb < nkb; kb += 8) {           // two k-blocks per trip: 2 + 8 loads in flight before the 8 MFMAs
-            float4 av[2];
-            float bv[2][4];
+        for (int kb = wave; kb < nkb; kb += 4 * SMALL_U) {           // SMALL_U k-blocks per trip: all their loads in flight before the MFMAs
+            float4 av[SMALL_U];
+            float bv[SMALL_U][4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < SMALL_U; ++u) {
                 const int k = (kb + 4 * u) * 8 + half * 4;
                 av[u] = ld4_guard(arow + k, row_ok, k_len - k, vec);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv[u][i] = (col_ok && k + i < k_len) ? w[(size_t)(k + i) * lw + col] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < SMALL_U; ++u) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u][2], acc, 0, 0, 0);
@@ -226,16 +230,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ dY, i
     const float* arow = dY + (size_t)(row_ok ? row : 0) * ldy;
     const float* brow = W + (size_t)(col_ok ? col : 0) * ldw;
     const int nkb = (Nout + 7) / 8;
-    for (int kb = wave; kb < nkb; kb += 8) {
-        float4 av[2], bv[2];
+    for (int kb = wave; kb < nkb; kb += 4 * SMALL_U) {
+        float4 av[SMALL_U], bv[SMALL_U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SMALL_U; ++u) {
             const int k = (kb + 4 * u) * 8 + half * 4;
             av[u] = ld4_guard(arow + k, row_ok, Nout - k, vec_a);
             bv[u] = ld4_guard(brow + k, col_ok, Nout - k, vec_b);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SMALL_U; ++u) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
