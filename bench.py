@@ -39,23 +39,35 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
 
 class SclkSampler(object):
-    """Shader clock of the bench's GPU while the timed region runs, sampled from sysfs (`pp_dpm_sclk`: the active DPM level
-    is starred) every 10 ms by a side thread: MI355X lowers its clock under the MFMA load of the recurrence (1.7-1.9 GHz seen
-    in the PMC passes against the 2.4 GHz the peak is quoted at), so `roofline.frac` is also reported against the measured
-    clock.  None when the file is not readable on this box."""
+    """Shader clock while the timed region runs, sampled from sysfs (`pp_dpm_sclk`: the active DPM level is starred) every 10 ms
+    by a side thread: MI355X lowers its clock under the MFMA load of the recurrence (1.8-1.9 GHz in the PMC passes against the
+    2.4 GHz the peak is quoted at), so `roofline.frac` is also reported against the measured clock.  Only the card whose PCI address
+    is this process' HIP device is sampled, and only a plausible mean (0.5 - 3 GHz) is used; None otherwise - then the PMC figure
+    under profiles/ (GRBM_GUI_ACTIVE / duration) is the reference."""
 
-    def __init__(self, index):
+    def __init__(self, device_index=0):
         import glob
         import threading
-        self.paths = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
-        self.path = self.paths[index] if index < len(self.paths) else None
-        self.samples = []
-        self._stop = threading.Event()
-        self._thread = threading.Thread(target=self._run, daemon=True) if self.path else None
-
-    def _read(self):
+        self.paths = []
         try:
-            for line in open(self.path).read().splitlines():
+            # the card of THIS process' HIP device, by PCI address (a box shows every GPU of the node in sysfs, most of them
+            # other tenants')
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for p in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+                if os.path.basename(os.path.realpath(os.path.dirname(p))) == addr:
+                    self.paths = [p]
+        except Exception:
+            self.paths = []
+        self.samples = dict((p, []) for p in self.paths)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.paths else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            for line in open(path).read().splitlines():
                 if line.strip().endswith('*'):
                     return float(line.split(':')[1].strip().lower().replace('mhz', '').replace('*', '').strip())
         except Exception:
@@ -64,9 +76,10 @@ class SclkSampler(object):
 
     def _run(self):
         while not self._stop.is_set():
-            v = self._read()
-            if v:
-                self.samples.append(v)
+            for p in self.paths:
+                v = self._read(p)
+                if v:
+                    self.samples[p].append(v)
             self._stop.wait(0.01)
 
     def __enter__(self):
@@ -80,7 +93,12 @@ class SclkSampler(object):
             self._thread.join(timeout=1.0)
 
     def mean_mhz(self):
-        return sum(self.samples) / len(self.samples) if self.samples else None
+        means = [sum(v) / len(v) for v in self.samples.values() if v]
+        best = max(means) if means else None
+        return best if best is not None and 500.0 <= best <= 3000.0 else None
+
+    def n_samples(self):
+        return max([len(v) for v in self.samples.values()] or [0])
 
 
 def make_config(args, workdir, rank):
@@ -570,8 +588,8 @@ def main():
             # the peak is quoted at the 2.4 GHz boost clock; under this kernel the part runs slower (power management)
             mhz = sclk.mean_mhz()
             roofline["sclk_mhz_measured"] = mhz
-            roofline["sclk_source"] = ("mean of %d sysfs pp_dpm_sclk samples over the timed region" % len(sclk.samples)) if mhz else \
-                "pp_dpm_sclk not readable on this box; see the GRBM_GUI_ACTIVE / duration figure in profiles/r04*_pmc.md"
+            roofline["sclk_source"] = ("mean of %d sysfs pp_dpm_sclk samples over the timed region (this device's card, matched by PCI address)" % sclk.n_samples()) if mhz else \
+                "no plausible pp_dpm_sclk reading on this box; see the GRBM_GUI_ACTIVE / duration figure in profiles/r04f_pmc.md"
             roofline["frac_at_measured_clock"] = (achieved / (peak * mhz / 2400.0)) if mhz else None
             if not seq and B == 4096 and T == 9 and not trainer:
                 # HBM bytes per launch from the PMC passes of this exact workload (rocprofv3 FETCH_SIZE, corrected by the factor
