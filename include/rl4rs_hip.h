@@ -706,6 +706,10 @@ int rl4rs_qnet_create(const rl4rs_qnet_cfg* cfg, const float* params_host, const
 int rl4rs_qnet_destroy(rl4rs_qnet* net);
 int rl4rs_qnet_params(rl4rs_qnet* net, float** params_dev, float** grad_dev, int64_t* count);
 int rl4rs_qnet_copy_params(rl4rs_qnet* dst, const rl4rs_qnet* src, void* stream);
+/* Adam moments (device pointers, `count` floats each) and step count of the handle: checkpointing (d3rlpy save_model / load_model,
+ * script/batchrl_train.py:132,141). */
+int rl4rs_qnet_adam_state(rl4rs_qnet* net, float** m_dev, float** v_dev, int64_t* step);
+int rl4rs_qnet_set_adam_step(rl4rs_qnet* net, int64_t step);
 int rl4rs_qnet_status(rl4rs_qnet* net, int32_t* flags, void* stream);
 int rl4rs_qnet_forward(rl4rs_qnet* net, int32_t N, const float* obs_dev, float* out_dev, void* stream);
 int rl4rs_qnet_backward(rl4rs_qnet* net, int32_t N, const float* obs_dev, const float* dout_dev, void* stream);
@@ -757,6 +761,8 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* cfg, const float* params_host, void*
 int rl4rs_amlp_destroy(rl4rs_amlp* net);
 int rl4rs_amlp_params(rl4rs_amlp* net, float** params_dev, float** grad_dev, int64_t* count);
 int rl4rs_amlp_copy_params(rl4rs_amlp* dst, const rl4rs_amlp* src, void* stream);
+int rl4rs_amlp_adam_state(rl4rs_amlp* net, float** m_dev, float** v_dev, int64_t* step);
+int rl4rs_amlp_set_adam_step(rl4rs_amlp* net, int64_t step);
 int rl4rs_amlp_soft_update(rl4rs_amlp* targ, const rl4rs_amlp* src, float tau, void* stream);
 int rl4rs_amlp_forward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev, float* out_dev,
                        void* stream);

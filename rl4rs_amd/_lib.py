@@ -215,6 +215,8 @@ SIGNATURES = {
     'rl4rs_qnet_destroy': (_I, [_P]),
     'rl4rs_qnet_params': (_I, [_P, _P, _P, _P]),
     'rl4rs_qnet_copy_params': (_I, [_P, _P, _P]),
+    'rl4rs_qnet_adam_state': (_I, [_P, _P, _P, _P]),
+    'rl4rs_qnet_set_adam_step': (_I, [_P, _I64]),
     'rl4rs_qnet_status': (_I, [_P, C.POINTER(_I32), _P]),
     'rl4rs_qnet_forward': (_I, [_P, _I32, _P, _P, _P]),
     'rl4rs_qnet_backward': (_I, [_P, _I32, _P, _P, _P]),
@@ -226,6 +228,8 @@ SIGNATURES = {
     'rl4rs_amlp_destroy': (_I, [_P]),
     'rl4rs_amlp_params': (_I, [_P, _P, _P, _P]),
     'rl4rs_amlp_copy_params': (_I, [_P, _P, _P]),
+    'rl4rs_amlp_adam_state': (_I, [_P, _P, _P, _P]),
+    'rl4rs_amlp_set_adam_step': (_I, [_P, _I64]),
     'rl4rs_amlp_soft_update': (_I, [_P, _P, C.c_float, _P]),
     'rl4rs_amlp_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P]),
     'rl4rs_amlp_backward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _I32, _P]),

@@ -385,6 +385,19 @@ int rl4rs_amlp_params(rl4rs_amlp* p, float** params_dev, float** grad_dev, int64
     return RL4RS_OK;
 }
 
+int rl4rs_amlp_adam_state(rl4rs_amlp* p, float** m_dev, float** v_dev, int64_t* step) {
+    RL4RS_REQUIRE(p, "amlp_adam_state: null handle");
+    if (m_dev) *m_dev = p->adam_m;
+    if (v_dev) *v_dev = p->adam_v;
+    if (step) *step = p->adam_t;
+    return RL4RS_OK;
+}
+int rl4rs_amlp_set_adam_step(rl4rs_amlp* p, int64_t step) {
+    RL4RS_REQUIRE(p && step >= 0, "amlp_set_adam_step: bad argument");
+    p->adam_t = step;
+    return RL4RS_OK;
+}
+
 int rl4rs_amlp_copy_params(rl4rs_amlp* dst, const rl4rs_amlp* src, void* stream) {
     RL4RS_REQUIRE(dst && src && dst->n_params == src->n_params, "amlp_copy_params: handles differ");
     RL4RS_HIP_TRY(hipMemcpyAsync(dst->params, src->params, (size_t)src->n_params * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

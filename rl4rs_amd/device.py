@@ -1434,6 +1434,38 @@ class DeviceQNet(object):
         assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
         check(self.lib.rl4rs_copy_d2d(g, _ptr(flat), n * 4, _stream()))
 
+    _PREFIX = 'rl4rs_qnet'
+
+    def flat_params(self):
+        return self._flat('params')
+
+    def set_flat_params(self, flat):
+        p, _, n = self._buffers()
+        assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
+        check(self.lib.rl4rs_copy_d2d(p, _ptr(flat), n * 4, _stream()))
+
+    def adam_state(self):
+        """(m, v, step): copies of the Adam moments and the step count (checkpointing)."""
+        pm, pv, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(getattr(self.lib, self._PREFIX + '_adam_state')(self.h, C.byref(pm), C.byref(pv), C.byref(t)))
+        n = self.n_params
+        m = torch.empty(n, dtype=torch.float32, device=self.device)
+        v = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(m), pm, n * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(_ptr(v), pv, n * 4, _stream()))
+        return m, v, int(t.value)
+
+    def set_adam_state(self, m, v, step):
+        pm, pv, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(getattr(self.lib, self._PREFIX + '_adam_state')(self.h, C.byref(pm), C.byref(pv), C.byref(t)))
+        n = self.n_params
+        m = m.to(device=self.device, dtype=torch.float32).contiguous()
+        v = v.to(device=self.device, dtype=torch.float32).contiguous()
+        assert m.numel() == n and v.numel() == n
+        check(self.lib.rl4rs_copy_d2d(pm, _ptr(m), n * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(pv, _ptr(v), n * 4, _stream()))
+        check(getattr(self.lib, self._PREFIX + '_set_adam_step')(self.h, int(step)))
+
     def copy_from(self, other):
         check(self.lib.rl4rs_qnet_copy_params(self.h, other.h, _stream()))
 
@@ -1580,6 +1612,30 @@ class DeviceAMLP(object):
         p, _, n = self._buffers()
         assert flat.numel() == n and flat.dtype == torch.float32 and flat.is_contiguous()
         check(self.lib.rl4rs_copy_d2d(p, _ptr(flat), n * 4, _stream()))
+
+    _PREFIX = 'rl4rs_amlp'
+
+    def adam_state(self):
+        """(m, v, step): copies of the Adam moments and the step count (checkpointing)."""
+        pm, pv, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(getattr(self.lib, self._PREFIX + '_adam_state')(self.h, C.byref(pm), C.byref(pv), C.byref(t)))
+        n = self.n_params
+        m = torch.empty(n, dtype=torch.float32, device=self.device)
+        v = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(self.lib.rl4rs_copy_d2d(_ptr(m), pm, n * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(_ptr(v), pv, n * 4, _stream()))
+        return m, v, int(t.value)
+
+    def set_adam_state(self, m, v, step):
+        pm, pv, t = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(getattr(self.lib, self._PREFIX + '_adam_state')(self.h, C.byref(pm), C.byref(pv), C.byref(t)))
+        n = self.n_params
+        m = m.to(device=self.device, dtype=torch.float32).contiguous()
+        v = v.to(device=self.device, dtype=torch.float32).contiguous()
+        assert m.numel() == n and v.numel() == n
+        check(self.lib.rl4rs_copy_d2d(pm, _ptr(m), n * 4, _stream()))
+        check(self.lib.rl4rs_copy_d2d(pv, _ptr(v), n * 4, _stream()))
+        check(getattr(self.lib, self._PREFIX + '_set_adam_step')(self.h, int(step)))
 
     def copy_from(self, other):
         check(self.lib.rl4rs_amlp_copy_params(self.h, other.h, _stream()))

@@ -80,7 +80,66 @@ def init_qnet_params(obs_dim, action_size, mask_size=0, emb_size=32, hidden1=256
     return p
 
 
-class _Learner(object):
+
+class _ModelIO(object):
+    """``save_model`` / ``load_model`` / ``fit_mdp`` shared by every learner of this module: what ``script/batchrl_train.py`` calls
+    on a d3rlpy algo (``model.fit(dataset, n_epochs=...)`` then ``model.save_model(path)``, :127-132; ``model.load_model(path)``
+    in the eval / ope stages, :140-142).  The file is this package's own (``numpy.savez``: every network's flat parameter vector,
+    Adam moments and step count, the learned scalars, the update counter) - d3rlpy's torch ``state_dict`` pickles need d3rlpy."""
+
+    def _io_nets(self):
+        seen, out = set(), []
+        for name, v in sorted(vars(self).items()):
+            if hasattr(v, 'flat_params') and hasattr(v, 'set_flat_params') and id(v) not in seen:
+                seen.add(id(v))
+                out.append((name, v))
+        return out
+
+    def save_model(self, fname):
+        blob = {'__class__': np.array(type(self).__name__), 'total_step': np.array(self.total_step, dtype=np.int64)}
+        for name, net in self._io_nets():
+            blob['net.' + name] = net.flat_params().cpu().numpy()
+            m, v, t = net.adam_state()
+            blob['adam_m.' + name], blob['adam_v.' + name] = m.cpu().numpy(), v.cpu().numpy()
+            blob['adam_t.' + name] = np.array(t, dtype=np.int64)
+        for name in ('log_temp', 'log_alpha'):
+            sp = getattr(self, name, None)
+            if sp is not None:
+                blob['scalar.' + name] = np.concatenate([sp.p.cpu().numpy(), sp.m.cpu().numpy(), sp.v.cpu().numpy(), [float(sp.t)]])
+        with open(fname, 'wb') as f:
+            np.savez(f, **blob)
+
+    def load_model(self, fname):
+        with np.load(fname) as z:
+            cls = str(z['__class__'])
+            if cls != type(self).__name__:
+                raise ValueError('%s holds a %s, this learner is a %s' % (fname, cls, type(self).__name__))
+            self.total_step = int(z['total_step'])
+            for name, net in self._io_nets():
+                flat = z['net.' + name]
+                if flat.size != net.n_params:
+                    raise ValueError('%s: network %r has %d parameters in the file, %d here' % (fname, name, flat.size, net.n_params))
+                dev = net.device
+                net.set_flat_params(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)).to(dev))
+                net.set_adam_state(torch.from_numpy(z['adam_m.' + name]).to(dev), torch.from_numpy(z['adam_v.' + name]).to(dev),
+                                   int(z['adam_t.' + name]))
+            for name in ('log_temp', 'log_alpha'):
+                sp = getattr(self, name, None)
+                if sp is not None:
+                    a = z['scalar.' + name]
+                    sp.p.fill_(float(a[0])); sp.m.fill_(float(a[1])); sp.v.fill_(float(a[2])); sp.t = int(a[3])
+
+    def fit_mdp(self, data, n_epochs=1, discrete_action=None, **kw):
+        """``fit`` on MDPDataset-style arrays (the dict ``offline.generate_offline_dataset`` returns) for ``n_epochs`` passes over its
+        transitions - d3rlpy's ``fit(dataset, n_epochs=...)``."""
+        if discrete_action is None:
+            discrete_action = isinstance(self, _Learner)
+        tr = transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=discrete_action)
+        steps = int(n_epochs) * (tr[0].shape[0] // self.batch_size)
+        return self.fit(tr, steps, **kw)
+
+
+class _Learner(_ModelIO):
     def __init__(self, config, obs_dim, batch_size, lr, seed, custom_encoder, device=None):
         self.config = config
         self.A = int(config['action_size'])
@@ -267,7 +326,7 @@ def _allreduce_group(nets):
         o += f.numel()
 
 
-class BCQ(object):
+class BCQ(_ModelIO):
     """d3rlpy.algos.BCQ(batch_size=256) as 'BCQ-conti' instantiates it (script/batchrl_trainer.py:61-73): default
     ``VectorEncoderWithAction([256, 256])`` everywhere, Adam 1e-3 for actor / critic / imitator, gamma 0.99, tau 0.005, two
     critics, lam 0.75, 100 sampled actions, action_flexibility 0.05, latent_size 32, beta 0.5, update_actor_interval 1,
@@ -480,7 +539,7 @@ class _ScalarParam(object):
         self.p.addcdiv_(self.m, denom, value=-lr / (1.0 - beta1 ** self.t))
 
 
-class CQL(object):
+class CQL(_ModelIO):
     """d3rlpy.algos.CQL (continuous) as 'CQL-conti' instantiates it (script/batchrl_trainer.py:91-107): default encoders,
     actor lr 1e-4, critic lr 3e-4, temperature / alpha lr 1e-4, tau 0.005, two critics, initial temperature 1, initial alpha 1,
     alpha threshold 10, conservative weight 5, 10 action samples, deterministic (non-soft) backup; the script sets gamma = 1 and

@@ -84,3 +84,59 @@ def test_continuous_learner_predict_with_mask_is_predict(tmp_path):
     q = pm.predict_q(x, a)
     assert q.shape == (x.shape[0],) and np.isfinite(q).all()
     model.close()
+
+
+@pytest.mark.parametrize('algo', ['BC', 'BCQ', 'CQL', 'BCQ-conti', 'CQL-conti'])
+def test_save_model_load_model_fit_mdp(tmp_path, algo):
+    """the d3rlpy calls of script/batchrl_train.py:127-142 - fit(dataset, n_epochs), save_model(path), load_model(path): a restored
+    learner predicts what the saved one predicts and CONTINUES training exactly like it (parameters, Adam moments and step counts,
+    the learned scalars)."""
+    import torch
+    from rl4rs_amd import offline_rl as R
+    cfg, tab, x = _setup(tmp_path)
+    conti = algo.endswith('conti')
+    rs = np.random.RandomState(8)
+    n = 512
+    obs = np.repeat(x, 1, axis=0)[:n].copy()
+    acts = rs.randn(n, 32).astype(np.float32) if conti else rs.randint(1, A, size=(n, 1)).astype(np.float32)
+    if conti:
+        acts /= np.linalg.norm(acts, axis=1, keepdims=True)
+    data = dict(observations=obs, actions=acts, rewards=(rs.rand(n) * 3).astype(np.float32),
+                terminals=(np.arange(n) % 10 == 9).astype(np.float32))
+
+    def make():
+        if algo == 'BCQ-conti':
+            return R.BCQ(cfg, D, batch_size=64, n_action_samples=5, seed=3)
+        if algo == 'CQL-conti':
+            return R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, reward_scaler=R.StandardRewardScaler(data['rewards']), seed=3)
+        return {'BC': R.DiscreteBC, 'BCQ': R.DiscreteBCQ, 'CQL': R.DiscreteCQL}[algo](cfg, D, batch_size=64, seed=3)
+
+    a = make()
+    hist = a.fit_mdp(data, n_epochs=2)
+    steps = 2 * ((n - 1) // 64)                        # a trailing episode without terminal flag drops its last row
+    assert a.total_step == steps
+    path = os.path.join(str(tmp_path), 'model.npz')
+    a.save_model(path)
+    b = make()
+    b.load_model(path)
+    assert b.total_step == a.total_step
+    xs = torch.from_numpy(x[:64]).cuda()
+    if algo == 'BCQ-conti':
+        z = torch.from_numpy(rs.randn(64 * 5, 32).astype(np.float32))
+        pa, pb = a.predict(xs, noise=z), b.predict(xs, noise=z)
+    else:
+        pa, pb = a.predict(xs), b.predict(xs)
+    assert torch.equal(pa, pb)
+    # identical continuation (same minibatch order and noise stream)
+    for m in (a, b):
+        if hasattr(m, '_gen'):
+            m._gen.manual_seed(77)
+    ha = a.fit_mdp(data, n_epochs=1, shuffle_seed=5)
+    hb = b.fit_mdp(data, n_epochs=1, shuffle_seed=5)
+    for name, net in a._io_nets():
+        assert torch.equal(net.flat_params(), getattr(b, name).flat_params()), name
+    with pytest.raises(ValueError):
+        other = R.DiscreteBC(cfg, D, batch_size=64, seed=3) if algo != 'BC' else R.DiscreteCQL(cfg, D, batch_size=64, seed=3)
+        other.load_model(path)
+    a.close()
+    b.close()
