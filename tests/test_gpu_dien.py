@@ -385,13 +385,43 @@ def test_first_generation_recurrence_still_matches(monkeypatch, scorer_precision
     test_dien_rowwise_matches_oracle(64)
 
 
-@pytest.mark.parametrize('kernels', ['din_v1', 'no_gru16', 'no_gemm16,no_cat16', 'no_head_tables'])
+@pytest.mark.parametrize('kernels', ['din_v1', 'no_gru16', 'no_gemm16,no_cat16', 'no_head_tables', 'cat_v1', 'cat_v1,no_cat16',
+                                     'no_cat16', 'cat_v1,no_head_tables'])
 def test_other_kernel_paths_match_the_oracle(monkeypatch, scorer_precision, kernels):
     """Every selectable kernel path of rl4rs_dien_cfg.kernel_opts against the same fp64 oracle and the same bars."""
     if scorer_precision != 'fp16x2':
         pytest.skip('fp16x2 only')
     monkeypatch.setitem(CFG, 'scorer_kernels', kernels)
     test_dien_rowwise_matches_oracle(64)
+
+
+@pytest.mark.parametrize('extra', ['', 'no_cat16', 'no_head_tables'])
+def test_category_kernels_are_bit_identical(scorer_precision, extra):
+    """k_cat_attn2 (half-K LDS image, pooled row from the gathered registers, staged table sums) against k_cat_attn
+    (scorer_kernels='cat_v1'): same products in the same order - the whole forward must be bit-identical, in the split and the
+    exact-fp32 form of the Gram matrix and with the flattened embeddings written out (no head tables)."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    cfg = dict(CFG, scorer_precision=scorer_precision)
+    B = 101
+    w = init_dien_weights(cfg, seed=6, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(2)
+    seq, dense, cat = _inputs(B, rs, cfg['category_hash_size'])
+
+    def run(kernels):
+        net = DeviceDien(dict(cfg, scorer_kernels=kernels), w, max_rows=B, max_slots=B)
+        for s_ in range(2):
+            net.encode(s_, torch.from_numpy(np.ascontiguousarray(seq[:, s_])).cuda(), 0)
+        sl = torch.arange(B, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+        obs, p = net.forward(B, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), sl, True, True)
+        obs, p = obs.clone(), p.clone()
+        net.close()
+        return obs, p
+
+    o2, p2 = run(extra)
+    o1, p1 = run(','.join(x for x in ('cat_v1', extra) if x))
+    assert torch.equal(o1, o2) and torch.equal(p1, p2)
 
 
 def test_kernel_options_are_validated():
