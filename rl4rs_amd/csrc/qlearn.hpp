@@ -334,7 +334,7 @@ int rl4rs_qnet_create(const rl4rs_qnet_cfg* c, const float* params_host, const u
     for (int i = 0; i < QP_COUNT; ++i) if (sizes[i] > wmax) wmax = sizes[i];
     p->cx.chunk = 512;
     QN_FAIL(al(&p->cx.wt, wmax));
-    QN_FAIL(al(&p->cx.part, (size_t)((B + 511) / 512) * wmax));
+    QN_FAIL(al(&p->cx.part, (size_t)((B + 511) / 512) * (wmax + std::max<int64_t>(std::max<int64_t>(A, H1), n2))));      // + the bias partials (st_tn_cs)
     QN_HIP(hipStreamSynchronize(st));
 #undef QN_HIP
 #undef QN_FAIL
@@ -412,19 +412,22 @@ int rl4rs_qnet_backward(rl4rs_qnet* p, int32_t N, const float* obs, const float*
     auto ew = [](int n) { return dim3((n + 255) / 256); };
     const dim3 b256(256);
     int rc;
-    st_tn(p->cx, st, p->enc, FH, FH, dout, A, A, N, G + o[QP_HW]);
-    st_cs(p->cx, st, dout, A, A, N, G + o[QP_HB]);
-    if ((rc = st_back(p->cx, st, dout, A, A, P + o[QP_HW], A, FH, p->d_enc, FH, N))) return rc;
-    if (p->custom) hipLaunchKernelGGL(k_q_mask_bwd, ew(N * A), b256, 0, st, p->d_enc, p->bits, N, A, p->W);
-    else hipLaunchKernelGGL(k_relu_bwd, ew(N * FH), b256, 0, st, p->d_enc, (int64_t)FH, p->enc, (int64_t)FH, N * FH, FH);
-    st_tn(p->cx, st, p->cat, F2, F2, p->d_enc, FH, FH, N, G + o[QP_W2]);
-    st_cs(p->cx, st, p->d_enc, FH, FH, N, G + o[QP_B2]);
-    if ((rc = st_back(p->cx, st, p->d_enc, FH, FH, P + o[QP_W2], FH, F2, p->d_cat, F2, N))) return rc;
-    if (p->custom)
+    st_tn_cs(p->cx, st, p->enc, FH, FH, dout, A, A, N, G + o[QP_HW], G + o[QP_HB]);      // weight + bias gradient: one launch
+    if (p->custom) {
+        if ((rc = st_back(p->cx, st, dout, A, A, P + o[QP_HW], A, FH, p->d_enc, FH, N))) return rc;
+        hipLaunchKernelGGL(k_q_mask_bwd, ew(N * A), b256, 0, st, p->d_enc, p->bits, N, A, p->W);
+    } else if ((rc = launch_gemm_nt(dout, A, P + o[QP_HW], A, p->d_enc, FH, N, FH, A, st, p->enc, FH))) {       // dY W^T with relu'(enc) folded in
+        return rc;
+    }
+    st_tn_cs(p->cx, st, p->cat, F2, F2, p->d_enc, FH, FH, N, G + o[QP_W2], G + o[QP_B2]);
+    if (p->custom) {
+        if ((rc = st_back(p->cx, st, p->d_enc, FH, FH, P + o[QP_W2], FH, F2, p->d_cat, F2, N))) return rc;
         hipLaunchKernelGGL(k_q_tail_emb_bwd, dim3(A), b256, 0, st, obs, N, D, M, A, ES, p->d_cat, (int64_t)F2, H1, G + o[QP_EMB]);
-    hipLaunchKernelGGL(k_relu_bwd, ew(N * H1), b256, 0, st, p->d_cat, (int64_t)F2, p->cat, (int64_t)F2, N * H1, H1);
-    st_tn(p->cx, st, obs, D, D, p->d_cat, F2, H1, N, G + o[QP_W1]);
-    st_cs(p->cx, st, p->d_cat, F2, H1, N, G + o[QP_B1]);
+        hipLaunchKernelGGL(k_relu_bwd, ew(N * H1), b256, 0, st, p->d_cat, (int64_t)F2, p->cat, (int64_t)F2, N * H1, H1);      // the hidden part only
+    } else if ((rc = launch_gemm_nt(p->d_enc, FH, P + o[QP_W2], FH, p->d_cat, F2, N, F2, FH, st, p->cat, F2))) {    // F2 == H1: all of cat is relu(fc1)
+        return rc;
+    }
+    st_tn_cs(p->cx, st, obs, D, D, p->d_cat, F2, H1, N, G + o[QP_W1], G + o[QP_B1]);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

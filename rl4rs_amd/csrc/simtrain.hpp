@@ -216,7 +216,12 @@ namespace {
 
 // sample-axis reductions / transposed-weight GEMM over an explicit number of samples
 struct TrainCtx { int chunk; float* part; float* wt; };
+constexpr int TN4_MAX_SAMPLES = 1024;      // up to here the whole sample axis is one workgroup's (four waves x Ns / 4 samples)
 void st_tn(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
+    if (Ns <= TN4_MAX_SAMPLES) {
+        hipLaunchKernelGGL(k_gemm_tn4, dim3(((M + 31) / 32) * ((Nc + 31) / 32)), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, dst, (float*)nullptr);
+        return;
+    }
     const int nz = (Ns + x.chunk - 1) / x.chunk;
     const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
     hipLaunchKernelGGL(k_gemm_tn, dim3((tiles + 3) / 4, nz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, x.chunk, nz == 1 ? dst : x.part, (float*)nullptr);
@@ -230,6 +235,10 @@ void st_cs(const TrainCtx& x, hipStream_t st, const float* X, int ld, int Nc, in
 // weight AND bias gradient of one Linear layer in one launch: dW [M, Nc] = A^T B, db [Nc] = column sums of B.  x.part must hold
 // nz * (M * Nc + Nc) floats when Ns > x.chunk.
 void st_tn_cs(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dW, float* db) {
+    if (Ns <= TN4_MAX_SAMPLES) {
+        hipLaunchKernelGGL(k_gemm_tn4, dim3(((M + 31) / 32) * ((Nc + 31) / 32)), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, dW, db);
+        return;
+    }
     const int nz = (Ns + x.chunk - 1) / x.chunk;
     const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
     float* bpart = x.part + (size_t)nz * M * Nc;
