@@ -180,15 +180,17 @@ class _Learner(_ModelIO):
         n = obs.shape[0]
         assert n >= self.batch_size, 'dataset smaller than one minibatch'
         rs = np.random.RandomState(self.seed if shuffle_seed is None else shuffle_seed)
-        losses, perm, pos = [], None, n
+        losses, ep, pos = [], None, n
         for _ in range(n_steps):
             if pos + self.batch_size > n:
+                # the epoch's permutation is applied to the five arrays ONCE: minibatches are then contiguous row ranges (views),
+                # not five gathers per update
                 perm = torch.from_numpy(rs.permutation(n)).to(obs.device)
+                ep = [t[perm] for t in (obs, act, rew, nxt, ter)]
                 pos = 0
-            idx = perm[pos:pos + self.batch_size]
-            pos += self.batch_size
-            losses.append(self.update(obs[idx].contiguous(), act[idx].contiguous(), rew[idx].contiguous(),
-                                      nxt[idx].contiguous(), ter[idx].contiguous()))
+            lo, hi = pos, pos + self.batch_size
+            pos = hi
+            losses.append(self.update(*[t[lo:hi] for t in ep]))
         out = [float(x) for x in torch.stack(losses).cpu()]
         for net in self.nets:
             net.check_status()
@@ -378,11 +380,19 @@ class BCQ(_ModelIO):
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(self.seed + 1000003 * rdist.rank())
         self._minus_inv_b = None
+        self._imit_w = torch.tensor([1.0 / self.E, self.beta / self.L], dtype=torch.float32, device=self.device)
 
     def _randn(self, rows, noise, key):
         if noise is not None and key in noise:
             return noise[key].to(device=self.device, dtype=torch.float32).contiguous()
         return torch.randn((rows, self.L), generator=self._gen, device=self.device, dtype=torch.float32)
+
+    def _clipped_latent(self, rows, noise, key):
+        """clamp(randn, -0.5, 0.5) (BCQImpl: the decoder's latent is clipped when actions are sampled); a caller-supplied noise
+        tensor is never modified"""
+        own = noise is None or key not in noise
+        z = self._randn(rows, noise, key)
+        return z.clamp_(-0.5, 0.5) if own else z.clamp(-0.5, 0.5)
 
     def _sample_actions(self, obs, z, policy, rep):
         """imitator.decode(x, clip(z)) -> policy residual: [rows, E] actions for ``rep`` latents per observation."""
@@ -405,10 +415,10 @@ class BCQ(_ModelIO):
         _allreduce_group([self.imit_enc, self.imit_dec])
         self.imit_enc.adam_step(self.imitator_lr)
         self.imit_dec.adam_step(self.imitator_lr)
-        metrics['imitator_loss'] = loss2[0] / self.E + self.beta * loss2[1] / self.L
+        metrics['imitator_loss'] = torch.dot(loss2, self._imit_w)          # mse / E + beta * kl / L as ONE launch
         if self.total_step >= self.rl_start_step:
             # --- critic (DDPGBaseImpl.update_critic with BCQImpl.compute_target) ---
-            zt = self._randn(B * n, noise, 'z_target').clamp(-0.5, 0.5)
+            zt = self._clipped_latent(B * n, noise, 'z_target')
             _, _, a_next = self._sample_actions(nxt, zt, self.policy_targ, n)
             q1n = self.q1_targ.forward(nxt, a_next, rep=n)
             q2n = self.q2_targ.forward(nxt, a_next, rep=n)
@@ -421,10 +431,10 @@ class BCQ(_ModelIO):
             _allreduce_group([self.q1, self.q2])
             self.q1.adam_step(self.critic_lr)
             self.q2.adam_step(self.critic_lr)
-            metrics['critic_loss'] = closs2[0] + closs2[1]
+            metrics['critic_loss'] = closs2.sum()
             if self.total_step % self.update_actor_interval == 0:
                 # --- actor (BCQImpl.compute_actor_loss: -Q_1(s, pi(s, decode(s, z))).mean()) ---
-                za = self._randn(B, noise, 'z_actor').clamp(-0.5, 0.5)
+                za = self._clipped_latent(B, noise, 'z_actor')
                 sampled, t, a_pi = self._sample_actions(obs, za, self.policy, 1)
                 qv = self.q1.forward(obs, a_pi)
                 if self._minus_inv_b is None or self._minus_inv_b.numel() != B:
@@ -434,7 +444,7 @@ class BCQ(_ModelIO):
                 self.policy.backward(obs, sampled, d_pre)
                 _allreduce_group([self.policy])
                 self.policy.adam_step(self.actor_lr)
-                metrics['actor_loss'] = -qv.mean()
+                metrics['actor_loss'] = torch.dot(qv.view(-1), self._minus_inv_b.view(-1))       # -mean(q) as ONE launch
                 self.policy_targ.soft_update_from(self.policy, self.tau)
                 self.q1_targ.soft_update_from(self.q1, self.tau)
                 self.q2_targ.soft_update_from(self.q2, self.tau)
@@ -451,15 +461,15 @@ class BCQ(_ModelIO):
         E = getattr(self, 'E', None) or self.A
         assert act.dim() == 2 and act.shape[1] == E and act.dtype == torch.float32, 'continuous actions [N, %d] needed' % E
         rs = np.random.RandomState(self.seed if shuffle_seed is None else shuffle_seed)
-        hist, perm, pos = [], None, n
+        hist, ep, pos = [], None, n
         for _ in range(n_steps):
             if pos + self.batch_size > n:
-                perm = torch.from_numpy(rs.permutation(n)).to(obs.device)
+                perm = torch.from_numpy(rs.permutation(n)).to(obs.device)          # applied once per epoch: minibatches are views
+                ep = [t[perm] for t in (obs, act, rew, nxt, ter)]
                 pos = 0
-            idx = perm[pos:pos + self.batch_size]
-            pos += self.batch_size
-            hist.append(self.update(obs[idx].contiguous(), act[idx].contiguous(), rew[idx].contiguous(), nxt[idx].contiguous(),
-                                    ter[idx].contiguous()))
+            lo, hi = pos, pos + self.batch_size
+            pos = hi
+            hist.append(self.update(*[t[lo:hi] for t in ep]))
         out = {}
         for k in self._LOSS_KEYS:
             vals = [h[k] for h in hist if k in h]
