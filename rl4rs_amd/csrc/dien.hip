@@ -72,6 +72,14 @@ __device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, 
     lo = __builtin_bit_cast(half2_t, l);
 }
 
+#ifndef RL4RS_CAT_FAST_EXP
+#define RL4RS_CAT_FAST_EXP 0     // 1: the softmax of the category self-attention on the hardware exp2 (timing A/B, round 4)
+#endif
+#if RL4RS_CAT_FAST_EXP
+#define CAT_EXP(x) __builtin_amdgcn_exp2f(1.4426950408889634f * (x))
+#else
+#define CAT_EXP(x) expf(x)
+#endif
 // -------------------------------------------------------------------------------------------------
 // Category branch (utils.py:16-25) + attention query (dien.py:29-30, utils.py:114-115).
 // One wave per row; 4 rows per block.  Writes allf[row, off_c : off_c + E] = mean_i(softmax(E E^T) E),
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
     float z = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float ev = (crow(r, half) < Cn) ? expf(acc[r] - m) : 0.f;
+        float ev = (crow(r, half) < Cn) ? CAT_EXP(acc[r] - m) : 0.f;
         acc[r] = ev;
         z += ev;
     }
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
     float z = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float ev = (crow(r, half) < Cn) ? expf(acc[r] - m) : 0.f;
+        float ev = (crow(r, half) < Cn) ? CAT_EXP(acc[r] - m) : 0.f;
         acc[r] = ev;
         z += ev;
     }
