@@ -766,6 +766,16 @@ int rl4rs_amlp_set_adam_step(rl4rs_amlp* net, int64_t step);
 int rl4rs_amlp_soft_update(rl4rs_amlp* targ, const rl4rs_amlp* src, float tau, void* stream);
 int rl4rs_amlp_forward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev, float* out_dev,
                        void* stream);
+/* The same forward for rows that never see a backward (target values, greedy evaluation: batch x n_action_samples rows), in
+ * fp16x2 arithmetic (operands as fp16 hi + lo, three f16 MFMAs per product, fp32 accumulation - the scorer's form) as ONE launch
+ * for the three layers behind the observation-side projection.  rl4rs_amlp_h16_ok: 1 when the network's shape has this form
+ * (hidden 256 x 256, act_dim 8..64 in multiples of 8, out_dim <= 64).  The fp16 planes are rebuilt from the current fp32
+ * parameters in front of every call; rows whose activations leave the fp16 range come back NaN; a following
+ * rl4rs_amlp_backward is refused (no activations are kept).  Replaces the torch.no_grad() forwards of
+ * d3rlpy BCQImpl.compute_target / _predict_best_action (script/batchrl_trainer.py:61-73 trains and evaluates through them). */
+int rl4rs_amlp_h16_ok(const rl4rs_amlp* net);
+int rl4rs_amlp_forward_h16(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev, float* out_dev,
+                           void* stream);
 int rl4rs_amlp_backward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev,
                         const float* dout_dev, float* dact_dev, int32_t want_param_grad, void* stream);
 int rl4rs_amlp_adam_step(rl4rs_amlp* net, float lr, float beta1, float beta2, float eps, void* stream);
@@ -841,6 +851,9 @@ int rl4rs_gemm_f32_packed(const float* a_dev, int64_t lda, const float* w_host, 
 int rl4rs_gemm_h16_packed(const float* a_dev, int64_t lda, const float* w_host, int64_t ldw,
                           const float* bias_dev, float* c_dev, int64_t ldc, int32_t M, int32_t N, int32_t K,
                           int act, void* stream);
+/* Test hook: the device-side fragment packer (k_pack_h16_dev, used in front of rl4rs_amlp_forward_h16) against the host one
+ * (pack_gemm_weight_h16, used when a scorer is loaded): number of 32-bit words that differ, 0 = bit-identical. */
+int rl4rs_pack_h16_selftest(const float* w_host, int64_t ldw, int32_t K, int32_t N, int64_t* mismatches, void* stream);
 
 #ifdef __cplusplus
 }

@@ -232,6 +232,9 @@ SIGNATURES = {
     'rl4rs_amlp_set_adam_step': (_I, [_P, _I64]),
     'rl4rs_amlp_soft_update': (_I, [_P, _P, C.c_float, _P]),
     'rl4rs_amlp_forward': (_I, [_P, _I32, _I32, _P, _P, _P, _P]),
+    'rl4rs_amlp_h16_ok': (_I, [_P]),
+    'rl4rs_pack_h16_selftest': (_I, [_P, _I64, _I32, _I32, _P, _P]),
+    'rl4rs_amlp_forward_h16': (_I, [_P, _I32, _I32, _P, _P, _P, _P]),
     'rl4rs_amlp_backward': (_I, [_P, _I32, _I32, _P, _P, _P, _P, _I32, _P]),
     'rl4rs_amlp_adam_step': (_I, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     'rl4rs_cvae_sample': (_I, [_I32, _I32, _P, _P, C.c_float, C.c_float, _P, _P]),

@@ -80,6 +80,19 @@ std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int 
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
                           const float* wp2, const float* bias2, float* c2, int64_t ldc2, int N2, int act2, int M, hipStream_t st);
 
+// device-side pack_gemm_weight_h16 (weights that change between launches): up to 4 matrices per launch, out = NT * KB * 512 + NT * 32 floats
+struct PackH16Desc { const float* w; float* out; int ldw, K, N; };
+struct PackH16Args { PackH16Desc d[4]; };
+int launch_pack_h16_dev(const PackH16Desc* d, int n, hipStream_t st);
+// whole no-grad forward of an amlp (contirl.hpp; hidden 256 x 256) in one launch, fp16x2 arithmetic; w*p = device-packed planes,
+// proj [N / rep, 256] = x W1[:D] + b1, act [N, E] (E % 8 == 0, <= 64), out [N, K3] (K3 <= 64)
+struct AmlpFwdH16 {
+    const float* act; const float* proj; const char* w1p; const char* w2p; const char* w3p;
+    const float* b2; const float* b3; float* out;
+    int N, E, rep, K3, head_act;
+};
+int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION, shared by every handle of the process: it is only ever
 // raised (a second handle with a smaller shape must not lower the limit under the first one's launches - ADVICE r2 on k_ppo_pass,
 // applied to every kernel whose LDS size depends on a handle's shape).  Defined in env.hip.

@@ -314,9 +314,17 @@ struct rl4rs_amlp {
     float *proj, *h1, *h2;              // forward: [max_rows, hidden1] observation-side projection (one row per DISTINCT observation), activations
     float *d_h1, *d_h2, *d_proj;        // backward scratch, [max_grad_rows, ...]
     int last_n, last_rep;               // rows of the last forward (the backward must match)
+    float *w1p, *w2p, *w3p;             // fp16 hi / lo fragment planes of W1's action rows, W2, W3 for rl4rs_amlp_forward_h16 (NULL: shape not eligible)
     int64_t adam_t;
     std::vector<void*> owned;
 };
+
+// the shapes k_amlp_fwd_h16 (gemm.hip) takes: d3rlpy's default 256 x 256 encoder with an action input of 8 .. 64 values in
+// multiples of 8 and at most 64 outputs - every network of BCQ and CQL except the plain-encoder policy of CQL
+static bool amlp_h16_shape_ok(const rl4rs_amlp_cfg& c) {
+    return c.act_dim >= 8 && c.act_dim <= 64 && (c.act_dim & 7) == 0 && c.hidden1 == 256 && c.hidden2 == 256 && c.out_dim <= 64 &&
+           (c.head_act == ACT_NONE || c.head_act == ACT_TANH || c.head_act == ACT_RELU || c.head_act == ACT_SIGMOID || c.head_act == ACT_ELU);
+}
 
 extern "C" {
 
@@ -341,6 +349,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
     p->c = *c;
     p->adam_t = 0;
     p->last_n = p->last_rep = 0;
+    p->w1p = p->w2p = p->w3p = nullptr;
     const int64_t sizes[AP_COUNT] = {(D + E) * H1, H1, H1 * H2, H2, H2 * K, K};
     int64_t o = 0;
     for (int i = 0; i < AP_COUNT; ++i) { p->off[i] = o; p->size[i] = sizes[i]; o += sizes[i]; }
@@ -369,6 +378,10 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
         p->cx.chunk = 256;
         AM_FAIL(al(&p->cx.wt, wmax));
         AM_FAIL(al(&p->cx.part, (size_t)((G + 255) / 256) * (wmax + std::max(H1, std::max(H2, K)))));
+    }
+    if (amlp_h16_shape_ok(*c)) {
+        const size_t KB1 = (size_t)(E + 15) / 16, NT3 = (size_t)(K + 31) / 32;
+        AM_FAIL(al(&p->w1p, 8 * KB1 * 512 + 256)); AM_FAIL(al(&p->w2p, 8 * 16 * 512 + 256)); AM_FAIL(al(&p->w3p, NT3 * 16 * 512 + NT3 * 32));
     }
     AM_HIP(hipStreamSynchronize(st));
 #undef AM_HIP
@@ -441,6 +454,32 @@ int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, 
     }
     p->last_n = N;
     p->last_rep = rep;
+    return RL4RS_OK;
+}
+
+int rl4rs_amlp_h16_ok(const rl4rs_amlp* p) { return (p && p->w1p) ? 1 : 0; }
+
+// The same forward for rows that will never see a backward (target values, greedy evaluation), fp16x2 arithmetic, ONE launch for the
+// three layers (k_amlp_fwd_h16) behind the observation-side projection: the weights' fp16 hi / lo planes are rebuilt from the
+// CURRENT fp32 parameters in front of every call (one small launch; the parameters may have been written through the raw
+// pointer of rl4rs_amlp_params, so no dirty flag is trusted).  Leaves no activations: a following rl4rs_amlp_backward is refused.
+int rl4rs_amlp_forward_h16(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, const float* act, float* out, void* stream) {
+    RL4RS_REQUIRE(p && obs && act && out && N > 0 && rep > 0 && N <= p->c.max_rows && N % rep == 0, "amlp_forward_h16: bad argument (N=%d, rep=%d, max_rows=%d)",
+                  N, rep, p ? p->c.max_rows : -1);
+    RL4RS_REQUIRE(p->w1p, "amlp_forward_h16: this network's shape has no fp16x2 form (rl4rs_amlp_h16_ok)");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = p->c.obs_dim, E = p->c.act_dim, H1 = p->c.hidden1, H2 = p->c.hidden2, K = p->c.out_dim, R = N / rep;
+    const float* P = p->params;
+    const int64_t* o = p->off;
+    int rc;
+    const PackH16Desc pk[3] = {{P + o[AP_W1] + (size_t)D * H1, p->w1p, H1, E, H1}, {P + o[AP_W2], p->w2p, H2, H1, H2}, {P + o[AP_W3], p->w3p, K, H2, K}};
+    if ((rc = launch_pack_h16_dev(pk, 3, st))) return rc;
+    if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st))) return rc;
+    AmlpFwdH16 a = {act, p->proj, reinterpret_cast<const char*>(p->w1p), reinterpret_cast<const char*>(p->w2p), reinterpret_cast<const char*>(p->w3p),
+                    P + o[AP_B2], P + o[AP_B3], out, N, E, rep, K, p->c.head_act};
+    if ((rc = launch_amlp_fwd_h16(a, st))) return rc;
+    p->last_n = -1;
+    p->last_rep = 0;
     return RL4RS_OK;
 }
 

@@ -1012,6 +1012,337 @@ static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, 
     return RL4RS_OK;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Device-side pack_gemm_weight_h16: the continuous learners' weights change every update, so the fp16 hi / lo fragment planes of
+// their no-grad forwards (k_amlp_fwd_h16) are rebuilt on the device in front of each use - same per-column power-of-two prescale,
+// same layout and trailer, bit-identical to the host function.  One workgroup per 32-column tile, grid.y = matrix (<= 4 per launch).
+__device__ __forceinline__ float pow2_prescale_dev(float maxabs) {
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
+    int e = 0;
+    (void)frexpf(maxabs, &e);
+    int k = 14 - e;
+#ifndef RL4RS_PRESCALE_UP
+    if (e <= 14 && e > -6) k = 0;
+#endif
+    if (k > 100) k = 100;
+    if (k < -100) k = -100;
+    return ldexpf(1.f, k);
+}
+
+__global__ __launch_bounds__(256) void k_pack_h16_dev(PackH16Args a) {
+    const PackH16Desc d = a.d[blockIdx.y];
+    if (!d.w) return;
+    const int KB = (d.K + 15) / 16, NT = (d.N + 31) / 32, nt = blockIdx.x;
+    if (nt >= NT) return;
+    __shared__ float s_mx[8][32];
+    __shared__ float s_scale[32];
+    const int tid = threadIdx.x, j = tid & 31, g = tid >> 5, col = nt * 32 + j;
+    float mx = 0.f;
+    if (col < d.N)
+        for (int k = g; k < d.K; k += 8) mx = fmaxf(mx, fabsf(d.w[(size_t)k * d.ldw + col]));
+    s_mx[g][j] = mx;
+    __syncthreads();
+    if (tid < 32) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, s_mx[i][tid]);
+        const float s = (nt * 32 + tid < d.N) ? pow2_prescale_dev(m) : 1.f;
+        s_scale[tid] = s;
+        d.out[(size_t)NT * KB * 512 + nt * 32 + tid] = 1.0f / s;
+    }
+    __syncthreads();
+    _Float16* oh = reinterpret_cast<_Float16*>(d.out);
+    for (int idx = tid; idx < KB * 64; idx += 256) {
+        const int kb = idx >> 6, lane = idx & 63, jj = lane & 31, c = nt * 32 + jj;
+        ghalf8_t hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = kb * 16 + (lane >> 5) * 8 + i;
+            float v = (k < d.K && c < d.N) ? d.w[(size_t)k * d.ldw + c] * s_scale[jj] : 0.f;
+            asm volatile("" : "+v"(v));                // ONE rounded fp32 value for both parts (see plane_store in augru_x.hpp)
+            const _Float16 h = (_Float16)v;
+            hi[i] = h;
+            lo[i] = (_Float16)(v - (float)h);
+        }
+        const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8;
+        *reinterpret_cast<ghalf8_t*>(oh + base) = hi;
+        *reinterpret_cast<ghalf8_t*>(oh + base + 512) = lo;
+    }
+}
+
+int launch_pack_h16_dev(const PackH16Desc* d, int n, hipStream_t st) {
+    if (n <= 0 || n > 4) { set_error("pack_h16_dev: 1..4 matrices per launch"); return RL4RS_EINVAL; }
+    PackH16Args a = {};
+    int nt = 1;
+    for (int i = 0; i < n; ++i) { a.d[i] = d[i]; nt = std::max(nt, (d[i].N + 31) / 32); }
+    hipLaunchKernelGGL(k_pack_h16_dev, dim3(nt, n), dim3(256), 0, st, a);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_amlp_fwd_h16: the WHOLE no-grad forward of an "amlp" (contirl.hpp: relu([x | a] W1 + b1) -> relu(. W2 + b2) -> act(. W3 + b3),
+// hidden 256 x 256) for many rows in ONE launch, fp16x2 arithmetic (operands as fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per
+// product, fp32 accumulation: the scorer's form).  What it replaces: three launches per network through HBM - the BCQ target and
+// the evaluation rollout push 25 600 / 409 600 sampled rows through three such networks per update / env step, and the middle
+// 256 x 256 layer alone wrote and re-read 2 x 419 MB per network at 409 600 rows (k_gemm_f32_t128: 645 us; the unfused fp16x2
+// GEMM: 340 us, HBM-bound).  Here a workgroup takes 64 rows through all three layers and the activations never leave the CU:
+//   * TRANSPOSED tiles like k_augru_x (A = weight fragment, B = activation fragment): a lane owns one row and 16 hidden columns
+//     in runs of 4, so an activated tile goes back to the LDS planes ([k-block][k-half][row][8 halfs], the next layer's B
+//     fragments are single conflict-free ds_read_b128) as packed 8-byte writes;
+//   * layer 1 multiplies only the ACTION side (K = act_dim <= 64); the observation side x W1[:D] + b1 arrives as the row-shared
+//     addend proj[row / rep] (one small GEMM over the distinct observations, contirl.hpp);
+//   * 4 waves, wave w owns hidden columns [64w, 64w + 64) (two 32-column tiles x two 32-row tiles = 64 accumulator registers),
+//     weight fragments stream from L2 through a 4-deep register ring (256 KB per workgroup for the middle layer);
+//   * the head (out_dim <= 64) runs as (column tile, row tile) units on the waves, k-blocks split over the idle waves and
+//     summed through LDS when there are only two units;
+//   * LDS 80 KB -> two workgroups per CU, whose MFMA and epilogue phases overlap.
+// Rows whose activations leave the fp16 range turn NaN (inf in the hi plane, -inf in the lo plane), as in k_gemm_h16.
+typedef _Float16 ghalf4_t __attribute__((ext_vector_type(4)));
+
+// ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
+__global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
+    constexpr int MT = 2, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 8 * SLAB, RING = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * HPLANE + 2 * XPLANE];
+    char* h_hi = smem;
+    char* h_lo = smem + HPLANE;
+    char* x_hi = smem + 2 * HPLANE;
+    char* x_lo = x_hi + XPLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * ROWS;
+    const int KB1 = (a.E + 15) >> 4;
+    const int vl16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w1p), 0, 8 * KB1 * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w2p), 0, 8 * 16 * 2048, 0x00020000);
+    const int NT3 = (a.K3 + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w3p), 0, NT3 * 16 * 2048, 0x00020000);
+
+    // ---- layer-1 weight fragments of this wave's two column tiles (requested first: their L2 latency hides behind the staging)
+    ghalf8_t w1h[2][4], w1l[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+            if (kb < KB1) {
+                const int so = ((2 * wave + t) * KB1 + kb) * 2048;
+                w1h[t][kb] = gbuf_load_h8(rs_w1, vl16, so);
+                w1l[t][kb] = gbuf_load_h8(rs_w1, vl16 + 1024, so);
+            }
+    // ---- stage the action-side input rows as fp16 hi / lo planes
+    {
+        const int nch = KB1 * 2;                       // chunks of 8 consecutive k per row
+        for (int c = tid; c < ROWS * nch; c += 256) {
+            const int r = c & (ROWS - 1), ck = c / ROWS;
+            const int row = m0 + r, gk = ck * 8;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            if (row < a.N && gk < a.E) {               // E % 8 == 0 (launcher)
+                const float4 v0 = *reinterpret_cast<const float4*>(a.act + (size_t)row * a.E + gk);
+                const float4 v1 = *reinterpret_cast<const float4*>(a.act + (size_t)row * a.E + gk + 4);
+                x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+            }
+            ghalf8_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 h = (_Float16)x[e];
+                hi[e] = h;
+                lo[e] = (_Float16)(x[e] - (float)h);
+            }
+            *reinterpret_cast<ghalf8_t*>(x_hi + ck * SLAB + r * 16) = hi;
+            *reinterpret_cast<ghalf8_t*>(x_lo + ck * SLAB + r * 16) = lo;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][MT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][m][i] = 0.f;
+    };
+    auto mfma3 = [&](f32x16& c, const ghalf8_t& wh, const ghalf8_t& wl, const ghalf8_t& bh, const ghalf8_t& bl) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, c, 0, 0, 0);
+    };
+    // activation fragments (B operand) of k-block kb, row tile m: lane (row li, k-half `half`)
+    auto bfrag = [&](const char* p_hi, const char* p_lo, int kb, ghalf8_t (&bh)[MT], ghalf8_t (&bl)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int off = (kb * 2 + half) * SLAB + (m * 32 + li) * 16;
+            bh[m] = *reinterpret_cast<const ghalf8_t*>(p_hi + off);
+            bl[m] = *reinterpret_cast<const ghalf8_t*>(p_lo + off);
+        }
+    };
+    // four consecutive hidden columns (tile nt, run q) of this lane's row (row tile m) -> the activation planes
+    auto plane_store = [&](int nt, int m, int q, const float (&v)[4]) {
+        ghalf4_t vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            asm volatile("" : "+v"(x));                // one rounded fp32 value for both parts
+            const _Float16 h = (_Float16)x;
+            vh[j] = h;
+            vl[j] = (_Float16)(x - (float)h);
+        }
+        const int o = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
+        *reinterpret_cast<ghalf4_t*>(h_hi + o) = vh;
+        *reinterpret_cast<ghalf4_t*>(h_lo + o) = vl;
+    };
+
+    // ---- layer 1: action side, K = E
+    zero_acc();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+        if (kb < KB1) {
+            ghalf8_t bh[MT], bl[MT];
+            bfrag(x_hi, x_lo, kb, bh, bl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma3(acc[t][m], w1h[t][kb], w1l[t][kb], bh[m], bl[m]);
+        }
+    // the middle layer's first fragments are requested before the epilogue: ring slot s holds k-block kb with kb % RING == s
+    ghalf8_t w2h[RING][2], w2l[RING][2];
+    auto w2load = [&](int kb) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int so = ((2 * wave + t) * 16 + kb) * 2048;
+            w2h[kb % RING][t] = gbuf_load_h8(rs_w2, vl16, so);
+            w2l[kb % RING][t] = gbuf_load_h8(rs_w2, vl16 + 1024, so);
+        }
+    };
+#pragma unroll
+    for (int kb = 0; kb < RING - 1; ++kb) w2load(kb);
+    {
+        const float* tr1 = reinterpret_cast<const float*>(a.w1p) + (size_t)8 * KB1 * 512;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = min(m0 + m * 32 + li, a.N - 1);
+            const float* prow = a.proj + (size_t)(row / a.rep) * 256;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
+                    const float4 is = *reinterpret_cast<const float4*>(tr1 + c0);
+                    const float4 pj = *reinterpret_cast<const float4*>(prow + c0);
+                    const float v[4] = {relu_nan(acc[t][m][4 * q + 0] * is.x + pj.x), relu_nan(acc[t][m][4 * q + 1] * is.y + pj.y),
+                                        relu_nan(acc[t][m][4 * q + 2] * is.z + pj.z), relu_nan(acc[t][m][4 * q + 3] * is.w + pj.w)};
+                    plane_store(2 * wave + t, m, q, v);
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 2: 256 x 256
+    zero_acc();
+    {
+        ghalf8_t bh[2][MT], bl[2][MT];
+        bfrag(h_hi, h_lo, 0, bh[0], bl[0]);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            if (kb + RING - 1 < 16) w2load(kb + RING - 1);
+            if (kb + 1 < 16) bfrag(h_hi, h_lo, kb + 1, bh[(kb + 1) & 1], bl[(kb + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mfma3(acc[t][m], w2h[kb % RING][t], w2l[kb % RING][t], bh[kb & 1][m], bl[kb & 1][m]);
+        }
+    }
+    // head fragments: unit = (column tile, row tile), KS waves share a unit's k-blocks
+    const int units = NT3 * MT;                        // 2 or 4
+    const int KS = 4 / units, unit = wave % units, ks = wave / units;
+    const int nt3 = unit / MT, m3 = unit % MT;
+    const int kb_lo = ks * (16 / KS), kb_n = 16 / KS;  // 16 or 8 k-blocks
+    ghalf8_t w3h[RING], w3l[RING];
+    auto w3load = [&](int i) {
+        const int so = (nt3 * 16 + kb_lo + i) * 2048;
+        w3h[i % RING] = gbuf_load_h8(rs_w3, vl16, so);
+        w3l[i % RING] = gbuf_load_h8(rs_w3, vl16 + 1024, so);
+    };
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) w3load(i);
+    __syncthreads();                                   // every wave has read the layer-1 planes
+    {
+        const float* tr2 = reinterpret_cast<const float*>(a.w2p) + (size_t)8 * 16 * 512;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
+                    const float4 is = *reinterpret_cast<const float4*>(tr2 + c0);
+                    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c0);
+                    const float v[4] = {relu_nan(acc[t][m][4 * q + 0] * is.x + bb.x), relu_nan(acc[t][m][4 * q + 1] * is.y + bb.y),
+                                        relu_nan(acc[t][m][4 * q + 2] * is.z + bb.z), relu_nan(acc[t][m][4 * q + 3] * is.w + bb.w)};
+                    plane_store(2 * wave + t, m, q, v);
+                }
+    }
+    __syncthreads();
+
+    // ---- head
+    f32x16 acc3;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc3[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < kb_n) {
+            if (i + RING - 1 < kb_n) w3load(i + RING - 1);
+            const int off = ((kb_lo + i) * 2 + half) * SLAB + (m3 * 32 + li) * 16;
+            const ghalf8_t bh = *reinterpret_cast<const ghalf8_t*>(h_hi + off);
+            const ghalf8_t bl = *reinterpret_cast<const ghalf8_t*>(h_lo + off);
+            mfma3(acc3, w3h[i % RING], w3l[i % RING], bh, bl);
+        }
+    }
+    if (KS == 2) {                                     // uniform: the upper k-half's partial tile through the dead input planes
+        float* part = reinterpret_cast<float*>(x_hi) + (size_t)unit * 1024;
+        if (ks == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) part[i * 64 + lane] = acc3[i];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc3[i] += part[i * 64 + lane];
+        }
+    }
+    if (ks == 0) {
+        const float* tr3 = reinterpret_cast<const float*>(a.w3p) + (size_t)NT3 * 16 * 512;
+        const int row = m0 + m3 * 32 + li;
+        if (row < a.N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = nt3 * 32 + 8 * q + 4 * half + j;
+                    if (col < a.K3) a.out[(size_t)row * a.K3 + col] = apply_act(acc3[4 * q + j] * tr3[col] + a.b3[col], a.head_act);
+                }
+        }
+    }
+}
+
+int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
+    if (a.N <= 0) return RL4RS_OK;
+    if (a.E <= 0 || a.E > 64 || (a.E & 7) || a.K3 <= 0 || a.K3 > 64 || a.rep <= 0 || (reinterpret_cast<uintptr_t>(a.act) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.proj) & 15) || (reinterpret_cast<uintptr_t>(a.b2) & 15)) {
+        set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
+        return RL4RS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_amlp_fwd_h16, dim3((a.N + 63) / 64), dim3(256), 0, st, a);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 // host: pack W [K,N] (leading dim ldw) into fragment order; returns floats ( NT * KB * 64 * 4 )
 std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N) {
     const int KB = (K + 7) / 8, NT = (N + 31) / 32;
@@ -1144,4 +1475,31 @@ extern "C" int rl4rs_gemm_h16_packed(const float* a_dev, int64_t lda, const floa
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
     (void)hipFree(d);
     return rc;
+}
+
+// test hook: pack W [K,N] on the host (pack_gemm_weight_h16) and on the device (k_pack_h16_dev) and count the 32-bit words that
+// differ (0 = bit-identical planes and trailer).  Synchronous.
+extern "C" int rl4rs_pack_h16_selftest(const float* w_host, int64_t ldw, int32_t K, int32_t N, int64_t* mismatches, void* stream) {
+    RL4RS_REQUIRE(w_host && mismatches && K > 0 && N > 0 && ldw >= N, "rl4rs_pack_h16_selftest: bad argument");
+    std::vector<float> pk = rl4rs::pack_gemm_weight_h16(w_host, ldw, K, N);
+    float *dw = nullptr, *dp = nullptr;
+    int rc = rl4rs::dev_alloc(&dw, (size_t)K * ldw);
+    if (rc) return rc;
+    if ((rc = rl4rs::dev_alloc(&dp, pk.size()))) { (void)hipFree(dw); return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> back(pk.size());
+    hipError_t e = hipMemcpyAsync(dw, w_host, (size_t)K * ldw * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(dp, 0, pk.size() * 4, st);
+    rl4rs::PackH16Desc d = {dw, dp, (int)ldw, K, N};
+    if (e == hipSuccess) rc = rl4rs::launch_pack_h16_dev(&d, 1, st);
+    if (e == hipSuccess && rc == RL4RS_OK) e = hipMemcpyAsync(back.data(), dp, pk.size() * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dw);
+    (void)hipFree(dp);
+    if (e != hipSuccess) { rl4rs::set_error("rl4rs_pack_h16_selftest: %s", hipGetErrorString(e)); return RL4RS_EHIP; }
+    if (rc) return rc;
+    int64_t bad = 0;
+    for (size_t i = 0; i < pk.size(); ++i) bad += memcmp(&pk[i], &back[i], 4) != 0;
+    *mismatches = bad;
+    return RL4RS_OK;
 }

@@ -1564,6 +1564,7 @@ class DeviceAMLP(object):
             check(self.lib.rl4rs_amlp_create(C.byref(cfg), flat.ctypes.data_as(_lib._FP), _stream(), C.byref(h)))
         self.h = h
         self.n_params = int(flat.size)
+        self.h16_ok = bool(self.lib.rl4rs_amlp_h16_ok(self.h))
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -1654,13 +1655,20 @@ class DeviceAMLP(object):
                 (tuple(act.shape), n, self.E)
         return n
 
-    def forward(self, obs, act=None, rep=1, out=None):
+    H16_MIN_ROWS = 4096      # below this the fused fp16x2 forward has nothing to win over the small fp32 forms
+
+    def forward(self, obs, act=None, rep=1, out=None, nograd=False):
         """out [N, out_dim] for obs [N / rep, obs_dim] (each observation shared by ``rep`` consecutive action rows) and act
-        [N, act_dim].  Keeps the activations for ``backward``."""
+        [N, act_dim].  Keeps the activations for ``backward``.  ``nograd='fp16x2'``: the rows will never see a backward and may be
+        computed in the scorer's fp16x2 arithmetic - one fused launch for the three layers (rl4rs_amlp_forward_h16) when the
+        network's shape has that form and there are at least ``H16_MIN_ROWS`` rows; anything else is the fp32 forward."""
         n = self._rows(obs, act, rep)
         if out is None:
             out = torch.empty((n, self.K), dtype=torch.float32, device=self.device)
-        check(self.lib.rl4rs_amlp_forward(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))
+        if nograd == 'fp16x2' and self.h16_ok and n >= self.H16_MIN_ROWS:
+            check(self.lib.rl4rs_amlp_forward_h16(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))
+        else:
+            check(self.lib.rl4rs_amlp_forward(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))
         return out
 
     def backward(self, obs, act, dout, rep=1, want_dact=False, want_param_grad=True):

@@ -343,7 +343,8 @@ class BCQ(_ModelIO):
 
     def __init__(self, config, obs_dim, action_size=None, batch_size=256, actor_learning_rate=1e-3, critic_learning_rate=1e-3,
                  imitator_learning_rate=1e-3, gamma=0.99, tau=0.005, update_actor_interval=1, lam=0.75, n_action_samples=100,
-                 action_flexibility=0.05, rl_start_step=0, latent_size=32, beta=0.5, predict_rows=512, seed=0, device=None):
+                 action_flexibility=0.05, rl_start_step=0, latent_size=32, beta=0.5, predict_rows=512, seed=0, device=None,
+                 nograd_precision='fp16x2'):
         self.config = config
         self.D = int(obs_dim)
         self.E = int(action_size if action_size is not None else config['action_emb_size'])
@@ -355,6 +356,10 @@ class BCQ(_ModelIO):
         self.update_actor_interval, self.rl_start_step = int(update_actor_interval), int(rl_start_step)
         self.scale, self.beta = float(action_flexibility), float(beta)
         self.predict_rows = max(int(predict_rows), 1)
+        # arithmetic of the forwards that never see a backward (the batch x n_action_samples rows of compute_target and of
+        # _predict_best_action): 'fp16x2' = the scorer's split form, one fused launch per network (DeviceAMLP.forward), or 'fp32'
+        assert nograd_precision in ('fp16x2', 'fp32')
+        self.nograd = nograd_precision
         self.seed = int(seed)
         self.total_step = 0
         B, n, D, E, L = self.batch_size, self.n, self.D, self.E, self.L
@@ -394,10 +399,10 @@ class BCQ(_ModelIO):
         z = self._randn(rows, noise, key)
         return z.clamp_(-0.5, 0.5) if own else z.clamp(-0.5, 0.5)
 
-    def _sample_actions(self, obs, z, policy, rep):
+    def _sample_actions(self, obs, z, policy, rep, nograd=False):
         """imitator.decode(x, clip(z)) -> policy residual: [rows, E] actions for ``rep`` latents per observation."""
-        sampled = self.imit_dec.forward(obs, z, rep=rep)
-        t = policy.forward(obs, sampled, rep=rep)
+        sampled = self.imit_dec.forward(obs, z, rep=rep, nograd=nograd)
+        t = policy.forward(obs, sampled, rep=rep, nograd=nograd)
         return sampled, t, D_.residual_action(sampled, t, self.scale)
 
     def update(self, obs, act, rew, nxt, ter, noise=None):
@@ -419,9 +424,9 @@ class BCQ(_ModelIO):
         if self.total_step >= self.rl_start_step:
             # --- critic (DDPGBaseImpl.update_critic with BCQImpl.compute_target) ---
             zt = self._clipped_latent(B * n, noise, 'z_target')
-            _, _, a_next = self._sample_actions(nxt, zt, self.policy_targ, n)
-            q1n = self.q1_targ.forward(nxt, a_next, rep=n)
-            q2n = self.q2_targ.forward(nxt, a_next, rep=n)
+            _, _, a_next = self._sample_actions(nxt, zt, self.policy_targ, n, nograd=self.nograd)
+            q1n = self.q1_targ.forward(nxt, a_next, rep=n, nograd=self.nograd)
+            q2n = self.q2_targ.forward(nxt, a_next, rep=n, nograd=self.nograd)
             yq, _ = D_.bcq_target(q1n, q2n, n, self.lam, rew, ter, self.gamma)
             q1v = self.q1.forward(obs, act)
             q2v = self.q2.forward(obs, act)
@@ -496,8 +501,8 @@ class BCQ(_ModelIO):
                 z = noise[lo * n:(lo + b) * n].to(device=self.device, dtype=torch.float32)
             else:
                 z = torch.randn((b * n, self.L), generator=self._gen, device=self.device, dtype=torch.float32)
-            _, _, a = self._sample_actions(x, z.clamp(-0.5, 0.5).contiguous(), self.policy, n)
-            q = self.q1.forward(x, a, rep=n)
+            _, _, a = self._sample_actions(x, z.clamp(-0.5, 0.5).contiguous(), self.policy, n, nograd=self.nograd)
+            q = self.q1.forward(x, a, rep=n, nograd=self.nograd)
             _, best = D_.bcq_target(q, None, n, 0.0, want_best=True)
             out[lo:lo + b] = D_.pick_rows(a, best, n)
         return out
@@ -510,7 +515,7 @@ class BCQ(_ModelIO):
         rows = max(self.batch_size, self.predict_rows) * self.n
         for lo in range(0, obs.shape[0], rows):
             x, a = obs[lo:lo + rows].contiguous(), actions[lo:lo + rows].contiguous()
-            out[lo:lo + x.shape[0]] = 0.5 * (self.q1.forward(x, a)[:, 0] + self.q2.forward(x, a)[:, 0])
+            out[lo:lo + x.shape[0]] = 0.5 * (self.q1.forward(x, a, nograd=self.nograd)[:, 0] + self.q2.forward(x, a, nograd=self.nograd)[:, 0])
         return out
 
     def close(self):

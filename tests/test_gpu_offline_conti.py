@@ -168,12 +168,17 @@ def test_logstd_clamp_blocks_the_gradient():
     assert (d[0, L:] == 0).all() and (d[1, L:] == 0).all() and (d[2, L:] != 0).all() and (d[3, L:] != 0).all()
 
 
-def _learner_pair(seed, B, n, scale=None):
+def _learner_pair(seed, B, n, scale=None, nograd='fp32'):
     """a device BCQ learner and float64 oracle networks holding the same parameters (``scale``: {network: factor} applied to
-    its initial parameters first)"""
+    its initial parameters first).  ``nograd='fp16x2'``: the sampled-action forwards through the fused fp16x2 kernel at ANY row
+    count (by default it takes over from 4096 rows: the bench's 25 600 / 409 600, not a test's few hundred)"""
     from oracle.offline_conti import OracleAMLP
     from rl4rs_amd.offline_rl import BCQ
-    bcq = BCQ({'action_emb_size': E}, D, batch_size=B, n_action_samples=n, predict_rows=64, seed=seed)
+    bcq = BCQ({'action_emb_size': E}, D, batch_size=B, n_action_samples=n, predict_rows=64, seed=seed, nograd_precision=nograd)
+    if nograd == 'fp16x2':
+        for net in bcq.nets:
+            assert net.h16_ok
+            net.H16_MIN_ROWS = 0
     for k, f in (scale or {}).items():
         net = getattr(bcq, k)
         net.set_flat_params((net.flat_params() * f).contiguous())
@@ -258,13 +263,14 @@ def test_residual_clamp_and_target_rules():
     assert best.cpu().tolist() == [1] and float(v) == 5.0
 
 
-def test_updates_track_the_fp64_restatement():
+@pytest.mark.parametrize('nograd', ['fp32', 'fp16x2'])
+def test_updates_track_the_fp64_restatement(nograd):
     """three whole updates (imitator, critic, actor, soft target updates) with the same noise on both sides"""
     import torch
     from oracle import offline_conti as O
     from oracle.offline_rl import torch_adam
     B, n, steps = 64, 8, 3
-    bcq, orc = _learner_pair(41, B, n)
+    bcq, orc = _learner_pair(41, B, n, nograd=nograd)
     P = dict((k, v.numpy_params()) for k, v in orc.items())
     heads = dict((k, v.head_act) for k, v in orc.items())
     M = dict((k, dict((pk, np.zeros_like(pv)) for pk, pv in P[k].items())) for k in P)
@@ -307,11 +313,12 @@ def test_updates_track_the_fp64_restatement():
     bcq.close()
 
 
-def test_predict_is_the_best_sampled_action():
+@pytest.mark.parametrize('nograd', ['fp32', 'fp16x2'])
+def test_predict_is_the_best_sampled_action(nograd):
     import torch
     from oracle import offline_conti as O
     B, n = 100, 12                                # more observations than predict_rows: exercises the chunking
-    bcq, orc = _learner_pair(51, 64, n, scale=dict(imit_dec=2.0, q1=2.0))       # spread the sampled actions and their values
+    bcq, orc = _learner_pair(51, 64, n, scale=dict(imit_dec=2.0, q1=2.0), nograd=nograd)       # spread the sampled actions and their values
     x = _batch(B, 52)[0]
     z = np.random.RandomState(53).randn(B * n, L).astype(np.float32)
     got = bcq.predict(torch.from_numpy(x).cuda(), noise=torch.from_numpy(z)).cpu().numpy()

@@ -20,7 +20,10 @@ def main():
     act /= np.linalg.norm(act, axis=1, keepdims=True)
     tr = tuple(torch.from_numpy(x).cuda() for x in (obs, act, rs.rand(n).astype(np.float32), np.roll(obs, -1, 0),
                                                      (rs.rand(n) < 0.1).astype(np.float32)))
-    bcq = R.BCQ({'action_emb_size': E}, D, batch_size=256, seed=1)
+    prec = __import__('os').environ.get('NOGRAD', 'fp16x2')
+    rows = int(__import__('os').environ.get('PREDICT_ROWS', '512'))
+    bcq = R.BCQ({'action_emb_size': E}, D, batch_size=256, seed=1, nograd_precision=prec, predict_rows=rows)
+    print('nograd_precision', prec, 'predict_rows', rows)
     bcq.fit(tr, n_steps=10)
     torch.cuda.synchronize()
     t0 = time.time()
