@@ -433,6 +433,9 @@ def bcq_leg(env, cfg, rank, update_steps=200, rollouts=3):
                        "what": "d3rlpy.algos.BCQ(batch_size=256) restated on the device: conditional-VAE imitator, residual actor, twin "
                                "critics, lam-weighted target over 100 sampled actions per row (25 600-row forward through 4 networks), soft "
                                "target updates; dataset = %d transitions generated on the device" % wl.tr[0].shape[0],
+                       "dtype": "f32; the no-grad forwards (25 600 target rows per update, 409 600 sampled rows per rollout step) in %s"
+                                % ("fp16x2 (fp16 hi + lo operands, three f16 MFMAs per product, fp32 accumulate: k_amlp_fwd_h16)"
+                                   if wl.bcq.nograd == 'fp16x2' else "f32"),
                        "last_losses": dict((k, float(v[-1])) for k, v in hist.items() if len(v))}}
     # the other continuous learner the reference offers for this config ('CQL-conti', batchrl_trainer.py:91-107): updates/s only
     from rl4rs_amd.offline_rl import CQL, StandardRewardScaler

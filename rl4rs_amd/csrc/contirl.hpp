@@ -314,7 +314,7 @@ struct rl4rs_amlp {
     float *proj, *h1, *h2;              // forward: [max_rows, hidden1] observation-side projection (one row per DISTINCT observation), activations
     float *d_h1, *d_h2, *d_proj;        // backward scratch, [max_grad_rows, ...]
     int last_n, last_rep;               // rows of the last forward (the backward must match)
-    float *w1p, *w2p, *w3p;             // fp16 hi / lo fragment planes of W1's action rows, W2, W3 for rl4rs_amlp_forward_h16 (NULL: shape not eligible)
+    float *w1p, *w2p, *w3p, *w1xp;      // fp16 hi / lo fragment planes of W1's action rows, W2, W3 (and W1's observation rows) for rl4rs_amlp_forward_h16 (NULL: shape not eligible)
     int64_t adam_t;
     std::vector<void*> owned;
 };
@@ -349,7 +349,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
     p->c = *c;
     p->adam_t = 0;
     p->last_n = p->last_rep = 0;
-    p->w1p = p->w2p = p->w3p = nullptr;
+    p->w1p = p->w2p = p->w3p = p->w1xp = nullptr;
     const int64_t sizes[AP_COUNT] = {(D + E) * H1, H1, H1 * H2, H2, H2 * K, K};
     int64_t o = 0;
     for (int i = 0; i < AP_COUNT; ++i) { p->off[i] = o; p->size[i] = sizes[i]; o += sizes[i]; }
@@ -382,6 +382,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
     if (amlp_h16_shape_ok(*c)) {
         const size_t KB1 = (size_t)(E + 15) / 16, NT3 = (size_t)(K + 31) / 32;
         AM_FAIL(al(&p->w1p, 8 * KB1 * 512 + 256)); AM_FAIL(al(&p->w2p, 8 * 16 * 512 + 256)); AM_FAIL(al(&p->w3p, NT3 * 16 * 512 + NT3 * 32));
+        AM_FAIL(al(&p->w1xp, 8 * (size_t)((D + 15) / 16) * 512 + 256));
     }
     AM_HIP(hipStreamSynchronize(st));
 #undef AM_HIP
@@ -472,9 +473,15 @@ int rl4rs_amlp_forward_h16(rl4rs_amlp* p, int32_t N, int32_t rep, const float* o
     const float* P = p->params;
     const int64_t* o = p->off;
     int rc;
-    const PackH16Desc pk[3] = {{P + o[AP_W1] + (size_t)D * H1, p->w1p, H1, E, H1}, {P + o[AP_W2], p->w2p, H2, H1, H2}, {P + o[AP_W3], p->w3p, K, H2, K}};
-    if ((rc = launch_pack_h16_dev(pk, 3, st))) return rc;
-    if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st))) return rc;
+    // the observation-side projection: a few hundred distinct rows (a training minibatch) through the small fp32 form, thousands (an
+    // evaluation batch) through the fp16x2 GEMM like the rest of this forward (the 128 x 64-tile fp32 form left half the CUs idle there)
+    const bool proj16 = R >= 1024;
+    const PackH16Desc pk[4] = {{P + o[AP_W1] + (size_t)D * H1, p->w1p, H1, E, H1}, {P + o[AP_W2], p->w2p, H2, H1, H2}, {P + o[AP_W3], p->w3p, K, H2, K},
+                               {P + o[AP_W1], p->w1xp, H1, D, H1}};
+    if ((rc = launch_pack_h16_dev(pk, proj16 ? 4 : 3, st))) return rc;
+    if (proj16) rc = launch_gemm_h16(obs, D, p->w1xp, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st);
+    else rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st);
+    if (rc) return rc;
     AmlpFwdH16 a = {act, p->proj, reinterpret_cast<const char*>(p->w1p), reinterpret_cast<const char*>(p->w2p), reinterpret_cast<const char*>(p->w3p),
                     P + o[AP_B2], P + o[AP_B3], out, N, E, rep, K, p->c.head_act};
     if ((rc = launch_amlp_fwd_h16(a, st))) return rc;

