@@ -1113,12 +1113,43 @@ int launch_pack_h16_dev(const PackH16Desc* d, int n, hipStream_t st) {
 //   * LDS 80 KB -> two workgroups per CU, whose MFMA and epilogue phases overlap.
 // Rows whose activations leave the fp16 range turn NaN (inf in the hi plane, -inf in the lo plane), as in k_gemm_h16.
 typedef _Float16 ghalf4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 ghalf2_t __attribute__((ext_vector_type(2)));
+typedef float gfloat2_t __attribute__((ext_vector_type(2)));
+#ifdef RL4RS_AMLP_TRACE        // s_memtime marks of two workgroups (first, middle of the grid), per wave: tools/amlp_trace.py
+__device__ unsigned long long g_amlp_trace[2 * 4 * 16];
+#define RL4RS_AT(k) do { if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
+        g_amlp_trace[((blockIdx.x == 0 ? 0 : 1) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RL4RS_AT(k) do { } while (0)
+#endif
+#ifndef RL4RS_AMLP_STAGGER
+#define RL4RS_AMLP_STAGGER 0
+#endif
+#ifndef RL4RS_AMLP_AB
+#define RL4RS_AMLP_AB 0
+#endif
+#ifndef RL4RS_AMLP_RING
+#define RL4RS_AMLP_RING 4         // k-blocks of weight fragments in flight per wave (middle layer and head)
+#endif
+
+// head activation of the fused forward: tanh through the hardware exp2 / rcp (3 ulp; libm's tanhf was a third of the kernel's
+// finalisation time), everything else as apply_act
+__device__ __forceinline__ float head_act_fast(float x, int act) {
+    if (act == ACT_TANH) {
+        const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));        // exp(-2|x|)
+        const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+        return x != x ? x : copysignf(r, x);
+    }
+    return apply_act(x, act);
+}
 
 // ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
 __device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
 
+// KBX: k-blocks of the action-side input the LDS image has room for (2: act_dim <= 32, 72 KB; 4: act_dim <= 64, 80 KB)
+template <int KBX>
 __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
-    constexpr int MT = 2, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 8 * SLAB, RING = 4;
+    constexpr int MT = 2, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 2 * KBX * SLAB, RING = RL4RS_AMLP_RING;
     __shared__ __attribute__((aligned(16))) char smem[2 * HPLANE + 2 * XPLANE];
     char* h_hi = smem;
     char* h_lo = smem + HPLANE;
@@ -1135,17 +1166,46 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     const int NT3 = (a.K3 + 31) >> 5;
     const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w3p), 0, NT3 * 16 * 2048, 0x00020000);
 
+    RL4RS_AT(0);
+#if RL4RS_AMLP_STAGGER
+    // the second workgroup of every CU (the launch's second resident set) starts a fraction of a workgroup's life late, so that the
+    // two workgroups of a CU are in DIFFERENT phases (MFMA loop vs epilogue / loads) instead of in lock step - and stay so, since
+    // every later workgroup starts when its predecessor ends
+    if (blockIdx.x >= (unsigned)a.stagger_lo && blockIdx.x < (unsigned)a.stagger_hi) {
+#pragma unroll
+        for (int i = 0; i < RL4RS_AMLP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     // ---- layer-1 weight fragments of this wave's two column tiles (requested first: their L2 latency hides behind the staging)
-    ghalf8_t w1h[2][4], w1l[2][4];
+    ghalf8_t w1h[2][KBX], w1l[2][KBX];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < KBX; ++kb)
             if (kb < KB1) {
                 const int so = ((2 * wave + t) * KB1 + kb) * 2048;
                 w1h[t][kb] = gbuf_load_h8(rs_w1, vl16, so);
                 w1l[t][kb] = gbuf_load_h8(rs_w1, vl16 + 1024, so);
             }
+    // ---- everything else layer 1 needs from global memory is requested NOW, in front of the staging loop: a workgroup has one
+    // exposed memory round trip at its start instead of one per phase (two workgroups of four waves per CU hide little: with the
+    // loads where they are used the kernel ran at a third of its MFMA time's pace even with a third of the MFMAs removed)
+    float4 pj[MT][2][4], is1[2][4];
+    {
+        const float* tr1 = reinterpret_cast<const float*>(a.w1p) + (size_t)8 * KB1 * 512;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
+                is1[t][q] = *reinterpret_cast<const float4*>(tr1 + c0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = min(m0 + m * 32 + li, a.N - 1);
+                    pj[m][t][q] = *reinterpret_cast<const float4*>(a.proj + (size_t)(row / a.rep) * 256 + c0);
+                }
+            }
+    }
     // ---- stage the action-side input rows as fp16 hi / lo planes
     {
         const int nch = KB1 * 2;                       // chunks of 8 consecutive k per row
@@ -1171,7 +1231,9 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
             *reinterpret_cast<ghalf8_t*>(x_lo + ck * SLAB + r * 16) = lo;
         }
     }
+    RL4RS_AT(1);
     __syncthreads();
+    RL4RS_AT(2);
 
     f32x16 acc[2][MT];
     auto zero_acc = [&]() {
@@ -1199,13 +1261,20 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     // four consecutive hidden columns (tile nt, run q) of this lane's row (row tile m) -> the activation planes
     auto plane_store = [&](int nt, int m, int q, const float (&v)[4]) {
         ghalf4_t vh, vl;
+        if (RL4RS_AMLP_AB & 4) {                       // timing only: no conversions
+            const int o4 = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
+            *reinterpret_cast<float2*>(h_hi + o4) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(h_lo + o4) = make_float2(v[2], v[3]);
+            return;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = v[j];
-            asm volatile("" : "+v"(x));                // one rounded fp32 value for both parts
-            const _Float16 h = (_Float16)x;
-            vh[j] = h;
-            vl[j] = (_Float16)(x - (float)h);
+        for (int j = 0; j < 4; j += 2) {               // as 2-vectors: packed conversions (v_cvt_pk_f16_f32) and one packed subtraction
+            gfloat2_t x2 = {v[j], v[j + 1]};
+            asm volatile("" : "+v"(x2));               // one rounded fp32 value per element for both parts
+            const ghalf2_t h2 = __builtin_convertvector(x2, ghalf2_t);
+            const ghalf2_t l2 = __builtin_convertvector(x2 - __builtin_convertvector(h2, gfloat2_t), ghalf2_t);
+            vh[j] = h2[0]; vh[j + 1] = h2[1];
+            vl[j] = l2[0]; vl[j + 1] = l2[1];
         }
         const int o = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
         *reinterpret_cast<ghalf4_t*>(h_hi + o) = vh;
@@ -1215,7 +1284,7 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     // ---- layer 1: action side, K = E
     zero_acc();
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < KBX; ++kb)
         if (kb < KB1) {
             ghalf8_t bh[MT], bl[MT];
             bfrag(x_hi, x_lo, kb, bh, bl);
@@ -1224,54 +1293,69 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) mfma3(acc[t][m], w1h[t][kb], w1l[t][kb], bh[m], bl[m]);
         }
+    RL4RS_AT(3);
     // the middle layer's first fragments are requested before the epilogue: ring slot s holds k-block kb with kb % RING == s
     ghalf8_t w2h[RING][2], w2l[RING][2];
     auto w2load = [&](int kb) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int so = ((2 * wave + t) * 16 + kb) * 2048;
+            const int so = ((2 * wave + t) * 16 + ((RL4RS_AMLP_AB & 1) ? 0 : kb)) * 2048;      // AB 1 (timing only, results wrong): every fragment load hits one L1-resident line set
             w2h[kb % RING][t] = gbuf_load_h8(rs_w2, vl16, so);
             w2l[kb % RING][t] = gbuf_load_h8(rs_w2, vl16 + 1024, so);
         }
     };
 #pragma unroll
     for (int kb = 0; kb < RING - 1; ++kb) w2load(kb);
-    {
-        const float* tr1 = reinterpret_cast<const float*>(a.w1p) + (size_t)8 * KB1 * 512;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int row = min(m0 + m * 32 + li, a.N - 1);
-            const float* prow = a.proj + (size_t)(row / a.rep) * 256;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
-                    const float4 is = *reinterpret_cast<const float4*>(tr1 + c0);
-                    const float4 pj = *reinterpret_cast<const float4*>(prow + c0);
-                    const float v[4] = {relu_nan(acc[t][m][4 * q + 0] * is.x + pj.x), relu_nan(acc[t][m][4 * q + 1] * is.y + pj.y),
-                                        relu_nan(acc[t][m][4 * q + 2] * is.z + pj.z), relu_nan(acc[t][m][4 * q + 3] * is.w + pj.w)};
-                    plane_store(2 * wave + t, m, q, v);
-                }
-        }
-    }
+            for (int q = 0; q < 4; ++q) {
+                const float4 is = is1[t][q], p4 = pj[m][t][q];
+                const float v[4] = {relu_nan(__builtin_fmaf(acc[t][m][4 * q + 0], is.x, p4.x)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 1], is.y, p4.y)),
+                                    relu_nan(__builtin_fmaf(acc[t][m][4 * q + 2], is.z, p4.z)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 3], is.w, p4.w))};
+                plane_store(2 * wave + t, m, q, v);
+            }
+    RL4RS_AT(4);
     __syncthreads();
+    RL4RS_AT(5);
 
     // ---- layer 2: 256 x 256
     zero_acc();
+    float4 is2[2][4], bb2[2][4];
     {
         ghalf8_t bh[2][MT], bl[2][MT];
         bfrag(h_hi, h_lo, 0, bh[0], bl[0]);
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             if (kb + RING - 1 < 16) w2load(kb + RING - 1);
+            if (kb == 16 - RING + 1) {                 // the ring stops filling here: the epilogue's constants take its place in the queue
+                const float* tr2 = reinterpret_cast<const float*>(a.w2p) + (size_t)8 * 16 * 512;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
+                        is2[t][q] = *reinterpret_cast<const float4*>(tr2 + c0);
+                        bb2[t][q] = *reinterpret_cast<const float4*>(a.b2 + c0);
+                    }
+            }
             if (kb + 1 < 16) bfrag(h_hi, h_lo, kb + 1, bh[(kb + 1) & 1], bl[(kb + 1) & 1]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) mfma3(acc[t][m], w2h[kb % RING][t], w2l[kb % RING][t], bh[kb & 1][m], bl[kb & 1][m]);
+                for (int m = 0; m < MT; ++m) {
+                    if (RL4RS_AMLP_AB & 2) {               // timing only: one MFMA instead of three (operands stay live)
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[kb % RING][t], bl[kb & 1][m], acc[t][m], 0, 0, 0);
+                        asm volatile("" :: "v"(w2l[kb % RING][t]), "v"(bh[kb & 1][m]));
+                    } else {
+                        mfma3(acc[t][m], w2h[kb % RING][t], w2l[kb % RING][t], bh[kb & 1][m], bl[kb & 1][m]);
+                    }
+                }
         }
     }
+    RL4RS_AT(6);
     // head fragments: unit = (column tile, row tile), KS waves share a unit's k-blocks
     const int units = NT3 * MT;                        // 2 or 4
     const int KS = 4 / units, unit = wave % units, ks = wave / units;
@@ -1286,23 +1370,34 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i) w3load(i);
     __syncthreads();                                   // every wave has read the layer-1 planes
+    RL4RS_AT(7);
+    // the head's constants (this lane's 16 columns) travel while the middle layer's epilogue runs
+    float is3[16], bb3[16];
     {
-        const float* tr2 = reinterpret_cast<const float*>(a.w2p) + (size_t)8 * 16 * 512;
+        const float* tr3 = reinterpret_cast<const float*>(a.w3p) + (size_t)NT3 * 16 * 512;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
-                    const float4 is = *reinterpret_cast<const float4*>(tr2 + c0);
-                    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c0);
-                    const float v[4] = {relu_nan(acc[t][m][4 * q + 0] * is.x + bb.x), relu_nan(acc[t][m][4 * q + 1] * is.y + bb.y),
-                                        relu_nan(acc[t][m][4 * q + 2] * is.z + bb.z), relu_nan(acc[t][m][4 * q + 3] * is.w + bb.w)};
-                    plane_store(2 * wave + t, m, q, v);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int col = nt3 * 32 + 8 * q + 4 * half + j;
+                is3[4 * q + j] = tr3[col];
+                bb3[4 * q + j] = a.b3[min(col, a.K3 - 1)];
+            }
     }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 is = is2[t][q], bb = bb2[t][q];
+                const float v[4] = {relu_nan(__builtin_fmaf(acc[t][m][4 * q + 0], is.x, bb.x)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 1], is.y, bb.y)),
+                                    relu_nan(__builtin_fmaf(acc[t][m][4 * q + 2], is.z, bb.z)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 3], is.w, bb.w))};
+                plane_store(2 * wave + t, m, q, v);
+            }
+    RL4RS_AT(8);
     __syncthreads();
+    RL4RS_AT(9);
 
     // ---- head
     f32x16 acc3;
@@ -1318,31 +1413,48 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
             mfma3(acc3, w3h[i % RING], w3l[i % RING], bh, bl);
         }
     }
-    if (KS == 2) {                                     // uniform: the upper k-half's partial tile through the dead input planes
-        float* part = reinterpret_cast<float*>(x_hi) + (size_t)unit * 1024;
-        if (ks == 1) {
+    RL4RS_AT(10);
+    // finalisation: with two k-halves per unit (KS == 2) the partial tiles are exchanged through the dead input planes and EACH half
+    // finalises 8 of the lane's 16 columns (runs q = 2 ks, 2 ks + 1); with one wave per unit it finalises all 16
+    const int q_lo = (KS == 2) ? 2 * ks : 0, q_n = (KS == 2) ? 2 : 4;
+    if (KS == 2) {                                     // uniform
+        // slot (unit, d): 8 elements x 64 lanes; d = 0: the upper k-half's partials of elements 0..7 (for ks 0), d = 1: the lower
+        // k-half's partials of elements 8..15 (for ks 1)
+        float* slots = reinterpret_cast<float*>(x_hi) + (size_t)unit * 1024;
+        float* wr = slots + (1 - ks) * 512;
+        const float* rd = slots + ks * 512;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) part[i * 64 + lane] = acc3[i];
-        }
+        for (int i = 0; i < 8; ++i) wr[i * 64 + lane] = ks == 0 ? acc3[8 + i] : acc3[i];
         __syncthreads();
-        if (ks == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc3[i] += part[i * 64 + lane];
+        for (int i = 0; i < 8; ++i) {
+            const float p = rd[i * 64 + lane];
+            if (ks == 0) acc3[i] += p;
+            else acc3[8 + i] += p;
         }
     }
-    if (ks == 0) {
-        const float* tr3 = reinterpret_cast<const float*>(a.w3p) + (size_t)NT3 * 16 * 512;
+    {
         const int row = m0 + m3 * 32 + li;
         if (row < a.N) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                if (q < q_lo || q >= q_lo + q_n) continue;
+                const int c0 = nt3 * 32 + 8 * q + 4 * half;
+                float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = nt3 * 32 + 8 * q + 4 * half + j;
-                    if (col < a.K3) a.out[(size_t)row * a.K3 + col] = apply_act(acc3[4 * q + j] * tr3[col] + a.b3[col], a.head_act);
+                for (int j = 0; j < 4; ++j) v[j] = head_act_fast(__builtin_fmaf(acc3[4 * q + j], is3[4 * q + j], bb3[4 * q + j]), a.head_act);
+                float* dst = a.out + (size_t)row * a.K3 + c0;
+                if ((a.K3 & 3) == 0 && c0 + 3 < a.K3) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < a.K3) dst[j] = v[j];
                 }
+            }
         }
     }
+    RL4RS_AT(11);
 }
 
 int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
@@ -1352,8 +1464,21 @@ int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
         set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
         return RL4RS_EINVAL;
     }
-    hipLaunchKernelGGL(k_amlp_fwd_h16, dim3((a.N + 63) / 64), dim3(256), 0, st, a);
+    AmlpFwdH16 b = a;
+    b.stagger_lo = device_cus();
+    b.stagger_hi = 2 * device_cus();
+    static const int pad = getenv("RL4RS_AMLP_PAD_LDS") ? atoi(getenv("RL4RS_AMLP_PAD_LDS")) : 0;      // occupancy experiments: unused dynamic LDS
+    if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<2>), dim3((a.N + 63) / 64), dim3(256), pad, st, b);
+    else hipLaunchKernelGGL((k_amlp_fwd_h16<4>), dim3((a.N + 63) / 64), dim3(256), pad, st, b);
     RL4RS_LAUNCH_CHECK();
+#ifdef RL4RS_AMLP_TRACE
+    if (const char* path = getenv("RL4RS_AMLP_TRACE_DUMP")) {
+        unsigned long long h[2 * 4 * 16];
+        (void)hipStreamSynchronize(st);
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_amlp_trace), sizeof(h)) == hipSuccess)
+            if (FILE* f = fopen(path, "wb")) { fwrite(h, 1, sizeof(h), f); fclose(f); }
+    }
+#endif
     return RL4RS_OK;
 }
 
