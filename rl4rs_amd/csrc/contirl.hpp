@@ -22,8 +22,11 @@
 // (266 of the 298 first-layer inputs) is the SAME for the 100 sampled actions of a row, so the first layer is split: the
 // observation side x W1[:D] + b1 is one GEMM over the 256 distinct rows, and the per-sample GEMM has K = act_dim only with that
 // projection as a row-shared addend (k_gemm_f32's add_div) - 89 % of the first layer's FLOPs and all of the repeated-observation
-// traffic (d3rlpy materialises the [25600, 266] expand) never happen.  Everything is exact fp32 on v_mfma_f32_32x32x2_f32;
-// sample-axis reductions use the fixed-order helpers of simtrain.hpp, so an update is bit-reproducible given its noise.
+// traffic (d3rlpy materialises the [25600, 266] expand) never happen.  Everything that is differentiated is exact fp32 on
+// v_mfma_f32_32x32x2_f32; sample-axis reductions use the fixed-order helpers of simtrain.hpp, so an update is bit-reproducible
+// given its noise.  The forwards that are NEVER differentiated - the batch x 100 target rows, the alpha step's rows, greedy
+// evaluation - may run in the scorer's fp16x2 arithmetic as one fused launch per network (rl4rs_amlp_forward_h16 ->
+// k_amlp_fwd_h16 in gemm.hip; the learners' `nograd_precision`, default 'fp16x2'): 3x on the evaluation rollout's predict.
 #pragma once
 
 namespace rl4rs {
@@ -323,7 +326,7 @@ struct rl4rs_amlp {
 // multiples of 8 and at most 64 outputs - every network of BCQ and CQL except the plain-encoder policy of CQL
 static bool amlp_h16_shape_ok(const rl4rs_amlp_cfg& c) {
     return c.act_dim >= 8 && c.act_dim <= 64 && (c.act_dim & 7) == 0 && c.hidden1 == 256 && c.hidden2 == 256 && c.out_dim <= 64 &&
-           (c.head_act == ACT_NONE || c.head_act == ACT_TANH || c.head_act == ACT_RELU || c.head_act == ACT_SIGMOID || c.head_act == ACT_ELU);
+           (c.head_act == ACT_NONE || c.head_act == ACT_TANH || c.head_act == ACT_RELU || c.head_act == ACT_SIGMOID);
 }
 
 extern "C" {

@@ -1132,6 +1132,9 @@ __device__ unsigned long long g_amlp_trace[2 * 4 * 16];
 #define RL4RS_AMLP_RING 4         // k-blocks of weight fragments in flight per wave (middle layer and head)
 #endif
 
+// ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 // head activation of the fused forward: tanh through the hardware exp2 / rcp (3 ulp; libm's tanhf was a third of the kernel's
 // finalisation time), everything else as apply_act
 __device__ __forceinline__ float head_act_fast(float x, int act) {
@@ -1140,11 +1143,10 @@ __device__ __forceinline__ float head_act_fast(float x, int act) {
         const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
         return x != x ? x : copysignf(r, x);
     }
-    return apply_act(x, act);
+    if (act == ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    if (act == ACT_RELU) return relu_nan(x);
+    return x;                                          // ACT_NONE (the launcher refuses anything else)
 }
-
-// ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
-__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
 
 // KBX: k-blocks of the action-side input the LDS image has room for (2: act_dim <= 32, 72 KB; 4: act_dim <= 64, 80 KB)
 template <int KBX>
@@ -1459,7 +1461,7 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
 
 int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
     if (a.N <= 0) return RL4RS_OK;
-    if (a.E <= 0 || a.E > 64 || (a.E & 7) || a.K3 <= 0 || a.K3 > 64 || a.rep <= 0 || (reinterpret_cast<uintptr_t>(a.act) & 15) ||
+    if (a.E <= 0 || a.E > 64 || (a.E & 7) || a.K3 <= 0 || a.K3 > 64 || a.rep <= 0 || a.head_act == ACT_ELU || (reinterpret_cast<uintptr_t>(a.act) & 15) ||
         (reinterpret_cast<uintptr_t>(a.proj) & 15) || (reinterpret_cast<uintptr_t>(a.b2) & 15)) {
         set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
         return RL4RS_EINVAL;

@@ -572,7 +572,9 @@ class CQL(_ModelIO):
     def __init__(self, config, obs_dim, action_size=None, batch_size=256, actor_learning_rate=1e-4, critic_learning_rate=3e-4,
                  temp_learning_rate=1e-4, alpha_learning_rate=1e-4, gamma=0.99, tau=0.005, initial_temperature=1.0, initial_alpha=1.0,
                  alpha_threshold=10.0, conservative_weight=5.0, n_action_samples=10, reward_scaler=None, predict_rows=4096, seed=0,
-                 device=None):
+                 device=None, nograd_precision='fp16x2'):
+        assert nograd_precision in ('fp16x2', 'fp32')
+        self.nograd = nograd_precision               # the alpha step's critic forwards (never differentiated): see BCQ
         self.config = config
         self.D = int(obs_dim)
         self.A = int(action_size if action_size is not None else config['action_emb_size'])
@@ -655,7 +657,7 @@ class CQL(_ModelIO):
         # --- alpha (CQLImpl.update_alpha): -conservative loss, gradient wrt log_alpha
         if self.alpha_lr > 0:
             fa, fo = self._conservative_rows(head_obs, head_nxt, act, noise.get('alpha'))
-            sums, _, _ = D_.cql_critic_loss(self.q1.forward(obs, fa, rep=m), self.q2.forward(obs, fa, rep=m), fo, m)
+            sums, _, _ = D_.cql_critic_loss(self.q1.forward(obs, fa, rep=m, nograd=self.nograd), self.q2.forward(obs, fa, rep=m, nograd=self.nograd), fo, m)
             gap = self._conservative_value(sums, B) - self.alpha_threshold
             ea = self.log_alpha.p.exp()
             metrics['alpha_loss'] = -(ea.clamp(0.0, 1e6) * gap)[0]
