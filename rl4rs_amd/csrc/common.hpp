@@ -90,7 +90,6 @@ struct AmlpFwdH16 {
     const float* act; const float* proj; const char* w1p; const char* w2p; const char* w3p;
     const float* b2; const float* b3; float* out;
     int N, E, rep, K3, head_act;
-    int stagger_lo, stagger_hi;      // set by the launcher
 };
 int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st);
 

@@ -486,7 +486,7 @@ int rl4rs_amlp_forward_h16(rl4rs_amlp* p, int32_t N, int32_t rep, const float* o
     else rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->proj, H1, R, H1, D, ACT_NONE, st);
     if (rc) return rc;
     AmlpFwdH16 a = {act, p->proj, reinterpret_cast<const char*>(p->w1p), reinterpret_cast<const char*>(p->w2p), reinterpret_cast<const char*>(p->w3p),
-                    P + o[AP_B2], P + o[AP_B3], out, N, E, rep, K, p->c.head_act, 0, 0};
+                    P + o[AP_B2], P + o[AP_B3], out, N, E, rep, K, p->c.head_act};
     if ((rc = launch_amlp_fwd_h16(a, st))) return rc;
     p->last_n = -1;
     p->last_rep = 0;

@@ -1116,20 +1116,17 @@ typedef _Float16 ghalf4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 ghalf2_t __attribute__((ext_vector_type(2)));
 typedef float gfloat2_t __attribute__((ext_vector_type(2)));
 #ifdef RL4RS_AMLP_TRACE        // s_memtime marks of two workgroups (first, middle of the grid), per wave: tools/amlp_trace.py
-__device__ unsigned long long g_amlp_trace[2 * 4 * 16];
+__device__ unsigned long long g_amlp_trace[2 * 8 * 16];
 #define RL4RS_AT(k) do { if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
-        g_amlp_trace[((blockIdx.x == 0 ? 0 : 1) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+        g_amlp_trace[((blockIdx.x == 0 ? 0 : 1) * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RL4RS_AT(k) do { } while (0)
 #endif
-#ifndef RL4RS_AMLP_STAGGER
-#define RL4RS_AMLP_STAGGER 0
-#endif
 #ifndef RL4RS_AMLP_AB
-#define RL4RS_AMLP_AB 0
-#endif
-#ifndef RL4RS_AMLP_RING
-#define RL4RS_AMLP_RING 4         // k-blocks of weight fragments in flight per wave (middle layer and head)
+#define RL4RS_AMLP_AB 0           // timing ablations (results WRONG): 1 every middle-layer fragment load hits one L1-resident line set,
+#endif                            // 2 one MFMA per product instead of three, 4 no fp16 conversions in the plane stores
+#ifndef RL4RS_AMLP_NW
+#define RL4RS_AMLP_NW 8           // waves per workgroup of the shipped form (4 or 8; RL4RS_AMLP_NW in the environment overrides: A/B)
 #endif
 
 // ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
@@ -1148,11 +1145,18 @@ __device__ __forceinline__ float head_act_fast(float x, int act) {
     return x;                                          // ACT_NONE (the launcher refuses anything else)
 }
 
-// KBX: k-blocks of the action-side input the LDS image has room for (2: act_dim <= 32, 72 KB; 4: act_dim <= 64, 80 KB)
-template <int KBX>
-__global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
-    constexpr int MT = 2, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 2 * KBX * SLAB, RING = RL4RS_AMLP_RING;
+// NW: waves per workgroup (4: two 32-column tiles per wave, 8: one); KBX: k-blocks of the action-side input the LDS image has
+// room for (2: act_dim <= 32, 74.5 KB; 4: act_dim <= 64, 82.5 KB: one workgroup per CU).  64 rows per workgroup; two workgroups per CU
+// for the learners' act_dim = 32.
+template <int NW, int KBX>
+__global__ __launch_bounds__(64 * NW, KBX == 2 ? NW / 2 : NW / 4) void k_amlp_fwd_h16(AmlpFwdH16 a) {
+    constexpr int MT = 2, CT = 8 / NW, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 2 * KBX * SLAB;
+    constexpr int RING = NW == 8 ? 3 : 4;              // k-blocks of weight fragments in flight per wave (middle layer and head)
     __shared__ __attribute__((aligned(16))) char smem[2 * HPLANE + 2 * XPLANE];
+    // per-column constants of the later phases: [0,256) 1 / prescale of W2's columns, [256,512) b2, [512,576) 1 / prescale of W3's
+    // columns, [576,640) b3 - fetched ONCE per workgroup at its start (a global load in front of a phase cost that phase ~2K cycles
+    // of exposed latency: a workgroup lives ~30K cycles and two per CU hide little)
+    __shared__ __attribute__((aligned(16))) float s_c[640];
     char* h_hi = smem;
     char* h_lo = smem + HPLANE;
     char* x_hi = smem + 2 * HPLANE;
@@ -1169,37 +1173,28 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w3p), 0, NT3 * 16 * 2048, 0x00020000);
 
     RL4RS_AT(0);
-#if RL4RS_AMLP_STAGGER
-    // the second workgroup of every CU (the launch's second resident set) starts a fraction of a workgroup's life late, so that the
-    // two workgroups of a CU are in DIFFERENT phases (MFMA loop vs epilogue / loads) instead of in lock step - and stay so, since
-    // every later workgroup starts when its predecessor ends
-    if (blockIdx.x >= (unsigned)a.stagger_lo && blockIdx.x < (unsigned)a.stagger_hi) {
+    // ---- layer-1 weight fragments of this wave's column tiles (requested first: their L2 latency hides behind the staging)
+    ghalf8_t w1h[CT][KBX], w1l[CT][KBX];
 #pragma unroll
-        for (int i = 0; i < RL4RS_AMLP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    // ---- layer-1 weight fragments of this wave's two column tiles (requested first: their L2 latency hides behind the staging)
-    ghalf8_t w1h[2][KBX], w1l[2][KBX];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int kb = 0; kb < KBX; ++kb)
             if (kb < KB1) {
-                const int so = ((2 * wave + t) * KB1 + kb) * 2048;
+                const int so = ((CT * wave + t) * KB1 + kb) * 2048;
                 w1h[t][kb] = gbuf_load_h8(rs_w1, vl16, so);
                 w1l[t][kb] = gbuf_load_h8(rs_w1, vl16 + 1024, so);
             }
     // ---- everything else layer 1 needs from global memory is requested NOW, in front of the staging loop: a workgroup has one
-    // exposed memory round trip at its start instead of one per phase (two workgroups of four waves per CU hide little: with the
-    // loads where they are used the kernel ran at a third of its MFMA time's pace even with a third of the MFMAs removed)
-    float4 pj[MT][2][4], is1[2][4];
+    // exposed memory round trip at its start instead of one per phase (with the loads where they are used the first form of this
+    // kernel ran at a third of its MFMA time's pace even with a third of the MFMAs removed)
+    float4 pj[MT][CT][4], is1[CT][4];
     {
         const float* tr1 = reinterpret_cast<const float*>(a.w1p) + (size_t)8 * KB1 * 512;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
+                const int c0 = (CT * wave + t) * 32 + 8 * q + 4 * half;
                 is1[t][q] = *reinterpret_cast<const float4*>(tr1 + c0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -1208,10 +1203,22 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
                 }
             }
     }
+    {
+        const float* tr2 = reinterpret_cast<const float*>(a.w2p) + (size_t)8 * 16 * 512;
+        const float* tr3 = reinterpret_cast<const float*>(a.w3p) + (size_t)NT3 * 16 * 512;
+        for (int c = tid; c < 640; c += 64 * NW) {
+            float v;
+            if (c < 256) v = tr2[c];
+            else if (c < 512) v = a.b2[c - 256];
+            else if (c < 576) v = (c - 512 < NT3 * 32) ? tr3[c - 512] : 1.f;
+            else v = (c - 576 < a.K3) ? a.b3[c - 576] : 0.f;
+            s_c[c] = v;
+        }
+    }
     // ---- stage the action-side input rows as fp16 hi / lo planes
     {
         const int nch = KB1 * 2;                       // chunks of 8 consecutive k per row
-        for (int c = tid; c < ROWS * nch; c += 256) {
+        for (int c = tid; c < ROWS * nch; c += 64 * NW) {
             const int r = c & (ROWS - 1), ck = c / ROWS;
             const int row = m0 + r, gk = ck * 8;
             float x[8];
@@ -1237,19 +1244,26 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     __syncthreads();
     RL4RS_AT(2);
 
-    f32x16 acc[2][MT];
+    f32x16 acc[CT][MT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][m][i] = 0.f;
     };
-    auto mfma3 = [&](f32x16& c, const ghalf8_t& wh, const ghalf8_t& wl, const ghalf8_t& bh, const ghalf8_t& bl) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, c, 0, 0, 0);
+    // the three products of one (weight fragment, activation fragment) pair for every tile of the wave, product terms outermost:
+    // consecutive MFMAs go to different accumulators
+    auto mfma_kb = [&](const ghalf8_t (&wh)[CT], const ghalf8_t (&wl)[CT], const ghalf8_t (&bh)[MT], const ghalf8_t (&bl)[MT]) {
+#pragma unroll
+        for (int term = 0; term < ((RL4RS_AMLP_AB & 2) ? 1 : 3); ++term)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? wl[t] : wh[t], term == 2 ? bl[m] : bh[m], acc[t][m], 0, 0, 0);
+        if (RL4RS_AMLP_AB & 2) asm volatile("" :: "v"(wl[0]), "v"(bl[0]));
     };
     // activation fragments (B operand) of k-block kb, row tile m: lane (row li, k-half `half`)
     auto bfrag = [&](const char* p_hi, const char* p_lo, int kb, ghalf8_t (&bh)[MT], ghalf8_t (&bl)[MT]) {
@@ -1263,10 +1277,10 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     // four consecutive hidden columns (tile nt, run q) of this lane's row (row tile m) -> the activation planes
     auto plane_store = [&](int nt, int m, int q, const float (&v)[4]) {
         ghalf4_t vh, vl;
+        const int o = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
         if (RL4RS_AMLP_AB & 4) {                       // timing only: no conversions
-            const int o4 = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
-            *reinterpret_cast<float2*>(h_hi + o4) = make_float2(v[0], v[1]);
-            *reinterpret_cast<float2*>(h_lo + o4) = make_float2(v[2], v[3]);
+            *reinterpret_cast<float2*>(h_hi + o) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(h_lo + o) = make_float2(v[2], v[3]);
             return;
         }
 #pragma unroll
@@ -1278,9 +1292,22 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
             vh[j] = h2[0]; vh[j + 1] = h2[1];
             vl[j] = l2[0]; vl[j + 1] = l2[1];
         }
-        const int o = ((2 * nt + (q >> 1)) * 2 + (q & 1)) * SLAB + (m * 32 + li) * 16 + half * 8;
         *reinterpret_cast<ghalf4_t*>(h_hi + o) = vh;
         *reinterpret_cast<ghalf4_t*>(h_lo + o) = vl;
+    };
+    // acc * (1 / column prescale) + addend -> ReLU -> planes.  1 / prescale is a power of two, so the fma rounds once, like a + b
+    auto epilogue = [&](const float4 (&is)[CT][4], const float4* add /* [MT][CT][4] or [CT][4] */, bool per_row) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 s4 = is[t][q], p4 = add[((per_row ? m * CT : 0) + t) * 4 + q];
+                    const float v[4] = {relu_nan(__builtin_fmaf(acc[t][m][4 * q + 0], s4.x, p4.x)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 1], s4.y, p4.y)),
+                                        relu_nan(__builtin_fmaf(acc[t][m][4 * q + 2], s4.z, p4.z)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 3], s4.w, p4.w))};
+                    plane_store(CT * wave + t, m, q, v);
+                }
     };
 
     // ---- layer 1: action side, K = E
@@ -1288,81 +1315,59 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
 #pragma unroll
     for (int kb = 0; kb < KBX; ++kb)
         if (kb < KB1) {
-            ghalf8_t bh[MT], bl[MT];
+            ghalf8_t bh[MT], bl[MT], wh[CT], wl[CT];
             bfrag(x_hi, x_lo, kb, bh, bl);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) mfma3(acc[t][m], w1h[t][kb], w1l[t][kb], bh[m], bl[m]);
+            for (int t = 0; t < CT; ++t) { wh[t] = w1h[t][kb]; wl[t] = w1l[t][kb]; }
+            mfma_kb(wh, wl, bh, bl);
         }
     RL4RS_AT(3);
     // the middle layer's first fragments are requested before the epilogue: ring slot s holds k-block kb with kb % RING == s
-    ghalf8_t w2h[RING][2], w2l[RING][2];
+    ghalf8_t w2h[RING][CT], w2l[RING][CT];
     auto w2load = [&](int kb) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int so = ((2 * wave + t) * 16 + ((RL4RS_AMLP_AB & 1) ? 0 : kb)) * 2048;      // AB 1 (timing only, results wrong): every fragment load hits one L1-resident line set
+        for (int t = 0; t < CT; ++t) {
+            const int so = ((CT * wave + t) * 16 + ((RL4RS_AMLP_AB & 1) ? 0 : kb)) * 2048;
             w2h[kb % RING][t] = gbuf_load_h8(rs_w2, vl16, so);
             w2l[kb % RING][t] = gbuf_load_h8(rs_w2, vl16 + 1024, so);
         }
     };
 #pragma unroll
     for (int kb = 0; kb < RING - 1; ++kb) w2load(kb);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 is = is1[t][q], p4 = pj[m][t][q];
-                const float v[4] = {relu_nan(__builtin_fmaf(acc[t][m][4 * q + 0], is.x, p4.x)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 1], is.y, p4.y)),
-                                    relu_nan(__builtin_fmaf(acc[t][m][4 * q + 2], is.z, p4.z)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 3], is.w, p4.w))};
-                plane_store(2 * wave + t, m, q, v);
-            }
+    epilogue(is1, &pj[0][0][0], true);
     RL4RS_AT(4);
     __syncthreads();
     RL4RS_AT(5);
 
     // ---- layer 2: 256 x 256
     zero_acc();
-    float4 is2[2][4], bb2[2][4];
+    float4 is2[CT][4], bb2[CT][4];
+    auto load_c2 = [&]() {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (CT * wave + t) * 32 + 8 * q + 4 * half;
+                is2[t][q] = *reinterpret_cast<const float4*>(s_c + c0);
+                bb2[t][q] = *reinterpret_cast<const float4*>(s_c + 256 + c0);
+            }
+    };
     {
         ghalf8_t bh[2][MT], bl[2][MT];
         bfrag(h_hi, h_lo, 0, bh[0], bl[0]);
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             if (kb + RING - 1 < 16) w2load(kb + RING - 1);
-            if (kb == 16 - RING + 1) {                 // the ring stops filling here: the epilogue's constants take its place in the queue
-                const float* tr2 = reinterpret_cast<const float*>(a.w2p) + (size_t)8 * 16 * 512;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c0 = (2 * wave + t) * 32 + 8 * q + 4 * half;
-                        is2[t][q] = *reinterpret_cast<const float4*>(tr2 + c0);
-                        bb2[t][q] = *reinterpret_cast<const float4*>(a.b2 + c0);
-                    }
-            }
             if (kb + 1 < 16) bfrag(h_hi, h_lo, kb + 1, bh[(kb + 1) & 1], bl[(kb + 1) & 1]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    if (RL4RS_AMLP_AB & 2) {               // timing only: one MFMA instead of three (operands stay live)
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[kb % RING][t], bl[kb & 1][m], acc[t][m], 0, 0, 0);
-                        asm volatile("" :: "v"(w2l[kb % RING][t]), "v"(bh[kb & 1][m]));
-                    } else {
-                        mfma3(acc[t][m], w2h[kb % RING][t], w2l[kb % RING][t], bh[kb & 1][m], bl[kb & 1][m]);
-                    }
-                }
+            mfma_kb(w2h[kb % RING], w2l[kb % RING], bh[kb & 1], bl[kb & 1]);
         }
     }
     RL4RS_AT(6);
-    // head fragments: unit = (column tile, row tile), KS waves share a unit's k-blocks
+    // head: unit = (column tile, row tile); the KS = NW / units waves of a unit split its 16 k-blocks
     const int units = NT3 * MT;                        // 2 or 4
-    const int KS = 4 / units, unit = wave % units, ks = wave / units;
+    const int KS = NW / units, unit = wave % units, ks = wave / units;
     const int nt3 = unit / MT, m3 = unit % MT;
-    const int kb_lo = ks * (16 / KS), kb_n = 16 / KS;  // 16 or 8 k-blocks
+    const int kb_n = 16 / KS, kb_lo = ks * kb_n;
     ghalf8_t w3h[RING], w3l[RING];
     auto w3load = [&](int i) {
         const int so = (nt3 * 16 + kb_lo + i) * 2048;
@@ -1373,30 +1378,8 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
     for (int i = 0; i < RING - 1; ++i) w3load(i);
     __syncthreads();                                   // every wave has read the layer-1 planes
     RL4RS_AT(7);
-    // the head's constants (this lane's 16 columns) travel while the middle layer's epilogue runs
-    float is3[16], bb3[16];
-    {
-        const float* tr3 = reinterpret_cast<const float*>(a.w3p) + (size_t)NT3 * 16 * 512;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = nt3 * 32 + 8 * q + 4 * half + j;
-                is3[4 * q + j] = tr3[col];
-                bb3[4 * q + j] = a.b3[min(col, a.K3 - 1)];
-            }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 is = is2[t][q], bb = bb2[t][q];
-                const float v[4] = {relu_nan(__builtin_fmaf(acc[t][m][4 * q + 0], is.x, bb.x)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 1], is.y, bb.y)),
-                                    relu_nan(__builtin_fmaf(acc[t][m][4 * q + 2], is.z, bb.z)), relu_nan(__builtin_fmaf(acc[t][m][4 * q + 3], is.w, bb.w))};
-                plane_store(2 * wave + t, m, q, v);
-            }
+    load_c2();
+    epilogue(is2, &bb2[0][0], false);
     RL4RS_AT(8);
     __syncthreads();
     RL4RS_AT(9);
@@ -1412,39 +1395,45 @@ __global__ __launch_bounds__(256, 2) void k_amlp_fwd_h16(AmlpFwdH16 a) {
             const int off = ((kb_lo + i) * 2 + half) * SLAB + (m3 * 32 + li) * 16;
             const ghalf8_t bh = *reinterpret_cast<const ghalf8_t*>(h_hi + off);
             const ghalf8_t bl = *reinterpret_cast<const ghalf8_t*>(h_lo + off);
-            mfma3(acc3, w3h[i % RING], w3l[i % RING], bh, bl);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[i % RING], bh, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3l[i % RING], bh, acc3, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[i % RING], bl, acc3, 0, 0, 0);
         }
     }
     RL4RS_AT(10);
-    // finalisation: with two k-halves per unit (KS == 2) the partial tiles are exchanged through the dead input planes and EACH half
-    // finalises 8 of the lane's 16 columns (runs q = 2 ks, 2 ks + 1); with one wave per unit it finalises all 16
-    const int q_lo = (KS == 2) ? 2 * ks : 0, q_n = (KS == 2) ? 2 : 4;
-    if (KS == 2) {                                     // uniform
-        // slot (unit, d): 8 elements x 64 lanes; d = 0: the upper k-half's partials of elements 0..7 (for ks 0), d = 1: the lower
-        // k-half's partials of elements 8..15 (for ks 1)
-        float* slots = reinterpret_cast<float*>(x_hi) + (size_t)unit * 1024;
-        float* wr = slots + (1 - ks) * 512;
-        const float* rd = slots + ks * 512;
+    // finalisation: the KS partial tiles of a unit meet in the (now dead) activation planes, [unit][ks][16 elements][64 lanes]; wave ks
+    // of the unit then owns the column runs q in [ks * 4 / KS, (ks + 1) * 4 / KS) and sums their partials in k order (fixed order)
+    const int q_n = 4 / KS, q_lo = ks * q_n;
+    if (KS > 1) {                                      // uniform
+        float* P = reinterpret_cast<float*>(smem);
+        __syncthreads();                               // every head MFMA has read its fragments
+        float* mine = P + (size_t)(unit * KS + ks) * 1024;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wr[i * 64 + lane] = ks == 0 ? acc3[8 + i] : acc3[i];
+        for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc3[i];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float p = rd[i * 64 + lane];
-            if (ks == 0) acc3[i] += p;
-            else acc3[8 + i] += p;
+        for (int q = 0; q < 4; ++q) {
+            if (q < q_lo || q >= q_lo + q_n) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = 0.f;
+                for (int k2 = 0; k2 < KS; ++k2) sum += P[(size_t)(unit * KS + k2) * 1024 + (4 * q + j) * 64 + lane];
+                acc3[4 * q + j] = sum;
+            }
         }
     }
     {
         const int row = m0 + m3 * 32 + li;
-        if (row < a.N) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < q_lo || q >= q_lo + q_n) continue;
-                const int c0 = nt3 * 32 + 8 * q + 4 * half;
-                float v[4];
+        for (int q = 0; q < 4; ++q) {
+            if (q < q_lo || q >= q_lo + q_n) continue;
+            const int c0 = nt3 * 32 + 8 * q + 4 * half;
+            const float4 s4 = *reinterpret_cast<const float4*>(s_c + 512 + c0), b4 = *reinterpret_cast<const float4*>(s_c + 576 + c0);
+            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, bs[4] = {b4.x, b4.y, b4.z, b4.w};
+            float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = head_act_fast(__builtin_fmaf(acc3[4 * q + j], is3[4 * q + j], bb3[4 * q + j]), a.head_act);
+            for (int j = 0; j < 4; ++j) v[j] = head_act_fast(__builtin_fmaf(acc3[4 * q + j], sc[j], bs[j]), a.head_act);
+            if (row < a.N) {
                 float* dst = a.out + (size_t)row * a.K3 + c0;
                 if ((a.K3 & 3) == 0 && c0 + 3 < a.K3) {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1466,16 +1455,20 @@ int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
         set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
         return RL4RS_EINVAL;
     }
-    AmlpFwdH16 b = a;
-    b.stagger_lo = device_cus();
-    b.stagger_hi = 2 * device_cus();
-    static const int pad = getenv("RL4RS_AMLP_PAD_LDS") ? atoi(getenv("RL4RS_AMLP_PAD_LDS")) : 0;      // occupancy experiments: unused dynamic LDS
-    if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<2>), dim3((a.N + 63) / 64), dim3(256), pad, st, b);
-    else hipLaunchKernelGGL((k_amlp_fwd_h16<4>), dim3((a.N + 63) / 64), dim3(256), pad, st, b);
+    static const int nw = getenv("RL4RS_AMLP_NW") ? atoi(getenv("RL4RS_AMLP_NW")) : RL4RS_AMLP_NW;
+    const dim3 grid((a.N + 63) / 64);
+    const AmlpFwdH16& b = a;
+    if (nw == 4) {
+        if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<4, 2>), grid, dim3(256), 0, st, b);
+        else hipLaunchKernelGGL((k_amlp_fwd_h16<4, 4>), grid, dim3(256), 0, st, b);
+    } else {
+        if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<8, 2>), grid, dim3(512), 0, st, b);
+        else hipLaunchKernelGGL((k_amlp_fwd_h16<8, 4>), grid, dim3(512), 0, st, b);
+    }
     RL4RS_LAUNCH_CHECK();
 #ifdef RL4RS_AMLP_TRACE
     if (const char* path = getenv("RL4RS_AMLP_TRACE_DUMP")) {
-        unsigned long long h[2 * 4 * 16];
+        unsigned long long h[2 * 8 * 16];
         (void)hipStreamSynchronize(st);
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_amlp_trace), sizeof(h)) == hipSuccess)
             if (FILE* f = fopen(path, "wb")) { fwrite(h, 1, sizeof(h), f); fclose(f); }
