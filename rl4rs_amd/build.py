@@ -27,7 +27,10 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off', '-fno-slp-vectorize',
+               # -fno-slp-vectorize: no v_pk_{fma,add,mul}_f32.  Packed fp32 VALU instructions do not overlap with another wave's MFMAs
+               # on a SIMD (tools/mfma_valu_overlap.hip, profiles/r04p_mfma_valu_overlap.txt: plain v_fma_f32, transcendentals,
+               # conversions and LDS reads do) - the epilogues of the MFMA kernels are written to run in that shadow
                '-mllvm', '-pragma-unroll-threshold=200000',     # k_augru_h16: 48 weight items per step, fully unrolled
                '-c', os.path.join(CSRC, src), '-o', obj] + list(extra_flags)
         if verbose:

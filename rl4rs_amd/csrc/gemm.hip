@@ -1284,11 +1284,12 @@ __global__ __launch_bounds__(64 * NW, KBX == 2 ? NW / 2 : NW / 4) void k_amlp_fw
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {               // as 2-vectors: packed conversions (v_cvt_pk_f16_f32) and one packed subtraction
+        for (int j = 0; j < 4; j += 2) {               // as 2-vectors: packed conversions (v_cvt_pk_f16_f32)
             gfloat2_t x2 = {v[j], v[j + 1]};
             asm volatile("" : "+v"(x2));               // one rounded fp32 value per element for both parts
             const ghalf2_t h2 = __builtin_convertvector(x2, ghalf2_t);
-            const ghalf2_t l2 = __builtin_convertvector(x2 - __builtin_convertvector(h2, gfloat2_t), ghalf2_t);
+            const gfloat2_t d2 = {x2[0] - (float)h2[0], x2[1] - (float)h2[1]};       // scalar subtractions: packed fp32 does not run beside MFMAs
+            const ghalf2_t l2 = __builtin_convertvector(d2, ghalf2_t);
             vh[j] = h2[0]; vh[j + 1] = h2[1];
             vl[j] = l2[0]; vl[j + 1] = l2[1];
         }

@@ -17,7 +17,7 @@ def main():
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(out, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off', '-fno-slp-vectorize',
                '-mllvm', '-pragma-unroll-threshold=200000', '-c', os.path.join(CSRC, src), '-o', obj] + flags
         procs.append(subprocess.Popen(cmd))
         objs.append(obj)
