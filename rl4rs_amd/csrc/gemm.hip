@@ -1126,7 +1126,7 @@ __device__ unsigned long long g_amlp_trace[2 * 8 * 16];
 #define RL4RS_AMLP_AB 0           // timing ablations (results WRONG): 1 every middle-layer fragment load hits one L1-resident line set,
 #endif                            // 2 one MFMA per product instead of three, 4 no fp16 conversions in the plane stores
 #ifndef RL4RS_AMLP_NW
-#define RL4RS_AMLP_NW 8           // waves per workgroup of the shipped form (4 or 8; RL4RS_AMLP_NW in the environment overrides: A/B)
+#define RL4RS_AMLP_NW 8           // waves per workgroup (4 or 8; compile-time only: the two forms sum the head's k-blocks in different groupings)
 #endif
 
 // ReLU that lets NaN through (fmaxf(NaN, 0) = 0 would hide an out-of-range row behind the first activation)
@@ -1456,16 +1456,9 @@ int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
         set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
         return RL4RS_EINVAL;
     }
-    static const int nw = getenv("RL4RS_AMLP_NW") ? atoi(getenv("RL4RS_AMLP_NW")) : RL4RS_AMLP_NW;
     const dim3 grid((a.N + 63) / 64);
-    const AmlpFwdH16& b = a;
-    if (nw == 4) {
-        if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<4, 2>), grid, dim3(256), 0, st, b);
-        else hipLaunchKernelGGL((k_amlp_fwd_h16<4, 4>), grid, dim3(256), 0, st, b);
-    } else {
-        if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<8, 2>), grid, dim3(512), 0, st, b);
-        else hipLaunchKernelGGL((k_amlp_fwd_h16<8, 4>), grid, dim3(512), 0, st, b);
-    }
+    if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 2>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
+    else hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 4>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
     RL4RS_LAUNCH_CHECK();
 #ifdef RL4RS_AMLP_TRACE
     if (const char* path = getenv("RL4RS_AMLP_TRACE_DUMP")) {

@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 tr = np.fromfile('/tmp/amlp_trace.bin', dtype=np.uint64).reshape(2, 8, 16).astype(np.int64)
 names = ['load+stage', 'bar', 'L1', 'epi1', 'bar', 'L2', 'bar', 'epi2', 'bar', 'head', 'red+store']
 for g in range(2):
-    for w in range(int(os.environ.get('RL4RS_AMLP_NW', '8'))):
+    for w in range(8):
         m = tr[g, w]
         print('wg %s wave %d: ' % ('first' if g == 0 else 'mid  ', w) + '  '.join('%s %5d' % (n, m[k + 1] - m[k]) for k, n in enumerate(names)) +
               '   total %d' % (m[11] - m[0]))
