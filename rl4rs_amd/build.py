@@ -7,6 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'librl4rs_hip.so')
 SOURCES = ['env.hip', 'gemm.hip', 'dien.hip', 'policy.hip', 'records.hip', 'step.hip']
+# Units whose MFMA kernels run VALU epilogues beside another wave's MFMAs are compiled without SLP vectorisation: packed fp32 VALU
+# (v_pk_fma / add / mul_f32) serialises with the matrix pipe (tools/mfma_valu_overlap.hip, profiles/r04p_mfma_valu_overlap.txt;
+# same-box A/B: k_cat_attn2 -8 %, k_din_x -2 %, end to end +0.7 %).  The other units keep it (the learners' element-wise and
+# reduction kernels are 1 - 4 % faster with it).
+NO_SLP = ('dien.hip', 'gemm.hip')
 HEADERS = ['common.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
 
 
@@ -27,12 +32,9 @@ def build_lib(force=False, verbose=False, extra_flags=()):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off', '-fno-slp-vectorize',
-               # -fno-slp-vectorize: no v_pk_{fma,add,mul}_f32.  Packed fp32 VALU instructions do not overlap with another wave's MFMAs
-               # on a SIMD (tools/mfma_valu_overlap.hip, profiles/r04p_mfma_valu_overlap.txt: plain v_fma_f32, transcendentals,
-               # conversions and LDS reads do) - the epilogues of the MFMA kernels are written to run in that shadow
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
                '-mllvm', '-pragma-unroll-threshold=200000',     # k_augru_h16: 48 weight items per step, fully unrolled
-               '-c', os.path.join(CSRC, src), '-o', obj] + list(extra_flags)
+               '-c', os.path.join(CSRC, src), '-o', obj] + (['-fno-slp-vectorize'] if src in NO_SLP else []) + list(extra_flags)
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rl4rs_amd.build import CSRC, SOURCES  # noqa: E402
+from rl4rs_amd.build import CSRC, SOURCES, NO_SLP  # noqa: E402
 
 
 def main():
@@ -17,8 +17,8 @@ def main():
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(out, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off', '-fno-slp-vectorize',
-               '-mllvm', '-pragma-unroll-threshold=200000', '-c', os.path.join(CSRC, src), '-o', obj] + flags
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=off',
+               '-mllvm', '-pragma-unroll-threshold=200000', '-c', os.path.join(CSRC, src), '-o', obj] + (['-fno-slp-vectorize'] if src in NO_SLP else []) + flags
         procs.append(subprocess.Popen(cmd))
         objs.append(obj)
     for p in procs:
