@@ -1125,6 +1125,9 @@ __device__ unsigned long long g_amlp_trace[2 * 8 * 16];
 #ifndef RL4RS_AMLP_AB
 #define RL4RS_AMLP_AB 0           // timing ablations (results WRONG): 1 every middle-layer fragment load hits one L1-resident line set,
 #endif                            // 2 one MFMA per product instead of three, 4 no fp16 conversions in the plane stores
+#ifndef RL4RS_AMLP_MT
+#define RL4RS_AMLP_MT 2           // 32-row tiles per workgroup (2: 64 rows; 1: 32 rows, half the LDS but twice the weight bytes per row: measured slower, 0.76 -> 0.91 ms predict)
+#endif
 #ifndef RL4RS_AMLP_NW
 #define RL4RS_AMLP_NW 8           // waves per workgroup (4 or 8; compile-time only: the two forms sum the head's k-blocks in different groupings)
 #endif
@@ -1148,9 +1151,10 @@ __device__ __forceinline__ float head_act_fast(float x, int act) {
 // NW: waves per workgroup (4: two 32-column tiles per wave, 8: one); KBX: k-blocks of the action-side input the LDS image has
 // room for (2: act_dim <= 32, 74.5 KB; 4: act_dim <= 64, 82.5 KB: one workgroup per CU).  64 rows per workgroup; two workgroups per CU
 // for the learners' act_dim = 32.
-template <int NW, int KBX>
-__global__ __launch_bounds__(64 * NW, KBX == 2 ? NW / 2 : NW / 4) void k_amlp_fwd_h16(AmlpFwdH16 a) {
-    constexpr int MT = 2, CT = 8 / NW, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 2 * KBX * SLAB;
+template <int NW, int KBX, int MT>
+__global__ __launch_bounds__(64 * NW, MT == 1 ? 3 : (KBX == 2 ? NW / 2 : NW / 4)) void k_amlp_fwd_h16(AmlpFwdH16 a) {
+    static_assert((NW == 4 || NW == 8) && (MT == 1 || MT == 2) && NW <= 4 * MT, "the head splits its k-blocks over at most 4 waves per unit");
+    constexpr int CT = 8 / NW, ROWS = 32 * MT, SLAB = ROWS * 16, HPLANE = 32 * SLAB, XPLANE = 2 * KBX * SLAB;
     constexpr int RING = NW == 8 ? 3 : 4;              // k-blocks of weight fragments in flight per wave (middle layer and head)
     __shared__ __attribute__((aligned(16))) char smem[2 * HPLANE + 2 * XPLANE];
     // per-column constants of the later phases: [0,256) 1 / prescale of W2's columns, [256,512) b2, [512,576) 1 / prescale of W3's
@@ -1456,9 +1460,9 @@ int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st) {
         set_error("amlp_fwd_h16: unsupported shape (act_dim %d, out_dim %d) or unaligned operand", a.E, a.K3);
         return RL4RS_EINVAL;
     }
-    const dim3 grid((a.N + 63) / 64);
-    if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 2>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
-    else hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 4>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
+    const dim3 grid((a.N + 32 * RL4RS_AMLP_MT - 1) / (32 * RL4RS_AMLP_MT));
+    if (a.E <= 32) hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 2, RL4RS_AMLP_MT>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
+    else hipLaunchKernelGGL((k_amlp_fwd_h16<RL4RS_AMLP_NW, 4, RL4RS_AMLP_MT>), grid, dim3(64 * RL4RS_AMLP_NW), 0, st, a);
     RL4RS_LAUNCH_CHECK();
 #ifdef RL4RS_AMLP_TRACE
     if (const char* path = getenv("RL4RS_AMLP_TRACE_DUMP")) {
