@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py — env-steps/s of the batched SlateRecEnv env.step() hot path on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: launched by torch.distributed.run, one
-rank per GPU).  A "step" is ONE episode-batch of the workload BASELINE.json's metric is quoted on
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1: one rank per GPU - launched by
+torch.distributed.run, or, when started plainly without WORLD_SIZE in the environment, bench.py starts its own
+N ranks through torch.distributed.run; WORLD_SIZE != --gpus or fewer visible GPUs than ranks is an error).  A "step" is ONE episode-batch of the workload BASELINE.json's metric is quoted on
 (configs[1]: SlateRecEnv-v0, batch 4096, 284-item catalogue, 9-slot slate, DIEN simulator scorer):
 ``env.reset()`` + 9 x ``env.step(offline_action)`` including the reward forward, i.e. B*T = 36 864
 env-steps.  Inputs (parsed log + catalogue + weights) are resident in HBM before the timed region.
@@ -454,6 +455,28 @@ def bcq_leg(env, cfg, rank, update_steps=200, rollouts=3):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_gpus, argv):
+    """``python bench.py --gpus N`` with N > 1 and no torch.distributed.run environment: start the N ranks ourselves (the command
+    the contract names: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>``), let rank 0's one JSON line through on stdout and hand back the launcher's exit code - a
+    plain ``--gpus 8`` can then never run as one silent rank."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -490,16 +513,28 @@ def main():
     if args.horizon is None:
         args.horizon = 9 if args.env == 'slate' else 32
     seq = args.env == 'seq'
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        raise SystemExit('bench.py: launched with WORLD_SIZE=%s but --gpus %d: the two must agree (the JSON line reports n_gpus = '
+                         'the ranks that actually ran)' % (os.environ['WORLD_SIZE'], args.gpus))
 
     import torch
     import torch.distributed as dist
     from rl4rs_amd import dist as rdist
-    rank, local_rank, world = rdist.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
     # RL4RS_DIST_BACKEND=gloo: dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices);
     # the driver's runs use the default: one rank per GPU over RCCL
     backend = os.environ.get('RL4RS_DIST_BACKEND', 'nccl')
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+        raise SystemExit('bench.py: --gpus %d over RCCL needs %d visible GPUs, this box shows %d (one rank per GPU; '
+                         'RL4RS_DIST_BACKEND=gloo is the dry-run mode in which ranks share devices)'
+                         % (args.gpus, args.gpus, torch.cuda.device_count()))
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # no launcher around us: start the N ranks ourselves
+    rank, local_rank, world = rdist.dist_env()
     if backend != 'nccl':
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -543,6 +578,8 @@ def main():
     # what the collective layer actually saw: the number of ranks that took part (an all-reduced count - equals --gpus only
     # if every rank joined the same process group) and every rank's own env-steps/s
     ranks_seen = int(round(rdist.sum_over_ranks(1.0, device='cuda')))
+    if ranks_seen != args.gpus:
+        raise SystemExit('bench.py: %d ranks joined the process group but --gpus is %d: nothing is reported' % (ranks_seen, args.gpus))
     per_rank = rdist.gather_floats(B * T * args.steps / my_elapsed, device='cuda')
     prof = net.profile()
     net.set_profiling(0)

@@ -1665,7 +1665,9 @@ class DeviceAMLP(object):
         n = self._rows(obs, act, rep)
         if out is None:
             out = torch.empty((n, self.K), dtype=torch.float32, device=self.device)
-        if nograd == 'fp16x2' and self.h16_ok and n >= self.H16_MIN_ROWS:
+        # (the fused kernel moves 16-byte vectors: an action view at an odd row offset takes the fp32 path, as documented)
+        aligned = obs.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and (act is None or act.data_ptr() % 16 == 0)
+        if nograd == 'fp16x2' and self.h16_ok and n >= self.H16_MIN_ROWS and aligned:
             check(self.lib.rl4rs_amlp_forward_h16(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))
         else:
             check(self.lib.rl4rs_amlp_forward(self.h, n, rep, _ptr(obs), _ptr(act), _ptr(out), _stream()))

@@ -8,6 +8,26 @@ loop (``allreduce_mean_``), both over ``torch.distributed`` (backend "nccl" = RC
 import os
 
 
+# RL4RS_DIST_FORCE=1 (or set_force(True)): an initialised process group of ONE rank still runs every collective below instead of
+# short-circuiting, and init() creates that one-rank group.  tests/test_gpu_nccl_one_rank.py executes the RCCL ("nccl")
+# device-memory branch of every wrapper this way on a 1-GPU box.
+FORCE_COLLECTIVES = os.environ.get('RL4RS_DIST_FORCE', '0') == '1'
+
+
+def set_force(flag):
+    global FORCE_COLLECTIVES
+    FORCE_COLLECTIVES = bool(flag)
+
+
+def collectives_active():
+    """True when the wrappers below really enter a collective: a process group of more than one rank, or any initialised group
+    while FORCE_COLLECTIVES is set."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
+
+
 def dist_env():
     """(rank, local_rank, world_size) from the torch.distributed.run environment."""
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
@@ -18,7 +38,7 @@ def init(backend=None):
     import torch
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -43,7 +63,7 @@ def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (the timed region of bench.py)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -53,7 +73,7 @@ def max_over_ranks(value, device=None):
 def sum_over_ranks(value, device=None):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -64,7 +84,7 @@ def gather_floats(value, device=None):
     """Every rank's python float, in rank order, on every rank (bench.py: per-rank rates beside the max-over-ranks time)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return [float(value)]
     W = dist.get_world_size()
     dev = None if dist.get_backend() == 'gloo' else device
@@ -101,7 +121,7 @@ def allreduce_mean_(flat):
     """In-place mean all-reduce of ONE flat fp32 gradient buffer (a single fused collective per optimiser step:
     the mask-model gradient is 140 KB, latency-bound, so bucketing would only add launches)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return flat
     if _needs_host_staging(flat):
         h = flat.detach().cpu()
@@ -117,7 +137,7 @@ def allreduce_sum_(t):
     """In-place SUM all-reduce of a (small) device tensor, enqueued like any other collective: nothing is read on the host
     (PPO's KL statistic of a data-parallel train call: every rank later derives the same kl_coeff from the same sum)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return t
     if _needs_host_staging(t):
         h = t.detach().cpu()
@@ -131,7 +151,7 @@ def allreduce_sum_(t):
 def broadcast_(t, src=0):
     """In-place broadcast of rank ``src``'s tensor (initial parameters / optimiser state of a data-parallel trainer)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return t
     if _needs_host_staging(t):
         h = t.detach().cpu()
@@ -143,6 +163,20 @@ def broadcast_(t, src=0):
 
 
 LAST_ROWS_PATH = None          # 'sparse' / 'dense': which exchange the last allreduce_rows_mean_ call of this process took (tests)
+
+
+_OVERFLOW = {}            # device -> bool scalar: a sparse-row exchange since the last take_row_overflow saw more distinct rows than its cap
+ROW_OVERFLOW_MESSAGE = ("a minibatch touched more distinct embedding rows than the static cap of the sparse gradient exchange "
+                        "(dist.calibrate_row_cap, measured on the first minibatch): the exchanged rows were NaN and have been stepped "
+                        "into the tables - rebuild the trainer (a larger headroom, or cap=None for the id-slot count)")
+
+
+def take_row_overflow(device):
+    """The accumulated overflow flag of ``allreduce_rows_mean_`` on ``device`` (a device bool scalar, or None when no sparse exchange
+    ran) - and reset it.  The trainers fold it into the status word of their deferred statistics, so an overflow raises at the next
+    settle instead of leaving NaN tables behind silently."""
+    import torch
+    return _OVERFLOW.pop(torch.device(device) if not isinstance(device, torch.device) else device, None)
 
 
 def calibrate_row_cap(ids, table_rows, headroom=4, floor=1024):
@@ -174,7 +208,7 @@ def allreduce_rows_mean_(table_grad, ids, cap=None):
     decision) the dense all-reduce is used."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return table_grad
     W = dist.get_world_size()
     H, E = table_grad.shape
@@ -200,6 +234,7 @@ def allreduce_rows_mean_(table_grad, ids, cap=None):
     safe = my_ids.clamp_min(0)
     my_rows = table_grad.index_select(0, safe) * valid[:, None].to(table_grad.dtype)
     my_rows = torch.where(overflow, torch.full_like(my_rows, float('nan')), my_rows)
+    _OVERFLOW[dev] = overflow if _OVERFLOW.get(dev) is None else (_OVERFLOW[dev] | overflow)
     stage = _needs_host_staging(table_grad)
     if stage:
         my_ids, my_rows = my_ids.cpu(), my_rows.cpu()
@@ -220,7 +255,7 @@ def barrier():
     import torch.distributed as dist
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()

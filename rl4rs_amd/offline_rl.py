@@ -96,6 +96,8 @@ class _ModelIO(object):
         return out
 
     def save_model(self, fname):
+        if hasattr(self, 'check_status'):
+            self.check_status()
         blob = {'__class__': np.array(type(self).__name__), 'total_step': np.array(self.total_step, dtype=np.int64)}
         for name, net in self._io_nets():
             blob['net.' + name] = net.flat_params().cpu().numpy()
@@ -106,6 +108,9 @@ class _ModelIO(object):
             sp = getattr(self, name, None)
             if sp is not None:
                 blob['scalar.' + name] = np.concatenate([sp.p.cpu().numpy(), sp.m.cpu().numpy(), sp.v.cpu().numpy(), [float(sp.t)]])
+        rs = getattr(self, 'reward_scaler', None)
+        if rs is not None:
+            blob['reward_scaler'] = np.array([rs.mean, rs.std, rs.eps], dtype=np.float64)
         with open(fname, 'wb') as f:
             np.savez(f, **blob)
 
@@ -128,6 +133,14 @@ class _ModelIO(object):
                 if sp is not None:
                     a = z['scalar.' + name]
                     sp.p.fill_(float(a[0])); sp.m.fill_(float(a[1])); sp.v.fill_(float(a[2])); sp.t = int(a[3])
+            # the reward scale the critics were trained on travels with them (d3rlpy keeps it in params.json): a learner restored
+            # onto a different scale would keep training / report predict_value in other units without any error
+            if 'reward_scaler' in z.files:
+                if not hasattr(self, 'reward_scaler'):
+                    raise ValueError('%s carries a reward scaler, %s has none' % (fname, type(self).__name__))
+                self.reward_scaler = StandardRewardScaler.from_stats(*[float(x) for x in z['reward_scaler']])
+            elif getattr(self, 'reward_scaler', None) is not None:
+                raise ValueError('%s was saved without a reward scaler, this learner has one' % fname)
 
     def fit_mdp(self, data, n_epochs=1, discrete_action=None, **kw):
         """``fit`` on MDPDataset-style arrays (the dict ``offline.generate_offline_dataset`` returns) for ``n_epochs`` passes over its
@@ -135,6 +148,9 @@ class _ModelIO(object):
         if discrete_action is None:
             discrete_action = isinstance(self, _Learner)
         tr = transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=discrete_action)
+        if getattr(self, 'reward_scaler', None) == 'standard':
+            # d3rlpy: a scaler given by name is fitted on the dataset when fit() builds the algorithm
+            self.reward_scaler = StandardRewardScaler(tr[2])
         steps = int(n_epochs) * (tr[0].shape[0] // self.batch_size)
         return self.fit(tr, steps, **kw)
 
@@ -167,7 +183,7 @@ class _Learner(_ModelIO):
         return D.DeviceQNet(self.D, self.A, params, mask_size=M, max_rows=self.batch_size, device=self.device, **kw)
 
     def _apply(self, net):
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             g = net.flat_gradient()
             rdist.allreduce_mean_(g)                      # data parallel: the one collective of an update (per network)
             net.set_flat_gradient(g)
@@ -317,7 +333,7 @@ def init_amlp_params(obs_dim, act_dim, out_dim, hidden1=256, hidden2=256, seed=0
 
 def _allreduce_group(nets):
     """Data parallel: ONE mean all-reduce for the flat gradients of a group of networks that are stepped together."""
-    if rdist.world_size() <= 1:
+    if not rdist.collectives_active():
         return
     flats = [net.flat_gradient() for net in nets]
     g = torch.cat(flats)
@@ -480,11 +496,26 @@ class BCQ(_ModelIO):
             vals = [h[k] for h in hist if k in h]
             if not vals:
                 out[k] = []
-            elif to_host:
-                out[k] = [float(x) for x in torch.stack(vals).cpu()]
-            else:
-                out[k] = torch.stack(vals)
+                continue
+            st = torch.stack(vals)
+            # a non-finite loss poisons Adam for good (the fused fp16x2 no-grad forward turns a row whose hidden activation
+            # leaves the fp16 range into NaN): the flag stays on the device, check_status() / to_host reads it
+            bad = ~torch.isfinite(st).all()
+            self._nonfinite = bad if getattr(self, '_nonfinite', None) is None else (self._nonfinite | bad)
+            out[k] = [float(x) for x in st.cpu()] if to_host else st
+        if to_host:
+            self.check_status()
         return out
+
+    NONFINITE_MESSAGE = ("a training loss of this learner became non-finite; with nograd_precision='fp16x2' a hidden activation that "
+                         "leaves the fp16 range does that - rebuild the learner with nograd_precision='fp32'")
+
+    def check_status(self):
+        """Raise if any loss of a ``fit`` so far was NaN / inf (one host read; ``fit(to_host=True)`` and ``save_model`` call it)."""
+        flag = getattr(self, '_nonfinite', None)
+        if flag is not None and bool(flag.item()):
+            self._nonfinite = None
+            raise RuntimeError(self.NONFINITE_MESSAGE)
 
     _LOSS_KEYS = ('imitator_loss', 'critic_loss', 'actor_loss')
 
@@ -533,6 +564,16 @@ class StandardRewardScaler(object):
     def transform(self, r):
         return ((r - self.mean) / (self.std + self.eps)).to(torch.float32)
 
+    def reverse_transform(self, q):
+        """d3rlpy ``StandardRewardScaler.reverse_transform``: q * (std + eps) + mean (policy_model.predict_q, policy_model.py:55-61)"""
+        return q * (self.std + self.eps) + self.mean
+
+    @classmethod
+    def from_stats(cls, mean, std, eps=1e-3):
+        s = cls.__new__(cls)
+        s.mean, s.std, s.eps = float(mean), float(std), float(eps)
+        return s
+
 
 class _ScalarParam(object):
     """One learned scalar (SAC's log-temperature, CQL's log-alpha) with torch-style Adam, kept on the device: a handful of
@@ -545,7 +586,7 @@ class _ScalarParam(object):
         self.t = 0
 
     def adam_step(self, grad, lr, beta1=0.9, beta2=0.999, eps=1e-8):
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             grad = rdist.allreduce_mean_(grad.clone())
         self.t += 1
         self.m.mul_(beta1).add_(grad, alpha=1.0 - beta1)
@@ -641,6 +682,9 @@ class CQL(_ModelIO):
         noise = noise or {}
         B, A, m = obs.shape[0], self.A, self.m
         if self.reward_scaler is not None:
+            if isinstance(self.reward_scaler, str):
+                raise ValueError("reward_scaler=%r is fitted by fit_mdp(dataset); pass StandardRewardScaler(rewards) to use update / fit "
+                                 "directly" % self.reward_scaler)
             rew = self.reward_scaler.transform(rew)
         metrics = {}
         # the policy does not change until the actor step: its heads on s' and s are computed once (s last: the handle keeps the
@@ -694,6 +738,8 @@ class CQL(_ModelIO):
         return metrics
 
     fit = BCQ.fit
+    check_status = BCQ.check_status
+    NONFINITE_MESSAGE = BCQ.NONFINITE_MESSAGE
     _LOSS_KEYS = ('critic_loss', 'actor_loss', 'temp_loss', 'alpha_loss')
 
     def predict(self, obs):

@@ -72,12 +72,17 @@ class policy_model(object):
         return self._out(out[0] if len(out) == 1 else torch.cat(out), obs)
 
     def predict_q(self, obs, action):
-        """AlgoBase.predict_value(obs, action) (no reward scaler is configured on these learners)."""
+        """AlgoBase.predict_value(obs, action), back on the reward's own scale when the learner has a reward scaler
+        (policy_model.py:55-61; 'CQL-conti' is built with reward_scaler='standard', batchrl_trainer.py:91-107)."""
         x = self._obs(obs)
         a = torch.as_tensor(np.asarray(action) if not isinstance(action, torch.Tensor) else action).to(x.device)
         n = self._rows()
         out = [self.policy.predict_value(x[lo:lo + n].contiguous(), a[lo:lo + n].contiguous()) for lo in range(0, x.shape[0], n)]
-        return self._out(out[0] if len(out) == 1 else torch.cat(out), obs)
+        q = out[0] if len(out) == 1 else torch.cat(out)
+        scaler = getattr(self.policy, 'reward_scaler', None)
+        if scaler is not None:
+            q = scaler.reverse_transform(q)
+        return self._out(q, obs)
 
     def _action_probs(self, x):
         if isinstance(self.policy, R.DiscreteBC):

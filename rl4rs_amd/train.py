@@ -114,6 +114,9 @@ class _DeferredStats(object):
         dev = stats.device
         status = (self.policy.status_words()[1:2].to(torch.float64) if hasattr(self.policy, 'status_words')
                   else torch.zeros(1, dtype=torch.float64, device=dev))
+        overflow = rdist.take_row_overflow(dev)
+        if overflow is not None:
+            status = status + 1000.0 * overflow.to(torch.float64)
         vec = torch.cat([mean_reward.reshape(1).to(torch.float64), stats.reshape(-1).to(torch.float64), status])
         pin = torch.empty(vec.shape, dtype=torch.float64, pin_memory=True)
         pin.copy_(vec, non_blocking=True)
@@ -129,6 +132,8 @@ class _DeferredStats(object):
             tok = self._pending.pop(0)
             tok['ev'].synchronize()
             v = tok['pin'].numpy().copy()
+            if v[-1] >= 1000.0:
+                raise RuntimeError(rdist.ROW_OVERFLOW_MESSAGE)
             if v[-1] != 0.0:
                 self.policy.check_status()                  # clears the flag and raises
                 raise RuntimeError(D.DevicePolicy.PASS_TIMEOUT_MESSAGE)
@@ -187,7 +192,7 @@ class RawStateTrainer(_DeferredStats):
                         logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
         self._grad = None
         self._row_caps = None            # static distinct-row bounds of the sparse table exchange (dist.calibrate_row_cap)
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             rdist.broadcast_(self.policy.flat_view('params'), src=0)      # replicas start identical (Adam state is zero)
             self._grad = self.policy.flat_view('grad')
 
@@ -275,7 +280,7 @@ class RawStateTrainer(_DeferredStats):
             nmb += 1
         stats8 = torch.cat([stats.reshape(-1)[:4].to(torch.float32), torch.zeros(3, dtype=torch.float32, device=kl_sum.device),
                             kl_sum.reshape(1)])
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             # every rank must take the same kl_coeff decision: the rule sees the mean over ALL ranks' samples.  The sum is
             # all-reduced ON THE DEVICE and travels with the deferred statistics: no rank reads a device scalar in a train call
             rdist.allreduce_sum_(stats8[7:8])
@@ -326,7 +331,7 @@ class Trainer(_DeferredStats):
                         logits=torch.empty((N, self.A), dtype=torch.float32, device=dev))
         self.grad = torch.empty(self.policy.n_params, dtype=torch.float32, device=dev)
         self._mb_stats = torch.empty(4, dtype=torch.float32, device=dev)
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -337,7 +342,7 @@ class Trainer(_DeferredStats):
         rdist.broadcast_(m, src)
         rdist.broadcast_(v, src)
         step = torch.tensor([t], dtype=torch.int64)
-        if rdist.world_size() > 1:
+        if rdist.collectives_active():
             import torch.distributed as dist
             if dist.get_backend() != 'gloo':
                 step = step.to(p.device)
@@ -412,7 +417,7 @@ class Trainer(_DeferredStats):
             self.last_batch = dict(sh, adv=adv_s, ret=ret_s, kl_coeff=self._kl_coeff)
         MB = self.minibatch
         nmb = N // MB
-        if world == 1:
+        if not rdist.collectives_active():
             # single GPU: the whole pass is one library call (no per-minibatch collective to interleave)
             stats = self.policy.ppo_epoch(sh['obs'], sh['act'], adv_s, ret_s, sh['mask'], sh['logp'], sh['val'],
                                           sh['logits'], minibatch=MB, vf_coeff=0.5, ent_coeff=0.0,

@@ -167,11 +167,13 @@ def _rows_worker(rank, world, port, out):
     D.allreduce_mean_(dense2.view(-1))
     dense += dense2
     D.allreduce_rows_mean_(table, slots, cap=64)           # buffer sizes must agree across ranks: the slot counts differ here
+    assert not bool(D.take_row_overflow(torch.device('cpu'))) and D.take_row_overflow('cpu') is None       # read once, then reset
     # a distinct-row hint that is too small must fail loudly (NaN rows), never drop rows silently
     bad = torch.zeros(H, E)
     bad[ids] = 1.0
     D.allreduce_rows_mean_(bad, ids, cap=3)
     assert torch.isnan(bad).any()
+    assert bool(D.take_row_overflow('cpu'))                # ... and the flag the trainers fold into their status word is set
     big = torch.zeros(16, 4)                               # touched rows are most of the table -> dense fallback
     big_ids = torch.arange(rank, 16, 2)
     big[big_ids] = float(rank + 1)
@@ -220,3 +222,50 @@ def test_sparse_row_allreduce_and_broadcast_world_2():
     assert (t0 != 0).any()
     assert torch.equal(b0, b1) and set(b0.unique().tolist()) == {0.5, 1.0}
     assert torch.equal(bc0, torch.ones(5)) and torch.equal(bc1, torch.ones(5))
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """`bench.py --gpus N` under a launcher whose WORLD_SIZE is not N exits non-zero before anything runs (the entry
+    point used to report n_gpus = 1 for `--gpus 8` without a launcher; now it starts its own ranks, and a mismatch is an error)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode != 0 and b'WORLD_SIZE=4 but --gpus 2' in out.stderr and not out.stdout.strip()
+
+
+def test_forced_collectives_on_a_one_rank_group():
+    """RL4RS_DIST_FORCE / set_force: a ONE-rank group still enters every collective (the switch the one-rank RCCL GPU test uses);
+    here over gloo on CPU: results are the identity."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RL4RS_DIST_FORCE='1')
+from rl4rs_amd import dist as D
+import torch.distributed as dist
+assert D.FORCE_COLLECTIVES and not D.collectives_active()
+assert D.init('gloo') == (0, 0, 1) and dist.is_initialized() and D.collectives_active()
+calls = []
+real = dist.all_reduce
+dist.all_reduce = lambda *a, **k: (calls.append('ar'), real(*a, **k))[1]
+g = torch.arange(10, dtype=torch.float32)
+assert torch.equal(D.allreduce_mean_(g.clone()), g) and calls == ['ar']
+assert D.max_over_ranks(2.5) == 2.5 and D.sum_over_ranks(1.0) == 1.0 and D.gather_floats(4.0) == [4.0]
+assert len(calls) == 3
+t = torch.zeros(5000, 4); ids = torch.tensor([5, 9, 5]); t[ids] = 1.0
+w = t.clone()
+D.allreduce_rows_mean_(t, ids, cap=8)
+assert D.LAST_ROWS_PATH == 'sparse' and torch.equal(t, w)
+D.set_force(False)
+assert not D.collectives_active()
+assert D.allreduce_mean_(g) is g and len(calls) == 3
+D.barrier()
+print('OK')
+''' % (repo, _free_port())
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0 and b'OK' in out.stdout, out.stderr.decode()[-2000:]

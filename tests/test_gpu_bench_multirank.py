@@ -43,3 +43,30 @@ def test_bench_two_ranks_over_gloo(leg):
     assert rec['value'] <= sum(rec['per_rank_env_steps_per_s']) * 1.001
     if leg[:2] == ['--train', 'bcq']:
         assert rec['bcq']['updates_per_step'] == 2 and all(v == v for v in rec['bcq']['last_losses'].values())
+
+
+def test_plain_launch_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO launcher around it (the shape of the driver's one known command): bench.py starts the
+    two ranks itself; the line says n_gpus == ranks_seen == 2."""
+    env = dict((k, v) for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'))
+    env.update(RL4RS_DIST_BACKEND='gloo')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '256',
+           '--log-records', '700', '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and len(rec['per_rank_env_steps_per_s']) == 2
+
+
+def test_more_ranks_than_gpus_over_rccl_is_refused():
+    """The default backend is one rank per GPU over RCCL: asking for more ranks than the box has GPUs fails loudly, before any
+    rank starts, instead of reporting a smaller job."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = dict((k, v) for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RL4RS_DIST_BACKEND'))
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                         cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b'visible GPUs' in out.stderr
+    assert not [l for l in out.stdout.decode().splitlines() if l.startswith('{')]

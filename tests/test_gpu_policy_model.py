@@ -140,3 +140,62 @@ def test_save_model_load_model_fit_mdp(tmp_path, algo):
         other.load_model(path)
     a.close()
     b.close()
+
+
+def test_predict_q_undoes_the_reward_scaling(tmp_path):
+    """policy_model.predict_q (rl4rs/policy/policy_model.py:55-61): with a reward scaler on the learner ('CQL-conti',
+    batchrl_trainer.py:91-107) the value comes back on the reward's own scale, q * (std + eps) + mean - checked against the float64
+    restatement's critics; the scaler's statistics travel through save_model / load_model and are fitted by fit_mdp when given by
+    name (d3rlpy: reward_scaler='standard')."""
+    import torch
+    from rl4rs.policy.policy_model import policy_model
+    from rl4rs_amd import offline_rl as R
+    from oracle.offline_conti import OracleAMLP
+    cfg, tab, x = _setup(tmp_path)
+    cfg = dict(cfg, support_conti_env=True)
+    rs = np.random.RandomState(3)
+    n = 256
+    rewards = (rs.rand(n) * 40 + 5).astype(np.float32)
+    acts = rs.randn(n, 32).astype(np.float32)
+    acts /= np.linalg.norm(acts, axis=1, keepdims=True)
+    scaler = R.StandardRewardScaler(rewards)
+    assert abs(scaler.mean - rewards.astype(np.float64).mean()) < 1e-9 and abs(scaler.std - rewards.astype(np.float64).std()) < 1e-9
+    r = torch.tensor([1.0, 30.0], dtype=torch.float64)
+    assert torch.allclose(scaler.reverse_transform(scaler.transform(r).to(torch.float64)), r, atol=1e-5)
+    cql = R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, reward_scaler=scaler, seed=3)
+    pm = policy_model(cql, config=cfg)
+    xs, a = x[:100], acts[:100]
+    raw = cql.predict_value(torch.from_numpy(xs).cuda(), torch.from_numpy(a).cuda()).cpu().numpy()
+    q = pm.predict_q(xs, a)
+    assert np.allclose(q, raw.astype(np.float64) * (scaler.std + scaler.eps) + scaler.mean, rtol=1e-6, atol=1e-5)
+    o1, o2 = (OracleAMLP(dict((k, v.cpu().numpy()) for k, v in net.weights().items()), 'none') for net in (cql.q1, cql.q2))
+    want = (0.5 * (o1(xs, a) + o2(xs, a))[:, 0].detach().numpy()) * (scaler.std + scaler.eps) + scaler.mean
+    assert np.abs(q - want).max() < 2e-4 * max(1.0, np.abs(want).max())
+    # a learner without a scaler: the raw value (BCQ)
+    bcq = R.BCQ(cfg, D, batch_size=64, n_action_samples=5, seed=3)
+    assert getattr(bcq, 'reward_scaler', None) is None
+    pb = policy_model(bcq, config=cfg)
+    assert np.array_equal(pb.predict_q(xs, a), bcq.predict_value(torch.from_numpy(xs).cuda(), torch.from_numpy(a).cuda()).cpu().numpy())
+    # the statistics travel with the file; a restored learner with other statistics takes the file's
+    path = os.path.join(str(tmp_path), 'cql.npz')
+    cql.save_model(path)
+    other = R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, reward_scaler=R.StandardRewardScaler(rewards * 0 + 1), seed=4)
+    other.load_model(path)
+    assert (other.reward_scaler.mean, other.reward_scaler.std, other.reward_scaler.eps) == (scaler.mean, scaler.std, scaler.eps)
+    assert np.allclose(policy_model(other, config=cfg).predict_q(xs, a), q, rtol=0, atol=0)
+    bare = R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, seed=4)
+    bare.load_model(path)                                   # the file carries a scaler: it is installed
+    assert bare.reward_scaler is not None and bare.reward_scaler.mean == scaler.mean
+    path2 = os.path.join(str(tmp_path), 'cql_bare.npz')
+    R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, seed=4).save_model(path2)
+    with pytest.raises(ValueError):
+        other.load_model(path2)                             # trained on a scale, file without one
+    # by name: fitted on the dataset by fit_mdp
+    named = R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, reward_scaler='standard', seed=3)
+    with pytest.raises(ValueError):
+        named.update(*[torch.zeros(1, device='cuda')] * 5)
+    data = dict(observations=x[:n].copy(), actions=acts, rewards=rewards, terminals=(np.arange(n) % 10 == 9).astype(np.float32))
+    named.fit_mdp(data, n_epochs=1)
+    assert isinstance(named.reward_scaler, R.StandardRewardScaler) and abs(named.reward_scaler.mean - scaler.mean) < 1.0
+    for m in (cql, bcq, other, bare, named):
+        m.close()
