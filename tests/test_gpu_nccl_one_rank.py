@@ -101,7 +101,7 @@ tg = torch.zeros(H, Ew, device=dev)
 tg[ids] = torch.randn(ids.numel(), Ew, device=dev)
 want = tg.clone()
 cap = D.calibrate_row_cap(ids, H)
-assert cap == 2048
+assert cap == ids.numel()                    # 4 x ~300 distinct rows, rounded to 2048, bounded by the id-slot count
 D.allreduce_rows_mean_(tg, ids, cap=cap)
 assert D.LAST_ROWS_PATH == 'sparse' and torch.equal(tg, want)
 # the same call on a small table: the dense all-reduce
@@ -112,14 +112,15 @@ assert D.LAST_ROWS_PATH == 'dense' and torch.equal(tg2, w2)
 # an overflowing cap is loud (NaN rows), not silent
 tg3 = want.clone()
 D.allreduce_rows_mean_(tg3, ids, cap=16)
-assert torch.isnan(tg3).any()
+assert torch.isnan(tg3).any() and bool(D.take_row_overflow(dev)) and D.take_row_overflow(dev) is None
 D.barrier()
 
 got = dict(a2c=trainer_params('A2C'), ppo=trainer_params('PPO'), raw=raw_params(), bcq=bcq_weights())
 for k in ('a2c', 'ppo'):
     assert torch.equal(got[k][0], ref[k][0]), (k, (got[k][0] - ref[k][0]).abs().max().item())
     assert got[k][1] == ref[k][1]
-assert torch.equal(got['raw'], ref['raw']), (got['raw'] - ref['raw']).abs().max().item()
+# (the raw-state backward accumulates embedding-row gradients with float atomics: equal up to their summation order)
+assert (got['raw'] - ref['raw']).abs().max().item() <= 1e-6 and not torch.equal(ref['raw'], torch.zeros_like(ref['raw']))
 for name in ref['bcq']:
     for k in ref['bcq'][name]:
         assert torch.equal(got['bcq'][name][k], ref['bcq'][name][k]), (name, k)
@@ -145,5 +146,6 @@ def test_every_wrapper_through_the_rccl_branch():
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     out = subprocess.run([sys.executable, '-c', CHILD % dict(repo=REPO)], cwd=REPO, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=600)
-    assert out.returncode == 0, (out.stdout.decode()[-2000:], out.stderr.decode()[-4000:])
+    if out.returncode != 0:
+        pytest.fail('child exited with %d\n%s\n%s' % (out.returncode, out.stdout.decode()[-2000:], out.stderr.decode()[-6000:]), pytrace=False)
     assert 'NCCL_ONE_RANK_OK' in out.stdout.decode()

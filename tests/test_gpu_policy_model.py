@@ -196,6 +196,9 @@ def test_predict_q_undoes_the_reward_scaling(tmp_path):
         named.update(*[torch.zeros(1, device='cuda')] * 5)
     data = dict(observations=x[:n].copy(), actions=acts, rewards=rewards, terminals=(np.arange(n) % 10 == 9).astype(np.float32))
     named.fit_mdp(data, n_epochs=1)
-    assert isinstance(named.reward_scaler, R.StandardRewardScaler) and abs(named.reward_scaler.mean - scaler.mean) < 1.0
+    tr = R.transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=False)
+    fitted = R.StandardRewardScaler(tr[2])                   # the statistics of the dataset's TRANSITION rewards, like d3rlpy's fit
+    assert isinstance(named.reward_scaler, R.StandardRewardScaler)
+    assert (named.reward_scaler.mean, named.reward_scaler.std) == (fitted.mean, fitted.std) and fitted.std > 1.0
     for m in (cql, bcq, other, bare, named):
         m.close()
