@@ -238,6 +238,14 @@ def main():
             cfg['iteminfo_file'] = 'catalog_synth.csv'
             emit('seq%d_%s' % (T, tag), g, cfg, True, conti, flag, 'catalog_synth.csv', 'records_seq.txt')
 
+    # ---------------- support_onehot_action (slate.py:22-25; the continuous dataset of script/batchrl_trainer.py:224-225 is built
+    # with it): the action embedding table is eye(284), a continuous action is a 284-d vector resolved by the masked K-NN
+    cfg = base_config(iteminfo_file=cat_path, support_onehot_action=True)
+    g = run_scenario('slate_onehot', SlateState, FeatureUtil, cfg, rec_a, False, True, np.random.RandomState(19), None)
+    assert g['action_emb'].shape == (284, 284) and g['action_in_0'].shape == (6, 284)
+    cfg['iteminfo_file'] = 'catalog_synth.csv'
+    emit('slate_onehot', g, cfg, False, True, None, 'catalog_synth.csv', 'records_slate.txt')
+
     # ---------------- BASELINE configs[0]: SlateRecEnv-v0 batch = 256, offline_action replay (the mask flags only change which
     # view of the state `state` returns - both views, obsmask_* and d3rl_*, are recorded at every step - so ONE episode serves
     # the plain, support_rllib_mask and support_d3rl_mask forms of the config)

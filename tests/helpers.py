@@ -43,4 +43,4 @@ def golden_has(g, key):
 
 
 SCENARIOS = ['slate_discrete', 'slate_conti', 'seq36_discrete', 'seq36_conti', 'seq32_discrete',
-             'seq32_conti', 'real_discrete', 'real_conti', 'slate256_discrete', 'seq36_b64_discrete']
+             'seq32_conti', 'real_discrete', 'real_conti', 'slate256_discrete', 'seq36_b64_discrete', 'slate_onehot']

@@ -15,7 +15,7 @@ def _mk_env(cfg, records, seq, log_steps=None, zero_on_violation=None):
     import torch
     from rl4rs_amd.data import CatalogTables, RecordColumns
     from rl4rs_amd.device import DeviceEnv
-    cat = CatalogTables(cfg['iteminfo_file'], cfg['action_size'], 32)
+    cat = CatalogTables(cfg['iteminfo_file'], cfg['action_size'], 32, cfg.get('support_onehot_action', False))
     cols = RecordColumns(records, cfg['maxlen'])
     if zero_on_violation is None:
         zero_on_violation = (not seq) or cfg.get('support_rllib_mask', False) or cfg.get('support_d3rl_mask', False)

@@ -52,10 +52,12 @@ def _oracle(cfg, records, w, seq):
 
 
 @pytest.mark.parametrize('seq,T', [(False, 9), (True, 36), (True, 32)])
-@pytest.mark.parametrize('mode', ['plain', 'rllib', 'd3rl', 'conti'])
+@pytest.mark.parametrize('mode', ['plain', 'rllib', 'd3rl', 'conti', 'onehot'])
 def test_episode_matches_oracle(tmp_path, seq, T, mode):
+    # onehot: support_onehot_action (slate.py:22-25; the continuous dataset of script/batchrl_trainer.py:224-225): the action
+    # embedding table is eye(284), a continuous action is a 284-d vector the masked K-NN resolves
     flags = {'plain': {}, 'rllib': {'support_rllib_mask': True}, 'd3rl': {'support_d3rl_mask': True},
-             'conti': {'support_conti_env': True}}[mode]
+             'conti': {'support_conti_env': True}, 'onehot': {'support_conti_env': True, 'support_onehot_action': True}}[mode]
     B = 12
     cfg, records, w = _setup(tmp_path, seq, B, T, **flags)
     env = _make(cfg, seq)
@@ -85,6 +87,13 @@ def test_episode_matches_oracle(tmp_path, seq, T, mode):
     for t in range(T):
         if mode == 'conti':
             a = rs.randn(B, 32).astype(np.float32)
+        elif mode == 'onehot':
+            assert env.config['action_emb_size'] == 284 and tuple(env.action_space.shape) == (284,)       # slate.py:23: the state rewrites the config
+            off = np.asarray(env.offline_action, dtype=np.float64)
+            assert off.shape == (B, 284) and np.array_equal(off, np.asarray(orc.samples.offline_action, dtype=np.float64))
+            assert ((off == 0) | (off == 1)).all() and (off.sum(axis=1) == 1).all()         # rows of eye(284)
+            a = rs.randn(B, 284).astype(np.float32)
+            a[:B // 3] = off[:B // 3]                        # a third of the batch replays the logged item's one-hot row
         else:
             a = env.offline_action
             assert a == orc.samples.offline_action
@@ -101,7 +110,7 @@ def test_episode_matches_oracle(tmp_path, seq, T, mode):
         assert np.array_equal(env.samples.prev_actions, orc.samples.prev_actions)
         assert np.allclose(np.asarray(env.offline_reward, dtype=np.float64),
                            np.asarray(orc.samples.offline_reward, dtype=np.float64), rtol=0, atol=0)
-    assert seq or mode == 'conti' or any(r != 0 for r in reward)
+    assert seq or mode in ('conti', 'onehot') or any(r != 0 for r in reward)
     assert np.array_equal(env.samples.get_violation(), orc.samples.get_violation())
     assert np.array_equal(env.samples.action_mask, orc.samples.action_mask)
     assert np.array_equal(env.samples.special_mask, orc.samples.special_mask)

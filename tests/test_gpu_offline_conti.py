@@ -445,3 +445,103 @@ def test_bcq_two_ranks_on_one_gpu(tmp_path):
         for k in w0[name]:
             assert (w0[name][k] - ref[k].cpu()).abs().max().item() < 5e-5, (name, k)
     one.close()
+
+
+@pytest.mark.parametrize('nograd', ['fp32', 'fp16x2'])
+def test_bcq_at_the_bench_shape(tmp_path, nograd):
+    """The shapes bench.py and the reference run (script/batchrl_trainer.py:61-73 batch_size 256, d3rlpy's 100 action samples;
+    :377-411 evaluate): ONE update of 256 transitions x 100 sampled actions (25 600 target rows through four networks) against the
+    float64 restatement, bars as in test_updates_track_the_fp64_restatement; then predict over 4 096 observations x 100 (409 600
+    rows, ONE pass: predict_rows = the env batch like bench.py's BcqWorkload) - the restatement's pick on a 256-observation subset,
+    and on ALL rows the size-independent properties: |a| <= 1, the pick's float64 value is the row maximum of the float64 values
+    of the 100 sampled actions to 2e-4, and the masked K-NN resolves every pick to a legal item (== the numpy rule)."""
+    import torch
+    from oracle import offline_conti as O
+    from oracle.offline_rl import torch_adam
+    from oracle.state import nearest_neighbor_with_mask
+    from rl4rs_amd import device as Dv
+    from rl4rs_amd import synth
+    from rl4rs_amd.data import CatalogTables
+    from rl4rs_amd.offline_rl import BCQ
+    B, n, NP = 256, 100, 4096
+    bcq = BCQ({'action_emb_size': E}, D, batch_size=B, n_action_samples=n, predict_rows=NP, seed=43, nograd_precision=nograd)
+    if nograd == 'fp16x2':
+        assert all(net.h16_ok for net in bcq.nets) and B * n >= bcq.q1.H16_MIN_ROWS        # the fused kernel takes these rows by itself
+    # spread the sampled actions and their values (fresh networks value every action almost alike)
+    for k, f in dict(imit_dec=2.0, q1=2.0, q1_targ=2.0, q2_targ=1.5).items():
+        net = getattr(bcq, k)
+        net.set_flat_params((net.flat_params() * f).contiguous())
+    names = ('imit_enc', 'imit_dec', 'policy', 'policy_targ', 'q1', 'q2', 'q1_targ', 'q2_targ')
+    heads = dict(imit_dec='tanh', policy='tanh', policy_targ='tanh')
+    P = dict((k, dict((pk, pv.cpu().numpy().astype(np.float64)) for pk, pv in getattr(bcq, k).weights().items())) for k in names)
+    net = lambda k: O.OracleAMLP(P[k], heads.get(k, 'none'))
+    # ---- one update
+    rs = np.random.RandomState(44)
+    x, a, rew, ter = _batch(B, 70)
+    nx = _batch(B, 71)[0]
+    nx[ter > 0.5] = 0.0
+    noise = dict(eps=torch.from_numpy(rs.randn(B, L).astype(np.float32)), z_target=torch.from_numpy(rs.randn(B * n, L).astype(np.float32)),
+                 z_actor=torch.from_numpy(rs.randn(B, L).astype(np.float32)))
+    m = bcq.update(*[torch.from_numpy(v).cuda() for v in (x, a, rew, nx, ter)], noise=noise)
+    M = dict((k, dict((pk, np.zeros_like(pv)) for pk, pv in P[k].items())) for k in P)
+    V = dict((k, dict((pk, np.zeros_like(pv)) for pk, pv in P[k].items())) for k in P)
+
+    def step(step_names, loss_fn):
+        nets = dict((k, net(k)) for k in P)
+        loss = loss_fn(nets)
+        loss.backward()
+        for k in step_names:
+            P[k] = torch_adam(P[k], nets[k].grads(), M[k], V[k], 1, 1e-3)
+        return float(loss)
+
+    li = step(('imit_enc', 'imit_dec'), lambda N: O.cvae_loss(N['imit_enc'], N['imit_dec'], x, a, noise['eps'].numpy(), bcq.beta))
+    y = O.bcq_target(net('imit_dec'), net('policy_targ'), [net('q1_targ'), net('q2_targ')], nx, noise['z_target'].numpy(), n, bcq.scale,
+                     bcq.lam, rew, ter, bcq.gamma)
+    lc = step(('q1', 'q2'), lambda N: O.critic_loss([N['q1'], N['q2']], x, a, y))
+    la = step(('policy',), lambda N: O.actor_loss(N['imit_dec'], N['policy'], N['q1'], x, noise['z_actor'].numpy(), bcq.scale))
+    for k in ('policy', 'q1', 'q2'):
+        P[k + '_targ'] = O.soft_sync(P[k + '_targ'], P[k], bcq.tau)
+    assert abs(float(m['imitator_loss']) - li) < 2e-4 * max(1.0, abs(li)), (float(m['imitator_loss']), li)
+    assert abs(float(m['critic_loss']) - lc) < 2e-3 * max(1.0, abs(lc)), (float(m['critic_loss']), lc)
+    assert abs(float(m['actor_loss']) - la) < 2e-3 * max(1.0, abs(la)), (float(m['actor_loss']), la)
+    for k in P:
+        w = getattr(bcq, k).weights()
+        for pk in P[k]:
+            err = np.abs(w[pk].cpu().numpy() - P[k][pk]).max()
+            assert err < 2e-4, (k, pk, err)
+    # ---- predict over the whole env batch (the updated networks on both sides)
+    xs = _batch(NP, 72)[0]
+    z = np.random.RandomState(73).randn(NP * n, L).astype(np.float32)
+    got_t = bcq.predict(torch.from_numpy(xs).cuda(), noise=torch.from_numpy(z))
+    got = got_t.cpu().numpy()
+    assert got.shape == (NP, E) and np.isfinite(got).all() and (np.abs(got) <= 1.0).all()
+    dec, pol, q1 = net('imit_dec'), net('policy'), net('q1')
+    S = 256
+    want, idx, v = O.predict_best_action(dec, pol, q1, xs[:S], z[:S * n], n, bcq.scale)
+    srt = np.sort(v.numpy(), axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-4                   # rows whose best value is not a near-tie in fp32
+    assert clear.sum() > S // 2, clear.sum()
+    assert np.abs(got[:S][clear] - want.numpy()[clear]).max() < 2e-4
+    # every row: the pick is worth (in float64) what the best of its 100 sampled actions is worth
+    worst = 0.0
+    for lo in range(0, NP, 512):
+        _, _, vv = O.predict_best_action(dec, pol, q1, xs[lo:lo + 512], z[lo * n:(lo + 512) * n], n, bcq.scale)
+        with torch.no_grad():
+            gv = q1(xs[lo:lo + 512], got[lo:lo + 512])[:, 0].numpy()
+        worst = max(worst, float(np.abs(gv - vv.numpy().max(axis=1)).max()))
+    assert worst < 2e-4, worst
+    # the masked K-NN of the continuous env resolves every pick to a legal item - and to the item numpy's rule picks
+    cpath = os.path.join(str(tmp_path), 'c.csv')
+    synth.write_text(cpath, synth.make_catalog_text(seed=4))
+    tab = CatalogTables(cpath, 284, E)
+    mask = (np.random.RandomState(74).rand(NP, 284) < 0.3).astype(np.int64) * np.asarray(tab.location_mask)[np.arange(NP) % 3]
+    r = np.arange(NP)
+    mask[r, 1 + r % 39] |= (r % 3 == 0)                       # never an empty row
+    mask[r, 40 + r % 108] |= (r % 3 == 1)
+    mask[r, 148 + r % 136] |= (r % 3 == 2)
+    item = Dv.knn(got_t, torch.from_numpy(tab.action_emb).cuda(), mask=mask).cpu().numpy()
+    assert (mask[np.arange(NP), item] == 1).all()
+    ref_item = nearest_neighbor_with_mask(got.astype(np.float64), tab.action_emb, mask)
+    # (a float32 action is exact in float64; the catalogue rows are float64 on both sides: the integer pick is the same)
+    assert np.array_equal(item, ref_item)
+    bcq.close()
