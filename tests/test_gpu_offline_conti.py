@@ -492,7 +492,7 @@ def test_bcq_at_the_bench_shape(tmp_path, nograd):
         loss.backward()
         for k in step_names:
             P[k] = torch_adam(P[k], nets[k].grads(), M[k], V[k], 1, 1e-3)
-        return float(loss)
+        return float(loss.detach())
 
     li = step(('imit_enc', 'imit_dec'), lambda N: O.cvae_loss(N['imit_enc'], N['imit_dec'], x, a, noise['eps'].numpy(), bcq.beta))
     y = O.bcq_target(net('imit_dec'), net('policy_targ'), [net('q1_targ'), net('q2_targ')], nx, noise['z_target'].numpy(), n, bcq.scale,
@@ -509,7 +509,9 @@ def test_bcq_at_the_bench_shape(tmp_path, nograd):
         for pk in P[k]:
             err = np.abs(w[pk].cpu().numpy() - P[k][pk]).max()
             assert err < 2e-4, (k, pk, err)
-    # ---- predict over the whole env batch (the updated networks on both sides)
+    # ---- predict over the whole env batch: the restatement takes the device's updated parameters (the 2e-4 parameter bar above
+    # is wider than the 2e-4 action bar below)
+    P = dict((k, dict((pk, pv.cpu().numpy().astype(np.float64)) for pk, pv in getattr(bcq, k).weights().items())) for k in names)
     xs = _batch(NP, 72)[0]
     z = np.random.RandomState(73).randn(NP * n, L).astype(np.float32)
     got_t = bcq.predict(torch.from_numpy(xs).cuda(), noise=torch.from_numpy(z))
