@@ -6,13 +6,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'librl4rs_hip.so')
-SOURCES = ['env.hip', 'gemm.hip', 'dien.hip', 'policy.hip', 'records.hip', 'step.hip']
+SOURCES = ['env.hip', 'gemm.hip', 'dien.hip', 'augru_x.hip', 'policy.hip', 'records.hip', 'step.hip']
 # Units whose MFMA kernels run VALU epilogues beside another wave's MFMAs are compiled without SLP vectorisation: packed fp32 VALU
 # (v_pk_fma / add / mul_f32) serialises with the matrix pipe (tools/mfma_valu_overlap.hip, profiles/r04p_mfma_valu_overlap.txt;
 # same-box A/B: k_cat_attn2 -8 %, k_din_x -2 %, end to end +0.7 %).  The other units keep it (the learners' element-wise and
-# reduction kernels are 1 - 4 % faster with it).
+# reduction kernels are 1 - 4 % faster with it) - and so does augru_x.hip: k_augru_x<2,4,2> sits at the register limit and spills without it.
 NO_SLP = ('dien.hip', 'gemm.hip')
-HEADERS = ['common.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
+HEADERS = ['common.hpp', 'recur_args.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
 
 
 def _stale():

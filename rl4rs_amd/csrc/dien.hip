@@ -16,10 +16,10 @@
 #include <vector>
 
 #include "common.hpp"
+#include "recur_args.hpp"
 
 namespace rl4rs {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float eluf_(float x) { return x > 0.f ? x : expm1f(x); }
@@ -36,41 +36,12 @@ constexpr int AUGRU_U = RL4RS_AUGRU_U, GRU_U = 2;   // k-blocks per register-rin
 #ifndef RL4RS_H16_NRES
 #define RL4RS_H16_NRES 14        // weight items of a step kept resident in registers (k_augru_h16)
 #endif
-#ifndef RL4RS_X_NRES
-#define RL4RS_X_NRES 12          // k_augru_x: weight items of a wave's step resident in registers (of 48)
-#endif
-#ifndef RL4RS_X_RING
-#define RL4RS_X_RING 4           // ... register ring of the streamed rest (48 - NRES items, a multiple of RING)
-#endif
-#ifndef RL4RS_X2_NRES
-#define RL4RS_X2_NRES 4          // the 64-row form of k_augru_x (registers hold the second row tile's accumulators instead)
-#endif
-#ifndef RL4RS_X2_RING
-#define RL4RS_X2_RING 2
-#endif
 #ifndef RL4RS_H16_RING1
 #define RL4RS_H16_RING1 4        // weight ring depth (items) of k_augru_h16: 3 items = 9 MFMAs ahead;
                                  // measured (ring, resident): (8,10) 60.6 ms, (6,12) 59.5, (4,14) 59.0 per 5 episodes
 #endif
 
 
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-struct h8bits { half8_t v; };
-
-// fp16 hi / lo split of two fp32 values: hi = RNE(x) as a packed pair, lo = RNE(x - hi).  The difference comes from ONE
-// v_fma_mix_f32 (f16 source read straight out of the packed pair, exact) instead of a conversion back plus a subtraction.
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_h16_pair(float x0, float x1, half2_t& hi, half2_t& lo) {
-    unsigned h;
-    float d0, d1;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(x1));
-    unsigned l;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(d0), "v"(d1));
-    hi = __builtin_bit_cast(half2_t, h);
-    lo = __builtin_bit_cast(half2_t, l);
-}
 
 #ifndef RL4RS_CAT_FAST_EXP
 #define RL4RS_CAT_FAST_EXP 0     // 1: the softmax of the category self-attention on the hardware exp2 (timing A/B, round 4)
@@ -463,36 +434,6 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
 //     phase is issued during the last group of the current one (weights do not depend on the recurrence);
 //   * the cached input projections of a phase are requested right after its first weight group and added in
 //     the phase's epilogue (thousands of MFMA cycles later), so their HBM latency never sits in front of an MFMA.
-struct RecurArgs {
-    int n_rows, L, group;
-    const float* xbase[4]; int64_t xld; int xoff; int64_t xbytes;   // xbytes = size of one x table (< 4 GB)
-    const int32_t* ids;      // GRU: [n_rows, L]
-    const int32_t* slots; int64_t slots_stride;    // AUGRU: [n_seq][n_rows/group]
-    const float* wg[4]; const float* wc[4];
-    const float* att; int64_t att_stride;          // AUGRU: [n_seq][att_stride] rows of L
-    float* out; int64_t out_ld; int out_off; int out_seq_off;   // GRU: h1 cache rows ; AUGRU: allf
-    int slot_base;
-    unsigned long long* trace;   // -DRL4RS_H16_TRACE timing experiments only
-    int* range_flag;             // k_augru_h16: set to 1 when a state leaves the fp16 range (|h| >= 6e4 or NaN)
-    int hard_gates;              // GRU mode: keras hard_sigmoid gates (simnet.hpp) instead of sigmoid
-    int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
-    const int32_t* order;        // k_augru_x: processing order of the row groups (NULL = identity)
-    int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
-    // fp16x2 AUGRU kernels: every 32-column tile of the reset / update / candidate weight matrices (and the same columns of the
-    // cached x-side projections, biases folded) is stored multiplied by its own power of two s (rl4rs_dien_create: max |w| * s in
-    // [2^13, 2^14) over the tile), so the fp16 hi + lo split keeps its 22 bits whatever the scale of a checkpoint's weights, no
-    // weight is "too large for fp16", and an outlier costs precision in its own tile only.  A wave owns exactly one tile per
-    // gate, so its three constants are wave-uniform scalars.  The pre-activation is acc / s; the division rides on the constant
-    // the activation multiplies by anyway: sigmoid(acc / s) = 1 / (1 + exp2(acc * k)), k = -log2(e) / s; tanh: k = 2 log2(e) / s -
-    // exact (powers of two), same instruction count.
-    float k_r[4][8], k_u[4][8], k_c[4][8];         // [sequence input][column tile = wave]
-    // k_recur<..., SAVE = true> (training forward, recur_train.hpp): per sequence input the attention rows [n_rows, L] (NULL = 0:
-    // a plain GRU) and, per (row, step), everything BPTT needs - reset gate, update gate BEFORE the attention factor, candidate,
-    // new state, r * h_prev - each [n_rows * L, NH] row-major.
-    const float* sv_att[4];
-    float *sv_r[4], *sv_u[4], *sv_c[4], *sv_h[4], *sv_rh[4];
-    int sv_blk[3];               // SAVE: column block of the r / u / c pre-activations inside a row of xbase (TF cells 0,1,2; keras GRU 1,0,2)
-};
 
 #ifndef RL4RS_FAST_ACT
 #define RL4RS_FAST_ACT 1
@@ -506,9 +447,6 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
     return 1.f / (1.f + expf(-x));
 #endif
 }
-// activations of a pre-activation that is stored scaled by a power of two (k = -log2(e) / s resp. 2 log2(e) / s, RecurArgs)
-__device__ __forceinline__ float gate_sigmoid_k(float x, float k) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * x)); }
-__device__ __forceinline__ float gate_tanh_k(float x, float k) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * x)); }
 __device__ __forceinline__ float gate_tanh(float x) {
 #if RL4RS_FAST_ACT
     // 1 - 2/(exp(2x)+1); exp2 saturates cleanly to 0 / inf
@@ -741,10 +679,6 @@ __global__ __launch_bounds__(NH * 2) void k_recur(RecurArgs a) {
 // (fp32 keeps 2^-24); products are exact in the fp32 accumulator.  h and r*h live in (-1,1), so the un-scaled lo parts
 // only reach fp16 subnormals (absolute error <= 2^-25) - no scaling needed; the weights are range-checked at load.
 // The matrix pipe runs this 16/3 = 5.3x faster than the fp32 form at the SAME weight bytes (2 planes x 2 B).
-__device__ __forceinline__ half8_t buf_load_h8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-    auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-    return __builtin_bit_cast(half8_t, v);
-}
 
 // Schedule ("gate-sliced", MT row tiles of 32 rows per workgroup, wave w owns hidden columns [32w, 32w+32)):
 //   one step = 3*KB weight items (gate g = r,u,c ; k-block kb), each item = 3*MT MFMAs on ONE weight fragment pair
@@ -1000,9 +934,9 @@ __global__ __launch_bounds__(512) void k_augru_h16(RecurArgs a) {
     if (out_of_range && a.range_flag) atomicOr(a.range_flag, 1);
 }
 
-}  // namespace rl4rs
-#include "augru_x.hpp"
-namespace rl4rs {
+// k_augru_x (augru_x.hpp) lives in its own translation unit, augru_x.hip (built WITH SLP vectorisation, see there)
+int augru_x_prepare();
+void augru_x_launch(int rows_per_wg, int n_seq, hipStream_t st, const RecurArgs& a);
 
 // -------------------------------------------------------------------------------------------------
 // First-layer GRU with the same fp16x2 operand splitting (scorer_mode fp16x2): NH = E = 128, 4 waves, 32 rows per
@@ -1901,8 +1835,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
         for (const void* f : augru_variants)
             if ((rc = raise_dyn_smem(f, sm_aug))) return rc;
         if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), augru_h16_smem(1, NH2, L)))) return rc;
-        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), augru_x_smem(1)))) return rc;
-        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), augru_x_smem(2)))) return rc;
+        if ((rc = augru_x_prepare())) return rc;
         if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur<128, false, GRU_U>), sm_gru))) return rc;
         if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_din_x), din_x_smem()))) return rc;
         if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_din_scores<true, false>), 96 * 1024))) return rc;
@@ -2073,10 +2006,8 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
             // (n->augru_rows = 32 / 64 pins the form: rl4rs_dien_cfg.kernel_opts, rl4rs_dien_set_augru_rows)
             const bool mt2 = n->augru_rows != 32 && group % 8 == 0 && R % 64 == 0 &&
                              (n->augru_rows == 64 || (int64_t)(R / 64) * S >= 2 * (int64_t)n->n_cu);
-            if (n->augru_x && mt2)
-                hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), dim3(R / 64, S), block, augru_x_smem(2), st, a);
-            else if (n->augru_x)
-                hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), grid, block, augru_x_smem(1), st, a);
+            if (n->augru_x)
+                augru_x_launch(mt2 ? 64 : 32, S, st, a);
             else
                 hipLaunchKernelGGL((k_augru_h16<1, RL4RS_H16_RING1, RL4RS_H16_NRES>), grid, block, augru_h16_smem(1, NH2, L), st, a);
         } else
