@@ -664,6 +664,12 @@ int rl4rs_simtrain_step(rl4rs_simtrain* tr, int32_t N, const float* dense_dev, c
  *     per sequence input: gru_gate_w, gru_gate_b, gru_cand_w, gru_cand_b, att_w1, att_b1, att_w2, att_b2, att_w3, att_b3,
  *                         augru_gate_w, augru_gate_b, augru_cand_w, augru_cand_b ]
  * Arguments of grad / step as for rl4rs_simtrain_grad / rl4rs_simtrain_step (seq_dev is required). */
+/* Row-tile form of the persistent training recurrences (the GRU / AUGRU layers of rl4rs_dientrain_* and of the lstm family of
+ * rl4rs_simtrain_*; reference: model.fit with batch_size 256, script/supervised_train.py:12-46): 0 = automatic (8-row workgroups
+ * on v_mfma_f32_4x4x1 while 32-row ones would occupy fewer than half of the CUs - a 256-sample minibatch is 64 workgroups
+ * instead of 16), 8 or 32 = pinned.  Process-wide; same arithmetic up to the summation order of a dot product. */
+int rl4rs_recur_train_set_rows(int32_t rows);
+
 typedef struct rl4rs_dientrain rl4rs_dientrain;
 int rl4rs_dientrain_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, int32_t max_batch, void* stream,
                            rl4rs_dientrain** out);

@@ -1,0 +1,448 @@
+// Small-tile forms of the persistent TRAINING recurrences (included by recur_train.hpp, compiled into dien.hip).
+//
+// Why: script/supervised_train.py:12-46 trains with batch 256.  In 32-row tiles (k_recur<NH, SAVE>, k_recur_bwd<NH>) that is
+// 8 workgroups per sequence input - 16 of 256 CUs for the DIEN cells - each MFMA-bound per CU: one AUGRU step is a
+// [32 x 256] x [256 x 768] fp32 product = 12.6 MFLOP at the 0.61 TF/s of ONE CU = 20 us of the 27 us a step takes, times 64
+// dependent steps.  The step time does not depend on how many CUs run, so the only lever is a smaller tile:
+// v_mfma_f32_4x4x1_16B_f32 multiplies a 4-ROW tile at close to the full fp32 matrix rate (tools/mfma_4x4_probe.hip:
+// A = X[lane % 4][k] the same for all 16 blocks, B = W[k][lane] = 64 distinct columns, register i of lane l = out[i][l]).
+//
+//   workgroup = 8 rows (two 4-row tiles) of ONE sequence input, 4 waves (one per SIMD);
+//   NH = 256: wave w owns hidden columns [64w, 64w + 64) of all three gates for BOTH tiles (every weight fragment is fetched once per
+//             workgroup and step: 786 KB through the 64 B/clk L1 return path = 12.3 k cycles, beside 1536 MFMAs per wave);
+//   NH = 128: wave (w & 1) owns 64 hidden columns, wave >> 1 picks the tile (weights fetched twice: 393 KB per step);
+//   a lane owns ONE hidden column: 4 rows of a tile in the 4 registers of an accumulator, so every gate / blend is a
+//   per-register scalar op, the saved tensors leave as 256-byte coalesced row segments, and h / r*h go to LDS as plain
+//   [8][NH + 4] rows (A operand = ds_read_b128 of 4 consecutive k of row lane % 4: four broadcast addresses, conflict-free);
+//   weights are read from the SAME fragment-order buffers the 32-row kernels use (launch_pack_frag): the 16-byte entry of
+//   (32-column tile, k-block, half, column) holds 4 consecutive k of one column - a wave's b128 load is two contiguous 512-byte
+//   pieces;
+//   independent accumulator chains (>= 4 per wave and phase: x4x1 MFMAs are 2 passes, a dependent one would stall), the x-side
+//   pre-activations enter as the first chain's initial value (MFMA C-in), weights stream through a 4-deep register ring that runs
+//   across phases and steps (they do not depend on the recurrence).
+// 256 samples x 2 inputs = 64 workgroups instead of 16.  Same equations, same saved quantities, same argument structs as the
+// 32-row forms; the launchers in recur_train.hpp pick the form from the grid it would fill.
+#pragma once
+#include <type_traits>
+
+namespace rl4rs {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+namespace r8 {
+constexpr int RW = 8;           // rows per workgroup
+constexpr int RS = 16;          // weight ring: 16-byte loads in flight per wave (64 registers), refilled in consumption order
+
+// byte offset of lane l's 16-byte weight entry inside a (column-group of 64, kq) slot of a fragment-order buffer with KB k-blocks:
+// tile nt = 2 * group + (l >> 5) -> + (l >> 5) * KB * 1024 ; column (l & 31) -> + (l & 31) * 16 ; (kb, half) = kq -> + kq * 512 (scalar)
+__device__ __forceinline__ int lane_off(int lane, int KB) { return (lane >> 5) * KB * 1024 + (lane & 31) * 16; }
+
+__device__ __forceinline__ float4 ldw(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    struct b4 { float x, y, z, w; } f = __builtin_bit_cast(b4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ float el(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float hard_sig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
+
+// One product phase of a wave: acc[g][m][chain] += A[tile m rows][k] * W_g[k][own 64 columns] over NQ quads of k.
+//   A: LDS rows (aptr[m] = row (lane & 3) of tile m), read one quad ahead into a ping-pong pair;
+//   W: NG weight streams consumed quad by quad through the RS-slot register ring: the slot an MFMA group has just used is
+//   refilled at once with the load RS positions further down the stream - `cur(q, g)` inside this phase, `next(i)` = the i-th
+//   load of the FOLLOWING phase's stream during the last round (weights do not depend on the recurrence, so the ring runs
+//   across phases and steps).  sched_barriers pin that order: left alone, the compiler sinks every load to its use and waits
+//   with vmcnt(0) in front of each MFMA group (seen in the ISA of the first version of this file: 2x slower).
+template <int NQ, int NG, int MTW, int P, typename CurLd, typename NextLd>
+__device__ __forceinline__ void phase(f32x4_t (&acc)[NG][MTW][P], const float* (&aptr)[MTW], float4 (&ring)[RS], CurLd cur, NextLd next) {
+    constexpr int QR = RS / NG, ROUNDS = NQ / QR, PR = QR / 2;
+    static_assert(NQ % QR == 0 && QR % 4 == 0 && ROUNDS >= 1, "ring rounds");
+    // A is read a PAIR of quads ahead (two quads of 8 - 16 MFMAs each cover the LDS round trip; one did not in the single-stream
+    // phases: 88 cycles of MFMAs against ~100 of latency)
+    float4 ab[2][2][MTW];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) ab[0][k][m] = *reinterpret_cast<const float4*>(aptr[m] + k * 4);
+    auto round = [&](int q0, auto last_tag) {
+        constexpr bool last = decltype(last_tag)::value;
+#pragma unroll
+        for (int ip = 0; ip < PR; ++ip) {
+            if (!(last && ip == PR - 1)) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        ab[(ip + 1) & 1][k][m] = *reinterpret_cast<const float4*>(aptr[m] + (q0 + 2 * ip + 2 + k) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = 2 * ip + k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][m][j % P] = __builtin_amdgcn_mfma_f32_4x4x1f32(el(ab[ip & 1][k][m], j), el(ring[i * NG + g], j), acc[g][m][j % P], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) ring[i * NG + g] = last ? next(i * NG + g) : cur(q0 + i + QR, g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS - 1; ++r) round(r * QR, std::false_type());
+    round((ROUNDS - 1) * QR, std::true_type());
+}
+}  // namespace r8
+
+// ------------------------------------------------------------------------------------------------------------------ forward
+// RecurArgs as k_recur<NH, true, U, 0, true> takes them (recur_train_fwd_t): xbase = [N * L, 3 NH] pre-activations, row n reads
+// row block n; wg / wc in fragment order; sv_* outputs; sv_att NULL = plain GRU; hard_gates; sv_blk.
+template <int NH>
+__global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
+    using namespace r8;
+    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB = NH / 8, NQ = NH / 4, LDH = NH + 4, NWT = NH / 32;
+    constexpr int P1 = (2 * MTW >= 4) ? 1 : 2, P2 = 4 / MTW;     // accumulator chains per (gate, tile) in phase 1 / 2
+    static_assert(NH == 128 || NH == 256, "hidden width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hb = reinterpret_cast<float*>(smem);                  // [8][LDH]  h_{t-1}
+    float* rhb = hb + RW * LDH;                                  // [8][LDH]  r * h_{t-1}
+    float* s_att = rhb + RW * LDH;                               // [8][L + 1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave % NCW, mt0 = (wave / NCW) * MTW;
+    const int row0 = blockIdx.x * RW, sq = blockIdx.y;
+    const int L = a.L, LDT = L + 1;
+    const int col = cw * 64 + lane;
+    const int xld4 = 3 * NH * 4;
+
+    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
+    const int vlw = lane_off(lane, KB);
+    const int so_r = (2 * cw) * KB * 1024, so_u = (NWT + 2 * cw) * KB * 1024, so_c = (2 * cw) * KB * 1024;     // + kq * 512
+
+    for (int i = tid; i < RW * LDH; i += 256) hb[i] = 0.f;
+    for (int i = tid; i < RW * L; i += 256) {
+        const int r = i / L, t = i - r * L;
+        const int gr = min(row0 + r, a.n_rows - 1);
+        s_att[r * LDT + t] = a.sv_att[sq] ? a.sv_att[sq][(size_t)gr * L + t] : 0.f;
+    }
+    // per (tile, row): byte offset of the row's x pre-activations at t = 0 (own column), flat index of its saved element at t = 0
+    int xo[MTW][4];
+    size_t so[MTW][4];
+    bool live[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (mt0 + m) * 4 + i;
+            const int gr = min(row0 + row, a.n_rows - 1);
+            xo[m][i] = gr * L * xld4 + col * 4;
+            so[m][i] = (size_t)gr * L * NH + col;
+            live[m][i] = row0 + row < a.n_rows;
+        }
+    const int blk_r = a.sv_blk[0] * NH * 4, blk_u = a.sv_blk[1] * NH * 4, blk_c = a.sv_blk[2] * NH * 4;
+    const float* arow[MTW];
+    const float* rrow[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        arow[m] = hb + ((mt0 + m) * 4 + (lane & 3)) * LDH;
+        rrow[m] = rhb + ((mt0 + m) * 4 + (lane & 3)) * LDH;
+    }
+    f32x4_t h_own[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) h_own[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    float xr_[MTW][4], xu_[MTW][4], xc_[MTW][4];
+    auto load_x = [&](float (&dst)[MTW][4], int t, int blk) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dst[m][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, xo[m][i], t * xld4 + blk, 0));
+    };
+    // weight streams: phase 1 consumes (q, r), (q, u), (q + 1, r), ... ; phase 2 (q) of the candidate matrix
+    float4 ring[RS];
+    auto ld1 = [&](int q, int g) { return ldw(rs_wg, vlw, (g == 0 ? so_r : so_u) + q * 512); };
+    auto ld2 = [&](int q, int) { return ldw(rs_wc, vlw, so_c + q * 512); };
+    auto head1 = [&](int i) { return ld1(i >> 1, i & 1); };
+    auto head2 = [&](int i) { return ld2(i, 0); };
+#pragma unroll
+    for (int i = 0; i < RS; ++i) ring[i] = head1(i);
+    load_x(xr_, 0, blk_r);
+    load_x(xu_, 0, blk_u);
+    __syncthreads();
+
+    for (int t = 0; t < L; ++t) {
+        // ---- phase 1: [r | u] pre-activations = x + h W
+        f32x4_t a1[2][MTW][P1];                       // [r | u][tile][chain]
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < P1; ++p) {
+                a1[0][m][p] = p == 0 ? f32x4_t{xr_[m][0], xr_[m][1], xr_[m][2], xr_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                a1[1][m][p] = p == 0 ? f32x4_t{xu_[m][0], xu_[m][1], xu_[m][2], xu_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        phase<NQ, 2, MTW, P1>(a1, arow, ring, ld1, head2);
+        // candidate x-side pre-activations: consumed after phase 2.  Requested HERE (vmcnt retires in order: the first weight wait
+        // behind these loads is an epilogue + a barrier + a ring depth of MFMAs away)
+        load_x(xc_, t, blk_c);
+        f32x4_t ug[MTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            f32x4_t pr = a1[0][m][0], pu = a1[1][m][0];
+#pragma unroll
+            for (int p = 1; p < P1; ++p) { pr += a1[0][m][p]; pu += a1[1][m][p]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rg = a.hard_gates ? hard_sig(pr[i]) : gate_sigmoid(pr[i]);
+                const float u = a.hard_gates ? hard_sig(pu[i]) : gate_sigmoid(pu[i]);
+                const float rh = rg * h_own[m][i];
+                ug[m][i] = u;
+                rhb[((mt0 + m) * 4 + i) * LDH + col] = rh;
+                if (live[m][i]) {
+                    const size_t si = so[m][i] + (size_t)t * NH;
+                    a.sv_r[sq][si] = rg;
+                    a.sv_u[sq][si] = u;
+                    a.sv_rh[sq][si] = rh;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: candidate pre-activation = x + (r h) Wc, then the state update
+        f32x4_t a2[1][MTW][P2];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < P2; ++p)
+                a2[0][m][p] = p == 0 ? f32x4_t{xc_[m][0], xc_[m][1], xc_[m][2], xc_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        phase<NQ, 1, MTW, P2>(a2, rrow, ring, ld2, head1);
+        if (t + 1 < L) {                              // the next step's gate pre-activations (become its accumulators' initial values)
+            load_x(xr_, t + 1, blk_r);
+            load_x(xu_, t + 1, blk_u);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            f32x4_t pc = a2[0][m][0];
+#pragma unroll
+            for (int p = 1; p < P2; ++p) pc += a2[0][m][p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (mt0 + m) * 4 + i;
+                const float c = gate_tanh(pc[i]);
+                const float u = (1.0f - s_att[row * LDT + t]) * ug[m][i];
+                const float hn = u * h_own[m][i] + (1.0f - u) * c;
+                h_own[m][i] = hn;
+                hb[row * LDH + col] = hn;
+                if (live[m][i]) {
+                    const size_t si = so[m][i] + (size_t)t * NH;
+                    a.sv_c[sq][si] = c;
+                    a.sv_h[sq][si] = hn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+inline size_t recur8_fwd_smem(int NH, int L) { return (size_t)(2 * 8 * (NH + 4) + 8 * (L + 1)) * 4; }
+
+// ----------------------------------------------------------------------------------------------------------------- backward
+// RecurBwdArgs as k_recur_bwd<NH> takes them; the same per-step equations (header of recur_train.hpp).
+// A FIFTH wave does nothing but fetch: while the four matrix waves work on step t it stages step t - 1's rows of the saved
+// tensors (R, U, C, H_{t-2}, the per-step upstream gradient) in LDS.  The matrix waves used to load those 32 - 40 values per lane
+// at the top of every step and use them at once - a full memory round trip in front of each step's first product (16.7 us per
+// AUGRU step against 9.9 us forwards with the same MFMA count), and vmcnt retires in order, so requesting them earlier from the
+// same wave would only move the stall into the weight ring.  The loader's waits are its own.
+template <int NH>
+__global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
+    using namespace r8;
+    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB1 = NH / 8, KB2 = 2 * NH / 8, NQ1 = NH / 4, NQ2 = 2 * NH / 4;
+    constexpr int LDA = NH + 4, LDG = 2 * NH + 4, PC = 4 / MTW;        // accumulator chains per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tA = reinterpret_cast<float*>(smem);          // [8][LDA]   dAc (A operand of the first product)
+    float* tG = tA + RW * LDA;                           // [8][LDG]   [dAg_r | dAg_u] (A operand of the second product)
+    float* s_att = tG + RW * LDG;                        // [8][L + 1]
+    float* s_red = s_att + RW * (a.L + 1);               // [NCW][8]   per-wave partial row sums of -dup u
+    float* stage = s_red + NCW * RW;                     // [5][8][NH] R, U, C, H_prev, upstream of the step about to be processed
+    constexpr int ST = RW * NH, LDR = NH + 8;
+    float* s_rv = stage + 5 * ST;                        // [8][LDR]   -dup u of every (row, column): the loader wave sums the rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * RW, sq = blockIdx.y;
+    const int L = a.L, LDT = L + 1;
+    const bool aug = a.att[sq] != nullptr;
+    for (int i = tid; i < RW * L; i += 320) {
+        const int r = i / L, t = i - r * L;
+        const int gr = min(row0 + r, a.n_rows - 1);
+        s_att[r * LDT + t] = aug ? a.att[sq][(size_t)gr * L + t] : 0.f;
+    }
+    if (wave == 4) {
+        // ---- loader wave: float4 k of lane l covers element 4 * (l + 64 k) of an [8][NH] tile
+        constexpr int NV = ST / 4 / 64;                  // float4 per lane and array (4 at NH = 128, 8 at NH = 256)
+        const float* src[5] = {a.R[sq], a.U[sq], a.C[sq], a.H[sq], a.up_all[sq]};
+        // the rows of step tt (H of step tt - 1) are requested a whole step before they are needed and wait in registers: their memory
+        // round trip overlaps a full step of the matrix waves, and this wave's barriers do not wait for loads in flight
+        float4 v[5][NV];
+        auto request = [&](int tt) {
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr) {
+                const bool zero = src[arr] == nullptr || (arr == 3 && tt == 0);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int e = (lane + 64 * k) * 4, r = e / NH, c = e - r * NH;
+                    const int gr = min(row0 + r, a.n_rows - 1);
+                    const int ts = arr == 3 ? tt - 1 : tt;
+                    v[arr][k] = zero ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                     : *reinterpret_cast<const float4*>(src[arr] + ((size_t)gr * L + ts) * NH + c);
+                }
+            }
+        };
+        auto deposit = [&]() {
+#pragma unroll
+            for (int arr = 0; arr < 5; ++arr)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) *reinterpret_cast<float4*>(stage + arr * ST + (lane + 64 * k) * 4) = v[arr][k];
+        };
+        request(L - 1);
+        deposit();
+        if (L > 1) request(L - 2);
+        __syncthreads();
+        for (int t = L - 1; t >= 0; --t) {
+            __syncthreads();                             // the matrix waves have taken step t out of the stage
+            if (aug && a.d_score[sq]) {
+                // d a_t of a row = sum over ALL hidden columns of -dup u: 8 lanes per row, NH / 8 values each, then three shuffle
+                // steps - a fixed order, off the matrix waves' critical path
+                const int r = lane >> 3, c0 = lane & 7;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < NH / 8; ++j) sum += s_rv[r * LDR + c0 + 8 * j];
+                sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 2);
+                sum += __shfl_xor(sum, 1);
+                if (c0 == 0 && row0 + r < a.n_rows) a.d_score[sq][(size_t)(row0 + r) * L + t] = sum;
+            }
+            if (t > 0) deposit();                        // step t - 1, requested during step t + 1
+            if (t > 1) request(t - 2);
+            __syncthreads();
+        }
+        return;
+    }
+    const int cw = wave % NCW, mt0 = (wave / NCW) * MTW;
+    const int col = cw * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wcT[sq]), 0, NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wgT[sq]), 0, 2 * NH * NH * 4, 0x00020000);
+    const int vl1 = lane_off(lane, KB1), vl2 = lane_off(lane, KB2);
+    const int so_c = (2 * cw) * KB1 * 1024, so_g = (2 * cw) * KB2 * 1024;       // this wave's 64 output columns; + kq * 512
+    size_t so[MTW][4];
+    int grow_[MTW][4];
+    bool live[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (mt0 + m) * 4 + i;
+            const int gr = min(row0 + row, a.n_rows - 1);
+            grow_[m][i] = gr;
+            so[m][i] = (size_t)gr * L * NH + col;
+            live[m][i] = row0 + row < a.n_rows;
+        }
+    const float* arow[MTW];
+    const float* grw[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        arow[m] = tA + ((mt0 + m) * 4 + (lane & 3)) * LDA;
+        grw[m] = tG + ((mt0 + m) * 4 + (lane & 3)) * LDG;
+    }
+    f32x4_t dh[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) dh[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float4 ring[RS];
+    auto ldc = [&](int q, int) { return ldw(rs_c, vl1, so_c + q * 512); };
+    auto ldg = [&](int q, int) { return ldw(rs_g, vl2, so_g + q * 512); };
+    auto headc = [&](int i) { return ldc(i, 0); };
+    auto headg = [&](int i) { return ldg(i, 0); };
+#pragma unroll
+    for (int i = 0; i < RS; ++i) ring[i] = headc(i);
+    __syncthreads();
+
+    for (int t = L - 1; t >= 0; --t) {
+        float dd[MTW][4], up[MTW][4], rg[MTW][4], hp[MTW][4], dagu[MTW][4];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (mt0 + m) * 4 + i;
+                const int sx = row * NH + col;
+                const float u = stage[ST + sx], c = stage[2 * ST + sx];
+                rg[m][i] = stage[sx];
+                hp[m][i] = stage[3 * ST + sx];
+                const float at = s_att[row * LDT + t];
+                float d = dh[m][i] + stage[4 * ST + sx];
+                if (t == L - 1 && a.up_last[sq]) d += a.up_last[sq][(size_t)grow_[m][i] * a.ld_up + col];
+                dd[m][i] = d;
+                up[m][i] = (1.0f - at) * u;
+                const float dac = d * (1.0f - up[m][i]) * (1.0f - c * c);
+                const float dup = d * (hp[m][i] - c);
+                dagu[m][i] = dup * (1.0f - at) * (a.hard ? ((u > 0.f && u < 1.f) ? 0.2f : 0.f) : u * (1.0f - u));
+                tA[row * LDA + col] = dac;
+                if (live[m][i]) a.dc[sq][((size_t)grow_[m][i] * L + t) * a.ld_c + col] = dac;
+                if (aug) s_rv[row * LDR + col] = -dup * u;                 // summed over the columns by the loader wave
+            }
+        __syncthreads();
+        // ---- d(r h) = dAc Wc_h^T
+        f32x4_t acc[1][MTW][PC];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < PC; ++p) acc[0][m][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        phase<NQ1, 1, MTW, PC>(acc, arow, ring, ldc, headg);
+        float dhp[MTW][4];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            f32x4_t s = acc[0][m][0];
+#pragma unroll
+            for (int p = 1; p < PC; ++p) s += acc[0][m][p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (mt0 + m) * 4 + i;
+                const float drh = s[i];
+                const float r = rg[m][i];
+                const float dagr = drh * hp[m][i] * (a.hard ? ((r > 0.f && r < 1.f) ? 0.2f : 0.f) : r * (1.0f - r));
+                dhp[m][i] = dd[m][i] * up[m][i] + drh * r;
+                tG[row * LDG + col] = dagr;
+                tG[row * LDG + NH + col] = dagu[m][i];
+                if (live[m][i]) {
+                    const size_t gi = ((size_t)grow_[m][i] * L + t) * a.ld_g + col;
+                    a.dr[sq][gi] = dagr;
+                    a.du[sq][gi] = dagu[m][i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dh_{t-1} = dhp + [dAg_r | dAg_u] Wg_h^T   (computed at t = 0 as well, unused there: the ring stays in step)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < PC; ++p) acc[0][m][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        phase<NQ2, 1, MTW, PC>(acc, grw, ring, ldg, headc);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            f32x4_t s = acc[0][m][0];
+#pragma unroll
+            for (int p = 1; p < PC; ++p) s += acc[0][m][p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dh[m][i] = dhp[m][i] + (t > 0 ? s[i] : 0.f);
+        }
+        // (tA is read before this step's second barrier and written after the NEXT step's loads; tG and s_red are read before
+        // the next step's first barrier and written after it / after this step's second barrier: no further barrier needed)
+    }
+}
+
+inline size_t recur8_bwd_smem(int NH, int L) { return (size_t)(8 * (NH + 4) + 8 * (2 * NH + 4) + 8 * (L + 1) + (NH / 64) * 8 + 5 * 8 * NH + 8 * (NH + 8)) * 4; }
+
+}  // namespace rl4rs

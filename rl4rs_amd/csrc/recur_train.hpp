@@ -189,6 +189,27 @@ __global__ __launch_bounds__(NH * 2) void k_recur_bwd(RecurBwdArgs a) {
 
 inline size_t recur_bwd_smem(int NH, int L) { return (size_t)(32 * (NH + 4) + 32 * (2 * NH + 4) + 32 * (L + 1) + (NH / 32) * 32) * 4; }
 
+}  // namespace rl4rs
+#include "recur8.hpp"
+namespace rl4rs {
+
+// Which tile form a training recurrence takes: 0 = by the grid it would fill (8-row workgroups while 32-row ones would occupy
+// fewer than half of the CUs), 8 / 32 = pinned (rl4rs_recur_train_set_rows: tests and A/B runs).
+static int g_recur_train_rows = 0;
+static int recur_train_n_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t pr;
+        n_cu = (hipGetDeviceProperties(&pr, current_device()) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+static bool recur_train_small(int N, int S) {
+    if (g_recur_train_rows == 8) return true;
+    if (g_recur_train_rows == 32) return false;
+    return (int64_t)((N + 31) / 32) * S * 2 <= recur_train_n_cu();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // launchers (declared in common.hpp; dientrain.hpp lives in another translation unit)
 int launch_pack_frag(const float* w, int64_t ld, int k_off, int K, int N, int transpose, float* out, hipStream_t st) {
@@ -229,6 +250,13 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
     }
     a.hard_gates = f.hard;
     for (int b = 0; b < 3; ++b) a.sv_blk[b] = f.xblk[b];
+    if (recur_train_small(f.N, f.S)) {
+        for (int s = 0; s < f.S; ++s)
+            if (!a.sv_r[s] || !a.sv_u[s] || !a.sv_c[s] || !a.sv_h[s] || !a.sv_rh[s]) { set_error("recur_train_fwd: a saved-tensor pointer is NULL"); return RL4RS_EINVAL; }
+        hipLaunchKernelGGL((k_recur8_fwd<NH>), dim3((f.N + 7) / 8, f.S), dim3(256), recur8_fwd_smem(NH, f.L), st, a);     // < 64 KB: no opt-in
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     hipLaunchKernelGGL((k_recur<NH, true, 2, 0, true>), dim3((f.N + 31) / 32, f.S), dim3(NH * 2), smem, st, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
@@ -263,10 +291,32 @@ static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
         a.dr[s] = b.dr[s]; a.du[s] = b.du[s]; a.dc[s] = b.dc[s]; a.d_score[s] = b.d_score[s];
     }
     a.ld_g = b.ld_g; a.ld_c = b.ld_c; a.hard = b.hard;
+    if (recur_train_small(b.N, b.S)) {
+        static bool attr8 = false;
+        if (!attr8) {
+            int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_bwd<NH>), recur8_bwd_smem(NH, 64));
+            if (rca) return rca;
+            attr8 = true;
+        }
+        hipLaunchKernelGGL((k_recur8_bwd<NH>), dim3((b.N + 7) / 8, b.S), dim3(320), recur8_bwd_smem(NH, b.L), st, a);
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     hipLaunchKernelGGL((k_recur_bwd<NH>), dim3((b.N + 31) / 32, b.S), dim3(NH * 2), smem, st, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
+
+}  // namespace rl4rs
+
+// include/rl4rs_hip.h: pin the row-tile form of the persistent training recurrences (0 automatic, 8, 32); returns the previous value
+extern "C" int rl4rs_recur_train_set_rows(int32_t rows) {
+    if (rows != 0 && rows != 8 && rows != 32) { rl4rs::set_error("rl4rs_recur_train_set_rows: %d (0 = automatic, 8, 32)", rows); return RL4RS_EINVAL; }
+    rl4rs::g_recur_train_rows = rows;
+    return RL4RS_OK;
+}
+
+namespace rl4rs {
 
 int launch_recur_train_bwd(const RecurTrainBwd& b, hipStream_t st) {
     if (b.S < 1 || b.S > 4 || b.L < 1 || b.L > 64) {

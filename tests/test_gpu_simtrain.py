@@ -17,10 +17,37 @@ def _batch(N, rs):
     return dense, cat, labels
 
 
+@pytest.fixture
+def recur_rows():
+    """pins the row-tile form of the persistent training recurrences for one test (rl4rs_recur_train_set_rows), automatic afterwards"""
+    from rl4rs_amd import _lib
+
+    def pin(rows):
+        _lib.check(_lib.load().rl4rs_recur_train_set_rows(rows))
+    yield pin
+    pin(0)
+
+
 @pytest.mark.parametrize('algo', ['dnn', 'widedeep', 'lstm'])
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 @pytest.mark.parametrize('N', [256, 700])
 def test_gradients_match_autograd(algo, rate, N):
+    _check_simnet_gradients(algo, rate, N)
+
+
+@pytest.mark.parametrize('rows', [8, 32])
+@pytest.mark.parametrize('N', [256, 203])
+def test_lstm_gradients_in_both_recurrence_tile_forms(recur_rows, rows, N):
+    """the keras GRUs of the lstm family through the 8-row (v_mfma_f32_4x4x1, recur8.hpp) and the 32-row persistent recurrences,
+    each against float64 autograd at the same bar; 203 rows: ragged last tile of both forms"""
+    from rl4rs_amd import _lib
+    recur_rows(rows)
+    _check_simnet_gradients('lstm', 0.2, N)
+    with pytest.raises(_lib.Rl4rsHipError):
+        recur_rows(16)
+
+
+def _check_simnet_gradients(algo, rate, N):
     import torch
     from rl4rs_amd.nets.simnets import init_simnet_weights
     from rl4rs_amd.device import DeviceSimTrainer
@@ -159,12 +186,23 @@ DIEN_CFG = {"maxlen": 64, "class_num": 2, "dense_feature_num": 432, "category_fe
 def test_dien_gradients_match_autograd(rate):
     """rl4rs_dientrain_grad: every parameter gradient of the DIEN training step (head, category self-attention, dense tower
     with dropout, attention MLP, AUGRU and first-GRU BPTT, both embedding tables) against torch float64 autograd."""
+    _check_dien_gradients(rate, 40)
+
+
+@pytest.mark.parametrize('rows', [8, 32])
+@pytest.mark.parametrize('N', [40, 43])
+def test_dien_gradients_in_both_recurrence_tile_forms(recur_rows, rows, N):
+    """the first GRU (Hd = 128) and the AUGRU (Hd = 256) with their BPTT through the 8-row and the 32-row persistent kernels"""
+    recur_rows(rows)
+    _check_dien_gradients(0.2, N)
+
+
+def _check_dien_gradients(rate, N):
     import torch
     from rl4rs_amd.nets.dien import init_dien_weights
     from rl4rs_amd.device import DeviceDienTrainer
     from oracle.dien import loss_and_grad
     rs = np.random.RandomState(7)
-    N = 40
     w = init_dien_weights(DIEN_CFG, seed=3, emb_scale=0.5, bias_noise=0.2)
     dense, cat, labels = _batch(N, rs)
     cat[:, 10:] = rs.randint(0, 284, size=(N, 11))

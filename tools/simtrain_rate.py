@@ -17,7 +17,10 @@ dense = t(np.abs(rs.randn(N, 432)).astype(np.float32))
 cat = t(rs.randint(0, 284, size=(N, 21)).astype(np.int32))
 labels = t(rs.randint(0, 2, size=N).astype(np.int32))
 seqs = [t(rs.randint(0, 284, size=(N, 64)).astype(np.int32)) for _ in range(2)]
-for algo in ('dnn', 'widedeep', 'lstm', 'dien'):
+# RECUR_ROWS=8|32 pins the row-tile form of the persistent recurrences (default: automatic); ALGOS=lstm,dien restricts the families
+from rl4rs_amd import _lib
+_lib.check(_lib.load().rl4rs_recur_train_set_rows(int(os.environ.get('RECUR_ROWS', '0'))))
+for algo in os.environ.get('ALGOS', 'dnn,widedeep,lstm,dien').split(','):
     if algo == 'dien':
         tr = DeviceDienTrainer(CFG, init_dien_weights(CFG, seed=1), max_batch=N)
     else:
