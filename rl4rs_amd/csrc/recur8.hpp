@@ -101,51 +101,101 @@ __device__ __forceinline__ void phase(f32x4_t (&acc)[NG][MTW][P], const float* (
 // ------------------------------------------------------------------------------------------------------------------ forward
 // RecurArgs as k_recur<NH, true, U, 0, true> takes them (recur_train_fwd_t): xbase = [N * L, 3 NH] pre-activations, row n reads
 // row block n; wg / wc in fragment order; sv_* outputs; sv_att NULL = plain GRU; hard_gates; sv_blk.
+// A FIFTH wave moves everything that is not a weight: it requests the x-side pre-activations a whole step ahead (they wait in its
+// registers, then go to an LDS stage the matrix waves take their accumulators' initial values from) and copies the saved r, u,
+// r*h, c, h tiles of a step from LDS to memory.  The matrix waves issue no global load but their weight ring and no global store:
+// vmcnt retires in order, so every x load or store in their queue was a wait in front of the ring (9.9 -> 8.x us per AUGRU step).
 template <int NH>
-__global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
+__global__ __launch_bounds__(320) void k_recur8_fwd(RecurArgs a) {
     using namespace r8;
-    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB = NH / 8, NQ = NH / 4, LDH = NH + 4, NWT = NH / 32;
+    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB = NH / 8, NQ = NH / 4, LDH = NH + 4, NWT = NH / 32, ST = RW * NH;
     constexpr int P1 = (2 * MTW >= 4) ? 1 : 2, P2 = 4 / MTW;     // accumulator chains per (gate, tile) in phase 1 / 2
     static_assert(NH == 128 || NH == 256, "hidden width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* hb = reinterpret_cast<float*>(smem);                  // [8][LDH]  h_{t-1}
-    float* rhb = hb + RW * LDH;                                  // [8][LDH]  r * h_{t-1}
-    float* s_att = rhb + RW * LDH;                               // [8][L + 1]
+    float* hb = reinterpret_cast<float*>(smem);                  // [8][LDH]  h_{t-1} (A operand of phase 1; saved as H)
+    float* rhb = hb + RW * LDH;                                  // [8][LDH]  r * h_{t-1} (A operand of phase 2; saved as RH)
+    float* tr = rhb + RW * LDH;                                  // [8][NH]   r, u, c of the step (saved by the fifth wave)
+    float* tu = tr + ST;
+    float* tc = tu + ST;
+    float* xs = tc + ST;                                         // [3][8][NH] x-side pre-activations of the step: r | u | c blocks
+    float* s_att = xs + 3 * ST;                                  // [8][L + 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave % NCW, mt0 = (wave / NCW) * MTW;
     const int row0 = blockIdx.x * RW, sq = blockIdx.y;
     const int L = a.L, LDT = L + 1;
-    const int col = cw * 64 + lane;
-    const int xld4 = 3 * NH * 4;
 
-    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xbase[sq]), 0, (int)a.xbytes, 0x00020000);
-    const int vlw = lane_off(lane, KB);
-    const int so_r = (2 * cw) * KB * 1024, so_u = (NWT + 2 * cw) * KB * 1024, so_c = (2 * cw) * KB * 1024;     // + kq * 512
-
-    for (int i = tid; i < RW * LDH; i += 256) hb[i] = 0.f;
-    for (int i = tid; i < RW * L; i += 256) {
+    for (int i = tid; i < RW * LDH; i += 320) hb[i] = 0.f;
+    for (int i = tid; i < RW * L; i += 320) {
         const int r = i / L, t = i - r * L;
         const int gr = min(row0 + r, a.n_rows - 1);
         s_att[r * LDT + t] = a.sv_att[sq] ? a.sv_att[sq][(size_t)gr * L + t] : 0.f;
     }
-    // per (tile, row): byte offset of the row's x pre-activations at t = 0 (own column), flat index of its saved element at t = 0
-    int xo[MTW][4];
-    size_t so[MTW][4];
-    bool live[MTW][4];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (mt0 + m) * 4 + i;
-            const int gr = min(row0 + row, a.n_rows - 1);
-            xo[m][i] = gr * L * xld4 + col * 4;
-            so[m][i] = (size_t)gr * L * NH + col;
-            live[m][i] = row0 + row < a.n_rows;
+    if (wave == 4) {
+        // ---- fifth wave.  float4 k of lane l covers element 4 * (l + 64 k) of an [8][NH] tile
+        constexpr int NV = ST / 4 / 64;
+        const float* xb = a.xbase[sq];
+        const int blk[3] = {a.sv_blk[0] * NH, a.sv_blk[1] * NH, a.sv_blk[2] * NH};
+        // (f32x4_t, not float4: a struct copy between address spaces is a memcpy the optimiser does not turn into register values - the
+        // arrays stayed in scratch memory)
+        f32x4_t vru[2][NV], vc[NV];
+        float* const sv_r = a.sv_r[sq]; float* const sv_u = a.sv_u[sq]; float* const sv_c = a.sv_c[sq];
+        float* const sv_h = a.sv_h[sq]; float* const sv_rh = a.sv_rh[sq];
+        // (macros and inline index arithmetic: index arrays / by-reference closures left the register arrays in scratch memory)
+#define R8_ER(k) (((lane + 64 * (k)) * 4) / NH)
+#define R8_EC(k) (((lane + 64 * (k)) * 4) % NH)
+#define R8_GRL(k) ((size_t)min(row0 + R8_ER(k), a.n_rows - 1) * L)
+#define R8_REQUEST_RU(T)                                                                                                               \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k)                                                                             \
+                vru[g][k] = *reinterpret_cast<const f32x4_t*>(xb + (R8_GRL(k) + (T)) * (3 * NH) + blk[g] + R8_EC(k));
+#define R8_REQUEST_C(T)                                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k)                                                                                 \
+            vc[k] = *reinterpret_cast<const f32x4_t*>(xb + (R8_GRL(k) + (T)) * (3 * NH) + blk[2] + R8_EC(k));
+#define R8_DEPOSIT_RU()                                                                                                                \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4_t*>(xs + g * ST + (lane + 64 * k) * 4) = vru[g][k];
+#define R8_DEPOSIT_C()                                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4_t*>(xs + 2 * ST + (lane + 64 * k) * 4) = vc[k];
+        // an LDS tile (row stride LD) -> rows of step T of a saved tensor
+#define R8_SAVE(DST, TILE, LD, T)                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k)                                                                                 \
+            if (row0 + R8_ER(k) < a.n_rows) *reinterpret_cast<f32x4_t*>((DST) + (R8_GRL(k) + (T)) * NH + R8_EC(k)) = *reinterpret_cast<const f32x4_t*>((TILE) + R8_ER(k) * (LD) + R8_EC(k));
+        R8_REQUEST_RU(0)
+        R8_DEPOSIT_RU()
+        R8_REQUEST_C(0)
+        R8_REQUEST_RU(min(1, L - 1))
+        __syncthreads();
+        // (requests past the last step re-read the last one and their deposits are never consumed: no conditional touches the
+        // register arrays)
+        for (int t = 0; t < L; ++t) {
+            // -- while the matrix waves run phase 1 of step t: c, h of step t - 1 leave; the candidate's x of step t arrives
+            if (t > 0) { R8_SAVE(sv_c, tc, NH, t - 1) R8_SAVE(sv_h, hb, LDH, t - 1) }
+            R8_DEPOSIT_C()
+            R8_REQUEST_C(min(t + 1, L - 1))
+            __syncthreads();
+            // -- phase 2 of step t: r, u, r*h of step t leave; the gates' x of step t + 1 arrives
+            R8_SAVE(sv_r, tr, NH, t) R8_SAVE(sv_u, tu, NH, t) R8_SAVE(sv_rh, rhb, LDH, t)
+            R8_DEPOSIT_RU()
+            R8_REQUEST_RU(min(t + 2, L - 1))
+            __syncthreads();
         }
-    const int blk_r = a.sv_blk[0] * NH * 4, blk_u = a.sv_blk[1] * NH * 4, blk_c = a.sv_blk[2] * NH * 4;
+        R8_SAVE(sv_c, tc, NH, L - 1) R8_SAVE(sv_h, hb, LDH, L - 1)
+#undef R8_REQUEST_RU
+#undef R8_REQUEST_C
+#undef R8_DEPOSIT_RU
+#undef R8_DEPOSIT_C
+#undef R8_SAVE
+#undef R8_ER
+#undef R8_EC
+#undef R8_GRL
+        return;
+    }
+    const int cw = wave % NCW, mt0 = (wave / NCW) * MTW;
+    const int col = cw * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rs_wg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg[sq]), 0, 2 * NH * NH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wc[sq]), 0, NH * NH * 4, 0x00020000);
+    const int vlw = lane_off(lane, KB);
+    const int so_r = (2 * cw) * KB * 1024, so_u = (NWT + 2 * cw) * KB * 1024, so_c = (2 * cw) * KB * 1024;     // + kq * 512
     const float* arow[MTW];
     const float* rrow[MTW];
 #pragma unroll
@@ -156,15 +206,6 @@ __global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
     f32x4_t h_own[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) h_own[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    float xr_[MTW][4], xu_[MTW][4], xc_[MTW][4];
-    auto load_x = [&](float (&dst)[MTW][4], int t, int blk) {
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                dst[m][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, xo[m][i], t * xld4 + blk, 0));
-    };
     // weight streams: phase 1 consumes (q, r), (q, u), (q + 1, r), ... ; phase 2 (q) of the candidate matrix
     float4 ring[RS];
     auto ld1 = [&](int q, int g) { return ldw(rs_wg, vlw, (g == 0 ? so_r : so_u) + q * 512); };
@@ -173,24 +214,21 @@ __global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
     auto head2 = [&](int i) { return ld2(i, 0); };
 #pragma unroll
     for (int i = 0; i < RS; ++i) ring[i] = head1(i);
-    load_x(xr_, 0, blk_r);
-    load_x(xu_, 0, blk_u);
     __syncthreads();
 
     for (int t = 0; t < L; ++t) {
-        // ---- phase 1: [r | u] pre-activations = x + h W
+        // ---- phase 1: [r | u] pre-activations = x + h W   (x from the stage: the first chain's initial value, MFMA C-in)
         f32x4_t a1[2][MTW][P1];                       // [r | u][tile][chain]
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+        for (int m = 0; m < MTW; ++m) {
+            const float* xr = xs + (mt0 + m) * 4 * NH + col;
 #pragma unroll
             for (int p = 0; p < P1; ++p) {
-                a1[0][m][p] = p == 0 ? f32x4_t{xr_[m][0], xr_[m][1], xr_[m][2], xr_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                a1[1][m][p] = p == 0 ? f32x4_t{xu_[m][0], xu_[m][1], xu_[m][2], xu_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                a1[0][m][p] = p == 0 ? f32x4_t{xr[0], xr[NH], xr[2 * NH], xr[3 * NH]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                a1[1][m][p] = p == 0 ? f32x4_t{xr[ST], xr[ST + NH], xr[ST + 2 * NH], xr[ST + 3 * NH]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
+        }
         phase<NQ, 2, MTW, P1>(a1, arow, ring, ld1, head2);
-        // candidate x-side pre-activations: consumed after phase 2.  Requested HERE (vmcnt retires in order: the first weight wait
-        // behind these loads is an epilogue + a barrier + a ring depth of MFMAs away)
-        load_x(xc_, t, blk_c);
         f32x4_t ug[MTW];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
@@ -199,32 +237,26 @@ __global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
             for (int p = 1; p < P1; ++p) { pr += a1[0][m][p]; pu += a1[1][m][p]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const int row = (mt0 + m) * 4 + i;
                 const float rg = a.hard_gates ? hard_sig(pr[i]) : gate_sigmoid(pr[i]);
                 const float u = a.hard_gates ? hard_sig(pu[i]) : gate_sigmoid(pu[i]);
-                const float rh = rg * h_own[m][i];
                 ug[m][i] = u;
-                rhb[((mt0 + m) * 4 + i) * LDH + col] = rh;
-                if (live[m][i]) {
-                    const size_t si = so[m][i] + (size_t)t * NH;
-                    a.sv_r[sq][si] = rg;
-                    a.sv_u[sq][si] = u;
-                    a.sv_rh[sq][si] = rh;
-                }
+                rhb[row * LDH + col] = rg * h_own[m][i];
+                tr[row * NH + col] = rg;
+                tu[row * NH + col] = u;
             }
         }
         __syncthreads();
         // ---- phase 2: candidate pre-activation = x + (r h) Wc, then the state update
         f32x4_t a2[1][MTW][P2];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+        for (int m = 0; m < MTW; ++m) {
+            const float* xc = xs + 2 * ST + (mt0 + m) * 4 * NH + col;
 #pragma unroll
             for (int p = 0; p < P2; ++p)
-                a2[0][m][p] = p == 0 ? f32x4_t{xc_[m][0], xc_[m][1], xc_[m][2], xc_[m][3]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        phase<NQ, 1, MTW, P2>(a2, rrow, ring, ld2, head1);
-        if (t + 1 < L) {                              // the next step's gate pre-activations (become its accumulators' initial values)
-            load_x(xr_, t + 1, blk_r);
-            load_x(xu_, t + 1, blk_u);
+                a2[0][m][p] = p == 0 ? f32x4_t{xc[0], xc[NH], xc[2 * NH], xc[3 * NH]} : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
+        phase<NQ, 1, MTW, P2>(a2, rrow, ring, ld2, head1);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             f32x4_t pc = a2[0][m][0];
@@ -238,18 +270,14 @@ __global__ __launch_bounds__(256) void k_recur8_fwd(RecurArgs a) {
                 const float hn = u * h_own[m][i] + (1.0f - u) * c;
                 h_own[m][i] = hn;
                 hb[row * LDH + col] = hn;
-                if (live[m][i]) {
-                    const size_t si = so[m][i] + (size_t)t * NH;
-                    a.sv_c[sq][si] = c;
-                    a.sv_h[sq][si] = hn;
-                }
+                tc[row * NH + col] = c;
             }
         }
         __syncthreads();
     }
 }
 
-inline size_t recur8_fwd_smem(int NH, int L) { return (size_t)(2 * 8 * (NH + 4) + 8 * (L + 1)) * 4; }
+inline size_t recur8_fwd_smem(int NH, int L) { return (size_t)(2 * 8 * (NH + 4) + 6 * 8 * NH + 8 * (L + 1)) * 4; }
 
 // ----------------------------------------------------------------------------------------------------------------- backward
 // RecurBwdArgs as k_recur_bwd<NH> takes them; the same per-step equations (header of recur_train.hpp).
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
         // the rows of step tt (H of step tt - 1) are requested a whole step before they are needed and wait in registers: their memory
         // round trip overlaps a full step of the matrix waves, and this wave's barriers do not wait for loads in flight
         float4 v[5][NV];
-        auto request = [&](int tt) {
+        auto request = [&](int tt) __attribute__((always_inline)) {
 #pragma unroll
             for (int arr = 0; arr < 5; ++arr) {
                 const bool zero = src[arr] == nullptr || (arr == 3 && tt == 0);
@@ -302,7 +330,7 @@ __global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
                 }
             }
         };
-        auto deposit = [&]() {
+        auto deposit = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int arr = 0; arr < 5; ++arr)
 #pragma unroll

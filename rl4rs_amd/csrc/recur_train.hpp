@@ -253,7 +253,13 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
     if (recur_train_small(f.N, f.S)) {
         for (int s = 0; s < f.S; ++s)
             if (!a.sv_r[s] || !a.sv_u[s] || !a.sv_c[s] || !a.sv_h[s] || !a.sv_rh[s]) { set_error("recur_train_fwd: a saved-tensor pointer is NULL"); return RL4RS_EINVAL; }
-        hipLaunchKernelGGL((k_recur8_fwd<NH>), dim3((f.N + 7) / 8, f.S), dim3(256), recur8_fwd_smem(NH, f.L), st, a);     // < 64 KB: no opt-in
+        static bool attr8 = false;
+        if (!attr8) {
+            int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_fwd<NH>), recur8_fwd_smem(NH, 64));
+            if (rca) return rca;
+            attr8 = true;
+        }
+        hipLaunchKernelGGL((k_recur8_fwd<NH>), dim3((f.N + 7) / 8, f.S), dim3(320), recur8_fwd_smem(NH, f.L), st, a);
         RL4RS_LAUNCH_CHECK();
         return RL4RS_OK;
     }
