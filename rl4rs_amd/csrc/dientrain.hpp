@@ -243,12 +243,11 @@ int cell_backward_post(rl4rs_dientrain* t, int N, const CellSave& cl, const floa
     const int Ns = N * L;
     hipLaunchKernelGGL(k_shift_prev_w, dim3((Ns * Hd + 255) / 256), b256, 0, st, cl.Hs, t->hprev, N, Hd, L);
     // gate_w = [x rows ; h rows] x 2Hd columns, cand_w likewise x Hd columns
-    st_tn(t->cx, st, Xin, E, E, dAg, 2 * Hd, 2 * Hd, Ns, gWg);
+    // (the bias gradients = column sums of dAg / dAc ride on the x-side reductions, whose first tile row holds those values anyway)
+    st_tn_cs(t->cx, st, Xin, E, E, dAg, 2 * Hd, 2 * Hd, Ns, gWg, gbg);
     st_tn(t->cx, st, t->hprev, Hd, Hd, dAg, 2 * Hd, 2 * Hd, Ns, gWg + (size_t)E * 2 * Hd);
-    st_cs(t->cx, st, dAg, 2 * Hd, 2 * Hd, Ns, gbg);
-    st_tn(t->cx, st, Xin, E, E, dAc, Hd, Hd, Ns, gWc);
+    st_tn_cs(t->cx, st, Xin, E, E, dAc, Hd, Hd, Ns, gWc, gbc);
     st_tn(t->cx, st, cl.RH, Hd, Hd, dAc, Hd, Hd, Ns, gWc + (size_t)E * Hd);
-    st_cs(t->cx, st, dAc, Hd, Hd, Ns, gbc);
     // gradient of the layer input: dAg Wg[:E]^T + dAc Wc[:E]^T
     float* dst = accumulate ? t->dX : dXin_acc;
     if ((rc = st_back(t->cx, st, dAg, 2 * Hd, 2 * Hd, Wg, 2 * Hd, E, dst, E, Ns))) return rc;
@@ -374,6 +373,7 @@ int rl4rs_dientrain_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w,
     const int nz_all = (int)((Ns + 511) / 512);
     DT_FAIL(al(&t->cx.wt, wmax));
     DT_FAIL(al(&t->cx.part, (size_t)nz_all * wmax));
+    t->cx.part_cap = (size_t)nz_all * wmax;
     DT_HIP(hipStreamSynchronize(st));
 #undef DT_HIP
 #undef DT_FAIL

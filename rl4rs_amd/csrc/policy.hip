@@ -399,14 +399,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     float cs = 0.f;
     // 8 sample pairs per trip: the 16 loads are issued together, then the 8 MFMAs (same accumulation order as a plain
     // loop; one load per MFMA made every step pay a full memory latency)
-    for (int n = n_lo; n < n_hi; n += 16) {
-        float a[8], b[8];
+    // The NEXT trip's 16 values are requested before this trip's MFMAs (round 5: with load -> wait -> 8 MFMAs every trip paid a
+    // memory round trip against 512 cycles of matrix work: 0.34 of the fp32 MFMA rate at the simulator trainers' 16 384-sample
+    // reductions); same values, same order of accumulation: bit-identical.
+    float an[8], bn[8];
+    auto fetch = [&](int n) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int nn = n + 2 * u + half;
-            a[u] = (m_ok && nn < n_hi) ? A[(size_t)nn * lda + m] : 0.f;
-            b[u] = (j_ok && nn < n_hi) ? B[(size_t)nn * ldb + j] : 0.f;
+            an[u] = (m_ok && nn < n_hi) ? A[(size_t)nn * lda + m] : 0.f;
+            bn[u] = (j_ok && nn < n_hi) ? B[(size_t)nn * ldb + j] : 0.f;
         }
+    };
+    fetch(n_lo);
+    for (int n = n_lo; n < n_hi; n += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+        fetch(n + 16);                              // (past the chunk: every lane's condition fails, nothing is read)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (n + 2 * u < n_hi) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 #pragma unroll
             for (int u = 0; u < 8; ++u) cs += b[u];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (want_cs) {
         cs += __shfl_xor(cs, 32);
@@ -424,6 +436,93 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
         int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < M && j_ok) out[(size_t)row * Nc + j] = acc[r];
     }
+}
+
+// The same reduction for LONG sample axes and wide outputs (round 5; the simulator trainers reduce over N * L = 16 384 (row, step)
+// pairs): a 32 x 32 tile per wave re-reads A once per column tile and B once per row tile - 8 flop per byte, 536 MB of L2 / MALL
+// traffic for the AUGRU's [256 x 512] gradient, 78 us where its MFMAs need 27.  Here a workgroup owns a 128 x 128 output tile:
+// slabs of 16 samples of both operands go through LDS once (straight row copies: the reduction axis is the row axis of both
+// operands, so the MFMA fragments are plain row reads, no transpose), each of the four waves multiplies a 64 x 64 quarter
+// (4 MFMAs per pair of samples), the next slab's 4 float4 per thread are in flight during the current slab's 32 MFMAs.
+// Same sample order inside a chunk as k_gemm_tn; chunk partials are summed by k_reduce_chunks in chunk order.
+// Needs lda, ldb, M, Nc multiples of 4 and 16-byte aligned operands (float4 rows); chunk a multiple of 16.
+__global__ __launch_bounds__(256) void k_gemm_tn_t128(const float* __restrict__ A, int lda, int M, const float* __restrict__ B, int ldb,
+                                                      int Nc, int Ns, int chunk, float* __restrict__ part, float* __restrict__ bias_part) {
+    __shared__ __attribute__((aligned(16))) float As[2][16][128];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
+    const int tiles_n = (Nc + 127) / 128;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, z = blockIdx.y;
+    const int m0 = tm * 128, j0 = tn * 128;
+    const int n_lo = z * chunk, n_hi = min(n_lo + chunk, Ns);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = tid >> 5, lc = (tid & 31) * 4;                  // this thread's float4: slab rows lr and lr + 8, columns lc .. lc + 3
+    const bool a_ok = m0 + lc < M, b_ok = j0 + lc < Nc;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 ra[2], rb[2];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = n0 + lr + 8 * q;
+            const bool in = row < n_hi;
+            ra[q] = (in && a_ok) ? *reinterpret_cast<const f4*>(A + (size_t)row * lda + m0 + lc) : f4{0.f, 0.f, 0.f, 0.f};
+            rb[q] = (in && b_ok) ? *reinterpret_cast<const f4*>(B + (size_t)row * ldb + j0 + lc) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<f4*>(&As[buf][lr + 8 * q][lc]) = ra[q];
+            *reinterpret_cast<f4*>(&Bs[buf][lr + 8 * q][lc]) = rb[q];
+        }
+    };
+    const bool want_cs = bias_part != nullptr && tm == 0 && tid < 128;
+    float cs = 0.f;
+    fetch(n_lo);
+    deposit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = n_lo; n0 < n_hi; n0 += 16, buf ^= 1) {
+        const bool more = n0 + 16 < n_hi;
+        if (more) fetch(n0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float a0 = As[buf][2 * s + half][wm + li], a1 = As[buf][2 * s + half][wm + 32 + li];
+            const float b0 = Bs[buf][2 * s + half][wn + li], b1 = Bs[buf][2 * s + half][wn + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (want_cs) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cs += Bs[buf][k][tid];            // rows past the chunk hold zeros
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) deposit(buf ^ 1);
+        __syncthreads();
+    }
+    if (want_cs && j0 + tid < Nc) bias_part[(size_t)z * Nc + j0 + tid] = cs;
+    float* out = part + (size_t)z * M * Nc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j0 + wn + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M && col < Nc) out[(size_t)row * Nc + col] = acc[i][j][r];
+            }
+        }
 }
 
 // The same reduction for a minibatch-sized sample axis (round 4): ONE 32x32 tile per workgroup, its four waves split the samples
@@ -504,6 +603,30 @@ __global__ void k_reduce_chunks(const float* __restrict__ part, int count, int n
     float s = 0.f;
     for (int z = 0; z < nz; ++z) s += part[(size_t)z * count + i];
     dst[i] = s;
+}
+
+// The same sum for MANY chunks (the 128 x 128 form splits the sample axis into up to 64): 64 outputs per workgroup, its four waves
+// take the chunks z = w, w + 4, ... (eight independent loads in flight each) and meet in LDS; dst = ((w0 + w1) + w2) + w3 with
+// every w a sum in ascending z: a fixed order, reproducible.
+__global__ __launch_bounds__(256) void k_reduce_chunks4(const float* __restrict__ part, int count, int nz, float* __restrict__ dst) {
+    __shared__ float sm[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + l;
+    float s = 0.f;
+    if (i < count) {
+        int z = w;
+        for (; z + 28 < nz; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(z + 4 * u) * count + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < nz; z += 4) s += part[(size_t)z * count + i];
+    }
+    sm[w][l] = s;
+    __syncthreads();
+    if (w == 0 && i < count) dst[i] = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
 }
 
 // stats[0..3] = sum over samples of {pi_loss, vf_loss, entropy, kl}; single block, fixed order

@@ -199,6 +199,7 @@ struct rl4rs_simtrain {
     rl4rs_simnet_cfg c;
     int64_t n_params;
     int64_t off[SP_COUNT], size[SP_COUNT];       // offsets / sizes in the flat buffers (size 0 = the family has no such array)
+    size_t part_cap;                             // floats behind `part`
     int max_batch, chunk, nz, OD, FCK;           // OD = width of 'simulator_obs', FCK = input width of the fc layer
     float *params, *grad, *adam_m, *adam_v;
     float *feat, *h1, *h1d, *h2, *a1, *obs, *logits;            // activations (feat = input of fc, a1 = its output for dnn)
@@ -215,11 +216,35 @@ struct rl4rs_simtrain {
 namespace {
 
 // sample-axis reductions / transposed-weight GEMM over an explicit number of samples
-struct TrainCtx { int chunk; float* part; float* wt; };
+struct TrainCtx { int chunk; float* part; float* wt; size_t part_cap = 0; };       // part_cap: floats behind `part` (0 = sized for `chunk` only)
+
+// Long reductions with wide outputs go through the LDS-tiled 128 x 128 form (k_gemm_tn_t128, policy.hip); the chunk count is chosen
+// to give every CU a workgroup (at most 64 chunks: the partials are summed by k_reduce_chunks4) within what `part` holds.  Returns the chunk count, 0 = not applicable (caller: k_gemm_tn).
+inline int tn_t128_plan(const TrainCtx& x, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, bool bias, int* chunk_out) {
+    if (Ns < 4096 || M < 64 || Nc < 64 || (lda | ldb | M | Nc) % 4 != 0 || ((uintptr_t)A | (uintptr_t)B) % 16 != 0) return 0;
+    const int tiles = ((M + 127) / 128) * ((Nc + 127) / 128);
+    int nz = (256 + tiles - 1) / tiles;
+    if (nz > 64) nz = 64;
+    const size_t per = (size_t)M * Nc + (bias ? Nc : 0);
+    const size_t cap = x.part_cap ? x.part_cap : (size_t)((Ns + x.chunk - 1) / x.chunk) * per;
+    if ((size_t)nz * per > cap) nz = (int)(cap / per);
+    if (nz < 1) return 0;
+    int chunk = (((Ns + nz - 1) / nz) + 15) / 16 * 16;
+    if (chunk < 64) chunk = 64;
+    *chunk_out = chunk;
+    return (Ns + chunk - 1) / chunk;
+}
 constexpr int TN4_MAX_SAMPLES = 1024;      // up to here the whole sample axis is one workgroup's (four waves x Ns / 4 samples)
 void st_tn(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M, const float* B, int ldb, int Nc, int Ns, float* dst) {
     if (Ns <= TN4_MAX_SAMPLES) {
         hipLaunchKernelGGL(k_gemm_tn4, dim3(((M + 31) / 32) * ((Nc + 31) / 32)), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, dst, (float*)nullptr);
+        return;
+    }
+    int big_chunk = 0;
+    if (const int bz = tn_t128_plan(x, A, lda, M, B, ldb, Nc, Ns, false, &big_chunk)) {
+        hipLaunchKernelGGL(k_gemm_tn_t128, dim3(((M + 127) / 128) * ((Nc + 127) / 128), bz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, big_chunk,
+                           bz == 1 ? dst : x.part, (float*)nullptr);
+        if (bz > 1) hipLaunchKernelGGL(k_reduce_chunks4, dim3((M * Nc + 63) / 64), dim3(256), 0, st, x.part, M * Nc, bz, dst);
         return;
     }
     const int nz = (Ns + x.chunk - 1) / x.chunk;
@@ -239,6 +264,17 @@ void st_tn_cs(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M,
         hipLaunchKernelGGL(k_gemm_tn4, dim3(((M + 31) / 32) * ((Nc + 31) / 32)), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, dW, db);
         return;
     }
+    int big_chunk = 0;
+    if (const int bz = tn_t128_plan(x, A, lda, M, B, ldb, Nc, Ns, true, &big_chunk)) {
+        float* bp = x.part + (size_t)bz * M * Nc;
+        hipLaunchKernelGGL(k_gemm_tn_t128, dim3(((M + 127) / 128) * ((Nc + 127) / 128), bz), dim3(256), 0, st, A, lda, M, B, ldb, Nc, Ns, big_chunk,
+                           bz == 1 ? dW : x.part, bz == 1 ? db : bp);
+        if (bz > 1) {
+            hipLaunchKernelGGL(k_reduce_chunks4, dim3((M * Nc + 63) / 64), dim3(256), 0, st, x.part, M * Nc, bz, dW);
+            hipLaunchKernelGGL(k_reduce_chunks4, dim3((Nc + 63) / 64), dim3(256), 0, st, bp, Nc, bz, db);
+        }
+        return;
+    }
     const int nz = (Ns + x.chunk - 1) / x.chunk;
     const int tiles = ((M + 31) / 32) * ((Nc + 31) / 32);
     float* bpart = x.part + (size_t)nz * M * Nc;
@@ -251,7 +287,9 @@ void st_tn_cs(const TrainCtx& x, hipStream_t st, const float* A, int lda, int M,
 }
 int st_back(const TrainCtx& x, hipStream_t st, const float* dY, int ldy, int Nout, const float* W, int ldw, int Kin, float* dX, int ldx,
             int Ns) {      // dX [Ns, Kin] = dY [Ns, Nout] W^T,  W [Kin, Nout] with leading dimension ldw
-    if ((int64_t)((Ns + 127) / 128) * ((Kin + 63) / 64) < 512)        // minibatch-sized: no transposed weight copy, 32 x 32 tiles
+    // minibatch-sized: no transposed weight copy, 32 x 32 tiles.  (Round 5: the bound is on the ROW count as well - the 16 384-row
+    // input gradients of the simulator trainers' recurrent layers took this form at up to 94 us a call)
+    if (Ns <= 2048 && (int64_t)((Ns + 127) / 128) * ((Kin + 63) / 64) < 512)
         return launch_gemm_nt(dY, ldy, W, ldw, dX, ldx, Ns, Kin, Nout, st);
     hipLaunchKernelGGL(k_transpose, dim3((Kin * Nout + 255) / 256), dim3(256), 0, st, W, (int64_t)ldw, Kin, Nout, x.wt);
     return launch_gemm_f32(dY, ldy, x.wt, Kin, nullptr, dX, ldx, Ns, Kin, Nout, 0, st);
@@ -373,9 +411,8 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     // parameter gradients over all (row, step) samples
     const int Ns = N * len;
     hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, t->g_hprev, N, U, len);
-    const TrainCtx cx = {t->chunk, t->part, t->wt};
-    st_tn(cx, st, g.X, E, E, dA, 3 * U, 3 * U, Ns, gK);
-    st_cs(cx, st, dA, 3 * U, 3 * U, Ns, gb);
+    const TrainCtx cx = {t->chunk, t->part, t->wt, t->part_cap};
+    st_tn_cs(cx, st, g.X, E, E, dA, 3 * U, 3 * U, Ns, gK, gb);
     st_tn(cx, st, t->g_hprev, U, U, dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
     RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, t->g_tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
     st_tn(cx, st, g.RH, U, U, dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
@@ -490,6 +527,7 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
     const int nz_all = (int)((B * maxlen_any + t->chunk - 1) / t->chunk);       // the GRU gradients reduce over N * len samples
     ST_FAIL(al(&t->wt, wmax));
     ST_FAIL(al(&t->part, (size_t)(nz_all > t->nz ? nz_all : t->nz) * wmax));
+    t->part_cap = (size_t)(nz_all > t->nz ? nz_all : t->nz) * wmax;
     for (int g = 0; g < 5; ++g) memset(&t->gru[g], 0, sizeof(GruSave));
     if (ls) {
         for (int g = 0; g < n_gru; ++g) {
