@@ -785,6 +785,16 @@ int rl4rs_amlp_forward_h16(rl4rs_amlp* net, int32_t N, int32_t rep, const float*
 int rl4rs_amlp_backward(rl4rs_amlp* net, int32_t N, int32_t rep, const float* obs_dev, const float* act_dev,
                         const float* dout_dev, float* dact_dev, int32_t want_param_grad, void* stream);
 int rl4rs_amlp_adam_step(rl4rs_amlp* net, float lr, float beta1, float beta2, float eps, void* stream);
+/* The optimiser of ONE phase of an update as one launch: torch.optim.Adam for the n <= 8 networks with do_adam[i] != 0 (learning
+ * rate lr[i]) and, for every i with targets[i] != NULL, d3rlpy's soft_sync targets[i] = (1 - tau) targets[i] + tau nets[i] computed
+ * from the parameters AFTER this call's step (do_adam[i] = 0: soft update only).  targets may be NULL.  Element for element the
+ * arithmetic of rl4rs_amlp_adam_step / rl4rs_amlp_soft_update. */
+int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, const int32_t* do_adam, rl4rs_amlp* const* targets,
+                          float beta1, float beta2, float eps, float tau, void* stream);
+/* Minibatch-sized rl4rs_amlp_forward / rl4rs_amlp_backward calls (hidden 256 x 256, out_dim / act_dim <= 64, rep = 1, N <= 2048 /
+ * 1024) run as fused launches - one for the three layers forwards; transposes + input-gradient chain + all parameter gradients
+ * backwards - instead of one launch per layer and product.  on = 0 restores the per-layer launches (process-wide; tests, A/B). */
+int rl4rs_amlp_set_fused(int32_t on);
 /* d3rlpy ConditionalVAE (the BCQ imitator).  enc_out_dev [N, 2L] = [mu | logstd] (the encoder amlp's two Linear heads side by
  * side); sample: z = mu + exp(clamp(logstd, min, max)) * eps (Normal.rsample with the caller's noise).
  * loss (compute_error): decoded_dev [N, E] = tanh output of the decoder amlp on (x, z); loss2_dev = {mean_n sum_e (y - a)^2,

@@ -1,0 +1,286 @@
+// Fused minibatch kernels of the amlp network (contirl.hpp; included by it, compiled into policy.hip).
+//
+// A BCQ / CQL update differentiates 256-row minibatches through eight small networks; in per-layer launches that was 3 launches
+// per forward and 6 - 7 per backward, every one of them at its 4 - 9 us latency floor (~95 launches, 0.62 ms per BCQ
+// update with the GPU never idle).  Here a minibatch-sized call is
+//     forward    ONE launch  k_amlp_fwd4   : [x | a] -> relu -> relu -> head, 4 rows per workgroup, every layer on
+//                                            v_mfma_f32_4x4x1 (mfma4.hpp: a lane owns one hidden column of its wave's 64), the
+//                                            activations of a row never leave LDS between the layers (h1, h2 are also written out
+//                                            for the backward), weights streamed ROW-MAJOR as they are (no packing: they change
+//                                            every update) through the register ring, which runs across the layers;
+//     backward   THREE launches: k_amlp_transposes (W2^T, W3^T, W1_action^T - the chain needs the weights with the OUTPUT index
+//                                            contiguous; built in front of every backward, no dirty flag is trusted)
+//                                k_amlp_bwd4 (dout -> d_h2 -> d_h1 -> d action, ReLU masks in the epilogues, same machine mapping)
+//                                k_gemm_tn4_group (every weight and bias gradient of the network: 4 sample-axis reductions,
+//                                            one grid over all their 32 x 32 tiles)
+// and the optimiser is one launch per phase for all its networks (k_adam_multi: torch Adam + the soft target updates).
+// Exact fp32; the summation order of a dot product differs from the per-layer GEMMs (4 interleaved chains over k instead of
+// MFMA-internal pairs): same tests, same bars.  Eligible: hidden 256 x 256, out_dim <= 64, act_dim <= 64, rep = 1, N <= 2048.
+#pragma once
+#include "mfma4.hpp"
+
+namespace rl4rs {
+
+struct AmlpFwd4 {
+    const float* obs; const float* act;       // [N, D], [N, E] (E may be 0)
+    const float* W1; const float* b1; const float* W2; const float* b2; const float* W3; const float* b3;
+    float* h1; float* h2; float* out;         // [N, 256], [N, 256], [N, K3]
+    int N, D, E, K3, head_act;
+};
+
+namespace a4 {
+constexpr int H = 256, LDH = H + 4;
+__device__ __forceinline__ float head_activation(float x, int act) {
+    if (act == ACT_TANH) return tanhf(x);
+    if (act == ACT_RELU) return fmaxf(x, 0.f);
+    if (act == ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+    if (act == ACT_ELU) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+// 4 consecutive rows k .. k + 3 of a row-major [*, ld] weight matrix at this lane's column: the B operands of 4 MFMAs
+// (rows past the matrix come back as zero: the descriptor's num_records ends with the last row)
+__device__ __forceinline__ float4 ldrows(__amdgpu_buffer_rsrc_t rs, int voff, int k, int ld4) {
+    return make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * ld4, 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (k + 1) * ld4, 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (k + 2) * ld4, 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (k + 3) * ld4, 0)));
+}
+}  // namespace a4
+
+// grid = ceil(N / 4) workgroups of 4 waves; dynamic LDS = amlp_fwd4_smem(D + E)
+__global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4 a) {
+    using namespace r8;
+    using namespace a4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KX = a.D + a.E, KXP = (KX + 63) / 64 * 64, LDX = KXP + 4;
+    float* xs = reinterpret_cast<float*>(smem);          // [4][LDX]  [x | a | 0]
+    float* h1s = xs + 4 * LDX;                           // [4][LDH]
+    float* h2s = h1s + 4 * LDH;                          // [4][LDH]
+    float* part = h2s + 4 * LDH;                         // [4 waves][4 rows][64]  head partials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 4;
+    const int col = wave * 64 + lane;
+    for (int i = tid; i < 4 * KXP; i += 256) {
+        const int r = i / KXP, k = i - r * KXP;
+        const int gr = min(row0 + r, a.N - 1);
+        float v = 0.f;
+        if (k < a.D) v = a.obs[(size_t)gr * a.D + k];
+        else if (k < KX) v = a.act[(size_t)gr * a.E + (k - a.D)];
+        xs[r * LDX + k] = v;
+    }
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W1), 0, KX * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2), 0, H * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W3), 0, H * a.K3 * 4, 0x00020000);
+    const int vcol = col * 4;
+    const int k3 = a.K3;
+    const int v3 = min(lane, k3 - 1) * 4;                // head: lane = output column (lanes >= K3 compute a duplicate that is never stored)
+    float4 ring[RS];
+    auto ld1 = [&](int q, int) { return ldrows(rs1, vcol, 4 * q, H * 4); };
+    auto ld2 = [&](int q, int) { return ldrows(rs2, vcol, 4 * q, H * 4); };
+    auto ld3 = [&](int q, int) { return ldrows(rs3, v3, wave * 64 + 4 * q, k3 * 4); };       // this wave's quarter of k
+    auto head2 = [&](int i) { return ld2(i, 0); };
+    auto head3 = [&](int i) { return ld3(i, 0); };
+    auto none = [&](int) { return make_float4(0.f, 0.f, 0.f, 0.f); };
+#pragma unroll
+    for (int i = 0; i < RS; ++i) ring[i] = ld1(i, 0);
+    __syncthreads();
+    const float* ap[1];
+    f32x4_t acc[1][1][4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[0][0][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    auto total = [&]() { return (acc[0][0][0] + acc[0][0][1]) + (acc[0][0][2] + acc[0][0][3]); };
+    // ---- layer 1
+    zero();
+    ap[0] = xs + (lane & 3) * LDX;
+    phase_rt<1, 1, 4>(acc, ap, ring, ld1, head2, KXP / 64);
+    {
+        const f32x4_t s = total();
+        const float b = a.b1[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaxf(s[i] + b, 0.f);
+            h1s[i * LDH + col] = v;
+            if (row0 + i < a.N) a.h1[(size_t)(row0 + i) * H + col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- layer 2
+    zero();
+    ap[0] = h1s + (lane & 3) * LDH;
+    phase_rt<1, 1, 4>(acc, ap, ring, ld2, head3, H / 64);
+    {
+        const f32x4_t s = total();
+        const float b = a.b2[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaxf(s[i] + b, 0.f);
+            h2s[i * LDH + col] = v;
+            if (row0 + i < a.N) a.h2[(size_t)(row0 + i) * H + col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- head: the four waves split k (64 each), lane = output column; partials meet in LDS and are summed in wave order
+    zero();
+    ap[0] = h2s + (lane & 3) * LDH + wave * 64;
+    phase_rt<1, 1, 4>(acc, ap, ring, ld3, none, 1);
+    {
+        const f32x4_t s = total();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(wave * 4 + i) * 64 + lane] = s[i];
+    }
+    __syncthreads();
+    if (tid < 4 * 64) {
+        const int i = tid >> 6, j = tid & 63;
+        if (j < k3 && row0 + i < a.N) {
+            const float v = ((part[(0 * 4 + i) * 64 + j] + part[(1 * 4 + i) * 64 + j]) + part[(2 * 4 + i) * 64 + j]) + part[(3 * 4 + i) * 64 + j];
+            a.out[(size_t)(row0 + i) * k3 + j] = head_activation(v + a.b3[j], a.head_act);
+        }
+    }
+}
+inline size_t amlp_fwd4_smem(int KX) { return (size_t)(4 * ((KX + 63) / 64 * 64 + 4) + 2 * 4 * (256 + 4) + 4 * 4 * 64) * 4; }
+
+// ---------------------------------------------------------------------------------------------------------------- backward chain
+struct AmlpBwd4 {
+    const float* dout; const float* h1; const float* h2;      // [N, K3] gradient wrt the head's pre-activation; saved activations
+    const float* w3t; const float* w2t; const float* w1at;    // W3^T [K3, 256], W2^T [256, 256], W1[D:, :]^T [256, E]
+    float* d_h2; float* d_h1; float* dact;                    // out: [N, 256], [N, 256], [N, E] or NULL
+    int N, K3, E;
+};
+
+// W3 [256, K3] -> w3t [K3, 256];  W2 [256, 256] -> w2t;  W1a = W1 rows D.. [E, 256] -> w1at [256, E]
+__global__ void k_amlp_transposes(const float* __restrict__ W3, int K3, float* __restrict__ w3t, const float* __restrict__ W2,
+                                  float* __restrict__ w2t, const float* __restrict__ W1a, int E, float* __restrict__ w1at) {
+    constexpr int H = 256;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H * H) { const int r = i >> 8, c = i & 255; w2t[i] = W2[c * H + r]; return; }
+    i -= H * H;
+    if (i < K3 * H) { const int r = i >> 8, c = i & 255; w3t[i] = W3[c * K3 + r]; return; }
+    i -= K3 * H;
+    if (i < H * E) { const int r = i / E, c = i - r * E; w1at[i] = W1a[c * H + r]; }
+}
+
+__global__ __launch_bounds__(256) void k_amlp_bwd4(AmlpBwd4 a) {
+    using namespace r8;
+    using namespace a4;
+    __shared__ __attribute__((aligned(16))) float ds[4][64 + 4];      // dout rows, zero-padded to 64
+    __shared__ __attribute__((aligned(16))) float d2s[4][LDH];
+    __shared__ __attribute__((aligned(16))) float d1s[4][LDH];
+    __shared__ float part[4 * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 4;
+    const int col = wave * 64 + lane;
+    const int k3 = a.K3, E = a.E;
+    {
+        const int r = tid >> 6, k = tid & 63;
+        const int gr = min(row0 + r, a.N - 1);
+        ds[r][k] = k < k3 ? a.dout[(size_t)gr * k3 + k] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w3t), 0, k3 * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w2t), 0, H * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1at), 0, (E > 0 ? H * E : 1) * 4, 0x00020000);
+    const int vcol = col * 4;
+    const int ve = min(lane, max(E, 1) - 1) * 4;
+    float4 ring[RS];
+    auto ld3 = [&](int q, int) { return ldrows(rs3, vcol, 4 * q, H * 4); };
+    auto ld2 = [&](int q, int) { return ldrows(rs2, vcol, 4 * q, H * 4); };
+    auto ld1 = [&](int q, int) { return ldrows(rs1, ve, wave * 64 + 4 * q, E * 4); };
+    auto head2 = [&](int i) { return ld2(i, 0); };
+    auto head1 = [&](int i) { return ld1(i, 0); };
+    auto none = [&](int) { return make_float4(0.f, 0.f, 0.f, 0.f); };
+#pragma unroll
+    for (int i = 0; i < RS; ++i) ring[i] = ld3(i, 0);
+    // the ReLU masks of this lane's column (requested early, used in the epilogues)
+    float m2[4], m1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gr = min(row0 + i, a.N - 1);
+        m2[i] = a.h2[(size_t)gr * H + col];
+        m1[i] = a.h1[(size_t)gr * H + col];
+    }
+    __syncthreads();
+    const float* ap[1];
+    f32x4_t acc[1][1][4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[0][0][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    auto total = [&]() { return (acc[0][0][0] + acc[0][0][1]) + (acc[0][0][2] + acc[0][0][3]); };
+    const bool want_dact = a.dact != nullptr && E > 0;
+    // ---- d_h2 = (dout W3^T) * [h2 > 0]
+    zero();
+    ap[0] = &ds[lane & 3][0];
+    phase_rt<1, 1, 4>(acc, ap, ring, ld3, head2, 1);
+    {
+        const f32x4_t s = total();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = m2[i] > 0.f ? s[i] : 0.f;
+            d2s[i][col] = v;
+            if (row0 + i < a.N) a.d_h2[(size_t)(row0 + i) * H + col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- d_h1 = (d_h2 W2^T) * [h1 > 0]
+    zero();
+    ap[0] = &d2s[lane & 3][0];
+    if (want_dact) phase_rt<1, 1, 4>(acc, ap, ring, ld2, head1, H / 64);
+    else phase_rt<1, 1, 4>(acc, ap, ring, ld2, none, H / 64);
+    {
+        const f32x4_t s = total();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = m1[i] > 0.f ? s[i] : 0.f;
+            d1s[i][col] = v;
+            if (row0 + i < a.N) a.d_h1[(size_t)(row0 + i) * H + col] = v;
+        }
+    }
+    if (!want_dact) return;
+    __syncthreads();
+    // ---- d action = d_h1 W1_action^T: the four waves split k, lane = action component
+    zero();
+    ap[0] = &d1s[lane & 3][wave * 64];
+    phase_rt<1, 1, 4>(acc, ap, ring, ld1, none, 1);
+    {
+        const f32x4_t s = total();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(wave * 4 + i) * 64 + lane] = s[i];
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 6, j = tid & 63;
+        if (j < E && row0 + i < a.N)
+            a.dact[(size_t)(row0 + i) * E + j] = ((part[(0 * 4 + i) * 64 + j] + part[(1 * 4 + i) * 64 + j]) + part[(2 * 4 + i) * 64 + j]) + part[(3 * 4 + i) * 64 + j];
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- optimiser: one launch per phase
+// torch.optim.Adam for up to 8 flat parameter tensors + the soft target update targ = (1 - tau) targ + tau p of those that have a
+// target network (g = NULL: soft update only).  Element-wise: same values as k_adam / k_soft_update per tensor.
+struct AdamMultiDesc { float* p; const float* g; float* m; float* v; float* targ; float lr_t, eps_t; };
+struct AdamMulti { AdamMultiDesc d[8]; long long start[9]; int n; float b1, b2, tau; };
+__global__ void k_adam_multi(AdamMulti a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.start[a.n]) return;
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += (k < a.n && i >= a.start[k]) ? 1 : 0;
+    const AdamMultiDesc& d = a.d[t];
+    const long long j = i - a.start[t];
+    float pj = d.p[j];
+    if (d.g) {
+        const float gj = d.g[j];
+        const float mj = a.b1 * d.m[j] + (1.f - a.b1) * gj;
+        const float vj = a.b2 * d.v[j] + (1.f - a.b2) * gj * gj;
+        d.m[j] = mj;
+        d.v[j] = vj;
+        pj -= d.lr_t * mj / (sqrtf(vj) + d.eps_t);
+        d.p[j] = pj;
+    }
+    if (d.targ) d.targ[j] = (1.f - a.tau) * d.targ[j] + a.tau * pj;
+}
+
+}  // namespace rl4rs

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void k_sum6(const float* __restrict__ rows, in
 }
 
 }  // namespace rl4rs
+#include "amlp_fused.hpp"
 
 enum { AP_W1 = 0, AP_B1, AP_W2, AP_B2, AP_W3, AP_B3, AP_COUNT };
 
@@ -317,6 +318,7 @@ struct rl4rs_amlp {
     float *proj, *h1, *h2;              // forward: [max_rows, hidden1] observation-side projection (one row per DISTINCT observation), activations
     float *d_h1, *d_h2, *d_proj;        // backward scratch, [max_grad_rows, ...]
     int last_n, last_rep;               // rows of the last forward (the backward must match)
+    float *w2t, *w3t, *w1at;            // transposed weights of the fused minibatch backward (amlp_fused.hpp; NULL: shape not eligible)
     float *w1p, *w2p, *w3p, *w1xp;      // fp16 hi / lo fragment planes of W1's action rows, W2, W3 (and W1's observation rows) for rl4rs_amlp_forward_h16 (NULL: shape not eligible)
     int64_t adam_t;
     std::vector<void*> owned;
@@ -329,7 +331,19 @@ static bool amlp_h16_shape_ok(const rl4rs_amlp_cfg& c) {
            (c.head_act == ACT_NONE || c.head_act == ACT_TANH || c.head_act == ACT_RELU || c.head_act == ACT_SIGMOID);
 }
 
+// the shapes the fused minibatch kernels take (amlp_fused.hpp): d3rlpy's default 256 x 256 encoder, at most 64 outputs / action inputs
+static bool amlp_fused_shape_ok(const rl4rs_amlp_cfg& c) {
+    return c.hidden1 == 256 && c.hidden2 == 256 && c.out_dim <= 64 && c.act_dim <= 64 && c.obs_dim + c.act_dim <= 4096;
+}
+static int g_amlp_fused = 1;            // rl4rs_amlp_set_fused: 0 = the per-layer launches for every call (tests, A/B runs)
+static bool amlp_fused_call(const rl4rs_amlp* p, int N, int rep) { return g_amlp_fused && amlp_fused_shape_ok(p->c) && rep == 1 && N <= 2048; }
+
 extern "C" {
+
+int rl4rs_amlp_set_fused(int32_t on) {
+    g_amlp_fused = on ? 1 : 0;
+    return RL4RS_OK;
+}
 
 int rl4rs_amlp_destroy(rl4rs_amlp* p) {
     if (!p) return RL4RS_OK;
@@ -353,6 +367,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
     p->adam_t = 0;
     p->last_n = p->last_rep = 0;
     p->w1p = p->w2p = p->w3p = p->w1xp = nullptr;
+    p->w2t = p->w3t = p->w1at = nullptr;
     const int64_t sizes[AP_COUNT] = {(D + E) * H1, H1, H1 * H2, H2, H2 * K, K};
     int64_t o = 0;
     for (int i = 0; i < AP_COUNT; ++i) { p->off[i] = o; p->size[i] = sizes[i]; o += sizes[i]; }
@@ -380,6 +395,9 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
         for (int i = 0; i < AP_COUNT; ++i) if (sizes[i] > wmax) wmax = sizes[i];
         p->cx.chunk = 256;
         AM_FAIL(al(&p->cx.wt, wmax));
+        if (amlp_fused_shape_ok(*c)) {
+            AM_FAIL(al(&p->w2t, H1 * H2)); AM_FAIL(al(&p->w3t, H2 * K)); AM_FAIL(al(&p->w1at, std::max<int64_t>(H1 * E, 1)));
+        }
         AM_FAIL(al(&p->cx.part, (size_t)((G + 255) / 256) * (wmax + std::max(H1, std::max(H2, K)))));
     }
     if (amlp_h16_shape_ok(*c)) {
@@ -438,6 +456,21 @@ int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, 
     const float* P = p->params;
     const int64_t* o = p->off;
     int rc;
+    if (amlp_fused_call(p, N, rep)) {
+        // minibatch-sized: the three layers as ONE launch (amlp_fused.hpp)
+        static bool attr = false;
+        if (!attr) {
+            if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4), amlp_fwd4_smem(4096)))) return rc;
+            attr = true;
+        }
+        AmlpFwd4 f = {obs, act, P + o[AP_W1], P + o[AP_B1], P + o[AP_W2], P + o[AP_B2], P + o[AP_W3], P + o[AP_B3], p->h1, p->h2, out,
+                      N, D, E, K, p->c.head_act};
+        hipLaunchKernelGGL(k_amlp_fwd4, dim3((N + 3) / 4), dim3(256), amlp_fwd4_smem(D + E), st, f);
+        RL4RS_LAUNCH_CHECK();
+        p->last_n = N;
+        p->last_rep = rep;
+        return RL4RS_OK;
+    }
     if (E == 0) {
         if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->h1, H1, N, H1, D, ACT_RELU, st))) return rc;
     } else if (rep == 1 && N <= 4096) {
@@ -511,6 +544,30 @@ int rl4rs_amlp_backward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs,
     auto ew = [](int n) { return dim3((n + 255) / 256); };
     const dim3 b256(256);
     int rc;
+    if (amlp_fused_call(p, N, rep) && p->w2t && N <= TN4_MAX_SAMPLES) {
+        // minibatch-sized: transposes + the whole input-gradient chain + every parameter gradient = three launches (amlp_fused.hpp)
+        const int nt = (int)(H1 * H2 + H2 * K + H1 * E);
+        hipLaunchKernelGGL(k_amlp_transposes, ew(nt), b256, 0, st, P + o[AP_W3], K, p->w3t, P + o[AP_W2], p->w2t, P + o[AP_W1] + (size_t)D * H1, E, p->w1at);
+        AmlpBwd4 b = {dout, p->h1, p->h2, p->w3t, p->w2t, p->w1at, p->d_h2, p->d_h1, dact, N, K, E};
+        hipLaunchKernelGGL(k_amlp_bwd4, dim3((N + 3) / 4), b256, 0, st, b);
+        if (want_param_grad) {
+            TnGroup g;
+            memset(&g, 0, sizeof(g));
+            auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst, float* bias) {
+                const int i = g.n++;
+                g.A[i] = A; g.lda[i] = lda; g.M[i] = M; g.B[i] = B; g.ldb[i] = ldb; g.Nc[i] = Nc; g.out[i] = dst; g.bias[i] = bias;
+                g.tile0[i + 1] = g.tile0[i] + ((M + 31) / 32) * ((Nc + 31) / 32);
+            };
+            add(p->h2, H2, H2, dout, K, K, G + o[AP_W3], G + o[AP_B3]);
+            add(p->h1, H1, H1, p->d_h2, H2, H2, G + o[AP_W2], G + o[AP_B2]);
+            add(obs, D, D, p->d_h1, H1, H1, G + o[AP_W1], G + o[AP_B1]);
+            if (E > 0) add(act, E, E, p->d_h1, H1, H1, G + o[AP_W1] + (size_t)D * H1, nullptr);
+            g.Ns = N;
+            hipLaunchKernelGGL(k_gemm_tn4_group, dim3(g.tile0[g.n]), b256, 0, st, g);
+        }
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     // per layer: ONE launch for the weight + bias gradient (k_gemm_tn with the column sums folded in) and ONE for the input
     // gradient (k_gemm_nt: no transposed weight copy, the ReLU derivative of the layer below in its epilogue)
     if (want_param_grad) st_tn_cs(p->cx, st, p->h2, H2, H2, dout, K, K, N, G + o[AP_W3], G + o[AP_B3]);
@@ -541,6 +598,38 @@ int rl4rs_amlp_adam_step(rl4rs_amlp* p, float lr, float beta1, float beta2, floa
     const float lr_t = (float)(lr * c2 / (1.0 - pow((double)beta1, t)));
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((p->n_params + 255) / 256)), dim3(256), 0, st, p->params, p->grad, p->adam_m, p->adam_v,
                        (int)p->n_params, lr_t, beta1, beta2, (float)(eps * c2), (const float*)nullptr, 0.f);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// torch.optim.Adam for n <= 8 networks in ONE launch, with the soft target updates that follow in the same phase: nets[i] steps
+// with lr[i] when do_adam[i] != 0; targets[i] (may be NULL) receives (1 - tau) target + tau nets[i] - computed from the parameters
+// AFTER this call's step.  Same element-wise arithmetic as rl4rs_amlp_adam_step / rl4rs_amlp_soft_update per network.
+int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, const int32_t* do_adam, rl4rs_amlp* const* targets, float beta1,
+                          float beta2, float eps, float tau, void* stream) {
+    RL4RS_REQUIRE(n >= 1 && n <= 8 && nets && lr && do_adam, "amlp_adam_multi: bad argument (n=%d)", n);
+    AdamMulti a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.b1 = beta1; a.b2 = beta2; a.tau = tau;
+    for (int i = 0; i < n; ++i) {
+        rl4rs_amlp* p = nets[i];
+        RL4RS_REQUIRE(p, "amlp_adam_multi: null handle %d", i);
+        rl4rs_amlp* tg = targets ? targets[i] : nullptr;
+        RL4RS_REQUIRE(do_adam[i] || tg, "amlp_adam_multi: network %d has neither a step nor a target", i);
+        RL4RS_REQUIRE(!tg || tg->n_params == p->n_params, "amlp_adam_multi: target %d has another shape", i);
+        AdamMultiDesc& d = a.d[i];
+        d.p = p->params; d.targ = tg ? tg->params : nullptr;
+        if (do_adam[i]) {
+            p->adam_t += 1;
+            const double t = (double)p->adam_t;
+            const double c2 = sqrt(1.0 - pow((double)beta2, t));
+            d.g = p->grad; d.m = p->adam_m; d.v = p->adam_v;
+            d.lr_t = (float)(lr[i] * c2 / (1.0 - pow((double)beta1, t)));
+            d.eps_t = (float)(eps * c2);
+        }
+        a.start[i + 1] = a.start[i] + p->n_params;
+    }
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)((a.start[n] + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

@@ -529,14 +529,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn_t128(const float* __restrict__ 
 // (a quarter each, interleaved by pairs) and meet in LDS - k_gemm_tn gives a tile to one wave, which then runs Ns / 2 dependent
 // MFMAs (4 us at 256 samples) on 20 workgroups; here the same tile takes a quarter of that on 80.  Fixed summation order
 // (wave 0 + 1 + 2 + 3), so results are reproducible; bias_out (optional) receives the column sums of B from tile row 0.
-__global__ __launch_bounds__(256) void k_gemm_tn4(const float* __restrict__ A, int lda, int M, const float* __restrict__ B, int ldb, int Nc,
-                                                  int Ns, float* __restrict__ out, float* __restrict__ bias_out) {
+__device__ __forceinline__ void gemm_tn4_tile(const float* __restrict__ A, int lda, int M, const float* __restrict__ B, int ldb, int Nc,
+                                              int Ns, float* __restrict__ out, float* __restrict__ bias_out, int tile) {
     __shared__ float red[4][16][64];
     __shared__ float cred[4][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, li = lane & 31;
     const int tiles_n = (Nc + 31) / 32;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m = tm * 32 + li, j = tn * 32 + li;
     const bool m_ok = m < M, j_ok = j < Nc;
     f32x16 acc;
@@ -576,6 +576,23 @@ __global__ __launch_bounds__(256) void k_gemm_tn4(const float* __restrict__ A, i
         }
         if (want_cs && wave == 0 && half == 0) bias_out[j] = cred[0][li] + cred[1][li] + cred[2][li] + cred[3][li];
     }
+}
+__global__ __launch_bounds__(256) void k_gemm_tn4(const float* __restrict__ A, int lda, int M, const float* __restrict__ B, int ldb, int Nc,
+                                                  int Ns, float* __restrict__ out, float* __restrict__ bias_out) {
+    gemm_tn4_tile(A, lda, M, B, ldb, Nc, Ns, out, bias_out, blockIdx.x);
+}
+// Up to four such reductions over the SAME sample axis as one grid (round 5: every weight and bias gradient of a fused amlp
+// backward - W3, W2, W1's observation rows, W1's action rows): tiles of problem i are workgroups [tile0[i], tile0[i + 1]).
+struct TnGroup {
+    const float* A[4]; const float* B[4]; float* out[4]; float* bias[4];
+    int lda[4], M[4], ldb[4], Nc[4], tile0[5];
+    int n, Ns;
+};
+__global__ __launch_bounds__(256) void k_gemm_tn4_group(TnGroup g) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) i += (k < g.n && (int)blockIdx.x >= g.tile0[k]) ? 1 : 0;
+    gemm_tn4_tile(g.A[i], g.lda[i], g.M[i], g.B[i], g.ldb[i], g.Nc[i], g.Ns, g.out[i], g.bias[i], (int)blockIdx.x - g.tile0[i]);
 }
 
 // column sums of X [Ns, ld] (first Nc columns) per sample chunk: part[z][Nc]

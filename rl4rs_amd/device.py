@@ -1687,6 +1687,26 @@ class DeviceAMLP(object):
         check(self.lib.rl4rs_amlp_adam_step(self.h, lr, beta1, beta2, eps, _stream()))
 
 
+def amlp_adam_multi(nets, lrs, targets=None, tau=0.0, step=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """The optimiser of one phase of an update as ONE launch (rl4rs_amlp_adam_multi): torch Adam with learning rate ``lrs[i]`` for
+    every ``nets[i]`` (``step[i]`` False: no step, soft update only) and, where ``targets[i]`` is given, the soft target update
+    target = (1 - tau) target + tau net from the stepped parameters."""
+    lib = _lib.load()
+    n = len(nets)
+    targets = list(targets) if targets is not None else [None] * n
+    step = list(step) if step is not None else [True] * n
+    H = (C.c_void_p * n)(*[net.h for net in nets])
+    T = (C.c_void_p * n)(*[(t.h if t is not None else None) for t in targets])
+    LR = (C.c_float * n)(*[float(x) for x in lrs])
+    DO = (C.c_int32 * n)(*[1 if x else 0 for x in step])
+    check(lib.rl4rs_amlp_adam_multi(n, H, LR, DO, T, beta1, beta2, eps, float(tau), _stream()))
+
+
+def amlp_set_fused(on):
+    """Fused minibatch forward / backward of the amlp networks on (default) or off (rl4rs_amlp_set_fused; tests and A/B runs)."""
+    check(_lib.load().rl4rs_amlp_set_fused(1 if on else 0))
+
+
 def cvae_sample(enc_out, eps, min_logstd=-20.0, max_logstd=2.0):
     """z = mu + exp(clamp(logstd)) * eps for enc_out [N, 2L] = [mu | logstd]."""
     lib = _lib.load()

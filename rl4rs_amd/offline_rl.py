@@ -434,8 +434,7 @@ class BCQ(_ModelIO):
         d_enc = D_.cvae_encoder_grad(enc_out, eps, dz, self.beta)
         self.imit_enc.backward(obs, act, d_enc)
         _allreduce_group([self.imit_enc, self.imit_dec])
-        self.imit_enc.adam_step(self.imitator_lr)
-        self.imit_dec.adam_step(self.imitator_lr)
+        D_.amlp_adam_multi([self.imit_enc, self.imit_dec], [self.imitator_lr] * 2)            # one optimiser launch per phase
         metrics['imitator_loss'] = torch.dot(loss2, self._imit_w)          # mse / E + beta * kl / L as ONE launch
         if self.total_step >= self.rl_start_step:
             # --- critic (DDPGBaseImpl.update_critic with BCQImpl.compute_target) ---
@@ -450,8 +449,7 @@ class BCQ(_ModelIO):
             self.q1.backward(obs, act, dq1)
             self.q2.backward(obs, act, dq2)
             _allreduce_group([self.q1, self.q2])
-            self.q1.adam_step(self.critic_lr)
-            self.q2.adam_step(self.critic_lr)
+            D_.amlp_adam_multi([self.q1, self.q2], [self.critic_lr] * 2)
             metrics['critic_loss'] = closs2.sum()
             if self.total_step % self.update_actor_interval == 0:
                 # --- actor (BCQImpl.compute_actor_loss: -Q_1(s, pi(s, decode(s, z))).mean()) ---
@@ -464,11 +462,10 @@ class BCQ(_ModelIO):
                 d_pre = D_.residual_grad(sampled, t, self.scale, da)
                 self.policy.backward(obs, sampled, d_pre)
                 _allreduce_group([self.policy])
-                self.policy.adam_step(self.actor_lr)
+                # Adam of the actor + the three soft target updates (the critics were stepped in their own phase): one launch
+                D_.amlp_adam_multi([self.policy, self.q1, self.q2], [self.actor_lr, 0.0, 0.0], targets=[self.policy_targ, self.q1_targ, self.q2_targ],
+                                   tau=self.tau, step=[True, False, False])
                 metrics['actor_loss'] = torch.dot(qv.view(-1), self._minus_inv_b.view(-1))       # -mean(q) as ONE launch
-                self.policy_targ.soft_update_from(self.policy, self.tau)
-                self.q1_targ.soft_update_from(self.q1, self.tau)
-                self.q2_targ.soft_update_from(self.q2, self.tau)
         self.total_step += 1
         return metrics
 
@@ -718,8 +715,7 @@ class CQL(_ModelIO):
         self.q1.backward(obs, fa, dq1, rep=m)
         self.q2.backward(obs, fa, dq2, rep=m)
         _allreduce_group([self.q1, self.q2])
-        self.q1.adam_step(self.critic_lr)
-        self.q2.adam_step(self.critic_lr)
+        D_.amlp_adam_multi([self.q1, self.q2], [self.critic_lr] * 2)
         metrics['critic_loss'] = (sums[0] + sums[1]) / B + (clipped_alpha * (self._conservative_value(sums, B) - self.alpha_threshold))[0]
         # --- actor (SACImpl.compute_actor_loss): (exp(log_temp) * logp - min_c Q_c(s, a)).mean()
         eps = self._randn((B, A), noise.get('eps_actor'))
@@ -730,10 +726,9 @@ class CQL(_ModelIO):
         d_head = D_.sac_actor_grad(head_obs, eps, a_pi, g_a, self.log_temp.p)
         self.policy.backward(obs, None, d_head)
         _allreduce_group([self.policy])
-        self.policy.adam_step(self.actor_lr)
+        D_.amlp_adam_multi([self.policy, self.q1, self.q2], [self.actor_lr, 0.0, 0.0], targets=[None, self.q1_targ, self.q2_targ], tau=self.tau,
+                           step=[True, False, False])
         metrics['actor_loss'] = (self.log_temp.p.exp() * logp - qmin).mean()
-        self.q1_targ.soft_update_from(self.q1, self.tau)
-        self.q2_targ.soft_update_from(self.q2, self.tau)
         self.total_step += 1
         return metrics
 

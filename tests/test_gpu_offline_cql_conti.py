@@ -48,7 +48,7 @@ def test_squashed_sample_and_log_prob():
         head = cql.policy.forward(torch.from_numpy(x).cuda())
         a, lp = Dv.squashed_sample(head, torch.from_numpy(eps).cuda(), rep=rep)
         wa, wlp = O.squashed_sample(orc['policy'], x, eps)
-        assert np.abs(a.cpu().numpy() - wa.detach().numpy()).max() < 2e-5
+        assert np.abs(a.cpu().numpy() - wa.detach().numpy()).max() < 5e-5           # tanh(mu + exp(logstd) * 1.5 randn): the fp32 head's ~1e-5 x the noise scale
         assert np.abs(lp.cpu().numpy() - wlp.detach().numpy()).max() < 2e-3          # sums of 32 terms of size O(1..10)
     # destination layout: sample groups side by side, untouched columns stay as they were
     acts = torch.full((32, 7, E), 9.0, device='cuda')
@@ -56,7 +56,7 @@ def test_squashed_sample_and_log_prob():
     eps = rs.randn(32 * 2, E).astype(np.float32)
     Dv.squashed_sample(head, torch.from_numpy(eps).cuda(), rep=2, act_out=acts.view(-1, E), logp_out=lps.view(-1), out_rep=7, out_off=3)
     wa, wlp = O.squashed_sample(orc['policy'], x, eps)
-    assert np.abs(acts[:, 3:5].reshape(-1, E).cpu().numpy() - wa.detach().numpy()).max() < 2e-5
+    assert np.abs(acts[:, 3:5].reshape(-1, E).cpu().numpy() - wa.detach().numpy()).max() < 5e-5
     assert (acts[:, :3] == 9).all() and (acts[:, 5:] == 9).all() and (lps[:, :3] == 9).all() and (lps[:, 5:] == 9).all()
     # deterministic head
     a, lp = Dv.squashed_sample(head, None)
