@@ -795,6 +795,13 @@ int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, c
  * 1024) run as fused launches - one for the three layers forwards; transposes + input-gradient chain + all parameter gradients
  * backwards - instead of one launch per layer and product.  on = 0 restores the per-layer launches (process-wide; tests, A/B). */
 int rl4rs_amlp_set_fused(int32_t on);
+/* n <= 4 networks with the same input widths on the SAME rows (d3rlpy's twin critics: both Q functions see (s, a)) - forward /
+ * backward of all of them as one launch each way when the call has the fused form, otherwise one rl4rs_amlp_forward / _backward
+ * per network.  rep = 1.  outs_dev[i] [N, out_dim_i]; douts_dev[i] as for rl4rs_amlp_backward; dacts_dev (or its entries) may be NULL. */
+int rl4rs_amlp_forward_multi(int32_t n, rl4rs_amlp* const* nets, int32_t N, const float* obs_dev, const float* act_dev,
+                             float* const* outs_dev, void* stream);
+int rl4rs_amlp_backward_multi(int32_t n, rl4rs_amlp* const* nets, int32_t N, const float* obs_dev, const float* act_dev,
+                              const float* const* douts_dev, float* const* dacts_dev, int32_t want_param_grad, void* stream);
 /* d3rlpy ConditionalVAE (the BCQ imitator).  enc_out_dev [N, 2L] = [mu | logstd] (the encoder amlp's two Linear heads side by
  * side); sample: z = mu + exp(clamp(logstd, min, max)) * eps (Normal.rsample with the caller's noise).
  * loss (compute_error): decoded_dev [N, E] = tanh output of the decoder amlp on (x, z); loss2_dev = {mean_n sum_e (y - a)^2,

@@ -241,6 +241,8 @@ SIGNATURES = {
     'rl4rs_amlp_adam_multi': (_I, [_I32, C.POINTER(_P), C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_P), C.c_float, C.c_float, C.c_float,
                                    C.c_float, _P]),
     'rl4rs_amlp_set_fused': (_I, [_I32]),
+    'rl4rs_amlp_forward_multi': (_I, [_I32, C.POINTER(_P), _I32, _P, _P, C.POINTER(_P), _P]),
+    'rl4rs_amlp_backward_multi': (_I, [_I32, C.POINTER(_P), _I32, _P, _P, C.POINTER(_P), C.POINTER(_P), _I32, _P]),
     'rl4rs_cvae_sample': (_I, [_I32, _I32, _P, _P, C.c_float, C.c_float, _P, _P]),
     'rl4rs_cvae_loss': (_I, [_I32, _I32, _I32, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
     'rl4rs_cvae_encoder_grad': (_I, [_I32, _I32, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P]),

@@ -8,11 +8,13 @@
 //                                            activations of a row never leave LDS between the layers (h1, h2 are also written out
 //                                            for the backward), weights streamed ROW-MAJOR as they are (no packing: they change
 //                                            every update) through the register ring, which runs across the layers;
-//     backward   THREE launches: k_amlp_transposes (W2^T, W3^T, W1_action^T - the chain needs the weights with the OUTPUT index
-//                                            contiguous; built in front of every backward, no dirty flag is trusted)
-//                                k_amlp_bwd4 (dout -> d_h2 -> d_h1 -> d action, ReLU masks in the epilogues, same machine mapping)
-//                                k_gemm_tn4_group (every weight and bias gradient of the network: 4 sample-axis reductions,
-//                                            one grid over all their 32 x 32 tiles)
+//     backward   TWO launches:   k_amlp_bwd4 (dout -> d_h2 -> d_h1 -> d action, ReLU masks in the epilogues, same machine mapping;
+//                                            it reads W2^T, W3^T, W1_action^T - the weights with the OUTPUT index contiguous - which
+//                                            extra workgroups of the FORWARD launch rebuild every time: a backward always follows a
+//                                            forward of the same rows under the same parameters, so no dirty flag is needed)
+//                                k_gemm_tn4_group (every weight and bias gradient: 4 sample-axis reductions per network, one
+//                                            grid over all their 32 x 32 tiles)
+//     networks that see the same rows (the twin critics) share each of these launches (grid.y = network)
 // and the optimiser is one launch per phase for all its networks (k_adam_multi: torch Adam + the soft target updates).
 // Exact fp32; the summation order of a dot product differs from the per-layer GEMMs (4 interleaved chains over k instead of
 // MFMA-internal pairs): same tests, same bars.  Eligible: hidden 256 x 256, out_dim <= 64, act_dim <= 64, rep = 1, N <= 2048.
@@ -25,8 +27,13 @@ struct AmlpFwd4 {
     const float* obs; const float* act;       // [N, D], [N, E] (E may be 0)
     const float* W1; const float* b1; const float* W2; const float* b2; const float* W3; const float* b3;
     float* h1; float* h2; float* out;         // [N, 256], [N, 256], [N, K3]
+    float* w3t; float* w2t; float* w1at;      // trainable networks: the transposed weights the backward chain reads are rebuilt by
+                                              // extra workgroups of THIS launch (a backward always follows a forward of the same rows
+                                              // under the same parameters); NULL: none
     int N, D, E, K3, head_act;
 };
+// up to 4 networks over the same rows in one launch (grid.y = network): the twin critics
+struct AmlpFwd4x { AmlpFwd4 n[4]; };
 
 namespace a4 {
 constexpr int H = 256, LDH = H + 4;
@@ -47,10 +54,33 @@ __device__ __forceinline__ float4 ldrows(__amdgpu_buffer_rsrc_t rs, int voff, in
 }
 }  // namespace a4
 
-// grid = ceil(N / 4) workgroups of 4 waves; dynamic LDS = amlp_fwd4_smem(D + E)
-__global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4 a) {
+// W3 [256, K3] -> w3t [K3, 256];  W2 [256, 256] -> w2t;  W1a = W1 rows D.. [E, 256] -> w1at [256, E]; element i of the three
+__device__ __forceinline__ void amlp_transpose_element(int i, const float* __restrict__ W3, int K3, float* __restrict__ w3t,
+                                                       const float* __restrict__ W2, float* __restrict__ w2t, const float* __restrict__ W1a,
+                                                       int E, float* __restrict__ w1at) {
+    constexpr int H = 256;
+    if (i < H * H) { const int r = i >> 8, c = i & 255; w2t[i] = W2[c * H + r]; return; }
+    i -= H * H;
+    if (i < K3 * H) { const int r = i >> 8, c = i & 255; w3t[i] = W3[c * K3 + r]; return; }
+    i -= K3 * H;
+    if (i < H * E) { const int r = i / E, c = i - r * E; w1at[i] = W1a[c * H + r]; }
+}
+constexpr int AMLP_T_PER_WG = 2048;           // transposed elements per extra workgroup of the forward launch
+
+// grid = (ceil(N / 4) [+ transposing workgroups], networks) workgroups of 4 waves; dynamic LDS = amlp_fwd4_smem(D + E)
+__global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4x x) {
     using namespace r8;
     using namespace a4;
+    const AmlpFwd4& a = x.n[blockIdx.y];
+    const int row_wgs = (a.N + 3) / 4;
+    if ((int)blockIdx.x >= row_wgs) {
+        if (a.w2t) {
+            const int base = ((int)blockIdx.x - row_wgs) * AMLP_T_PER_WG;
+            for (int i = threadIdx.x; i < AMLP_T_PER_WG; i += 256)
+                amlp_transpose_element(base + i, a.W3, a.K3, a.w3t, a.W2, a.w2t, a.W1 + (size_t)a.D * 256, a.E, a.w1at);
+        }
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KX = a.D + a.E, KXP = (KX + 63) / 64 * 64, LDX = KXP + 4;
     float* xs = reinterpret_cast<float*>(smem);          // [4][LDX]  [x | a | 0]
@@ -149,22 +179,17 @@ struct AmlpBwd4 {
     float* d_h2; float* d_h1; float* dact;                    // out: [N, 256], [N, 256], [N, E] or NULL
     int N, K3, E;
 };
+struct AmlpBwd4x { AmlpBwd4 n[4]; };
 
-// W3 [256, K3] -> w3t [K3, 256];  W2 [256, 256] -> w2t;  W1a = W1 rows D.. [E, 256] -> w1at [256, E]
 __global__ void k_amlp_transposes(const float* __restrict__ W3, int K3, float* __restrict__ w3t, const float* __restrict__ W2,
                                   float* __restrict__ w2t, const float* __restrict__ W1a, int E, float* __restrict__ w1at) {
-    constexpr int H = 256;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < H * H) { const int r = i >> 8, c = i & 255; w2t[i] = W2[c * H + r]; return; }
-    i -= H * H;
-    if (i < K3 * H) { const int r = i >> 8, c = i & 255; w3t[i] = W3[c * K3 + r]; return; }
-    i -= K3 * H;
-    if (i < H * E) { const int r = i / E, c = i - r * E; w1at[i] = W1a[c * H + r]; }
+    amlp_transpose_element(blockIdx.x * blockDim.x + threadIdx.x, W3, K3, w3t, W2, w2t, W1a, E, w1at);
 }
 
-__global__ __launch_bounds__(256) void k_amlp_bwd4(AmlpBwd4 a) {
+__global__ __launch_bounds__(256) void k_amlp_bwd4(AmlpBwd4x x) {
     using namespace r8;
     using namespace a4;
+    const AmlpBwd4& a = x.n[blockIdx.y];
     __shared__ __attribute__((aligned(16))) float ds[4][64 + 4];      // dout rows, zero-padded to 64
     __shared__ __attribute__((aligned(16))) float d2s[4][LDH];
     __shared__ __attribute__((aligned(16))) float d1s[4][LDH];

@@ -338,6 +338,64 @@ static bool amlp_fused_shape_ok(const rl4rs_amlp_cfg& c) {
 static int g_amlp_fused = 1;            // rl4rs_amlp_set_fused: 0 = the per-layer launches for every call (tests, A/B runs)
 static bool amlp_fused_call(const rl4rs_amlp* p, int N, int rep) { return g_amlp_fused && amlp_fused_shape_ok(p->c) && rep == 1 && N <= 2048; }
 
+// n <= 4 networks with the same input widths over the SAME rows as one launch each way (amlp_fused.hpp)
+static int amlp_forward_fused(int n, rl4rs_amlp* const* nets, int N, const float* obs, const float* act, float* const* outs, hipStream_t st) {
+    static bool attr = false;
+    int rc;
+    if (!attr) {
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4), amlp_fwd4_smem(4096)))) return rc;
+        attr = true;
+    }
+    AmlpFwd4x x;
+    memset(&x, 0, sizeof(x));
+    int t_elems = 0;
+    for (int i = 0; i < n; ++i) {
+        rl4rs_amlp* p = nets[i];
+        const float* P = p->params;
+        const int64_t* o = p->off;
+        const int D = p->c.obs_dim, E = p->c.act_dim, K = p->c.out_dim;
+        x.n[i] = AmlpFwd4{obs, act, P + o[AP_W1], P + o[AP_B1], P + o[AP_W2], P + o[AP_B2], P + o[AP_W3], P + o[AP_B3], p->h1, p->h2, outs[i],
+                          p->w3t, p->w2t, p->w1at, N, D, E, K, p->c.head_act};
+        if (p->w2t) t_elems = std::max(t_elems, 256 * 256 + 256 * K + 256 * E);
+        p->last_n = N;
+        p->last_rep = 1;
+    }
+    const int row_wgs = (N + 3) / 4, t_wgs = (t_elems + AMLP_T_PER_WG - 1) / AMLP_T_PER_WG;
+    hipLaunchKernelGGL(k_amlp_fwd4, dim3(row_wgs + t_wgs, n), dim3(256), amlp_fwd4_smem(nets[0]->c.obs_dim + nets[0]->c.act_dim), st, x);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+static int amlp_backward_fused(int n, rl4rs_amlp* const* nets, int N, const float* obs, const float* act, const float* const* douts,
+                               float* const* dacts, int want_param_grad, hipStream_t st) {
+    AmlpBwd4x x;
+    memset(&x, 0, sizeof(x));
+    TnGroup g;
+    memset(&g, 0, sizeof(g));
+    g.Ns = N;
+    auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst, float* bias) {
+        const int i = g.n++;
+        g.A[i] = A; g.lda[i] = lda; g.M[i] = M; g.B[i] = B; g.ldb[i] = ldb; g.Nc[i] = Nc; g.out[i] = dst; g.bias[i] = bias;
+        g.tile0[i + 1] = g.tile0[i] + ((M + 31) / 32) * ((Nc + 31) / 32);
+    };
+    for (int i = 0; i < n; ++i) {
+        rl4rs_amlp* p = nets[i];
+        const int64_t* o = p->off;
+        float* G = p->grad;
+        const int D = p->c.obs_dim, E = p->c.act_dim, K = p->c.out_dim, H1 = 256, H2 = 256;
+        x.n[i] = AmlpBwd4{douts[i], p->h1, p->h2, p->w3t, p->w2t, p->w1at, p->d_h2, p->d_h1, dacts ? dacts[i] : nullptr, N, K, E};
+        if (want_param_grad) {
+            add(p->h2, H2, H2, douts[i], K, K, G + o[AP_W3], G + o[AP_B3]);
+            add(p->h1, H1, H1, p->d_h2, H2, H2, G + o[AP_W2], G + o[AP_B2]);
+            add(obs, D, D, p->d_h1, H1, H1, G + o[AP_W1], G + o[AP_B1]);
+            if (E > 0) add(act, E, E, p->d_h1, H1, H1, G + o[AP_W1] + (size_t)D * H1, nullptr);
+        }
+    }
+    hipLaunchKernelGGL(k_amlp_bwd4, dim3((N + 3) / 4, n), dim3(256), 0, st, x);
+    if (want_param_grad) hipLaunchKernelGGL(k_gemm_tn4_group, dim3(g.tile0[g.n]), dim3(256), 0, st, g);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 extern "C" {
 
 int rl4rs_amlp_set_fused(int32_t on) {
@@ -457,19 +515,11 @@ int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, 
     const int64_t* o = p->off;
     int rc;
     if (amlp_fused_call(p, N, rep)) {
-        // minibatch-sized: the three layers as ONE launch (amlp_fused.hpp)
-        static bool attr = false;
-        if (!attr) {
-            if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4), amlp_fwd4_smem(4096)))) return rc;
-            attr = true;
-        }
-        AmlpFwd4 f = {obs, act, P + o[AP_W1], P + o[AP_B1], P + o[AP_W2], P + o[AP_B2], P + o[AP_W3], P + o[AP_B3], p->h1, p->h2, out,
-                      N, D, E, K, p->c.head_act};
-        hipLaunchKernelGGL(k_amlp_fwd4, dim3((N + 3) / 4), dim3(256), amlp_fwd4_smem(D + E), st, f);
-        RL4RS_LAUNCH_CHECK();
-        p->last_n = N;
-        p->last_rep = rep;
-        return RL4RS_OK;
+        // minibatch-sized: the three layers as ONE launch (amlp_fused.hpp); a trainable network's launch also rebuilds the transposed
+        // weights its backward reads
+        rl4rs_amlp* one[1] = {p};
+        float* outs[1] = {out};
+        return amlp_forward_fused(1, one, N, obs, act, outs, st);
     }
     if (E == 0) {
         if ((rc = launch_gemm_f32(obs, D, P + o[AP_W1], H1, P + o[AP_B1], p->h1, H1, N, H1, D, ACT_RELU, st))) return rc;
@@ -545,28 +595,12 @@ int rl4rs_amlp_backward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs,
     const dim3 b256(256);
     int rc;
     if (amlp_fused_call(p, N, rep) && p->w2t && N <= TN4_MAX_SAMPLES) {
-        // minibatch-sized: transposes + the whole input-gradient chain + every parameter gradient = three launches (amlp_fused.hpp)
-        const int nt = (int)(H1 * H2 + H2 * K + H1 * E);
-        hipLaunchKernelGGL(k_amlp_transposes, ew(nt), b256, 0, st, P + o[AP_W3], K, p->w3t, P + o[AP_W2], p->w2t, P + o[AP_W1] + (size_t)D * H1, E, p->w1at);
-        AmlpBwd4 b = {dout, p->h1, p->h2, p->w3t, p->w2t, p->w1at, p->d_h2, p->d_h1, dact, N, K, E};
-        hipLaunchKernelGGL(k_amlp_bwd4, dim3((N + 3) / 4), b256, 0, st, b);
-        if (want_param_grad) {
-            TnGroup g;
-            memset(&g, 0, sizeof(g));
-            auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int Nc, float* dst, float* bias) {
-                const int i = g.n++;
-                g.A[i] = A; g.lda[i] = lda; g.M[i] = M; g.B[i] = B; g.ldb[i] = ldb; g.Nc[i] = Nc; g.out[i] = dst; g.bias[i] = bias;
-                g.tile0[i + 1] = g.tile0[i] + ((M + 31) / 32) * ((Nc + 31) / 32);
-            };
-            add(p->h2, H2, H2, dout, K, K, G + o[AP_W3], G + o[AP_B3]);
-            add(p->h1, H1, H1, p->d_h2, H2, H2, G + o[AP_W2], G + o[AP_B2]);
-            add(obs, D, D, p->d_h1, H1, H1, G + o[AP_W1], G + o[AP_B1]);
-            if (E > 0) add(act, E, E, p->d_h1, H1, H1, G + o[AP_W1] + (size_t)D * H1, nullptr);
-            g.Ns = N;
-            hipLaunchKernelGGL(k_gemm_tn4_group, dim3(g.tile0[g.n]), b256, 0, st, g);
-        }
-        RL4RS_LAUNCH_CHECK();
-        return RL4RS_OK;
+        // minibatch-sized: the whole input-gradient chain + every parameter gradient = two launches (amlp_fused.hpp; the transposed
+        // weights were rebuilt by the forward's launch)
+        rl4rs_amlp* one[1] = {p};
+        const float* douts[1] = {dout};
+        float* dacts[1] = {dact};
+        return amlp_backward_fused(1, one, N, obs, act, douts, dacts, want_param_grad, st);
     }
     // per layer: ONE launch for the weight + bias gradient (k_gemm_tn with the column sums folded in) and ONE for the input
     // gradient (k_gemm_nt: no transposed weight copy, the ReLU derivative of the layer below in its epilogue)
@@ -631,6 +665,44 @@ int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, c
     }
     hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)((a.start[n] + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+// n <= 4 networks of the same input widths on the SAME rows (the twin critics): forward / backward of all of them as ONE launch each
+// way when the call has the fused form (rl4rs_amlp_set_fused), else one rl4rs_amlp_forward / _backward per network (rep = 1).
+int rl4rs_amlp_forward_multi(int32_t n, rl4rs_amlp* const* nets, int32_t N, const float* obs, const float* act, float* const* outs, void* stream) {
+    RL4RS_REQUIRE(n >= 1 && n <= 4 && nets && outs && obs && N > 0, "amlp_forward_multi: bad argument (n=%d)", n);
+    bool fused = true;
+    for (int i = 0; i < n; ++i) {
+        RL4RS_REQUIRE(nets[i] && outs[i], "amlp_forward_multi: null handle / output %d", i);
+        RL4RS_REQUIRE(nets[i]->c.obs_dim == nets[0]->c.obs_dim && nets[i]->c.act_dim == nets[0]->c.act_dim, "amlp_forward_multi: network %d has other input widths", i);
+        RL4RS_REQUIRE(N <= nets[i]->c.max_rows && (act || nets[i]->c.act_dim == 0), "amlp_forward_multi: bad argument for network %d", i);
+        fused = fused && amlp_fused_call(nets[i], N, 1);
+    }
+    if (fused) return amlp_forward_fused(n, nets, N, obs, act, outs, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i) {
+        const int rc = rl4rs_amlp_forward(nets[i], N, 1, obs, act, outs[i], stream);
+        if (rc) return rc;
+    }
+    return RL4RS_OK;
+}
+int rl4rs_amlp_backward_multi(int32_t n, rl4rs_amlp* const* nets, int32_t N, const float* obs, const float* act, const float* const* douts,
+                              float* const* dacts, int32_t want_param_grad, void* stream) {
+    RL4RS_REQUIRE(n >= 1 && n <= 4 && nets && douts && obs && N > 0, "amlp_backward_multi: bad argument (n=%d)", n);
+    bool fused = N <= TN4_MAX_SAMPLES;
+    for (int i = 0; i < n; ++i) {
+        RL4RS_REQUIRE(nets[i] && douts[i], "amlp_backward_multi: null handle / gradient %d", i);
+        RL4RS_REQUIRE(nets[i]->c.obs_dim == nets[0]->c.obs_dim && nets[i]->c.act_dim == nets[0]->c.act_dim, "amlp_backward_multi: network %d has other input widths", i);
+        RL4RS_REQUIRE(N <= nets[i]->c.max_grad_rows, "amlp_backward_multi: N=%d exceeds max_grad_rows=%d of network %d", N, nets[i]->c.max_grad_rows, i);
+        RL4RS_REQUIRE(N == nets[i]->last_n && nets[i]->last_rep == 1, "amlp_backward_multi: network %d: does not follow the forward of the same rows", i);
+        RL4RS_REQUIRE(!(dacts && dacts[i]) || nets[i]->c.act_dim > 0, "amlp_backward_multi: no action input to differentiate");
+        fused = fused && amlp_fused_call(nets[i], N, 1) && nets[i]->w2t;
+    }
+    if (fused) return amlp_backward_fused(n, nets, N, obs, act, douts, dacts, want_param_grad, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i) {
+        const int rc = rl4rs_amlp_backward(nets[i], N, 1, obs, act, douts[i], dacts ? dacts[i] : nullptr, want_param_grad, stream);
+        if (rc) return rc;
+    }
     return RL4RS_OK;
 }
 

@@ -581,17 +581,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn4(const float* __restrict__ A, i
                                                   int Ns, float* __restrict__ out, float* __restrict__ bias_out) {
     gemm_tn4_tile(A, lda, M, B, ldb, Nc, Ns, out, bias_out, blockIdx.x);
 }
-// Up to four such reductions over the SAME sample axis as one grid (round 5: every weight and bias gradient of a fused amlp
+// Up to 16 such reductions over the SAME sample axis as one grid (round 5: every weight and bias gradient of a fused amlp
 // backward - W3, W2, W1's observation rows, W1's action rows): tiles of problem i are workgroups [tile0[i], tile0[i + 1]).
+constexpr int TN_GROUP_MAX = 16;
 struct TnGroup {
-    const float* A[4]; const float* B[4]; float* out[4]; float* bias[4];
-    int lda[4], M[4], ldb[4], Nc[4], tile0[5];
+    const float* A[TN_GROUP_MAX]; const float* B[TN_GROUP_MAX]; float* out[TN_GROUP_MAX]; float* bias[TN_GROUP_MAX];
+    int lda[TN_GROUP_MAX], M[TN_GROUP_MAX], ldb[TN_GROUP_MAX], Nc[TN_GROUP_MAX], tile0[TN_GROUP_MAX + 1];
     int n, Ns;
 };
 __global__ __launch_bounds__(256) void k_gemm_tn4_group(TnGroup g) {
     int i = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) i += (k < g.n && (int)blockIdx.x >= g.tile0[k]) ? 1 : 0;
+    for (int k = 1; k < TN_GROUP_MAX; ++k) i += (k < g.n && (int)blockIdx.x >= g.tile0[k]) ? 1 : 0;
     gemm_tn4_tile(g.A[i], g.lda[i], g.M[i], g.B[i], g.ldb[i], g.Nc[i], g.Ns, g.out[i], g.bias[i], (int)blockIdx.x - g.tile0[i]);
 }
 

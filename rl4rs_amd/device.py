@@ -1702,6 +1702,36 @@ def amlp_adam_multi(nets, lrs, targets=None, tau=0.0, step=None, beta1=0.9, beta
     check(lib.rl4rs_amlp_adam_multi(n, H, LR, DO, T, beta1, beta2, eps, float(tau), _stream()))
 
 
+def amlp_forward_multi(nets, obs, act=None):
+    """``net.forward(obs, act)`` for several networks with the same input widths on the SAME rows - the twin critics - as ONE launch
+    when the call has the fused form (rl4rs_amlp_forward_multi).  Returns the list of outputs; every network keeps its activations
+    for a following backward."""
+    lib = _lib.load()
+    n0 = nets[0]
+    N = n0._rows(obs, act, 1)
+    outs = [torch.empty((N, net.K), dtype=torch.float32, device=net.device) for net in nets]
+    H = (C.c_void_p * len(nets))(*[net.h for net in nets])
+    O = (C.c_void_p * len(nets))(*[_ptr(o) for o in outs])
+    check(lib.rl4rs_amlp_forward_multi(len(nets), H, N, _ptr(obs), _ptr(act), O, _stream()))
+    return outs
+
+
+def amlp_backward_multi(nets, obs, act, douts, want_dact=False, want_param_grad=True):
+    """``net.backward(obs, act, dout)`` for the networks of ``amlp_forward_multi`` as one input-gradient launch + one parameter-
+    gradient launch (rl4rs_amlp_backward_multi).  Returns the list of action-input gradients (or None)."""
+    lib = _lib.load()
+    n0 = nets[0]
+    N = n0._rows(obs, act, 1)
+    for net, d in zip(nets, douts):
+        assert d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.numel() == N * net.K
+    dacts = [torch.empty((N, net.E), dtype=torch.float32, device=net.device) for net in nets] if want_dact else None
+    H = (C.c_void_p * len(nets))(*[net.h for net in nets])
+    DO = (C.c_void_p * len(nets))(*[_ptr(d) for d in douts])
+    DA = (C.c_void_p * len(nets))(*[_ptr(d) for d in dacts]) if want_dact else None
+    check(lib.rl4rs_amlp_backward_multi(len(nets), H, N, _ptr(obs), _ptr(act), DO, DA, 1 if want_param_grad else 0, _stream()))
+    return dacts
+
+
 def amlp_set_fused(on):
     """Fused minibatch forward / backward of the amlp networks on (default) or off (rl4rs_amlp_set_fused; tests and A/B runs)."""
     check(_lib.load().rl4rs_amlp_set_fused(1 if on else 0))

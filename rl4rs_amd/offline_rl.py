@@ -443,11 +443,9 @@ class BCQ(_ModelIO):
             q1n = self.q1_targ.forward(nxt, a_next, rep=n, nograd=self.nograd)
             q2n = self.q2_targ.forward(nxt, a_next, rep=n, nograd=self.nograd)
             yq, _ = D_.bcq_target(q1n, q2n, n, self.lam, rew, ter, self.gamma)
-            q1v = self.q1.forward(obs, act)
-            q2v = self.q2.forward(obs, act)
+            q1v, q2v = D_.amlp_forward_multi([self.q1, self.q2], obs, act)              # the twin critics as one launch each way
             closs2, dq1, dq2 = D_.critic_mse(q1v, q2v, yq)
-            self.q1.backward(obs, act, dq1)
-            self.q2.backward(obs, act, dq2)
+            D_.amlp_backward_multi([self.q1, self.q2], obs, act, [dq1, dq2])
             _allreduce_group([self.q1, self.q2])
             D_.amlp_adam_multi([self.q1, self.q2], [self.critic_lr] * 2)
             metrics['critic_loss'] = closs2.sum()
@@ -720,9 +718,10 @@ class CQL(_ModelIO):
         # --- actor (SACImpl.compute_actor_loss): (exp(log_temp) * logp - min_c Q_c(s, a)).mean()
         eps = self._randn((B, A), noise.get('eps_actor'))
         a_pi, logp = D_.squashed_sample(head_obs, eps)
-        qmin, dq1, dq2 = D_.twin_min(self.q1.forward(obs, a_pi), self.q2.forward(obs, a_pi), want_grad=True)
-        g_a = self.q1.backward(obs, a_pi, dq1.view(B, 1), want_dact=True, want_param_grad=False)
-        g_a += self.q2.backward(obs, a_pi, dq2.view(B, 1), want_dact=True, want_param_grad=False)
+        q1p, q2p = D_.amlp_forward_multi([self.q1, self.q2], obs, a_pi)
+        qmin, dq1, dq2 = D_.twin_min(q1p, q2p, want_grad=True)
+        g1, g2 = D_.amlp_backward_multi([self.q1, self.q2], obs, a_pi, [dq1.view(B, 1), dq2.view(B, 1)], want_dact=True, want_param_grad=False)
+        g_a = g1.add_(g2)
         d_head = D_.sac_actor_grad(head_obs, eps, a_pi, g_a, self.log_temp.p)
         self.policy.backward(obs, None, d_head)
         _allreduce_group([self.policy])

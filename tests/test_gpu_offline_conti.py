@@ -97,6 +97,31 @@ def _check_amlp_forward_and_gradients(act_dim, out_dim, head_act, rep, R):
     dev.close()
 
 
+@pytest.mark.parametrize('fused', [True, False])
+def test_twin_networks_in_one_launch_equal_single_calls(amlp_fused, fused):
+    """rl4rs_amlp_forward_multi / _backward_multi (the twin critics over the same rows as one launch each way) == one
+    rl4rs_amlp_forward / _backward per network, bit for bit: outputs, action-input gradients, parameter gradients"""
+    import torch
+    from rl4rs_amd import device as Dv
+    amlp_fused(fused)
+    rs = np.random.RandomState(12)
+    N = 203
+    x = torch.from_numpy(_batch(N, 13)[0]).cuda()
+    a = torch.from_numpy(rs.randn(N, E).astype(np.float32) * 0.5).cuda()
+    pair = [_pair(E, 1, 31)[0], _pair(E, 1, 32)[0]]
+    solo = [_pair(E, 1, 31)[0], _pair(E, 1, 32)[0]]
+    outs = Dv.amlp_forward_multi(pair, x, a)
+    douts = [torch.from_numpy(rs.randn(N, 1).astype(np.float32)).cuda() for _ in range(2)]
+    dacts = Dv.amlp_backward_multi(pair, x, a, douts, want_dact=True)
+    for net, o, d, da in zip(solo, outs, douts, dacts):
+        assert torch.equal(net.forward(x, a), o)
+        assert torch.equal(net.backward(x, a, d, want_dact=True), da)
+    for p, q in zip(pair, solo):
+        assert torch.equal(p.flat_gradient(), q.flat_gradient())
+        p.close()
+        q.close()
+
+
 def test_adam_multi_equals_separate_launches():
     """rl4rs_amlp_adam_multi (Adam of several networks + soft target updates as one launch) == rl4rs_amlp_adam_step and
     rl4rs_amlp_soft_update per network, bit for bit, over three steps; a soft-update-only entry leaves its source untouched"""
