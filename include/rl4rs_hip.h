@@ -793,7 +793,8 @@ int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, c
                           float beta1, float beta2, float eps, float tau, void* stream);
 /* Minibatch-sized rl4rs_amlp_forward / rl4rs_amlp_backward calls (hidden 256 x 256, out_dim / act_dim <= 64, rep = 1, N <= 2048 /
  * 1024) run as fused launches - one for the three layers forwards; transposes + input-gradient chain + all parameter gradients
- * backwards - instead of one launch per layer and product.  on = 0 restores the per-layer launches (process-wide; tests, A/B). */
+ * backwards - instead of one launch per layer and product.  on = 0 restores the per-layer launches, 2 selects the 8-rows-per-
+ * workgroup form of the fused kernels (measured slower at 256 rows; default 1 = 4 rows).  Process-wide; tests, A/B. */
 int rl4rs_amlp_set_fused(int32_t on);
 /* n <= 4 networks with the same input widths on the SAME rows (d3rlpy's twin critics: both Q functions see (s, a)) - forward /
  * backward of all of them as one launch each way when the call has the fused form, otherwise one rl4rs_amlp_forward / _backward
@@ -856,6 +857,29 @@ int rl4rs_twin_min(int32_t B, const float* q1_dev, const float* q2_dev, float* q
 int rl4rs_cql_critic_loss(int32_t B, int32_t m, const float* q1_dev, const float* q2_dev, const float* offs_dev, const float* y_dev,
                           const float* alpha_w_dev, float* dq1_dev, float* dq2_dev, float* rows_scratch_dev, float* sums6_dev,
                           void* stream);
+
+/* One whole BCQ update (d3rlpy BCQ._update: imitator step, critic step, actor step, soft target updates - the sequence of
+ * rl4rs_amlp_* / rl4rs_cvae_* / rl4rs_residual_* / rl4rs_bcq_target / rl4rs_critic_mse calls rl4rs_amd/offline_rl.py::BCQ.update
+ * makes, with the same arguments, as ONE host call: after the fused kernels an update was bound by the ~55 Python -> C calls it
+ * takes, not by the GPU).  Single-process only: the data-parallel learner keeps the per-phase calls around its all-reduces.
+ *   noise_dev      (B + B * n + B) * L floats of N(0, 1): eps [B, L] | z_target [B * n, L] | z_actor [B, L]; the two z parts are
+ *                  clamped to +-0.5 IN PLACE (BCQImpl: the decoder's latent is clipped when actions are sampled)
+ *   workspace_dev  rl4rs_bcq_workspace_floats(B, n, E, L) floats, 16-byte aligned
+ *   metrics_dev    float[3] = {imitator loss, critic loss, actor loss} (entries of skipped phases are left alone)
+ *   do_rl / do_actor   total_step >= rl_start_step / total_step % update_actor_interval == 0;  nograd_h16: the B * n target rows
+ *                  through rl4rs_amlp_forward_h16 where the network and the row count allow (the learner's nograd_precision) */
+typedef struct rl4rs_bcq_step {
+    rl4rs_amlp *imit_enc, *imit_dec, *policy, *policy_targ, *q1, *q2, *q1_targ, *q2_targ;
+    int32_t B, n, E, L;
+    float beta, action_flexibility, lam, gamma, tau, imitator_lr, critic_lr, actor_lr;
+    int32_t do_rl, do_actor, nograd_h16, h16_min_rows;
+    const float *obs_dev, *act_dev, *rew_dev, *nxt_dev, *ter_dev;
+    float* noise_dev;
+    float* workspace_dev;
+    float* metrics_dev;
+} rl4rs_bcq_step;
+int64_t rl4rs_bcq_workspace_floats(int32_t B, int32_t n, int32_t E, int32_t L);
+int rl4rs_bcq_update(const rl4rs_bcq_step* step, void* stream);
 
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh, 4 ReLU. */

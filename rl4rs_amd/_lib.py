@@ -80,6 +80,15 @@ class AmlpCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('obs_dim', 'act_dim', 'hidden1', 'hidden2', 'out_dim', 'head_act', 'max_rows', 'max_grad_rows')]
 
 
+class BcqStep(C.Structure):
+    """rl4rs_bcq_step (include/rl4rs_hip.h)"""
+    _fields_ = ([(n, C.c_void_p) for n in ('imit_enc', 'imit_dec', 'policy', 'policy_targ', 'q1', 'q2', 'q1_targ', 'q2_targ')] +
+                [(n, C.c_int32) for n in ('B', 'n', 'E', 'L')] +
+                [(n, C.c_float) for n in ('beta', 'action_flexibility', 'lam', 'gamma', 'tau', 'imitator_lr', 'critic_lr', 'actor_lr')] +
+                [(n, C.c_int32) for n in ('do_rl', 'do_actor', 'nograd_h16', 'h16_min_rows')] +
+                [(n, C.c_void_p) for n in ('obs_dev', 'act_dev', 'rew_dev', 'nxt_dev', 'ter_dev', 'noise_dev', 'workspace_dev', 'metrics_dev')])
+
+
 class RawPolicyCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num', 'category_hash_size',
@@ -241,6 +250,8 @@ SIGNATURES = {
     'rl4rs_amlp_adam_multi': (_I, [_I32, C.POINTER(_P), C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_P), C.c_float, C.c_float, C.c_float,
                                    C.c_float, _P]),
     'rl4rs_amlp_set_fused': (_I, [_I32]),
+    'rl4rs_bcq_workspace_floats': (_I64, [_I32, _I32, _I32, _I32]),
+    'rl4rs_bcq_update': (_I, [C.POINTER(BcqStep), _P]),
     'rl4rs_amlp_forward_multi': (_I, [_I32, C.POINTER(_P), _I32, _P, _P, C.POINTER(_P), _P]),
     'rl4rs_amlp_backward_multi': (_I, [_I32, C.POINTER(_P), _I32, _P, _P, C.POINTER(_P), C.POINTER(_P), _I32, _P]),
     'rl4rs_cvae_sample': (_I, [_I32, _I32, _P, _P, C.c_float, C.c_float, _P, _P]),

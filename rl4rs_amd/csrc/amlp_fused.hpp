@@ -67,12 +67,16 @@ __device__ __forceinline__ void amlp_transpose_element(int i, const float* __res
 }
 constexpr int AMLP_T_PER_WG = 2048;           // transposed elements per extra workgroup of the forward launch
 
-// grid = (ceil(N / 4) [+ transposing workgroups], networks) workgroups of 4 waves; dynamic LDS = amlp_fwd4_smem(D + E)
+// grid = (ceil(N / (4 MTW)) [+ transposing workgroups], networks) workgroups of 4 waves; dynamic LDS = amlp_fwd4_smem(D + E, MTW).
+// MTW = 1 (4 rows per workgroup: 64 workgroups for a 256-row minibatch) is what runs; MTW = 2 (every weight value feeds two row
+// tiles, half the workgroups) was measured slower there (BCQ update 0.371 -> 0.406 ms) and is built for A/B runs only.
+template <int MTW>
 __global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4x x) {
     using namespace r8;
     using namespace a4;
+    constexpr int RWS = 4 * MTW;
     const AmlpFwd4& a = x.n[blockIdx.y];
-    const int row_wgs = (a.N + 3) / 4;
+    const int row_wgs = (a.N + RWS - 1) / RWS;
     if ((int)blockIdx.x >= row_wgs) {
         if (a.w2t) {
             const int base = ((int)blockIdx.x - row_wgs) * AMLP_T_PER_WG;
@@ -83,15 +87,15 @@ __global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4x x) {
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KX = a.D + a.E, KXP = (KX + 63) / 64 * 64, LDX = KXP + 4;
-    float* xs = reinterpret_cast<float*>(smem);          // [4][LDX]  [x | a | 0]
-    float* h1s = xs + 4 * LDX;                           // [4][LDH]
-    float* h2s = h1s + 4 * LDH;                          // [4][LDH]
-    float* part = h2s + 4 * LDH;                         // [4 waves][4 rows][64]  head partials
+    float* xs = reinterpret_cast<float*>(smem);          // [RWS][LDX]  [x | a | 0]
+    float* h1s = xs + RWS * LDX;                         // [RWS][LDH]
+    float* h2s = h1s + RWS * LDH;                        // [RWS][LDH]
+    float* part = h2s + RWS * LDH;                       // [4 waves][RWS rows][64]  head partials
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * 4;
+    const int row0 = blockIdx.x * RWS;
     const int col = wave * 64 + lane;
-    for (int i = tid; i < 4 * KXP; i += 256) {
+    for (int i = tid; i < RWS * KXP; i += 256) {
         const int r = i / KXP, k = i - r * KXP;
         const int gr = min(row0 + r, a.N - 1);
         float v = 0.f;
@@ -115,62 +119,80 @@ __global__ __launch_bounds__(256) void k_amlp_fwd4(AmlpFwd4x x) {
 #pragma unroll
     for (int i = 0; i < RS; ++i) ring[i] = ld1(i, 0);
     __syncthreads();
-    const float* ap[1];
-    f32x4_t acc[1][1][4];
+    constexpr int P = 4 / MTW;                           // accumulator chains per tile (>= 4 independent MFMA chains per wave)
+    const float* ap[MTW];
+    f32x4_t acc[1][MTW][P];
     auto zero = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[0][0][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[0][m][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     };
-    auto total = [&]() { return (acc[0][0][0] + acc[0][0][1]) + (acc[0][0][2] + acc[0][0][3]); };
+    auto total = [&](int m) {
+        f32x4_t s = acc[0][m][0];
+#pragma unroll
+        for (int p = 1; p < P; ++p) s += acc[0][m][p];
+        return s;
+    };
     // ---- layer 1
     zero();
-    ap[0] = xs + (lane & 3) * LDX;
-    phase_rt<1, 1, 4>(acc, ap, ring, ld1, head2, KXP / 64);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) ap[m] = xs + (m * 4 + (lane & 3)) * LDX;
+    phase_rt<1, MTW, P>(acc, ap, ring, ld1, head2, KXP / 64);
     {
-        const f32x4_t s = total();
         const float b = a.b1[col];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = fmaxf(s[i] + b, 0.f);
-            h1s[i * LDH + col] = v;
-            if (row0 + i < a.N) a.h1[(size_t)(row0 + i) * H + col] = v;
+        for (int m = 0; m < MTW; ++m) {
+            const f32x4_t s = total(m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaxf(s[i] + b, 0.f);
+                h1s[(m * 4 + i) * LDH + col] = v;
+                if (row0 + m * 4 + i < a.N) a.h1[(size_t)(row0 + m * 4 + i) * H + col] = v;
+            }
         }
     }
     __syncthreads();
     // ---- layer 2
     zero();
-    ap[0] = h1s + (lane & 3) * LDH;
-    phase_rt<1, 1, 4>(acc, ap, ring, ld2, head3, H / 64);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) ap[m] = h1s + (m * 4 + (lane & 3)) * LDH;
+    phase_rt<1, MTW, P>(acc, ap, ring, ld2, head3, H / 64);
     {
-        const f32x4_t s = total();
         const float b = a.b2[col];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = fmaxf(s[i] + b, 0.f);
-            h2s[i * LDH + col] = v;
-            if (row0 + i < a.N) a.h2[(size_t)(row0 + i) * H + col] = v;
+        for (int m = 0; m < MTW; ++m) {
+            const f32x4_t s = total(m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaxf(s[i] + b, 0.f);
+                h2s[(m * 4 + i) * LDH + col] = v;
+                if (row0 + m * 4 + i < a.N) a.h2[(size_t)(row0 + m * 4 + i) * H + col] = v;
+            }
         }
     }
     __syncthreads();
     // ---- head: the four waves split k (64 each), lane = output column; partials meet in LDS and are summed in wave order
     zero();
-    ap[0] = h2s + (lane & 3) * LDH + wave * 64;
-    phase_rt<1, 1, 4>(acc, ap, ring, ld3, none, 1);
-    {
-        const f32x4_t s = total();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) part[(wave * 4 + i) * 64 + lane] = s[i];
+    for (int m = 0; m < MTW; ++m) ap[m] = h2s + (m * 4 + (lane & 3)) * LDH + wave * 64;
+    phase_rt<1, MTW, P>(acc, ap, ring, ld3, none, 1);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const f32x4_t s = total(m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(wave * RWS + m * 4 + i) * 64 + lane] = s[i];
     }
     __syncthreads();
-    if (tid < 4 * 64) {
-        const int i = tid >> 6, j = tid & 63;
+    for (int e = tid; e < RWS * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
         if (j < k3 && row0 + i < a.N) {
-            const float v = ((part[(0 * 4 + i) * 64 + j] + part[(1 * 4 + i) * 64 + j]) + part[(2 * 4 + i) * 64 + j]) + part[(3 * 4 + i) * 64 + j];
+            const float v = ((part[(0 * RWS + i) * 64 + j] + part[(1 * RWS + i) * 64 + j]) + part[(2 * RWS + i) * 64 + j]) + part[(3 * RWS + i) * 64 + j];
             a.out[(size_t)(row0 + i) * k3 + j] = head_activation(v + a.b3[j], a.head_act);
         }
     }
 }
-inline size_t amlp_fwd4_smem(int KX) { return (size_t)(4 * ((KX + 63) / 64 * 64 + 4) + 2 * 4 * (256 + 4) + 4 * 4 * 64) * 4; }
+inline size_t amlp_fwd4_smem(int KX, int MTW) { const int R = 4 * MTW; return (size_t)(R * ((KX + 63) / 64 * 64 + 4) + 2 * R * (256 + 4) + 4 * R * 64) * 4; }
 
 // ---------------------------------------------------------------------------------------------------------------- backward chain
 struct AmlpBwd4 {
@@ -186,21 +208,23 @@ __global__ void k_amlp_transposes(const float* __restrict__ W3, int K3, float* _
     amlp_transpose_element(blockIdx.x * blockDim.x + threadIdx.x, W3, K3, w3t, W2, w2t, W1a, E, w1at);
 }
 
+template <int MTW>
 __global__ __launch_bounds__(256) void k_amlp_bwd4(AmlpBwd4x x) {
     using namespace r8;
     using namespace a4;
+    constexpr int RWS = 4 * MTW, P = 4 / MTW;
     const AmlpBwd4& a = x.n[blockIdx.y];
-    __shared__ __attribute__((aligned(16))) float ds[4][64 + 4];      // dout rows, zero-padded to 64
-    __shared__ __attribute__((aligned(16))) float d2s[4][LDH];
-    __shared__ __attribute__((aligned(16))) float d1s[4][LDH];
-    __shared__ float part[4 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float ds[RWS][64 + 4];      // dout rows, zero-padded to 64
+    __shared__ __attribute__((aligned(16))) float d2s[RWS][LDH];
+    __shared__ __attribute__((aligned(16))) float d1s[RWS][LDH];
+    __shared__ float part[4 * RWS * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * 4;
+    const int row0 = blockIdx.x * RWS;
     const int col = wave * 64 + lane;
     const int k3 = a.K3, E = a.E;
-    {
-        const int r = tid >> 6, k = tid & 63;
+    for (int e = tid; e < RWS * 64; e += 256) {
+        const int r = e >> 6, k = e & 63;
         const int gr = min(row0 + r, a.N - 1);
         ds[r][k] = k < k3 ? a.dout[(size_t)gr * k3 + k] : 0.f;
     }
@@ -219,66 +243,81 @@ __global__ __launch_bounds__(256) void k_amlp_bwd4(AmlpBwd4x x) {
 #pragma unroll
     for (int i = 0; i < RS; ++i) ring[i] = ld3(i, 0);
     // the ReLU masks of this lane's column (requested early, used in the epilogues)
-    float m2[4], m1[4];
+    float m2[MTW][4], m1[MTW][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gr = min(row0 + i, a.N - 1);
-        m2[i] = a.h2[(size_t)gr * H + col];
-        m1[i] = a.h1[(size_t)gr * H + col];
-    }
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr = min(row0 + m * 4 + i, a.N - 1);
+            m2[m][i] = a.h2[(size_t)gr * H + col];
+            m1[m][i] = a.h1[(size_t)gr * H + col];
+        }
     __syncthreads();
-    const float* ap[1];
-    f32x4_t acc[1][1][4];
+    const float* ap[MTW];
+    f32x4_t acc[1][MTW][P];
     auto zero = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[0][0][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[0][m][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     };
-    auto total = [&]() { return (acc[0][0][0] + acc[0][0][1]) + (acc[0][0][2] + acc[0][0][3]); };
+    auto total = [&](int m) {
+        f32x4_t s = acc[0][m][0];
+#pragma unroll
+        for (int p = 1; p < P; ++p) s += acc[0][m][p];
+        return s;
+    };
     const bool want_dact = a.dact != nullptr && E > 0;
     // ---- d_h2 = (dout W3^T) * [h2 > 0]
     zero();
-    ap[0] = &ds[lane & 3][0];
-    phase_rt<1, 1, 4>(acc, ap, ring, ld3, head2, 1);
-    {
-        const f32x4_t s = total();
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) ap[m] = &ds[m * 4 + (lane & 3)][0];
+    phase_rt<1, MTW, P>(acc, ap, ring, ld3, head2, 1);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const f32x4_t s = total(m);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v = m2[i] > 0.f ? s[i] : 0.f;
-            d2s[i][col] = v;
-            if (row0 + i < a.N) a.d_h2[(size_t)(row0 + i) * H + col] = v;
+            const float v = m2[m][i] > 0.f ? s[i] : 0.f;
+            d2s[m * 4 + i][col] = v;
+            if (row0 + m * 4 + i < a.N) a.d_h2[(size_t)(row0 + m * 4 + i) * H + col] = v;
         }
     }
     __syncthreads();
     // ---- d_h1 = (d_h2 W2^T) * [h1 > 0]
     zero();
-    ap[0] = &d2s[lane & 3][0];
-    if (want_dact) phase_rt<1, 1, 4>(acc, ap, ring, ld2, head1, H / 64);
-    else phase_rt<1, 1, 4>(acc, ap, ring, ld2, none, H / 64);
-    {
-        const f32x4_t s = total();
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) ap[m] = &d2s[m * 4 + (lane & 3)][0];
+    if (want_dact) phase_rt<1, MTW, P>(acc, ap, ring, ld2, head1, H / 64);
+    else phase_rt<1, MTW, P>(acc, ap, ring, ld2, none, H / 64);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const f32x4_t s = total(m);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v = m1[i] > 0.f ? s[i] : 0.f;
-            d1s[i][col] = v;
-            if (row0 + i < a.N) a.d_h1[(size_t)(row0 + i) * H + col] = v;
+            const float v = m1[m][i] > 0.f ? s[i] : 0.f;
+            d1s[m * 4 + i][col] = v;
+            if (row0 + m * 4 + i < a.N) a.d_h1[(size_t)(row0 + m * 4 + i) * H + col] = v;
         }
     }
     if (!want_dact) return;
     __syncthreads();
     // ---- d action = d_h1 W1_action^T: the four waves split k, lane = action component
     zero();
-    ap[0] = &d1s[lane & 3][wave * 64];
-    phase_rt<1, 1, 4>(acc, ap, ring, ld1, none, 1);
-    {
-        const f32x4_t s = total();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) part[(wave * 4 + i) * 64 + lane] = s[i];
+    for (int m = 0; m < MTW; ++m) ap[m] = &d1s[m * 4 + (lane & 3)][wave * 64];
+    phase_rt<1, MTW, P>(acc, ap, ring, ld1, none, 1);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const f32x4_t s = total(m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(wave * RWS + m * 4 + i) * 64 + lane] = s[i];
     }
     __syncthreads();
-    {
-        const int i = tid >> 6, j = tid & 63;
+    for (int e = tid; e < RWS * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
         if (j < E && row0 + i < a.N)
-            a.dact[(size_t)(row0 + i) * E + j] = ((part[(0 * 4 + i) * 64 + j] + part[(1 * 4 + i) * 64 + j]) + part[(2 * 4 + i) * 64 + j]) + part[(3 * 4 + i) * 64 + j];
+            a.dact[(size_t)(row0 + i) * E + j] = ((part[(0 * RWS + i) * 64 + j] + part[(1 * RWS + i) * 64 + j]) + part[(2 * RWS + i) * 64 + j]) + part[(3 * RWS + i) * 64 + j];
     }
 }
 
@@ -306,6 +345,33 @@ __global__ void k_adam_multi(AdamMulti a) {
         d.p[j] = pj;
     }
     if (d.targ) d.targ[j] = (1.f - a.tau) * d.targ[j] + a.tau * pj;
+}
+
+// ------------------------------------------------------------------------------------------------ whole-update helpers (rl4rs_bcq_update)
+// z parts of the update's noise clamped to +-0.5 in place; the constant -1 / B seed of the actor loss
+__global__ void k_bcq_prep(float* __restrict__ z, long long nz, float* __restrict__ minus_inv_b, int B) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nz) z[i] = fminf(fmaxf(z[i], -0.5f), 0.5f);
+    if (i < B) minus_inv_b[i] = -1.0f / (float)B;
+}
+// metrics[0] = mse / E + beta kl / L;  [1] = sum of the critics' losses;  [2] = -mean q  (each only when its inputs are given)
+__global__ __launch_bounds__(256) void k_bcq_metrics(const float* __restrict__ loss2, float inv_e, float beta_over_l, const float* __restrict__ closs2,
+                                                     const float* __restrict__ qv, int B, float* __restrict__ metrics) {
+    __shared__ float sm[256];
+    if (threadIdx.x == 0) {
+        metrics[0] = loss2[0] * inv_e + loss2[1] * beta_over_l;
+        if (closs2) metrics[1] = closs2[0] + closs2[1];
+    }
+    if (!qv) return;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += qv[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) metrics[2] = -sm[0] / (float)B;
 }
 
 }  // namespace rl4rs

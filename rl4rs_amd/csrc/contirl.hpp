@@ -335,7 +335,7 @@ static bool amlp_h16_shape_ok(const rl4rs_amlp_cfg& c) {
 static bool amlp_fused_shape_ok(const rl4rs_amlp_cfg& c) {
     return c.hidden1 == 256 && c.hidden2 == 256 && c.out_dim <= 64 && c.act_dim <= 64 && c.obs_dim + c.act_dim <= 4096;
 }
-static int g_amlp_fused = 1;            // rl4rs_amlp_set_fused: 0 = the per-layer launches for every call (tests, A/B runs)
+static int g_amlp_fused = 1;            // rl4rs_amlp_set_fused: 0 = the per-layer launches for every call, 2 = the 8-row fused form (tests, A/B runs)
 static bool amlp_fused_call(const rl4rs_amlp* p, int N, int rep) { return g_amlp_fused && amlp_fused_shape_ok(p->c) && rep == 1 && N <= 2048; }
 
 // n <= 4 networks with the same input widths over the SAME rows as one launch each way (amlp_fused.hpp)
@@ -343,9 +343,13 @@ static int amlp_forward_fused(int n, rl4rs_amlp* const* nets, int N, const float
     static bool attr = false;
     int rc;
     if (!attr) {
-        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4), amlp_fwd4_smem(4096)))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<1>), amlp_fwd4_smem(4096, 1)))) return rc;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<2>), amlp_fwd4_smem(4096, 2)))) return rc;
         attr = true;
     }
+    // 4 rows per workgroup.  The 8-row form (MTW = 2: every weight value feeds two row tiles) was measured SLOWER at the learners'
+    // 256-row minibatches - 32 workgroups instead of 64, BCQ update 0.371 -> 0.406 ms - and is kept for A/B only (rl4rs_amlp_set_fused(2))
+    const int mtw = g_amlp_fused == 2 ? 2 : 1;
     AmlpFwd4x x;
     memset(&x, 0, sizeof(x));
     int t_elems = 0;
@@ -360,8 +364,10 @@ static int amlp_forward_fused(int n, rl4rs_amlp* const* nets, int N, const float
         p->last_n = N;
         p->last_rep = 1;
     }
-    const int row_wgs = (N + 3) / 4, t_wgs = (t_elems + AMLP_T_PER_WG - 1) / AMLP_T_PER_WG;
-    hipLaunchKernelGGL(k_amlp_fwd4, dim3(row_wgs + t_wgs, n), dim3(256), amlp_fwd4_smem(nets[0]->c.obs_dim + nets[0]->c.act_dim), st, x);
+    const int row_wgs = (N + 4 * mtw - 1) / (4 * mtw), t_wgs = (t_elems + AMLP_T_PER_WG - 1) / AMLP_T_PER_WG;
+    const size_t smem = amlp_fwd4_smem(nets[0]->c.obs_dim + nets[0]->c.act_dim, mtw);
+    if (mtw == 2) hipLaunchKernelGGL(k_amlp_fwd4<2>, dim3(row_wgs + t_wgs, n), dim3(256), smem, st, x);
+    else hipLaunchKernelGGL(k_amlp_fwd4<1>, dim3(row_wgs + t_wgs, n), dim3(256), smem, st, x);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
@@ -390,7 +396,9 @@ static int amlp_backward_fused(int n, rl4rs_amlp* const* nets, int N, const floa
             if (E > 0) add(act, E, E, p->d_h1, H1, H1, G + o[AP_W1] + (size_t)D * H1, nullptr);
         }
     }
-    hipLaunchKernelGGL(k_amlp_bwd4, dim3((N + 3) / 4, n), dim3(256), 0, st, x);
+    const int mtw = g_amlp_fused == 2 ? 2 : 1;          // (see amlp_forward_fused)
+    if (mtw == 2) hipLaunchKernelGGL(k_amlp_bwd4<2>, dim3((N + 7) / 8, n), dim3(256), 0, st, x);
+    else hipLaunchKernelGGL(k_amlp_bwd4<1>, dim3((N + 3) / 4, n), dim3(256), 0, st, x);
     if (want_param_grad) hipLaunchKernelGGL(k_gemm_tn4_group, dim3(g.tile0[g.n]), dim3(256), 0, st, g);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
@@ -399,7 +407,7 @@ static int amlp_backward_fused(int n, rl4rs_amlp* const* nets, int N, const floa
 extern "C" {
 
 int rl4rs_amlp_set_fused(int32_t on) {
-    g_amlp_fused = on ? 1 : 0;
+    g_amlp_fused = on == 2 ? 2 : (on ? 1 : 0);
     return RL4RS_OK;
 }
 
@@ -803,6 +811,109 @@ int rl4rs_cql_critic_loss(int32_t B, int32_t m, const float* q1, const float* q2
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_cql_rows, dim3((B + 3) / 4), dim3(256), 0, st, B, m, q1, q2, offs, y, alpha_w, dq1, dq2, rows_scratch);
     hipLaunchKernelGGL(k_sum6, dim3(1), dim3(256), 0, st, rows_scratch, B, sums6);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
+
+// ---- one whole BCQ update as one host call (include/rl4rs_hip.h: rl4rs_bcq_step)
+namespace {
+struct BcqWs {
+    float *enc_out, *z, *y, *d_dec, *rows, *loss2, *dz, *d_enc, *sampled, *t, *a_next, *q1n, *q2n, *yq, *q1v, *q2v, *dq1, *dq2, *closs2,
+          *sampled2, *t2, *a_pi, *qv, *minus_inv_b, *da, *d_pre;
+    int64_t total;
+};
+BcqWs bcq_ws(float* base, int64_t B, int64_t n, int64_t E, int64_t L) {
+    BcqWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t cnt) { float* p = base ? base + o : nullptr; o += (cnt + 3) / 4 * 4; return p; };
+    const int64_t R = B * n;
+    w.enc_out = take(B * 2 * L); w.z = take(B * L); w.y = take(B * E); w.d_dec = take(B * E); w.rows = take(B * 2); w.loss2 = take(2);
+    w.dz = take(B * L); w.d_enc = take(B * 2 * L);
+    w.sampled = take(R * E); w.t = take(R * E); w.a_next = take(R * E); w.q1n = take(R); w.q2n = take(R); w.yq = take(B);
+    w.q1v = take(B); w.q2v = take(B); w.dq1 = take(B); w.dq2 = take(B); w.closs2 = take(2);
+    w.sampled2 = take(B * E); w.t2 = take(B * E); w.a_pi = take(B * E); w.qv = take(B); w.minus_inv_b = take(B); w.da = take(B * E);
+    w.d_pre = take(B * E);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+int64_t rl4rs_bcq_workspace_floats(int32_t B, int32_t n, int32_t E, int32_t L) { return bcq_ws(nullptr, B, n, E, L).total; }
+
+int rl4rs_bcq_update(const rl4rs_bcq_step* s, void* stream) {
+    RL4RS_REQUIRE(s && s->imit_enc && s->imit_dec && s->policy && s->policy_targ && s->q1 && s->q2 && s->q1_targ && s->q2_targ, "bcq_update: null handle");
+    RL4RS_REQUIRE(s->B > 0 && s->n > 0 && s->E > 0 && s->L > 0 && s->obs_dev && s->act_dev && s->rew_dev && s->nxt_dev && s->ter_dev && s->noise_dev &&
+                  s->workspace_dev && s->metrics_dev && ((uintptr_t)s->workspace_dev & 15) == 0 && ((uintptr_t)s->noise_dev & 15) == 0,
+                  "bcq_update: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, n = s->n, E = s->E, L = s->L, R = B * n;
+    const BcqWs w = bcq_ws(s->workspace_dev, B, n, E, L);
+    const float* eps = s->noise_dev;
+    float* zt = s->noise_dev + (size_t)B * L;
+    float* za = zt + (size_t)R * L;
+    const float lo = -20.f, hi = 2.f;
+    int rc;
+#define BU(expr) do { if ((rc = (expr)) != RL4RS_OK) return rc; } while (0)
+    {
+        const long long nz = (long long)(R + B) * L;
+        hipLaunchKernelGGL(k_bcq_prep, dim3((unsigned)((std::max<long long>(nz, B) + 255) / 256)), dim3(256), 0, st, zt, nz, w.minus_inv_b, B);
+    }
+    // --- imitator (BCQImpl.update_imitator: ConditionalVAE.compute_error)
+    BU(rl4rs_amlp_forward(s->imit_enc, B, 1, s->obs_dev, s->act_dev, w.enc_out, stream));
+    BU(rl4rs_cvae_sample(B, L, w.enc_out, eps, lo, hi, w.z, stream));
+    BU(rl4rs_amlp_forward(s->imit_dec, B, 1, s->obs_dev, w.z, w.y, stream));
+    BU(rl4rs_cvae_loss(B, E, L, w.y, s->act_dev, w.enc_out, lo, hi, w.d_dec, w.rows, w.loss2, stream));
+    BU(rl4rs_amlp_backward(s->imit_dec, B, 1, s->obs_dev, w.z, w.d_dec, w.dz, 1, stream));
+    BU(rl4rs_cvae_encoder_grad(B, L, w.enc_out, eps, w.dz, s->beta, lo, hi, w.d_enc, stream));
+    BU(rl4rs_amlp_backward(s->imit_enc, B, 1, s->obs_dev, s->act_dev, w.d_enc, nullptr, 1, stream));
+    {
+        rl4rs_amlp* nets[2] = {s->imit_enc, s->imit_dec};
+        const float lr[2] = {s->imitator_lr, s->imitator_lr};
+        const int32_t on[2] = {1, 1};
+        BU(rl4rs_amlp_adam_multi(2, nets, lr, on, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, stream));
+    }
+    if (s->do_rl) {
+        // --- critic (DDPGBaseImpl.update_critic with BCQImpl.compute_target): the B * n target rows are never differentiated
+        auto nograd_forward = [&](rl4rs_amlp* p, const float* act, float* out) {
+            if (s->nograd_h16 && p->w1p && R >= s->h16_min_rows && ((uintptr_t)act & 15) == 0 && ((uintptr_t)out & 15) == 0)
+                return rl4rs_amlp_forward_h16(p, R, n, s->nxt_dev, act, out, stream);
+            return rl4rs_amlp_forward(p, R, n, s->nxt_dev, act, out, stream);
+        };
+        BU(nograd_forward(s->imit_dec, zt, w.sampled));
+        BU(nograd_forward(s->policy_targ, w.sampled, w.t));
+        BU(rl4rs_residual_action(R, E, w.sampled, w.t, s->action_flexibility, w.a_next, stream));
+        BU(nograd_forward(s->q1_targ, w.a_next, w.q1n));
+        BU(nograd_forward(s->q2_targ, w.a_next, w.q2n));
+        BU(rl4rs_bcq_target(B, n, w.q1n, w.q2n, s->lam, s->rew_dev, s->ter_dev, s->gamma, w.yq, nullptr, stream));
+        rl4rs_amlp* twin[2] = {s->q1, s->q2};
+        float* qv2[2] = {w.q1v, w.q2v};
+        BU(rl4rs_amlp_forward_multi(2, twin, B, s->obs_dev, s->act_dev, qv2, stream));
+        BU(rl4rs_critic_mse(B, w.q1v, w.q2v, w.yq, w.dq1, w.dq2, w.closs2, stream));
+        const float* dq[2] = {w.dq1, w.dq2};
+        BU(rl4rs_amlp_backward_multi(2, twin, B, s->obs_dev, s->act_dev, dq, nullptr, 1, stream));
+        const float lr[2] = {s->critic_lr, s->critic_lr};
+        const int32_t on[2] = {1, 1};
+        BU(rl4rs_amlp_adam_multi(2, twin, lr, on, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, stream));
+        if (s->do_actor) {
+            // --- actor (BCQImpl.compute_actor_loss: -Q_1(s, pi(s, decode(s, z))).mean()) + the soft target updates
+            BU(rl4rs_amlp_forward(s->imit_dec, B, 1, s->obs_dev, za, w.sampled2, stream));
+            BU(rl4rs_amlp_forward(s->policy, B, 1, s->obs_dev, w.sampled2, w.t2, stream));
+            BU(rl4rs_residual_action(B, E, w.sampled2, w.t2, s->action_flexibility, w.a_pi, stream));
+            BU(rl4rs_amlp_forward(s->q1, B, 1, s->obs_dev, w.a_pi, w.qv, stream));
+            BU(rl4rs_amlp_backward(s->q1, B, 1, s->obs_dev, w.a_pi, w.minus_inv_b, w.da, 0, stream));
+            BU(rl4rs_residual_grad(B, E, w.sampled2, w.t2, s->action_flexibility, w.da, w.d_pre, stream));
+            BU(rl4rs_amlp_backward(s->policy, B, 1, s->obs_dev, w.sampled2, w.d_pre, nullptr, 1, stream));
+            rl4rs_amlp* nets[3] = {s->policy, s->q1, s->q2};
+            rl4rs_amlp* targ[3] = {s->policy_targ, s->q1_targ, s->q2_targ};
+            const float lr3[3] = {s->actor_lr, 0.f, 0.f};
+            const int32_t on3[3] = {1, 0, 0};
+            BU(rl4rs_amlp_adam_multi(3, nets, lr3, on3, targ, 0.9f, 0.999f, 1e-8f, s->tau, stream));
+        }
+    }
+#undef BU
+    hipLaunchKernelGGL(k_bcq_metrics, dim3(1), dim3(256), 0, st, w.loss2, 1.0f / (float)E, s->beta / (float)L, s->do_rl ? w.closs2 : nullptr,
+                       (s->do_rl && s->do_actor) ? w.qv : nullptr, B, s->metrics_dev);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }

@@ -1733,8 +1733,9 @@ def amlp_backward_multi(nets, obs, act, douts, want_dact=False, want_param_grad=
 
 
 def amlp_set_fused(on):
-    """Fused minibatch forward / backward of the amlp networks on (default) or off (rl4rs_amlp_set_fused; tests and A/B runs)."""
-    check(_lib.load().rl4rs_amlp_set_fused(1 if on else 0))
+    """Fused minibatch forward / backward of the amlp networks on (default), off, or 2 = their 8-rows-per-workgroup form
+    (rl4rs_amlp_set_fused; tests and A/B runs)."""
+    check(_lib.load().rl4rs_amlp_set_fused(2 if on == 2 else (1 if on else 0)))
 
 
 def cvae_sample(enc_out, eps, min_logstd=-20.0, max_logstd=2.0):

@@ -28,6 +28,8 @@ every gradient is checked against torch autograd of the restated model in ``test
 ``torch.distributed`` initialised each rank trains on its own minibatches and the flat gradient is mean-all-reduced
 before Adam (data parallel, one collective per network per update).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -402,6 +404,8 @@ class BCQ(_ModelIO):
         self._gen.manual_seed(self.seed + 1000003 * rdist.rank())
         self._minus_inv_b = None
         self._imit_w = torch.tensor([1.0 / self.E, self.beta / self.L], dtype=torch.float32, device=self.device)
+        self.one_call = True             # update() as one library call on a single rank (False: the per-phase calls; tests compare the two)
+        self._ws = {}                    # minibatch size -> workspace of rl4rs_bcq_update
 
     def _randn(self, rows, noise, key):
         if noise is not None and key in noise:
@@ -421,7 +425,41 @@ class BCQ(_ModelIO):
         t = policy.forward(obs, sampled, rep=rep, nograd=nograd)
         return sampled, t, D_.residual_action(sampled, t, self.scale)
 
+    def _update_one_call(self, obs, act, rew, nxt, ter, noise):
+        """The whole update as ONE library call (rl4rs_bcq_update: the same launches with the same arguments as ``update`` below
+        issues one by one - after the fused kernels the update was bound by its ~55 Python -> C calls, not by the GPU)."""
+        from . import _lib
+        B, n, E, L = obs.shape[0], self.n, self.E, self.L
+        lib = _lib.load()
+        ws = self._ws.get(B)
+        if ws is None:
+            ws = self._ws[B] = torch.empty(int(lib.rl4rs_bcq_workspace_floats(B, n, E, L)), dtype=torch.float32, device=self.device)
+        total = (B + B * n + B) * L
+        if noise is None:
+            nz = torch.randn(total, generator=self._gen, device=self.device, dtype=torch.float32)      # eps | z_target | z_actor: one draw
+        else:
+            parts = [self._randn(B, noise, 'eps'), self._randn(B * n, noise, 'z_target'), self._randn(B, noise, 'z_actor')]
+            nz = torch.cat([p.reshape(-1) for p in parts])                                           # (a copy: the caller's noise is never modified)
+        metrics = torch.zeros(3, dtype=torch.float32, device=self.device)
+        do_rl = self.total_step >= self.rl_start_step
+        do_actor = do_rl and self.total_step % self.update_actor_interval == 0
+        cont = [t if t.is_contiguous() else t.contiguous() for t in (obs, act, rew, nxt, ter)]
+        st = _lib.BcqStep(*[net.h.value for net in (self.imit_enc, self.imit_dec, self.policy, self.policy_targ, self.q1, self.q2, self.q1_targ, self.q2_targ)],
+                          B, n, E, L, self.beta, self.scale, self.lam, self.gamma, self.tau, self.imitator_lr, self.critic_lr, self.actor_lr,
+                          1 if do_rl else 0, 1 if do_actor else 0, 1 if self.nograd == 'fp16x2' else 0, int(self.q1.H16_MIN_ROWS),
+                          *[t.data_ptr() for t in cont], nz.data_ptr(), ws.data_ptr(), metrics.data_ptr())
+        _lib.check(lib.rl4rs_bcq_update(C.byref(st), D_._stream()))
+        self.total_step += 1
+        out = {'imitator_loss': metrics[0]}
+        if do_rl:
+            out['critic_loss'] = metrics[1]
+        if do_actor:
+            out['actor_loss'] = metrics[2]
+        return out
+
     def update(self, obs, act, rew, nxt, ter, noise=None):
+        if self.one_call and not rdist.collectives_active():
+            return self._update_one_call(obs, act, rew, nxt, ter, noise)
         B, n = obs.shape[0], self.n
         metrics = {}
         # --- imitator (BCQImpl.update_imitator: ConditionalVAE.compute_error) ---

@@ -53,12 +53,14 @@ def amlp_fused():
     Dv.amlp_set_fused(True)
 
 
-@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('fused', [True, False, 2])
 @pytest.mark.parametrize('act_dim,out_dim,head_act,rep', [(E, 1, 'none', 1), (E, 1, 'none', 7), (L, E, 'tanh', 5), (E, 2 * L, 'none', 1),
                                                           (0, 2 * E, 'none', 1), (E, E, 'tanh', 1)])
 def test_amlp_forward_and_gradients(amlp_fused, fused, act_dim, out_dim, head_act, rep):
     """rep = 1 cases: the fused one-launch forward / three-launch backward (default) and the per-layer launches, same bars;
     R = 36 and 255 rows (whole and ragged 4-row workgroups of the fused form)"""
+    if fused == 2 and rep != 1:
+        pytest.skip('the 8-row fused form only differs for rep = 1 calls')
     amlp_fused(fused)
     for R in (36, 255) if rep == 1 else (36,):
         _check_amlp_forward_and_gradients(act_dim, out_dim, head_act, rep, R)
@@ -120,6 +122,44 @@ def test_twin_networks_in_one_launch_equal_single_calls(amlp_fused, fused):
         assert torch.equal(p.flat_gradient(), q.flat_gradient())
         p.close()
         q.close()
+
+
+@pytest.mark.parametrize('nograd', ['fp32', 'fp16x2'])
+def test_update_as_one_library_call_equals_the_per_phase_calls(nograd):
+    """rl4rs_bcq_update (the whole update as one host call, the default on one rank) issues the same launches with the same
+    arguments as BCQ.update's per-phase path: parameters and Adam state bit-identical over four updates with shared noise,
+    with and without the actor phase (update_actor_interval = 2)"""
+    import torch
+    B, n = 64, 8
+    a, _ = _learner_pair(61, B, n, nograd=nograd)
+    b, _ = _learner_pair(61, B, n, nograd=nograd)
+    a.update_actor_interval = b.update_actor_interval = 2
+    assert a.one_call
+    b.one_call = False
+    rs = np.random.RandomState(62)
+    f = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32))
+    for it in range(4):
+        x, act, rew, ter = _batch(B, 70 + it)
+        nx = _batch(B, 80 + it)[0]
+        noise = dict(eps=f(rs.randn(B, L)), z_target=f(rs.randn(B * n, L)), z_actor=f(rs.randn(B, L)))
+        keep = dict((k, v.clone()) for k, v in noise.items())
+        args = [f(v).cuda() for v in (x, act, rew, nx, ter)]
+        ma = a.update(*args, noise=noise)
+        mb = b.update(*args, noise=noise)
+        assert set(ma) == set(mb) and ('actor_loss' in ma) == (it % 2 == 0)
+        for k in ma:
+            # (the reported losses are reductions in another order - one metrics kernel against torch.dot / sum: equal to rounding)
+            assert abs(float(ma[k]) - float(mb[k])) <= 2e-6 * max(1.0, abs(float(mb[k]))), (it, k, float(ma[k]), float(mb[k]))
+        for k in noise:
+            assert torch.equal(noise[k], keep[k])                 # the caller's noise is never modified
+    for na, nb in zip(a.nets, b.nets):
+        assert torch.equal(na.flat_params(), nb.flat_params())
+    for na, nb in zip((a.imit_enc, a.imit_dec, a.policy, a.q1, a.q2), (b.imit_enc, b.imit_dec, b.policy, b.q1, b.q2)):
+        (ma_, va_, ta_), (mb_, vb_, tb_) = na.adam_state(), nb.adam_state()
+        assert torch.equal(ma_, mb_) and torch.equal(va_, vb_) and ta_ == tb_
+    assert a.total_step == b.total_step == 4
+    a.close()
+    b.close()
 
 
 def test_adam_multi_equals_separate_launches():

@@ -20,6 +20,8 @@ def main():
     act /= np.linalg.norm(act, axis=1, keepdims=True)
     tr = tuple(torch.from_numpy(x).cuda() for x in (obs, act, rs.rand(n).astype(np.float32), np.roll(obs, -1, 0),
                                                      (rs.rand(n) < 0.1).astype(np.float32)))
+    from rl4rs_amd import device as Dv
+    Dv.amlp_set_fused(int(__import__('os').environ.get('FUSED', '1')))          # 0: per-layer launches, 1: fused (default), 2: 8-row fused form
     prec = __import__('os').environ.get('NOGRAD', 'fp16x2')
     rows = int(__import__('os').environ.get('PREDICT_ROWS', '512'))
     bcq = R.BCQ({'action_emb_size': E}, D, batch_size=256, seed=1, nograd_precision=prec, predict_rows=rows)
