@@ -881,6 +881,31 @@ typedef struct rl4rs_bcq_step {
 int64_t rl4rs_bcq_workspace_floats(int32_t B, int32_t n, int32_t E, int32_t L);
 int rl4rs_bcq_update(const rl4rs_bcq_step* step, void* stream);
 
+/* One whole continuous-CQL update (d3rlpy CQL._update as 'CQL-conti' runs it: temperature step, alpha step, critic step with the
+ * conservative term over m = 1 + 3 n rows per transition, actor step, soft critic-target updates) as ONE host call - the sequence
+ * rl4rs_amd/offline_rl.py::CQL.update issues, with the two learned scalars' Adam on the device.  Single-process only.
+ *   log_temp / log_alpha   device float[3] each = {value, Adam m, Adam v}; *_step = the number of Adam steps taken so far (host)
+ *   normal_dev   N(0, 1): eps_temp [B, A] | alpha eps_t [B n, A] | alpha eps_tp1 [B n, A] | critic eps_t | critic eps_tp1 | eps_actor [B, A]
+ *   uniform_dev  U[-1, 1): alpha [B, n, A] | critic [B, n, A]
+ *   rew_dev      rewards as the critic sees them (the caller applies the reward scaler)
+ *   workspace_dev  rl4rs_cql_workspace_floats(B, n, A) floats, 16-byte aligned;  metrics_dev float[4] = {critic, actor, temp, alpha loss} */
+typedef struct rl4rs_cql_step {
+    rl4rs_amlp *policy, *q1, *q2, *q1_targ, *q2_targ;
+    int32_t B, n, A;
+    float gamma, tau, actor_lr, critic_lr, temp_lr, alpha_lr, alpha_threshold, conservative_weight;
+    int32_t nograd_h16, h16_min_rows;
+    int64_t temp_step, alpha_step;
+    float* log_temp_dev;
+    float* log_alpha_dev;
+    const float *obs_dev, *act_dev, *rew_dev, *nxt_dev, *ter_dev;
+    const float* normal_dev;
+    const float* uniform_dev;
+    float* workspace_dev;
+    float* metrics_dev;
+} rl4rs_cql_step;
+int64_t rl4rs_cql_workspace_floats(int32_t B, int32_t n, int32_t A);
+int rl4rs_cql_update(const rl4rs_cql_step* step, void* stream);
+
 /* Plain fp32 GEMM used by the scorer, exposed for tests: C[M,N] = act(A[M,K] @ W[K,N] + bias).
  * act: 0 none, 1 ELU, 2 sigmoid, 3 tanh, 4 ReLU. */
 int rl4rs_gemm_f32(const float* a_dev, int64_t lda, const float* w_dev, int64_t ldw,

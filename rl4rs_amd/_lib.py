@@ -89,6 +89,17 @@ class BcqStep(C.Structure):
                 [(n, C.c_void_p) for n in ('obs_dev', 'act_dev', 'rew_dev', 'nxt_dev', 'ter_dev', 'noise_dev', 'workspace_dev', 'metrics_dev')])
 
 
+class CqlStep(C.Structure):
+    """rl4rs_cql_step (include/rl4rs_hip.h)"""
+    _fields_ = ([(n, C.c_void_p) for n in ('policy', 'q1', 'q2', 'q1_targ', 'q2_targ')] +
+                [(n, C.c_int32) for n in ('B', 'n', 'A')] +
+                [(n, C.c_float) for n in ('gamma', 'tau', 'actor_lr', 'critic_lr', 'temp_lr', 'alpha_lr', 'alpha_threshold', 'conservative_weight')] +
+                [(n, C.c_int32) for n in ('nograd_h16', 'h16_min_rows')] +
+                [(n, C.c_int64) for n in ('temp_step', 'alpha_step')] +
+                [(n, C.c_void_p) for n in ('log_temp_dev', 'log_alpha_dev', 'obs_dev', 'act_dev', 'rew_dev', 'nxt_dev', 'ter_dev', 'normal_dev',
+                                           'uniform_dev', 'workspace_dev', 'metrics_dev')])
+
+
 class RawPolicyCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'maxlen', 'emb_size', 'hidden_units', 'dense_feature_num', 'category_feature_num', 'category_hash_size',
@@ -250,6 +261,8 @@ SIGNATURES = {
     'rl4rs_amlp_adam_multi': (_I, [_I32, C.POINTER(_P), C.POINTER(C.c_float), C.POINTER(_I32), C.POINTER(_P), C.c_float, C.c_float, C.c_float,
                                    C.c_float, _P]),
     'rl4rs_amlp_set_fused': (_I, [_I32]),
+    'rl4rs_cql_workspace_floats': (_I64, [_I32, _I32, _I32]),
+    'rl4rs_cql_update': (_I, [C.POINTER(CqlStep), _P]),
     'rl4rs_bcq_workspace_floats': (_I64, [_I32, _I32, _I32, _I32]),
     'rl4rs_bcq_update': (_I, [C.POINTER(BcqStep), _P]),
     'rl4rs_amlp_forward_multi': (_I, [_I32, C.POINTER(_P), _I32, _P, _P, C.POINTER(_P), _P]),

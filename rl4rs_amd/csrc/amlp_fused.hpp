@@ -374,4 +374,80 @@ __global__ __launch_bounds__(256) void k_bcq_metrics(const float* __restrict__ l
     if (threadIdx.x == 0) metrics[2] = -sm[0] / (float)B;
 }
 
+// ---- rl4rs_cql_update: the learned scalars (SAC's log-temperature, CQL's log-alpha) with torch-style Adam on the device.
+// st = {p, m, v}; c1 = 1 / (1 - beta1^t), c2 = 1 / (1 - beta2^t) of the step being taken (host-side powers, like the networks' Adam)
+__device__ __forceinline__ void scalar_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float g, float lr, float c1, float c2) {
+    const float mj = 0.9f * m[0] + (1.f - 0.9f) * g;
+    const float vj = 0.999f * v[0] + (1.f - 0.999f) * g * g;
+    m[0] = mj;
+    v[0] = vj;
+    p[0] -= lr * c1 * mj / (sqrtf(vj * c2) + 1e-8f);
+}
+// SACImpl.update_temp: loss = -(exp(log_temp) * mean(logp - A)); its gradient wrt log_temp is the same expression
+__global__ __launch_bounds__(256) void k_sac_temp_step(const float* __restrict__ logp, int B, int A, float* p, float* m, float* v, float lr, float c1,
+                                                       float c2, float* __restrict__ metric) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += logp[i] - (float)A;
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float g = -(expf(p[0]) * (sm[0] / (float)B));
+        metric[0] = g;
+        scalar_adam(p, m, v, g, lr, c1, c2);
+    }
+}
+// CQLImpl.update_alpha from the six sums of rl4rs_cql_critic_loss: gap = conservative value - threshold, loss = -(clamp(e^la, 0, 1e6) gap),
+// gradient -(e^la gap) while e^la <= 1e6 (the clamp blocks it above).  do_step = 0: no update.  Always: aw = clamp(e^la) * weight AFTER the step.
+__global__ void k_cql_alpha_step(const float* __restrict__ sums, int B, float weight, float threshold, float* p, float* m, float* v, float lr,
+                                 float c1, float c2, int do_step, float* __restrict__ metric, float* __restrict__ aw) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (do_step) {
+        const float gap = weight * ((sums[2] + sums[3]) - (sums[4] + sums[5])) / (2.0f * (float)B) - threshold;
+        const float ea = expf(p[0]);
+        metric[0] = -(fminf(fmaxf(ea, 0.f), 1e6f) * gap);
+        scalar_adam(p, m, v, ea <= 1e6f ? -(ea * gap) : 0.f, lr, c1, c2);
+    }
+    aw[0] = fminf(fmaxf(expf(p[0]), 0.f), 1e6f) * weight;
+}
+// rows of the conservative term: acts [B, m, A] column 0 <- the dataset action, columns 1 + 2n .. m - 1 <- the caller's uniform samples on [-1, 1)^A
+// and their importance offsets offs [B, m]: 0 for the dataset action, A log 0.5 (the uniform density) for the uniform samples
+__global__ void k_cql_fill_rows(float* __restrict__ acts, float* __restrict__ offs, const float* __restrict__ act, const float* __restrict__ uni,
+                                int B, int m, int n, int A, float log_uniform) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (1 + n) * A) return;
+    const int a = i % A, j = (i / A) % (1 + n), b = i / (A * (1 + n));
+    const int col = j == 0 ? 0 : 2 * n + j;
+    acts[((size_t)b * m + col) * A + a] = j == 0 ? act[(size_t)b * A + a] : uni[((size_t)b * n + (j - 1)) * A + a];
+    if (a == 0) offs[(size_t)b * m + col] = j == 0 ? 0.f : log_uniform;
+}
+__global__ void k_add2(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] + y[i];
+}
+// critic_loss = (s0 + s1) / B + clamp(e^la) (conservative value - threshold);  actor_loss = mean(e^lt logp - qmin)
+__global__ __launch_bounds__(256) void k_cql_metrics(const float* __restrict__ sums, int B, float weight, float threshold, const float* __restrict__ log_alpha,
+                                                     const float* __restrict__ log_temp, const float* __restrict__ logp, const float* __restrict__ qmin,
+                                                     float* __restrict__ critic_metric, float* __restrict__ actor_metric) {
+    __shared__ float sm[256];
+    if (threadIdx.x == 0) {
+        const float cv = weight * ((sums[2] + sums[3]) - (sums[4] + sums[5])) / (2.0f * (float)B);
+        critic_metric[0] = (sums[0] + sums[1]) / (float)B + fminf(fmaxf(expf(log_alpha[0]), 0.f), 1e6f) * (cv - threshold);
+    }
+    const float et = expf(log_temp[0]);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += et * logp[i] - qmin[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) actor_metric[0] = sm[0] / (float)B;
+}
+
 }  // namespace rl4rs

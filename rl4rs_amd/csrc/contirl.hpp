@@ -918,4 +918,131 @@ int rl4rs_bcq_update(const rl4rs_bcq_step* s, void* stream) {
     return RL4RS_OK;
 }
 
+
+// ---- one whole continuous-CQL update as one host call (include/rl4rs_hip.h: rl4rs_cql_step)
+namespace {
+struct CqlWs {
+    float *head_nxt, *head_obs, *a_tmp, *logp, *acts, *offs, *q1m, *q2m, *rows, *sums, *aw, *a_next, *q1n, *q2n, *yq, *dq1, *dq2, *a_pi, *q1p, *q2p,
+          *qmin, *dqa, *dqb, *g1, *g2, *d_head;
+    int64_t total;
+};
+CqlWs cql_ws(float* base, int64_t B, int64_t n, int64_t A) {
+    CqlWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t cnt) { float* p = base ? base + o : nullptr; o += (cnt + 3) / 4 * 4; return p; };
+    const int64_t m = 1 + 3 * n;
+    w.head_nxt = take(B * 2 * A); w.head_obs = take(B * 2 * A); w.a_tmp = take(B * A); w.logp = take(B);
+    w.acts = take(B * m * A); w.offs = take(B * m); w.q1m = take(B * m); w.q2m = take(B * m); w.rows = take(B * 6); w.sums = take(8); w.aw = take(4);
+    w.a_next = take(B * A); w.q1n = take(B); w.q2n = take(B); w.yq = take(B); w.dq1 = take(B * m); w.dq2 = take(B * m);
+    w.a_pi = take(B * A); w.q1p = take(B); w.q2p = take(B); w.qmin = take(B); w.dqa = take(B); w.dqb = take(B); w.g1 = take(B * A); w.g2 = take(B * A);
+    w.d_head = take(B * 2 * A);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+int64_t rl4rs_cql_workspace_floats(int32_t B, int32_t n, int32_t A) { return cql_ws(nullptr, B, n, A).total; }
+
+int rl4rs_cql_update(const rl4rs_cql_step* s, void* stream) {
+    RL4RS_REQUIRE(s && s->policy && s->q1 && s->q2 && s->q1_targ && s->q2_targ && s->log_temp_dev && s->log_alpha_dev, "cql_update: null handle");
+    RL4RS_REQUIRE(s->B > 0 && s->n > 0 && s->A > 0 && s->obs_dev && s->act_dev && s->rew_dev && s->nxt_dev && s->ter_dev && s->normal_dev && s->uniform_dev &&
+                  s->workspace_dev && s->metrics_dev && ((uintptr_t)s->workspace_dev & 15) == 0 && ((uintptr_t)s->normal_dev & 15) == 0,
+                  "cql_update: bad argument");
+    RL4RS_REQUIRE(s->policy->c.act_dim == 0 && s->policy->c.out_dim == 2 * s->A, "cql_update: the policy must be a plain encoder with a [mu | logstd] head");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, n = s->n, A = s->A, m = 1 + 3 * n, R = B * m;
+    const CqlWs w = cql_ws(s->workspace_dev, B, n, A);
+    const float lo = -20.f, hi = 2.f;
+    const float* eps_temp = s->normal_dev;
+    const float* eps_alpha_t = eps_temp + (size_t)B * A;
+    const float* eps_alpha_tp1 = eps_alpha_t + (size_t)B * n * A;
+    const float* eps_critic_t = eps_alpha_tp1 + (size_t)B * n * A;
+    const float* eps_critic_tp1 = eps_critic_t + (size_t)B * n * A;
+    const float* eps_actor = eps_critic_tp1 + (size_t)B * n * A;
+    const float* uni_alpha = s->uniform_dev;
+    const float* uni_critic = uni_alpha + (size_t)B * n * A;
+    const float log_uniform = (float)((double)A * log(0.5));
+    int rc;
+#define CU(expr) do { if ((rc = (expr)) != RL4RS_OK) return rc; } while (0)
+    auto adam_c = [](int64_t step_after, double beta) { return (float)(1.0 / (1.0 - pow(beta, (double)step_after))); };
+    // the [B, m, A] actions and [B, m] importance offsets of the conservative term (CQLImpl._compute_policy_is_values / _compute_random_is_values)
+    auto conservative_rows = [&](const float* e_t, const float* e_tp1, const float* uni) {
+        hipLaunchKernelGGL(k_cql_fill_rows, dim3((B * (1 + n) * A + 255) / 256), dim3(256), 0, st, w.acts, w.offs, s->act_dev, uni, B, m, n, A, log_uniform);
+        int r2;
+        if ((r2 = rl4rs_squashed_sample(B * n, n, A, w.head_obs, e_t, lo, hi, m, 1, w.acts, w.offs, stream))) return r2;
+        return rl4rs_squashed_sample(B * n, n, A, w.head_nxt, e_tp1, lo, hi, m, 1 + n, w.acts, w.offs, stream);
+    };
+    // the policy does not change until the actor step: its heads on s' and s are computed once (s last: the handle keeps the
+    // activations of s for the actor's backward)
+    CU(rl4rs_amlp_forward(s->policy, B, 1, s->nxt_dev, nullptr, w.head_nxt, stream));
+    CU(rl4rs_amlp_forward(s->policy, B, 1, s->obs_dev, nullptr, w.head_obs, stream));
+    // --- temperature (SACImpl.update_temp)
+    if (s->temp_lr > 0.f) {
+        CU(rl4rs_squashed_sample(B, 1, A, w.head_obs, eps_temp, lo, hi, 1, 0, w.a_tmp, w.logp, stream));
+        hipLaunchKernelGGL(k_sac_temp_step, dim3(1), dim3(256), 0, st, w.logp, B, A, s->log_temp_dev, s->log_temp_dev + 1, s->log_temp_dev + 2, s->temp_lr,
+                           adam_c(s->temp_step + 1, 0.9), adam_c(s->temp_step + 1, 0.999), s->metrics_dev + 2);
+    }
+    // --- alpha (CQLImpl.update_alpha): the critics' values of the 31 rows are never differentiated here
+    const bool alpha_on = s->alpha_lr > 0.f;
+    if (alpha_on) {
+        CU(conservative_rows(eps_alpha_t, eps_alpha_tp1, uni_alpha));
+        auto nograd_forward = [&](rl4rs_amlp* p, float* out) {
+            if (s->nograd_h16 && p->w1p && R >= s->h16_min_rows && ((uintptr_t)out & 15) == 0) return rl4rs_amlp_forward_h16(p, R, m, s->obs_dev, w.acts, out, stream);
+            return rl4rs_amlp_forward(p, R, m, s->obs_dev, w.acts, out, stream);
+        };
+        CU(nograd_forward(s->q1, w.q1m));
+        CU(nograd_forward(s->q2, w.q2m));
+        CU(rl4rs_cql_critic_loss(B, m, w.q1m, w.q2m, w.offs, nullptr, nullptr, nullptr, nullptr, w.rows, w.sums, stream));
+    }
+    hipLaunchKernelGGL(k_cql_alpha_step, dim3(1), dim3(64), 0, st, w.sums, B, s->conservative_weight, s->alpha_threshold, s->log_alpha_dev,
+                       s->log_alpha_dev + 1, s->log_alpha_dev + 2, s->alpha_lr, adam_c(s->alpha_step + 1, 0.9), adam_c(s->alpha_step + 1, 0.999),
+                       alpha_on ? 1 : 0, s->metrics_dev + 3, w.aw);
+    // --- critic (DDPGBaseImpl.update_critic with CQLImpl.compute_critic_loss / _compute_deterministic_target)
+    CU(rl4rs_squashed_sample(B, 1, A, w.head_nxt, nullptr, lo, hi, 1, 0, w.a_next, nullptr, stream));
+    {
+        rl4rs_amlp* targ[2] = {s->q1_targ, s->q2_targ};
+        float* qn[2] = {w.q1n, w.q2n};
+        CU(rl4rs_amlp_forward_multi(2, targ, B, s->nxt_dev, w.a_next, qn, stream));
+    }
+    CU(rl4rs_bcq_target(B, 1, w.q1n, w.q2n, 1.0f, s->rew_dev, s->ter_dev, s->gamma, w.yq, nullptr, stream));
+    CU(conservative_rows(eps_critic_t, eps_critic_tp1, uni_critic));
+    CU(rl4rs_amlp_forward(s->q1, R, m, s->obs_dev, w.acts, w.q1m, stream));
+    CU(rl4rs_amlp_forward(s->q2, R, m, s->obs_dev, w.acts, w.q2m, stream));
+    CU(rl4rs_cql_critic_loss(B, m, w.q1m, w.q2m, w.offs, w.yq, w.aw, w.dq1, w.dq2, w.rows, w.sums, stream));
+    CU(rl4rs_amlp_backward(s->q1, R, m, s->obs_dev, w.acts, w.dq1, nullptr, 1, stream));
+    CU(rl4rs_amlp_backward(s->q2, R, m, s->obs_dev, w.acts, w.dq2, nullptr, 1, stream));
+    rl4rs_amlp* twin[2] = {s->q1, s->q2};
+    {
+        const float lr[2] = {s->critic_lr, s->critic_lr};
+        const int32_t on[2] = {1, 1};
+        CU(rl4rs_amlp_adam_multi(2, twin, lr, on, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, stream));
+    }
+    // --- actor (SACImpl.compute_actor_loss): (exp(log_temp) * logp - min_c Q_c(s, a)).mean()
+    CU(rl4rs_squashed_sample(B, 1, A, w.head_obs, eps_actor, lo, hi, 1, 0, w.a_pi, w.logp, stream));
+    {
+        float* qp[2] = {w.q1p, w.q2p};
+        CU(rl4rs_amlp_forward_multi(2, twin, B, s->obs_dev, w.a_pi, qp, stream));
+        CU(rl4rs_twin_min(B, w.q1p, w.q2p, w.qmin, w.dqa, w.dqb, stream));
+        const float* dq[2] = {w.dqa, w.dqb};
+        float* ga[2] = {w.g1, w.g2};
+        CU(rl4rs_amlp_backward_multi(2, twin, B, s->obs_dev, w.a_pi, dq, ga, 0, stream));
+    }
+    hipLaunchKernelGGL(k_add2, dim3((B * A + 255) / 256), dim3(256), 0, st, w.g1, w.g2, w.g1, B * A);
+    CU(rl4rs_sac_actor_grad(B, A, w.head_obs, eps_actor, w.a_pi, w.g1, s->log_temp_dev, lo, hi, w.d_head, stream));
+    // (the policy handle's activations are those of the forward on obs, the last one above)
+    CU(rl4rs_amlp_backward(s->policy, B, 1, s->obs_dev, nullptr, w.d_head, nullptr, 1, stream));
+    {
+        rl4rs_amlp* nets[3] = {s->policy, s->q1, s->q2};
+        rl4rs_amlp* targ[3] = {nullptr, s->q1_targ, s->q2_targ};
+        const float lr3[3] = {s->actor_lr, 0.f, 0.f};
+        const int32_t on3[3] = {1, 0, 0};
+        CU(rl4rs_amlp_adam_multi(3, nets, lr3, on3, targ, 0.9f, 0.999f, 1e-8f, s->tau, stream));
+    }
+#undef CU
+    hipLaunchKernelGGL(k_cql_metrics, dim3(1), dim3(256), 0, st, w.sums, B, s->conservative_weight, s->alpha_threshold, s->log_alpha_dev, s->log_temp_dev,
+                       w.logp, w.qmin, s->metrics_dev, s->metrics_dev + 1);
+    RL4RS_LAUNCH_CHECK();
+    return RL4RS_OK;
+}
+
 }  // extern "C"

@@ -613,9 +613,9 @@ class _ScalarParam(object):
     one-element tensor ops per update (plumbing; no network arithmetic)."""
 
     def __init__(self, value, device):
-        self.p = torch.full((1,), float(value), dtype=torch.float32, device=device)
-        self.m = torch.zeros_like(self.p)
-        self.v = torch.zeros_like(self.p)
+        self.state = torch.zeros(4, dtype=torch.float32, device=device)         # {value, Adam m, Adam v, pad}: what rl4rs_cql_update steps in place
+        self.p, self.m, self.v = self.state[0:1], self.state[1:2], self.state[2:3]
+        self.p.fill_(float(value))
         self.t = 0
 
     def adam_step(self, grad, lr, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -685,6 +685,8 @@ class CQL(_ModelIO):
         self._acts = torch.zeros((B, m, A), dtype=torch.float32, device=self.device)
         self._offs = torch.zeros((B, m), dtype=torch.float32, device=self.device)
         self._offs[:, 1 + 2 * self.n:] = float(A * np.log(0.5))                       # log of the uniform density on [-1, 1]^A
+        self.one_call = True             # update() as one library call on a single rank (False: the per-phase calls; tests compare the two)
+        self._ws = {}
 
     def _randn(self, shape, given):
         if given is not None:
@@ -711,6 +713,41 @@ class CQL(_ModelIO):
         """conservative_weight * (mean_c mean_b logsumexp - mean_c mean_b Q(s, a))"""
         return self.conservative_weight * ((sums[2] + sums[3]) - (sums[4] + sums[5])) / (2.0 * B)
 
+    def _update_one_call(self, obs, act, rew, nxt, ter, noise):
+        """The whole update as ONE library call (rl4rs_cql_update: the launches of ``update`` below, the two learned scalars' Adam on
+        the device)."""
+        from . import _lib
+        B, n, A = obs.shape[0], self.n, self.A
+        lib = _lib.load()
+        ws = self._ws.get(B)
+        if ws is None:
+            ws = self._ws[B] = torch.empty(int(lib.rl4rs_cql_workspace_floats(B, n, A)), dtype=torch.float32, device=self.device)
+        if noise:
+            (a_t, a_tp1, a_u), (c_t, c_tp1, c_u) = noise['alpha'], noise['critic']
+            f = lambda x: x.to(device=self.device, dtype=torch.float32).reshape(-1)
+            normal = torch.cat([f(noise['eps_temp']), f(a_t), f(a_tp1), f(c_t), f(c_tp1), f(noise['eps_actor'])])
+            uniform = torch.cat([f(a_u), f(c_u)])
+        else:
+            normal = torch.randn((2 * B + 4 * B * n) * A, generator=self._gen, device=self.device, dtype=torch.float32)
+            uniform = torch.empty(2 * B * n * A, dtype=torch.float32, device=self.device).uniform_(-1.0, 1.0, generator=self._gen)
+        metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
+        cont = [t if t.is_contiguous() else t.contiguous() for t in (obs, act, rew, nxt, ter)]
+        st = _lib.CqlStep(*[net.h.value for net in (self.policy, self.q1, self.q2, self.q1_targ, self.q2_targ)], B, n, A,
+                          self.gamma, self.tau, self.actor_lr, self.critic_lr, self.temp_lr, self.alpha_lr, self.alpha_threshold, self.conservative_weight,
+                          1 if self.nograd == 'fp16x2' else 0, int(self.q1.H16_MIN_ROWS), self.log_temp.t, self.log_alpha.t,
+                          self.log_temp.state.data_ptr(), self.log_alpha.state.data_ptr(), *[t.data_ptr() for t in cont],
+                          normal.data_ptr(), uniform.data_ptr(), ws.data_ptr(), metrics.data_ptr())
+        _lib.check(lib.rl4rs_cql_update(C.byref(st), D_._stream()))
+        out = {'critic_loss': metrics[0], 'actor_loss': metrics[1]}
+        if self.temp_lr > 0:
+            self.log_temp.t += 1
+            out['temp_loss'] = metrics[2]
+        if self.alpha_lr > 0:
+            self.log_alpha.t += 1
+            out['alpha_loss'] = metrics[3]
+        self.total_step += 1
+        return out
+
     def update(self, obs, act, rew, nxt, ter, noise=None):
         noise = noise or {}
         B, A, m = obs.shape[0], self.A, self.m
@@ -719,6 +756,8 @@ class CQL(_ModelIO):
                 raise ValueError("reward_scaler=%r is fitted by fit_mdp(dataset); pass StandardRewardScaler(rewards) to use update / fit "
                                  "directly" % self.reward_scaler)
             rew = self.reward_scaler.transform(rew)
+        if self.one_call and not rdist.collectives_active():
+            return self._update_one_call(obs, act, rew, nxt, ter, noise)
         metrics = {}
         # the policy does not change until the actor step: its heads on s' and s are computed once (s last: the handle keeps the
         # activations of s for the actor's backward)

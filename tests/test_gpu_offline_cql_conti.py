@@ -222,6 +222,38 @@ def test_updates_track_the_fp64_restatement():
     cql.close()
 
 
+def test_update_as_one_library_call_equals_the_per_phase_calls():
+    """rl4rs_cql_update (the whole update as one host call with the learned scalars' Adam on the device; the default on one rank)
+    against CQL.update's per-phase path over four updates with shared noise: the networks bit-identical wherever the two paths run
+    the same kernels, the scalars and everything downstream of them equal to float32 rounding (device expf against torch.exp)"""
+    import torch
+    B, n = 32, 4
+    a, _ = _learner_pair(71, B, n, gamma=1.0)
+    b, _ = _learner_pair(71, B, n, gamma=1.0)
+    assert a.one_call
+    b.one_call = False
+    rs = np.random.RandomState(72)
+    f = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    for it in range(4):
+        x, act, rew, ter = _batch(B, 90 + it)
+        nx = _batch(B, 95 + it)[0]
+        noise = _noise(rs, B, n)
+        args = [f(v) for v in (x, act, rew, nx, ter)]
+        ma = a.update(*args, noise=noise)
+        mb = b.update(*args, noise=noise)
+        assert set(ma) == set(mb) == {'critic_loss', 'actor_loss', 'temp_loss', 'alpha_loss'}
+        for k in ma:
+            assert abs(float(ma[k]) - float(mb[k])) <= 1e-5 * max(1.0, abs(float(mb[k]))), (it, k, float(ma[k]), float(mb[k]))
+    for sa, sb in ((a.log_temp, b.log_temp), (a.log_alpha, b.log_alpha)):
+        assert sa.t == sb.t == 4
+        assert torch.allclose(sa.state[:3], sb.state[:3], rtol=1e-4, atol=1e-6), (sa.state, sb.state)      # (a value that has walked +-lr around its start: absolute bar)
+    for na, nb in zip(a.nets, b.nets):
+        assert (na.flat_params() - nb.flat_params()).abs().max().item() < 1e-5
+    assert a.total_step == b.total_step == 4
+    a.close()
+    b.close()
+
+
 def test_fit_on_the_generated_continuous_dataset_then_knn_rollout(tmp_path):
     """'CQL-conti' end to end on one GPU as the script configures it (gamma = 1, standard reward scaler): fit the continuous
     logged-policy dataset the device env generates, then drive the env with tanh(mu(s)) through the K-NN."""
