@@ -255,16 +255,22 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
         for (int a = lane + 64 * OLR; a < d.A; a += 64) os += expf(L.old_logits[(size_t)n * d.A + a] - om);
         old_lse = om + logf(wave_sum(os));
     }
+    // p = softmax probability and q = old probability of this lane's columns are kept for the gradient pass below (round 5: they
+    // were recomputed there - 10 of the 30 libm expf per lane of a 284-action row; same expressions, same values)
+    float pr[OLR], qr[OLR];
 #pragma unroll
     for (int c = 0; c < OLR; ++c) {
         const int a = lane + 64 * c;
+        pr[c] = 0.f; qr[c] = 0.f;
         if (a < d.A) {
             const float lp = s_out[a] - lse;
             const float p = expf(lp);
+            pr[c] = p;
             if (p > 0.f) ent -= p * lp;
             if (L.algo == 1) {
                 const float olp = olr[c] - old_lse;
                 const float q = expf(olp);
+                qr[c] = q;
                 if (q > 0.f) kl += q * (olp - lp);
             }
         }
@@ -309,19 +315,17 @@ __device__ __forceinline__ float4 policy_row_loss(const PolDims& d, const LossAr
         float g;
         if (a < d.A) {
             const float lp = s_out[a] - lse;
-            const float p = expf(lp);
+            float p, q;
+            switch (c) {                // register file is not indexable: select the lane's c-th kept pair
+                case 0: p = pr[0]; q = qr[0]; break; case 1: p = pr[1]; q = qr[1]; break; case 2: p = pr[2]; q = qr[2]; break;
+                case 3: p = pr[3]; q = qr[3]; break; case 4: p = pr[4]; q = qr[4]; break; case 5: p = pr[5]; q = qr[5]; break;
+                case 6: p = pr[6]; q = qr[6]; break; case 7: p = pr[7]; q = qr[7]; break;
+                default: p = expf(lp); q = L.algo == 1 ? expf(L.old_logits[(size_t)n * d.A + a] - old_lse) : 0.f;
+            }
             // d logp_act/dl_a = [a==act] - p ; dH/dl_a = -p (log p + H) ; dKL/dl_a = p - q
             g = g_lp * ((a == act ? 1.f : 0.f) - p);
             if (p > 0.f) g += ce * p * (lp + ent);
-            if (L.algo == 1) {
-                float ol;
-                switch (c) {            // register file is not indexable: select the lane's c-th old logit
-                    case 0: ol = olr[0]; break; case 1: ol = olr[1]; break; case 2: ol = olr[2]; break; case 3: ol = olr[3]; break;
-                    case 4: ol = olr[4]; break; case 5: ol = olr[5]; break; case 6: ol = olr[6]; break; case 7: ol = olr[7]; break;
-                    default: ol = L.old_logits[(size_t)n * d.A + a];
-                }
-                g += ck * (p - expf(ol - old_lse));
-            }
+            if (L.algo == 1) g += ck * (p - q);
         } else {
             g = g_v;
         }
