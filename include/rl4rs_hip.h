@@ -242,7 +242,10 @@ typedef struct rl4rs_dien_cfg {
  *   NO_HEAD_TABLES  head GEMM over all 3456 inputs instead of the per-category-slot tables
  *   NO_HEAD_FUSED   k_head_finish as its own launch instead of the table sums inside k_cat_attn
  *   CAT_V1          category branch through the first-generation k_cat_attn (full [Cn, E] LDS image per row: 12 rows in flight
- *                   per CU) instead of k_cat_attn2 (half-K image, 16+ rows per CU; E = 128 and Cn <= 24 only) */
+ *                   per CU) instead of k_cat_attn2 (half-K image, 16+ rows per CU; E = 128 and Cn <= 24 only)
+ *   NO_CAT_GROUP    launches whose rows come in groups of 8 or 9 per cache slot (the reward forward over the complete states):
+ *                   category branch per row (k_cat_attn2) instead of one workgroup per group that gathers the category rows the
+ *                   group shares once (k_cat_attn2g; a group that shares nothing takes the per-row body inside it) (=) */
 enum {
     RL4RS_DIEN_OPT_AUGRU_H16 = 1 << 0,
     RL4RS_DIEN_OPT_AUGRU_ROWS32 = 1 << 1,
@@ -256,7 +259,8 @@ enum {
     RL4RS_DIEN_OPT_NO_HEAD_TABLES = 1 << 9,
     RL4RS_DIEN_OPT_NO_HEAD_FUSED = 1 << 10,
     RL4RS_DIEN_OPT_CAT_V1 = 1 << 11,
-    RL4RS_DIEN_OPT_ALL = (1 << 12) - 1
+    RL4RS_DIEN_OPT_NO_CAT_GROUP = 1 << 12,
+    RL4RS_DIEN_OPT_ALL = (1 << 13) - 1
 };
 
 /* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):

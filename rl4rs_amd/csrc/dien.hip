@@ -254,26 +254,23 @@ __global__ __launch_bounds__(256) void k_cat_attn(const int32_t* __restrict__ ca
 // still holds E[j][e], E[j][e + 64] of every row j) instead of re-reading the image.  22.9 KB per workgroup: seven fit a CU,
 // the register file (<= 128 VGPRs) allows 16 waves = 16 rows: an obs-sized launch is ONE round.  Bit-identical arithmetic to
 // k_cat_attn except the pooled row (register FMAs in the same j order: identical too).
-__global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict__ cat, int R, int Cn, int H,
-                                                      const float* __restrict__ cat_emb, const float* __restrict__ seq_emb,
-                                                      float* __restrict__ allf, int ldf, int off_c, float* __restrict__ q, int write_flat,
-                                                      int h16, const float* __restrict__ ptab, const float* __restrict__ obs_b,
-                                                      float* __restrict__ tsum) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int E = 128, HK = 64, LE = HK + 4, MAXC = 24, TCH = 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+template <int MAXC, bool EXACT>
+__device__ __forceinline__ void cat_attn2_row(float* sE, int row, int lane, const int32_t* __restrict__ cat, int Cn_arg, int H,
+                                              const float* __restrict__ cat_emb, const float* __restrict__ seq_emb,
+                                              float* __restrict__ allf, int ldf, int off_c, float* __restrict__ q, int write_flat,
+                                              int h16, const float* __restrict__ ptab, const float* __restrict__ obs_b,
+                                              float* __restrict__ tsum) {
+    constexpr int E = 128, HK = 64, LE = HK + 4, TCH = 4;       // MAXC: rows held in registers; EXACT: Cn == MAXC at compile time
+    const int Cn = EXACT ? MAXC : Cn_arg;                       // (the default shape, Cn = 21: no clamps, no guards, fewer registers)
     const int half = lane >> 5, li = lane & 31;
-    float* sE = reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * LE + 32);
     float* sW = sE + Cn * LE;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= R) return;
     const int32_t* crowp = cat + (size_t)row * Cn;
     float* frow = allf + (size_t)row * ldf + off_c;
     const int myid = (lane < Cn) ? min(max(crowp[lane], 0), H - 1) : 0;
     const int nq = min(10, Cn);
     // register budget (<= 128 for four waves per SIMD): the query rows are requested first and folded into two sums as soon as
     // they are there (they return in request order, ahead of the 48 category-row requests behind them); the head-table rows
-    // come in six chunks of 4, each requested one stage ahead of where it is summed
+    // come as two chunks of 4 (requested at the top and at the half-K boundary) and the rest in one go behind the MFMAs
     float qv0[10], qv1[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
@@ -293,6 +290,10 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
 #pragma unroll
     for (int u = 0; u < 10; ++u)
         if (u >= 10 - nq) { q0 += qv0[u]; q1 += qv1[u]; }
+    // pinned HERE: the sums are only stored at the very end, and LLVM's sinking pass otherwise moves the twenty adds down there -
+    // which kept the twenty loaded values alive across the whole kernel and made the allocator spill eight of them, each spill a
+    // "s_waitcnt vmcnt(0); scratch_store" right behind its load: eight serialised memory round trips at the top of every row
+    asm volatile("" : "+v"(q0), "+v"(q1));
     __builtin_amdgcn_sched_barrier(0);
     const bool do_t = tsum != nullptr;
     float4 tacc = make_float4(0.f, 0.f, 0.f, 0.f), tv[TCH];
@@ -364,7 +365,27 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
     }
     // (the second half of the block stays in the LDS image: the pooled row reads its columns 64..127 from there, columns
     // 0..63 from the registers - the v1 registers are free from here on)
-    CAT2_T_STAGE(2);
+    // the rest of the head-table rows (8 .. Cn-1) are requested HERE - the second-half registers and the MFMA operands are dead -
+    // instead of one chunk of 4 per later stage, each of which exposed a memory round trip in front of the next.  Default shape
+    // (EXACT): all 13 in one go, summed at the end; other shapes: two batches of 8 (the second behind the softmax).
+    constexpr int TW = MAXC - 2 * TCH, TWB = EXACT ? TW : 8;
+    float4 tw[TWB];
+    auto rest_request = [&](int b0) {
+#pragma unroll
+        for (int u = 0; u < TWB; ++u) {
+            const int j = min(2 * TCH + b0 + u, Cn - 1);
+            tw[u] = reinterpret_cast<const float4*>(ptab + ((size_t)j * H + __builtin_amdgcn_readlane(myid, j)) * OBS_DIM)[lane];
+        }
+    };
+    auto rest_add = [&](int b0) {
+#pragma unroll
+        for (int u = 0; u < TWB; ++u)
+            if (2 * TCH + b0 + u < Cn) { tacc.x += tw[u].x; tacc.y += tw[u].y; tacc.z += tw[u].z; tacc.w += tw[u].w; }
+    };
+    if (do_t) {
+        t_add(1);
+        rest_request(0);
+    }
     float m = -3.4e38f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -378,7 +399,6 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
         z += ev;
     }
     z += __shfl_xor(z, 32);
-    CAT2_T_STAGE(3);
     const float inv = row_ok ? 1.f / z : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -392,7 +412,10 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    CAT2_T_STAGE(4);
+    if (do_t && TWB < TW) {
+        rest_add(0);
+        if (2 * TCH + TWB < Cn) rest_request(TWB);
+    }
     {
         const float invc = 1.f / (float)Cn;
         float s0 = 0.f, s1 = 0.f;
@@ -406,15 +429,249 @@ __global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict_
         frow[lane] = s0 * invc;
         frow[lane + 64] = s1 * invc;
     }
-    CAT2_T_STAGE(5);
     const float invq = 1.f / (float)nq;
     q[(size_t)row * E + lane] = q0 * invq;
     q[(size_t)row * E + lane + 64] = q1 * invq;
     if (do_t) {
-        t_add(5);
+        rest_add(TWB < TW ? TWB : 0);
         reinterpret_cast<float4*>(tsum + (size_t)row * OBS_DIM)[lane] = tacc;
     }
 #undef CAT2_T_STAGE
+}
+
+template <int MAXC, bool EXACT>
+__global__ __launch_bounds__(256, 4) void k_cat_attn2(const int32_t* __restrict__ cat, int R, int Cn, int H,
+                                                      const float* __restrict__ cat_emb, const float* __restrict__ seq_emb,
+                                                      float* __restrict__ allf, int ldf, int off_c, float* __restrict__ q, int write_flat,
+                                                      int h16, const float* __restrict__ ptab, const float* __restrict__ obs_b,
+                                                      float* __restrict__ tsum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    cat_attn2_row<MAXC, EXACT>(reinterpret_cast<float*>(smem) + (size_t)wave * (Cn * (64 + 4) + 32), row, lane, cat, Cn, H, cat_emb, seq_emb, allf, ldf,
+                  off_c, q, write_flat, h16, ptab, obs_b, tsum);
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_cat_attn2g<G>: the category branch for a launch whose rows come in groups of G that share every category id but the last.
+// That is what the reward forward is (rl4rs/env/slate.py:117-131, get_complete_states): the category row of complete state j of
+// an env is [user portrait (10), sequence id, ALL nine chosen items, item j] - 20 of the 21 ids are the env's, only the last
+// is the row's - and the per-row kernel gathers the same 20 embedding rows (512 B each), the same 20 head-table rows (1 KB
+// each) and nine of the ten query rows once PER ROW: 37 KB of gathers per row, 83 vector loads per wave in a six-trip
+// dependent chain, which is what bounded the reward-sized launch (166 us for 32 768 rows = the L2 at ~8 TB/s).
+// Here a workgroup is one group, wave w = row w of it:
+//   * the Cn - 1 shared embedding rows, their head-table rows and the nine shared query rows are gathered ONCE per group into LDS
+//     (wave w takes rows w, w + G, ..: at most 3 + 3 + 2 requests per wave), each wave gathers only its own last id's three
+//     rows beside them: ~14 vector loads per wave in ONE round trip instead of 83 in six;
+//   * one barrier, then every wave runs its row off the shared image: the Gram tile / softmax / pooled row (lane li = Cn - 1
+//     reads the wave's private row; all k ascending as in k_cat_attn), the query sum and the head addend - each summed in the
+//     per-row kernel's own order (shared rows in id order, the row's own term last), so every output is BIT-IDENTICAL to
+//     k_cat_attn2 (tests/test_gpu_dien.py::test_group_category_kernel_is_bit_identical).
+// Nothing is assumed about the ids: each wave compares its row's with the staged ("lead") row's while the loads are in flight,
+// and rows that differ are served by further passes of the same loop with the next open row as the lead.
+template <int G>
+__global__ __launch_bounds__(64 * G, 4) void k_cat_attn2g(const int32_t* __restrict__ cat, int Cn, int H,
+                                                          const float* __restrict__ cat_emb, const float* __restrict__ seq_emb,
+                                                          float* __restrict__ allf, int ldf, int off_c, float* __restrict__ q, int write_flat,
+                                                          int h16, const float* __restrict__ ptab, const float* __restrict__ obs_b,
+                                                          float* __restrict__ tsum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 128, LE = E + 4, MAXS = 23;              // MAXS: shared rows at most (Cn <= 24)
+    constexpr int RJ = (MAXS + G - 1) / G, RQ = (9 + G - 1) / G;   // shared rows / shared query rows per wave
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = lane >> 5, li = lane & 31;
+    const int CS = Cn - 1;                                     // shared rows
+    float* fs = reinterpret_cast<float*>(smem);
+    int* s_flag = reinterpret_cast<int*>(fs);                  // [16] per-wave "my ids are row 0's"
+    float* sQ = fs + 16;                                       // [9][E] the nine shared query rows
+    float* sT = sQ + 9 * E;                                    // [CS][OBS_DIM] shared head-table rows
+    float* sE = sT + (size_t)CS * OBS_DIM;                     // [CS][LE] shared embedding rows
+    float* sP = sE + (size_t)CS * LE + (size_t)wave * (LE + 32);   // per wave: own last row [LE] + column weights [32]
+    float* sW = sP + LE;
+    const int row0 = blockIdx.x * G, row = row0 + wave;
+    const int myid = (lane < Cn) ? min(max(cat[(size_t)row * Cn + lane], 0), H - 1) : 0;
+    const bool do_t = tsum != nullptr;
+    // this row's own last id: embedding row, query row, head-table row (requested once, kept across passes)
+    const int last = __builtin_amdgcn_readlane(myid, Cn - 1);
+    const float pc0 = cat_emb[(size_t)last * E + lane], pc1 = cat_emb[(size_t)last * E + lane + 64];
+    const float pq0 = seq_emb[(size_t)last * E + lane], pq1 = seq_emb[(size_t)last * E + lane + 64];
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (do_t) pt = reinterpret_cast<const float4*>(ptab + ((size_t)CS * H + last) * OBS_DIM)[lane];
+    // Pass p stages the shared rows of the first row not served yet (the "lead"; pass 0: row 0) and serves every row whose
+    // shared ids equal the lead's.  A group of complete states is one pass; a group that shares nothing is G passes - the same
+    // results either way (each row is always computed from exactly its own ids), the sharing only decides the speed.
+    uint32_t done = 0;                                         // bit w: row w served (kept identically by every wave)
+    int lead = 0;
+    while (true) {
+        const int id0 = (lane < Cn) ? min(max(cat[(size_t)(row0 + lead) * Cn + lane], 0), H - 1) : 0;
+        // every wave gathers its share of the lead's shared rows into LDS: embedding rows and head-table rows j = wave, wave + G, ..,
+        // query rows u = wave, wave + G (all requested before the first is stored)
+        {
+            float v0[RJ], v1[RJ];
+            float4 tv[RJ];
+            float qv0[RQ], qv1[RQ];
+#pragma unroll
+            for (int u = 0; u < RJ; ++u) {
+                const int j = wave + u * G;                    // wave-uniform
+                v0[u] = 0.f;
+                v1[u] = 0.f;
+                tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < CS) {
+                    const int id = __builtin_amdgcn_readlane(id0, j);
+                    v0[u] = cat_emb[(size_t)id * E + lane];
+                    v1[u] = cat_emb[(size_t)id * E + lane + 64];
+                    if (do_t) tv[u] = reinterpret_cast<const float4*>(ptab + ((size_t)j * H + id) * OBS_DIM)[lane];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RQ; ++u) {
+                const int k = wave + u * G;
+                qv0[u] = 0.f;
+                qv1[u] = 0.f;
+                if (k < 9) {
+                    const float* src = seq_emb + (size_t)__builtin_amdgcn_readlane(id0, Cn - 10 + k) * E;
+                    qv0[u] = src[lane];
+                    qv1[u] = src[lane + 64];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RJ; ++u) {
+                const int j = wave + u * G;
+                if (j < CS) {
+                    sE[j * LE + lane] = v0[u];
+                    sE[j * LE + lane + 64] = v1[u];
+                    if (do_t) reinterpret_cast<float4*>(sT + (size_t)j * OBS_DIM)[lane] = tv[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RQ; ++u) {
+                const int k = wave + u * G;
+                if (k < 9) { sQ[k * E + lane] = qv0[u]; sQ[k * E + lane + 64] = qv1[u]; }
+            }
+        }
+        sP[lane] = pc0;                                        // (behind the pass's requests; the same values every pass)
+        sP[lane + 64] = pc1;
+        {
+            const bool same = __all((lane >= CS) || (myid == id0));
+            if (lane == 0) s_flag[wave] = same ? 1 : 0;
+        }
+        __syncthreads();
+        uint32_t hit = 0;
+#pragma unroll
+        for (int w = 0; w < G; ++w) hit |= (s_flag[w] != 0 ? 1u : 0u) << w;
+        hit &= ~done;
+        if ((hit >> wave) & 1u) {                              // this row is served by this pass
+            float* frow = allf + (size_t)row * ldf + off_c;
+            if (write_flat) {                                          // Flatten()(category_emb) of the GEMM-form head
+                for (int u = 0; u < Cn; ++u) {
+                    const float* er = (u < CS) ? sE + u * LE : sP;
+                    frow[E + u * E + lane] = er[lane];
+                    frow[E + u * E + lane + 64] = er[lane + 64];
+                }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const bool row_ok = li < Cn;
+            const float* erow = (li < CS) ? sE + li * LE : sP;         // lanes beyond Cn read the private row, results unused
+            if (h16) {
+                const float* er16 = erow + half * 8;
+#pragma unroll
+                for (int kb = 0; kb < E / 16; ++kb) {
+                    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+                    if (row_ok) { f0 = *reinterpret_cast<const float4*>(er16 + kb * 16); f1 = *reinterpret_cast<const float4*>(er16 + kb * 16 + 4); }
+                    const float x[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                    half8_t fh, fl;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        half2_t h2, l2;
+                        split_h16_pair(x[e], x[e + 1], h2, l2);
+                        fh[e] = h2[0]; fh[e + 1] = h2[1];
+                        fl[e] = l2[0]; fl[e + 1] = l2[1];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, fh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, fl, acc, 0, 0, 0);
+                }
+            } else {
+                const float* er32 = erow + half * 4;
+#pragma unroll
+                for (int kb = 0; kb < E / 8; ++kb) {
+                    float4 f = row_ok ? *reinterpret_cast<const float4*>(er32 + kb * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, f.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, f.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, f.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, f.w, acc, 0, 0, 0);
+                }
+            }
+            float m = -3.4e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (crow(r, half) < Cn) m = fmaxf(m, acc[r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float z = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ev = (crow(r, half) < Cn) ? CAT_EXP(acc[r] - m) : 0.f;
+                acc[r] = ev;
+                z += ev;
+            }
+            z += __shfl_xor(z, 32);
+            const float inv = row_ok ? 1.f / z : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] * inv;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);
+                if (li == 0) sW[crow(r, half)] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            {
+                const float invc = 1.f / (float)Cn;
+                float s0 = 0.f, s1 = 0.f;
+                for (int j = 0; j < CS; ++j) {
+                    const float w = sW[j];
+                    s0 = fmaf(w, sE[j * LE + lane], s0);
+                    s1 = fmaf(w, sE[j * LE + lane + 64], s1);
+                }
+                s0 = fmaf(sW[CS], pc0, s0);
+                s1 = fmaf(sW[CS], pc1, s1);
+                frow[lane] = s0 * invc;
+                frow[lane + 64] = s1 * invc;
+            }
+            // query = mean of the last ten ids' rows, head addend = bias + table rows: both summed in the per-row kernel's order
+            // (shared rows in id order, this row's own one last)
+            const float invq = 1.f / (float)min(10, Cn);
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { q0 += sQ[u * E + lane]; q1 += sQ[u * E + lane + 64]; }
+            q[(size_t)row * E + lane] = (q0 + pq0) * invq;
+            q[(size_t)row * E + lane + 64] = (q1 + pq1) * invq;
+            if (do_t) {
+                float4 t = reinterpret_cast<const float4*>(obs_b)[lane];
+                for (int j = 0; j < CS; ++j) {
+                    const float4 v = reinterpret_cast<const float4*>(sT + (size_t)j * OBS_DIM)[lane];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                t.x += pt.x; t.y += pt.y; t.z += pt.z; t.w += pt.w;
+                reinterpret_cast<float4*>(tsum + (size_t)row * OBS_DIM)[lane] = t;
+            }
+        }
+        done |= hit;
+        if (done == (1u << G) - 1u) break;
+        __syncthreads();                                       // the served rows have read the image; the next pass overwrites it
+        lead = __ffs(~done) - 1;
+    }
+}
+
+inline size_t cat_attn2g_smem(int G, int Cn) {
+    const size_t grp = 16 + 9 * 128 + (size_t)(Cn - 1) * (OBS_DIM + 132) + (size_t)G * (132 + 32);
+    return grp * 4;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1429,6 +1686,7 @@ struct rl4rs_dien {
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
+    bool cat_group;        // reward-sized launches (rows in groups of 8 / 9): k_cat_attn2g, one workgroup per group (RL4RS_DIEN_OPT_NO_CAT_GROUP: per row)
     bool cat_v2;           // category branch through k_cat_attn2 (half-K LDS image) when the shape allows (RL4RS_DIEN_OPT_CAT_V1: first form)
     bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
     bool gemm16;           // fp16x2 mode: the plain GEMMs (dense tower, q-side DIN term, cache projections, head) through k_gemm_h16
@@ -1606,6 +1864,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->gemm16 = false;
     n->cat16 = false;
     n->cat_v2 = !(opts & RL4RS_DIEN_OPT_CAT_V1);
+    n->cat_group = !(opts & RL4RS_DIEN_OPT_NO_CAT_GROUP);
     n->dense_chain = !(opts & RL4RS_DIEN_OPT_NO_DENSE_CHAIN);
     n->gru16 = false;
     n->gru16_attr = false;
@@ -1912,11 +2171,25 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     int rc;
     {
         Prof p(n, KID_CAT, st);
-        if (n->cat_v2 && E == 128 && Cn <= 24) {
+        if (n->cat_v2 && n->cat_group && E == 128 && Cn >= 11 && Cn <= 24 && (group == 8 || group == 9)) {
+            // rows in groups that (normally) share all but the last category id: one workgroup per group, shared gathers once
+            const size_t smem = cat_attn2g_smem(group, Cn);
+            if (group == 8)
+                hipLaunchKernelGGL(k_cat_attn2g<8>, dim3(ngroups), dim3(512), smem, st, cat, Cn, n->H, n->cat_emb, n->seq_emb, n->allf, F,
+                                   off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0, n->ptab, n->obs_b, n->tsum);
+            else
+                hipLaunchKernelGGL(k_cat_attn2g<9>, dim3(ngroups), dim3(576), smem, st, cat, Cn, n->H, n->cat_emb, n->seq_emb, n->allf, F,
+                                   off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0, n->ptab, n->obs_b, n->tsum);
+        } else if (n->cat_v2 && E == 128 && Cn <= 24) {
             size_t smem = (size_t)4 * (Cn * (64 + 4) + 32) * 4;
-            hipLaunchKernelGGL(k_cat_attn2, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, n->H, n->cat_emb,
-                               n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
-                               n->ptab, n->obs_b, n->tsum);
+            if (Cn == 21)
+                hipLaunchKernelGGL((k_cat_attn2<21, true>), dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, n->H, n->cat_emb,
+                                   n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
+                                   n->ptab, n->obs_b, n->tsum);
+            else
+                hipLaunchKernelGGL((k_cat_attn2<24, false>), dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, n->H, n->cat_emb,
+                                   n->seq_emb, n->allf, F, off_c, n->q, n->ptab ? 0 : 1, (n->fp16x2 && n->cat16) ? 1 : 0,
+                                   n->ptab, n->obs_b, n->tsum);
         } else {
             size_t smem = (size_t)4 * (Cn * (E + 4) + 32) * 4;
             hipLaunchKernelGGL(k_cat_attn, dim3((R + 3) / 4), dim3(256), smem, st, cat, R, Cn, E, n->H, n->cat_emb,
@@ -2136,7 +2409,7 @@ int rl4rs_dien_kernel_label(rl4rs_dien* n, int which, char* buf, int32_t cap) {
     const bool din_x = n->fp16x2 && n->din16 && n->h1f[0];
     std::string s;
     switch (which) {
-        case KID_CAT: s = (n->cat_v2 && n->E == 128 && n->Cn <= 24) ? "k_cat_attn2" : "k_cat_attn"; break;
+        case KID_CAT: s = (n->cat_v2 && n->E == 128 && n->Cn <= 24) ? (n->cat_group ? "k_cat_attn2 / k_cat_attn2g (grouped rows)" : "k_cat_attn2") : "k_cat_attn"; break;
         case KID_DENSE:
             s = (n->gemm16 && n->dense_chain && n->U <= 128 && n->U % 16 == 0) ? "k_gemm_h16<chain>(dense tower, both layers)"
                                                                                 : std::string(gemm) + " x2 (dense tower)";

@@ -424,6 +424,50 @@ def test_category_kernels_are_bit_identical(scorer_precision, extra):
     assert torch.equal(o1, o2) and torch.equal(p1, p2)
 
 
+@pytest.mark.parametrize('group', [8, 9])
+@pytest.mark.parametrize('extra', ['', 'no_head_tables', 'no_cat16'])
+def test_group_category_kernel_is_bit_identical(scorer_precision, group, extra):
+    """k_cat_attn2g (one workgroup per group of rows that share a cache slot: the category rows the group shares gathered once,
+    sums in the per-row kernel's order) against k_cat_attn2 (scorer_kernels='no_cat_group') on a reward-shaped launch: groups of
+    complete states (rl4rs/env/slate.py:117-131: every id but the last shared), groups where a few rows differ in a shared id
+    (extra passes of the kernel's loop), one group that shares nothing, ids outside the table (clamped alike) - the whole forward
+    must be bit-identical."""
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    cfg = dict(CFG, scorer_precision=scorer_precision)
+    B = 37
+    R = B * group
+    w = init_dien_weights(cfg, seed=8, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(5)
+    seq, dense, _ = _inputs(B, rs, cfg['category_hash_size'])
+    dense = np.abs(rs.randn(R, 432) * 3).astype(np.float32)
+    _, _, cat_env = _inputs(B, rs, cfg['category_hash_size'])
+    cat = np.repeat(cat_env, group, axis=0).reshape(B, group, 21)
+    cat[:, :, 20] = rs.randint(0, 284, size=(B, group))             # the row's own item
+    cat[3, 2, 5] += 1                                                # one row of a group differs in a shared id
+    cat[4, 1::2, 12] = 7                                             # every second row of a group: two sets of rows
+    cat[5] = rs.randint(0, 284, size=(group, 21))                    # a group that shares nothing
+    cat[6, :, 0] = cfg['category_hash_size'] + 5                     # outside the table: clamped by both kernels
+    cat[7, 3, 19] = -2
+    cat = np.ascontiguousarray(cat.reshape(R, 21)).astype(np.int32)
+
+    def run(kernels):
+        net = DeviceDien(dict(cfg, scorer_kernels=kernels), w, max_rows=R, max_slots=B)
+        for s_ in range(2):
+            net.encode(s_, torch.from_numpy(np.ascontiguousarray(seq[:, s_])).cuda(), 0)
+        sl = torch.arange(B, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+        obs, p = net.forward(R, group, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), sl, True, True)
+        obs, p = obs.clone(), p.clone()
+        net.close()
+        return obs, p
+
+    og, pg = run(extra)
+    o1, p1 = run(','.join(x for x in ('no_cat_group', extra) if x))
+    assert torch.isfinite(og).all() and torch.isfinite(pg).all()
+    assert torch.equal(o1, og) and torch.equal(p1, pg)
+
+
 def test_kernel_options_are_validated():
     from rl4rs_amd.nets.dien import init_dien_weights
     from rl4rs_amd.device import DeviceDien
