@@ -378,17 +378,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32_t128(const float* __restric
         // a column beyond N gets an offset outside the descriptor: its stores are dropped like the rows beyond M
         const int c_voff = col_ok ? (4 * half * (int)ldc + col) * 4 : 0x7ffffff0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            // the sixteen addend values of an accumulator tile are requested together (one load + wait + activation + store per
+            // element was sixteen serialised round trips per tile: the ISA showed `s_waitcnt vmcnt(0)` behind every one)
+            float ad[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ad[r] = 0.f;
+                if (addend) {
+                    const int g = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, M - 1);
+                    ad[r] = addend[(size_t)(g / add_div) * ldadd + min(col, N - 1)];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);           // local row without the half part
                 float v = acc[i][j][r] + bv;
-                if (addend) {
-                    const int g = min(m0 + lr + 4 * half, M - 1);
-                    v += col_ok ? addend[(size_t)(g / add_div) * ldadd + col] : 0.f;
-                }
+                if (addend) v += ad[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(v, act)), rs_c, c_voff, lr * ldc4, 0);
             }
+        }
     }
 }
 
