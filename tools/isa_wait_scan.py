@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Find loads the compiler serialised: per kernel, how many vector-memory loads are followed (within two instructions) by
+``s_waitcnt vmcnt(0)`` - each one a full memory round trip nothing else is in flight behind - and how many spills / scratch
+reloads sit in the kernel.  Two real finds of round 5 came from this scan: k_cat_attn2 (eight gathered values spilled behind
+their loads because the sums that consume them had been sunk to the end of the kernel) and k_gemm_f32_t128's epilogue (one
+addend load, wait, activation and store per element).
+
+    python tools/isa_wait_scan.py [unit.hip ...]        (default: every unit of rl4rs_amd/build.py; needs hipcc, no GPU)
+
+The ISA comes from ``hipcc -S --cuda-device-only`` with the flags of the in-tree build."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rl4rs_amd.build import CSRC, SOURCES, NO_SLP  # noqa: E402
+
+LOADS = ('global_load', 'buffer_load', 'scratch_load', 'flat_load')
+
+
+def scan(path):
+    stats, name, window = {}, None, []
+    for line in open(path):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            name, window = m.group(1), []
+            stats[name] = dict(serial=0, loads=0, waits0=0, spills=0)
+            continue
+        t = line.strip()
+        if t.startswith('.Lfunc_end'):
+            name = None
+        if name is None or not t or t[0] in ';.':
+            continue
+        st = stats[name]
+        if t.startswith(LOADS):
+            st['loads'] += 1
+        if 'Folded Spill' in t:
+            st['spills'] += 1
+        if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
+            st['waits0'] += 1
+            if any(x.startswith(LOADS) for x in window[-2:]):
+                st['serial'] += 1
+        window.append(t)
+    return stats
+
+
+def main():
+    units = sys.argv[1:] or SOURCES
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    rows = []
+    with tempfile.TemporaryDirectory() as d:
+        for u in units:
+            out = os.path.join(d, os.path.basename(u).replace('.hip', '.s'))
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-mllvm', '-pragma-unroll-threshold=200000',
+                   '-S', '--cuda-device-only', '-I', os.path.join(os.path.dirname(CSRC), '..', 'include'), '-o', out,
+                   os.path.join(CSRC, os.path.basename(u))] + (['-fno-slp-vectorize'] if os.path.basename(u) in NO_SLP else [])
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for k, st in scan(out).items():
+                if st['serial'] >= 3 or st['spills']:
+                    rows.append((st['serial'], st['spills'], st['loads'], st['waits0'], k, os.path.basename(u)))
+    demangle = subprocess.run(['c++filt'] + [r[4] for r in rows], capture_output=True, text=True).stdout.split('\n') if rows else []
+    print('| serialised loads | vector spills | loads | vmcnt(0) waits | kernel | unit |\n|---|---|---|---|---|---|')
+    for r, dn in sorted(zip(rows, demangle), reverse=True):
+        print('| %d | %d | %d | %d | `%s` | %s |' % (r[0], r[1], r[2], r[3], dn[:100], r[5]))
+
+
+if __name__ == '__main__':
+    main()
