@@ -1357,6 +1357,7 @@ struct DinArgs {
     const float* w2[4]; const float* b2[4]; const float* w3[4]; const float* b3[4];
     float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
     const int32_t* order;        // processing order of the row groups (NULL = identity): rl4rs_dien_set_row_order
+    unsigned long long* trace;   // -DRL4RS_DINX_TRACE timing experiments only
 };
 
 template <bool STAGE, bool H16>
@@ -2233,6 +2234,20 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         }
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
         a.order = (n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
+#ifdef RL4RS_DINX_TRACE      // timing experiments only (tools/dinx_trace.py)
+        {
+            static unsigned long long* din_trace = nullptr;
+            if (!din_trace) { (void)hipMalloc((void**)&din_trace, 8 * 5 * 8 * 8); (void)hipMemset(din_trace, 0, 8 * 5 * 8 * 8); }
+            a.trace = din_trace;
+            if (getenv("RL4RS_DINX_TRACE_DUMP")) {       // the marks of the PREVIOUS launch
+                unsigned long long host[8 * 5 * 8];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(host, din_trace, sizeof(host), hipMemcpyDeviceToHost);
+                FILE* f = fopen(getenv("RL4RS_DINX_TRACE_DUMP"), "wb");
+                if (f) { fwrite(host, 1, sizeof(host), f); fclose(f); }
+            }
+        }
+#endif
         if (h16 && n->h1f[0]) {
             // 16 rows per 8-wave workgroup: an obs-sized launch (R = 4096, two inputs) is two workgroups per CU, one round
             hipLaunchKernelGGL(k_din_x, dim3((R + 15) / 16, S), dim3(512), din_x_smem(), st, a, 16);

@@ -28,6 +28,13 @@
 
 namespace rl4rs {
 
+#ifdef RL4RS_DINX_TRACE    // s_memtime marks of workgroup (40, 0): [wave][tile 0..3 | 4 = workgroup marks][mark] (tools/dinx_trace.py)
+#define DINX_TR(tile, k) do { if (a.trace && blockIdx.x == 40 && blockIdx.y == 0 && lane == 0) \
+        a.trace[(wave * 5 + (tile)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DINX_TR(tile, k) do { } while (0)
+#endif
+
 // h1 [slot, L, E = 128] -> fragment order [slot][NT][8][64][8]; steps >= L of the last tile are zero
 __global__ __launch_bounds__(256) void k_h1_frag(const float* __restrict__ h1, float* __restrict__ h1f, int slot_base, int cnt, int L) {
     const int NT = (L + 31) / 32;
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, li = lane & 31;
+    DINX_TR(4, 0);
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.w1d16[sq]);
         uint4* dst = reinterpret_cast<uint4*>(s_w1);
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
         if (tid == 0) s_misc[32] = a.b3[sq][0];
     }
     __syncthreads();
+    DINX_TR(4, 1);
     float* s_q = s_wave + (size_t)wave * (E + ATT_H1);
     float* s_qa = s_q + E;
     const int ntile = (L + 31) / 32;
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
         const float* qp = s_q + half * 8;
 
         for (int n = 0; n < ntile; ++n) {
+            DINX_TR((j / NW) * 2 + n, 0);
             const int t = n * 32 + li;
             const int tc = min(t, L - 1);                  // steps >= L re-read the last row (results never stored)
             const float* hp = a.h1f[sq] + (((size_t)slot * ntile + n) * KB * 64 + lane) * 8;
@@ -156,12 +166,15 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
             // per k-block: weight fragments (LDS) requested first, the split operand built behind them, then the six MFMAs; the
             // cache rows of k-block kb + RING are requested as soon as kb's have been consumed.  A wave alternates a VALU and an
             // MFMA stretch; the four waves of a SIMD fill each other's gaps (registers kept under 128 for that).
+            DINX_TR((j / NW) * 2 + n, 1);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 ldw(0, kb);
                 ldw(1, kb);
                 mkb(kb % RL4RS_DINX_RING, kb);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kb == 0) DINX_TR((j / NW) * 2 + n, 2);
+                if (kb == 4) DINX_TR((j / NW) * 2 + n, 3);
                 if (kb + RL4RS_DINX_RING < KB) ldh(kb % RL4RS_DINX_RING, kb + RL4RS_DINX_RING);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], bh, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[1], bh, acc[1], 0, 0, 0);
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[1], bl, acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            DINX_TR((j / NW) * 2 + n, 4);
             // epilogue: hid1 = sigmoid(acc); layer 2 on the matrix pipe in the same split form; layer 3 in registers
             f32x16 acc2;
 #pragma unroll
@@ -208,8 +222,10 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
             sc += __shfl_xor(sc, 32);
             sc += s_misc[32];
             if (half == 0 && t < L) a.scores[(size_t)sq * a.scores_stride + (size_t)row * L + t] = sc;
+            DINX_TR((j / NW) * 2 + n, 5);
         }
     }
+    DINX_TR(4, 2);
 }
 
 
@@ -224,6 +240,19 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
 // issued right behind that MFMA, and the 8-pass v_mfma_f32_32x32x16_f16 was still reading it: wrong scores in 4-lane groups
 // (tests/test_gpu_dien.py::test_dien_rowwise_matches_oracle caught it).  In this kernel every asm definition sits behind an LDS
 // or cache wait; keep it that way, or write the split with compiler-visible conversions where a definition can follow an MFMA.
+//
+// Round 5, measured and dropped (same-box A/Bs of the DIN ms per episode-batch; head = this kernel, 0.90 ms):
+//   * the ring of first-GRU states 3 / 4 / 8 k-blocks deep instead of 2: 0.909 / 0.919 / (18 spills); the ring running ACROSS tiles and
+//     rows (the slots freed by a tile's last k-blocks take the next tile's first ones): 0.908.  The s_memtime marks
+//     (tools/dinx_trace.py, -DRL4RS_DINX_TRACE) do show 1 - 4 k cycles of waiting at every tile start on a workload with 4096
+//     distinct histories (HBM-bound there: 537 MB per launch), but on the bench's sharing (1 771 distinct, duplicates adjacent) the
+//     wait only moves into the first k-blocks: a tile is ~4 k cycles of requests + first operand, ~10.5 k of k loop (1.3 k per
+//     k-block), 2.3 k of epilogue whichever way the requests are arranged; workgroup life 85 - 95 k cycles of which 11 k staging.
+//   * W1d's hi planes (or both planes) resident in registers, two waves per SIMD, 32 rows per workgroup (4 instead of 6 / 2
+//     instead of 6 ds_read_b128 per k-block): 1.01 / 0.99 ms - fewer LDS reads do not pay for half the waves.
+//   So the k loop runs at ~325 cycles per wave and k-block on a SIMD whose matrix pipe needs 192, whose VALU ~160 and whose LDS
+//   issue ~120 for it: three comparably loaded resources overlapping at ~60 %, four waves per SIMD being what makes them overlap
+//   at all.  Neither more bytes in flight nor fewer LDS reads nor fewer, fatter waves moves it.
 
 inline size_t din_x_smem() { return 40960 + 48 * 4 + (size_t)8 * (128 + ATT_H1) * 4; }
 
