@@ -65,19 +65,38 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
     const int half = lane >> 5, li = lane & 31;
     DINX_TR(4, 0);
     {
-        const uint4* src = reinterpret_cast<const uint4*>(a.w1d16[sq]);
-        uint4* dst = reinterpret_cast<uint4*>(s_w1);
-        for (int i = tid; i < 2048; i += 512) dst[i] = src[i];
+        // staging: every request of the workgroup's 40 KB of weights goes out before the first is stored.  (As two plain loops the
+        // ISA was "load, s_waitcnt vmcnt(0), store" per iteration: eight serialised memory round trips = 11 k of a workgroup's
+        // ~88 k cycles, tools/dinx_trace.py.)  W2 entries beyond the 16 real output units read a clamped address and are zeroed.
+        // (ext_vector_type, not HIP's uint4 struct: a struct copied out of global memory is a memcpy the optimiser leaves in scratch)
+        typedef float stage4_t __attribute__((ext_vector_type(4)));
+        const stage4_t* src = reinterpret_cast<const stage4_t*>(a.w1d16[sq]);
+        stage4_t* dst = reinterpret_cast<stage4_t*>(s_w1);
+        stage4_t wv[4];
+        float w2v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wv[p] = src[tid + p * 512];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = tid + p * 512, e = i & 7, ln = (i >> 3) & 63, f = i >> 9, o = ln & 31;
+            w2v[p] = a.w2[sq][((f >> 1) * 32 + crow((f & 1) * 8 + e, ln >> 5)) * ATT_H2 + min(o, ATT_H2 - 1)];
+        }
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        if (tid < ATT_H2) { m0 = a.b2[sq][tid]; m1 = a.w3[sq][tid]; }
+        if (tid == 0) m2 = a.b3[sq][0];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dst[tid + p * 512] = wv[p];
         _Float16* s_w2h = reinterpret_cast<_Float16*>(s_w2b);
-        for (int i = tid; i < 4 * 64 * 8; i += 512) {
-            const int e = i & 7, ln = (i >> 3) & 63, f = i >> 9, o = ln & 31;
-            const float v = o < ATT_H2 ? a.w2[sq][((f >> 1) * 32 + crow((f & 1) * 8 + e, ln >> 5)) * ATT_H2 + o] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = tid + p * 512, e = i & 7, ln = (i >> 3) & 63, f = i >> 9, o = ln & 31;
+            const float v = o < ATT_H2 ? w2v[p] : 0.f;
             const _Float16 hi = (_Float16)v;
             s_w2h[(f * 2) * 512 + ln * 8 + e] = hi;
             s_w2h[(f * 2 + 1) * 512 + ln * 8 + e] = (_Float16)(v - (float)hi);
         }
-        if (tid < ATT_H2) { s_misc[tid] = a.b2[sq][tid]; s_misc[16 + tid] = a.w3[sq][tid]; }
-        if (tid == 0) s_misc[32] = a.b3[sq][0];
+        if (tid < ATT_H2) { s_misc[tid] = m0; s_misc[16 + tid] = m1; }
+        if (tid == 0) s_misc[32] = m2;
     }
     __syncthreads();
     DINX_TR(4, 1);
