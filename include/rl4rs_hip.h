@@ -571,8 +571,11 @@ int rl4rs_policy_status_words(rl4rs_policy* pol, uint32_t** words_dev);
  *   TILE          [1] 0 = one-wave-per-sample forward / loss kernels instead of k_policy_tile
  *   PPO_FUSED     [1] 0 = per-minibatch kernel chain instead of the persistent k_ppo_pass
  *   PPO_ROWS      [8] samples per workgroup of k_ppo_pass: 8, 16 or 32
- *   RESIDENT_WGS [-1] >= 0: pretend the device holds only this many workgroups of k_ppo_pass at once (co-residency tests) */
-enum { RL4RS_POLICY_OPT_TILE = 0, RL4RS_POLICY_OPT_PPO_FUSED = 1, RL4RS_POLICY_OPT_PPO_ROWS = 2, RL4RS_POLICY_OPT_RESIDENT_WGS = 3 };
+ *   RESIDENT_WGS [-1] >= 0: pretend the device holds only this many workgroups of k_ppo_pass at once (co-residency tests)
+ *   PPO_STD       [1] 0 = the all-runtime instantiation of k_ppo_pass even at the default shape (256 -> 64 -> 284 + 1, 8 rows,
+ *                     minibatch % 256 == 0), which otherwise runs the compile-time one (bit-identical results) */
+enum { RL4RS_POLICY_OPT_TILE = 0, RL4RS_POLICY_OPT_PPO_FUSED = 1, RL4RS_POLICY_OPT_PPO_ROWS = 2, RL4RS_POLICY_OPT_RESIDENT_WGS = 3,
+       RL4RS_POLICY_OPT_PPO_STD = 4 };
 int rl4rs_policy_set_option(rl4rs_policy* pol, int32_t which, int32_t value);
 /* Adam state of the handle (first / second moments, device pointers owned by the handle; same layout as the
  * parameters) and its step counter: a data-parallel trainer broadcasts rank 0's at start, a checkpoint saves them. */

@@ -319,6 +319,9 @@ struct rl4rs_amlp {
     float *d_h1, *d_h2, *d_proj;        // backward scratch, [max_grad_rows, ...]
     int last_n, last_rep;               // rows of the last forward (the backward must match)
     float *w2t, *w3t, *w1at;            // transposed weights of the fused minibatch backward (amlp_fused.hpp; NULL: shape not eligible)
+    bool t_valid;                       // the transposes equal the current parameters: set by the fused forward (which rebuilds them),
+                                        // cleared by everything that may write the parameters (Adam, copies, soft updates, handing out the
+                                        // raw pointer) and by a non-fused forward; the fused backward rebuilds them when it is unset
     float *w1p, *w2p, *w3p, *w1xp;      // fp16 hi / lo fragment planes of W1's action rows, W2, W3 (and W1's observation rows) for rl4rs_amlp_forward_h16 (NULL: shape not eligible)
     int64_t adam_t;
     std::vector<void*> owned;
@@ -340,13 +343,10 @@ static bool amlp_fused_call(const rl4rs_amlp* p, int N, int rep) { return g_amlp
 
 // n <= 4 networks with the same input widths over the SAME rows as one launch each way (amlp_fused.hpp)
 static int amlp_forward_fused(int n, rl4rs_amlp* const* nets, int N, const float* obs, const float* act, float* const* outs, hipStream_t st) {
-    static bool attr = false;
     int rc;
-    if (!attr) {
-        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<1>), amlp_fwd4_smem(4096, 1)))) return rc;
-        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<2>), amlp_fwd4_smem(4096, 2)))) return rc;
-        attr = true;
-    }
+    // (every call: a cached lookup keyed by device and function - a process-wide flag skipped the second GPU of a process)
+    if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<1>), amlp_fwd4_smem(4096, 1)))) return rc;
+    if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_amlp_fwd4<2>), amlp_fwd4_smem(4096, 2)))) return rc;
     // 4 rows per workgroup.  The 8-row form (MTW = 2: every weight value feeds two row tiles) was measured SLOWER at the learners'
     // 256-row minibatches - 32 workgroups instead of 64, BCQ update 0.371 -> 0.406 ms - and is kept for A/B only (rl4rs_amlp_set_fused(2))
     const int mtw = g_amlp_fused == 2 ? 2 : 1;
@@ -360,7 +360,7 @@ static int amlp_forward_fused(int n, rl4rs_amlp* const* nets, int N, const float
         const int D = p->c.obs_dim, E = p->c.act_dim, K = p->c.out_dim;
         x.n[i] = AmlpFwd4{obs, act, P + o[AP_W1], P + o[AP_B1], P + o[AP_W2], P + o[AP_B2], P + o[AP_W3], P + o[AP_B3], p->h1, p->h2, outs[i],
                           p->w3t, p->w2t, p->w1at, N, D, E, K, p->c.head_act};
-        if (p->w2t) t_elems = std::max(t_elems, 256 * 256 + 256 * K + 256 * E);
+        if (p->w2t) { t_elems = std::max(t_elems, 256 * 256 + 256 * K + 256 * E); p->t_valid = true; }
         p->last_n = N;
         p->last_rep = 1;
     }
@@ -388,6 +388,15 @@ static int amlp_backward_fused(int n, rl4rs_amlp* const* nets, int N, const floa
         const int64_t* o = p->off;
         float* G = p->grad;
         const int D = p->c.obs_dim, E = p->c.act_dim, K = p->c.out_dim, H1 = 256, H2 = 256;
+        if (!p->t_valid) {
+            // the forward of these rows did not take the fused path (rl4rs_amlp_set_fused toggled in between, a rep > 1 forward) or the
+            // parameters may have been written since: nothing tracked that before ADVICE r5 and the chain read stale transposes
+            const float* P = p->params;
+            const int t_elems = 256 * 256 + 256 * K + 256 * E;
+            hipLaunchKernelGGL(k_amlp_transposes, dim3((t_elems + 255) / 256), dim3(256), 0, st, P + o[AP_W3], K, p->w3t, P + o[AP_W2], p->w2t,
+                               P + o[AP_W1] + (size_t)D * 256, E, p->w1at);
+            p->t_valid = true;
+        }
         x.n[i] = AmlpBwd4{douts[i], p->h1, p->h2, p->w3t, p->w2t, p->w1at, p->d_h2, p->d_h1, dacts ? dacts[i] : nullptr, N, K, E};
         if (want_param_grad) {
             add(p->h2, H2, H2, douts[i], K, K, G + o[AP_W3], G + o[AP_B3]);
@@ -434,6 +443,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
     p->last_n = p->last_rep = 0;
     p->w1p = p->w2p = p->w3p = p->w1xp = nullptr;
     p->w2t = p->w3t = p->w1at = nullptr;
+    p->t_valid = false;
     const int64_t sizes[AP_COUNT] = {(D + E) * H1, H1, H1 * H2, H2, H2 * K, K};
     int64_t o = 0;
     for (int i = 0; i < AP_COUNT; ++i) { p->off[i] = o; p->size[i] = sizes[i]; o += sizes[i]; }
@@ -480,7 +490,7 @@ int rl4rs_amlp_create(const rl4rs_amlp_cfg* c, const float* params_host, void* s
 
 int rl4rs_amlp_params(rl4rs_amlp* p, float** params_dev, float** grad_dev, int64_t* count) {
     RL4RS_REQUIRE(p, "amlp_params: null handle");
-    if (params_dev) *params_dev = p->params;
+    if (params_dev) { *params_dev = p->params; p->t_valid = false; }       // (a writable pointer leaves the library)
     if (grad_dev) *grad_dev = p->grad;
     if (count) *count = p->n_params;
     return RL4RS_OK;
@@ -502,6 +512,7 @@ int rl4rs_amlp_set_adam_step(rl4rs_amlp* p, int64_t step) {
 int rl4rs_amlp_copy_params(rl4rs_amlp* dst, const rl4rs_amlp* src, void* stream) {
     RL4RS_REQUIRE(dst && src && dst->n_params == src->n_params, "amlp_copy_params: handles differ");
     RL4RS_HIP_TRY(hipMemcpyAsync(dst->params, src->params, (size_t)src->n_params * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    dst->t_valid = false;
     return RL4RS_OK;
 }
 
@@ -510,6 +521,7 @@ int rl4rs_amlp_soft_update(rl4rs_amlp* targ, const rl4rs_amlp* src, float tau, v
     hipLaunchKernelGGL(k_soft_update, dim3((unsigned)((src->n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, targ->params,
                        src->params, src->n_params, tau);
     RL4RS_LAUNCH_CHECK();
+    targ->t_valid = false;
     return RL4RS_OK;
 }
 
@@ -549,6 +561,7 @@ int rl4rs_amlp_forward(rl4rs_amlp* p, int32_t N, int32_t rep, const float* obs, 
     }
     p->last_n = N;
     p->last_rep = rep;
+    p->t_valid = false;                 // (this launch sequence rebuilt nothing: a fused backward of these rows transposes first)
     return RL4RS_OK;
 }
 
@@ -641,6 +654,7 @@ int rl4rs_amlp_adam_step(rl4rs_amlp* p, float lr, float beta1, float beta2, floa
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((p->n_params + 255) / 256)), dim3(256), 0, st, p->params, p->grad, p->adam_m, p->adam_v,
                        (int)p->n_params, lr_t, beta1, beta2, (float)(eps * c2), (const float*)nullptr, 0.f);
     RL4RS_LAUNCH_CHECK();
+    p->t_valid = false;
     return RL4RS_OK;
 }
 
@@ -661,7 +675,9 @@ int rl4rs_amlp_adam_multi(int32_t n, rl4rs_amlp* const* nets, const float* lr, c
         RL4RS_REQUIRE(!tg || tg->n_params == p->n_params, "amlp_adam_multi: target %d has another shape", i);
         AdamMultiDesc& d = a.d[i];
         d.p = p->params; d.targ = tg ? tg->params : nullptr;
+        if (tg) tg->t_valid = false;
         if (do_adam[i]) {
+            p->t_valid = false;
             p->adam_t += 1;
             const double t = (double)p->adam_t;
             const double c2 = sqrt(1.0 - pow((double)beta2, t));

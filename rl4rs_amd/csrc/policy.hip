@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "gather_kernels.hpp"
+#include "mfma4.hpp"
 
 namespace rl4rs {
 
@@ -708,441 +709,7 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 }
 
 
-// -------------------------------------------------------------------------------------------------
-// One PPO SGD pass (all minibatches: forward, loss, backward, gradient reductions, Adam) as ONE persistent kernel.
-// The per-minibatch path above is a chain of 7 small dependent kernels (144 x 7 per pass at RLlib's 256-sample
-// minibatches) and is bound by that serial depth.  Here MB / 32 workgroups of 8 waves stay resident for the whole pass and
-// meet at two grid barriers per minibatch:
-//   phase A  workgroup g owns samples [32g, 32g+32) of the minibatch: obs tile -> LDS, hidden = tanh(obs W1 + b1) and
-//            out = h W2e + b2e on 32x32x2 fp32 MFMA tiles (layer 1 split over K across waves, partials summed in a fixed
-//            order), the A2C/PPO row loss (policy_row_loss, one wave per row), dH = dOut W2e^T (k-permuted so that both
-//            operands read 4 consecutive k per lane), dHpre = dH (1 - h^2); H, dOut, dHpre go to a [MB, .] scratch
-//   barrier
-//   phase B  45 wave-sized tasks over all waves: the 32x32 tiles of dW1 = obs^T dHpre and dW2e = H^T dOut (sample-axis
-//            MFMA reductions as in k_gemm_tn) and the bias column sums, each followed by the Adam update of exactly the
-//            parameters it produced (no separate gradient / Adam kernels, no clip: the caller falls back to the
-//            per-minibatch path when grad_clip > 0)
-//   barrier
-// Grid barrier: monotonically increasing arrival counter, agent-scope release / acquire fences on both sides (the
-// XCDs' L2s are not coherent with each other without them).  Parameters are mutated in-kernel: no const / __restrict__.
-struct PassArgs {
-    PolDims d;
-    int N, MB, rows;
-    float *prm, *am, *av;
-    float* w2t;              // [AE, HID] transposed copy of W2e, kept current by the Adam updates (coalesced dH operand)
-    const float* obs;
-    const uint32_t* mask;
-    LossArgs L;
-    float *H, *dOut, *dHpre;
-    float4* terms;
-    float* grad;
-    unsigned* bar;
-    unsigned* dead_host;     // pinned host word raised next to bar[1]: the host sees a timeout without synchronising
-    float lr, b1, b2, eps;
-    long long t0;
-    int mb_begin, mb_end;    // minibatches [mb_begin, mb_end) of the pass
-    int apply;               // 1: Adam inside phase B (single GPU); 0: gradient only (the caller all-reduces it, then rl4rs_policy_adam_step)
-    unsigned long long* trace;
-};
-
-#ifdef RL4RS_PASS_TRACE     // s_memtime marks of workgroup 0 / wave 0 in minibatch 10 (timing experiments)
-#define RL4RS_PT(k) do { if (a.trace && blockIdx.x == 0 && tid == 0 && mb == 10) a.trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RL4RS_PT(k) do { } while (0)
-#endif
-
-// Grid barrier (all workgroups resident): monotonically increasing arrival counter.  Producer side: every wave drains its
-// stores, lane 0 writes the XCD's dirty L2 lines back (agent release), and - the compiler may drop the wait that belongs to the
-// release when it believes nothing is outstanding - an explicit s_waitcnt before the RELAXED arrival, so the counter cannot
-// overtake the write-back.  Consumer side: relaxed polling, ONE agent acquire (invalidates this CU's L1), workgroup barrier,
-// then plain loads.
-// Returns false once any workgroup has given up (bar[1] != 0): the caller then stops touching the parameters, so a pass whose
-// workgroups were not co-resident leaves them at the last consistent minibatch instead of running racy updates.
-#ifndef RL4RS_PASS_WT
-#define RL4RS_PASS_WT 1      // 1: everything another workgroup reads is stored write-through (store_wt) and the barrier has no release
-#endif                       //    fence; 0: plain stores + lane-0 agent release (L2 write-back) before the arrival
-#if RL4RS_PASS_WT
-#define PUB(ptr, val) store_wt(&(ptr), (val))
-#else
-#define PUB(ptr, val) ((ptr) = (val))
-#endif
-// `mid` runs on every thread between the arrival and the poll: the place to REQUEST data that does not depend on what the
-// other workgroups publish (the next minibatch's observations and loss inputs) - the loads fly while the barrier waits.
-struct NoMid { __device__ void operator()() const {} };
-template <typename Mid = NoMid>
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen, Mid mid = Mid()) {
-    __shared__ unsigned s_dead;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    gen += 1;
-    if (threadIdx.x == 0) {
-#if !RL4RS_PASS_WT
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    mid();
-    if (threadIdx.x == 0) {
-        const unsigned target = gen * nwg;
-        // bounded wait (~seconds): if the workgroups are not all resident (a tool that serialises workgroups, a shared GPU)
-        // the pass gives up instead of hanging the device - bar[1] is raised and rl4rs_policy_ppo_epoch reports it
-        unsigned spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
-               __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 21)) {   // ~1 us per poll: gives up after a few seconds
-                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dead_host) __hip_atomic_store(dead_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        s_dead = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return s_dead == 0u;
-}
-
-__device__ __forceinline__ void adam_elem(float* p, float* m, float* v, float g, float lr_t, float b1, float b2, float eps) {
-    const float mi = b1 * *m + (1.f - b1) * g;
-    const float vi = b2 * *v + (1.f - b2) * g * g;
-    *m = mi;
-    *v = vi;
-    *p -= lr_t * mi / (sqrtf(vi) + eps);
-}
-
-__global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const PolDims d = a.d;
-    const int OD = d.OD, HID = d.HID, AE = d.AE, MB = a.MB;
-    const int SO = OD | 1, SH = HID | 1, SA = AE | 1;               // odd row strides: conflict-free column walks
-    float* s_obs = reinterpret_cast<float*>(smem);                   // [32][SO]
-    float* s_h = s_obs + 32 * SO;                                    // [32][SH]
-    float* s_out = s_h + 32 * SH;                                    // [32][SA]  (scratch for the dH partials afterwards)
-    float* s_d = s_out + 32 * SA;                                    // [32][SA]  (scratch for the layer-1 partials before)
-    float* s_old = s_d + 32 * SA;                                    // [32][A]   old logits of the tile's rows
-    float* s_sc = s_old + 32 * d.A;                                  // [5][32]   action (as int), adv, ret, old logp, old value
-    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_sc + 5 * 32);   // [32][W]   action-mask words of the tile's rows
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, li = lane & 31;
-    float* W1 = a.prm;
-    float* b1p = W1 + (size_t)OD * HID;
-    float* W2 = b1p + HID;
-    float* b2p = W2 + (size_t)HID * AE;
-    const int NT1 = HID / 32, NT2 = (AE + 31) / 32, parts = 8 / NT1;
-    const int R = a.rows;                    // samples of this workgroup (8, 16 or 32): rows R..31 of every MFMA tile are idle
-    const int r0 = blockIdx.x * R;
-    unsigned gen = 0;
-    for (int i = blockIdx.x * 512 + tid; i < HID * AE; i += gridDim.x * 512) {
-        const int j = i / AE, c = i - j * AE;
-        PUB(a.w2t[(size_t)c * HID + j], W2[i]);
-    }
-    // The inputs of a minibatch that no workgroup writes (observation rows, old logits, mask words, per-sample scalars) are
-    // requested INSIDE the grid barrier in front of it, between this workgroup's arrival and its poll, and go to LDS from
-    // registers afterwards: their HBM round trip (2.1 us of the 33 per minibatch when it followed the barrier) runs while the
-    // barrier waits.  Only when they fit a few registers per thread (8 rows per workgroup: 4 + 5 + 1 + 5).
-    constexpr int PF_OBS = 4, PF_OLD = 5;
-    const bool can_pf = R * OD <= 512 * PF_OBS && R * d.A <= 512 * PF_OLD && R * d.W <= 512 && R <= 512;
-    float pf_obs[PF_OBS], pf_old[PF_OLD], pf_sc[5];
-    uint32_t pf_mask = 0;
-    int pf_act = 0;
-    auto prefetch = [&](int mbn) {
-        if (!can_pf || mbn >= a.mb_end) return;
-        const size_t ln = (size_t)mbn * MB;
-#pragma unroll
-        for (int u = 0; u < PF_OBS; ++u) pf_obs[u] = a.obs[(ln + r0) * OD + min(tid + 512 * u, R * OD - 1)];
-#pragma unroll
-        for (int u = 0; u < PF_OLD; ++u) pf_old[u] = a.L.old_logits[(ln + r0) * d.A + min(tid + 512 * u, R * d.A - 1)];
-        if (a.mask) pf_mask = a.mask[(ln + r0) * d.W + min(tid, R * d.W - 1)];
-        const int tr = min(tid, R - 1);
-        pf_act = a.L.actions[ln + r0 + tr];
-        pf_sc[0] = a.L.adv[ln + r0 + tr]; pf_sc[1] = a.L.ret[ln + r0 + tr];
-        pf_sc[2] = a.L.old_logp[ln + r0 + tr]; pf_sc[3] = a.L.old_value[ln + r0 + tr];
-    };
-    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { prefetch(a.mb_begin); })) return;
-    for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
-        const size_t lo = (size_t)mb * MB;
-        // ------------------------------------------------------------------ phase A
-        RL4RS_PT(0);
-        if (can_pf) {
-#pragma unroll
-            for (int u = 0; u < PF_OBS; ++u) {
-                const int i = tid + 512 * u;
-                if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = pf_obs[u];
-            }
-#pragma unroll
-            for (int u = 0; u < PF_OLD; ++u)
-                if (tid + 512 * u < R * d.A) s_old[tid + 512 * u] = pf_old[u];
-            if (a.mask && tid < R * d.W) s_mask[tid] = pf_mask;
-            if (tid < R) {
-                reinterpret_cast<int32_t*>(s_sc)[tid] = pf_act;
-                s_sc[32 + tid] = pf_sc[0]; s_sc[64 + tid] = pf_sc[1]; s_sc[96 + tid] = pf_sc[2]; s_sc[128 + tid] = pf_sc[3];
-            }
-        } else {
-            for (int i0 = tid; i0 < R * OD; i0 += 512 * 16) {               // 16 loads in flight per thread and trip
-                float x[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = a.obs[(lo + r0) * OD + min(i0 + 512 * u, R * OD - 1)];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int i = i0 + 512 * u;
-                    if (i < R * OD) s_obs[(i / OD) * SO + i % OD] = x[u];
-                }
-            }
-            // the row-loss inputs do not depend on the parameters: staged here, in one round trip with the observations
-            for (int i0 = tid; i0 < R * d.A; i0 += 512 * 16) {
-                float x[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = a.L.old_logits[(lo + r0) * d.A + min(i0 + 512 * u, R * d.A - 1)];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (i0 + 512 * u < R * d.A) s_old[i0 + 512 * u] = x[u];
-            }
-            if (a.mask)
-                for (int i = tid; i < R * d.W; i += 512) s_mask[i] = a.mask[(lo + r0) * d.W + i];
-            if (tid < R) {
-                reinterpret_cast<int32_t*>(s_sc)[tid] = a.L.actions[lo + r0 + tid];
-                s_sc[32 + tid] = a.L.adv[lo + r0 + tid];
-                s_sc[64 + tid] = a.L.ret[lo + r0 + tid];
-                s_sc[96 + tid] = a.L.old_logp[lo + r0 + tid];
-                s_sc[128 + tid] = a.L.old_value[lo + r0 + tid];
-            }
-        }
-        __syncthreads();
-        RL4RS_PT(1);
-        {   // layer 1, split over K: wave -> (tile t, part q)
-            const int t = wave % NT1, q = wave / NT1, kper = OD / parts;
-            f32x16 acc;
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int k = q * kper; k < (q + 1) * kper; k += 64) {       // one memory round trip per 64 k (kper % 64 == 0)
-                float bv[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) bv[u] = W1[(size_t)(k + 2 * u + half) * HID + t * 32 + li];
-                __builtin_amdgcn_sched_barrier(0);      // all loads of the trip in flight before the first MFMA
-#pragma unroll
-                for (int u = 0; u < 32; ++u)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_obs[li * SO + k + 2 * u + half], bv[u], acc, 0, 0, 0);
-            }
-            float* part = s_d + (size_t)(t * parts + q) * 1024;
-            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
-        }
-        __syncthreads();
-        for (int i = tid; i < R * HID; i += 512) {
-            const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
-            float s = b1p[j];
-            for (int q = 0; q < parts; ++q) s += s_d[(size_t)(t * parts + q) * 1024 + r * 32 + c];
-            const float h = tanhf(s);
-            s_h[r * SH + j] = h;
-            PUB(a.H[(size_t)(r0 + r) * HID + j], h);
-        }
-        __syncthreads();
-        RL4RS_PT(2);
-        for (int t = wave; t < NT2; t += 8) {   // layer 2 (+ action mask): one memory round trip per tile and 64 k
-            const int col = t * 32 + li;
-            const bool c_ok = col < AE;
-            const int colc = c_ok ? col : AE - 1;          // clamped: the loads stay unconditional and issue together
-            f32x16 acc;
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int k = 0; k < HID; k += 64) {            // HID % 64 == 0
-                float bv[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) bv[u] = W2[(size_t)(k + 2 * u + half) * AE + colc];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 32; ++u)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_h[li * SH + k + 2 * u + half], bv[u], acc, 0, 0, 0);
-            }
-            {
-                const float bias = b2p[colc];
-                if (c_ok)
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (row < R) {
-                            float v = acc[r] + bias;
-                            const uint32_t mw = a.mask ? s_mask[row * d.W + (colc >> 5)] : 0xffffffffu;
-                            if (col < d.A && !((mw >> (col & 31)) & 1u)) v = v + (-3.4028235e38f);
-                            s_out[row * SA + col] = v;
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-        RL4RS_PT(3);
-        {   // row losses: wave w takes rows 4w .. 4w+3
-            LossArgs L = a.L;                      // inputs from the LDS copies, indexed by the row within the tile
-            L.actions = reinterpret_cast<const int32_t*>(s_sc); L.adv = s_sc + 32; L.ret = s_sc + 64; L.old_logp = s_sc + 96;
-            L.old_value = s_sc + 128; L.old_logits = s_old;
-            for (int row = wave; row < R; row += 8) {
-                const float* so = s_out + row * SA;
-                float mx = -3.4028235e38f;
-                for (int c = lane; c < d.A; c += 64) mx = fmaxf(mx, so[c]);
-                mx = wave_max(mx);
-                float se = 0.f;
-                for (int c = lane; c < d.A; c += 64) se += expf(so[c] - mx);
-                const float lse = mx + logf(wave_sum(se));
-                const float4 tm = policy_row_loss<RL4RS_PASS_WT != 0>(d, L, so, lse, row, lane, s_d + row * SA, a.dOut + (size_t)r0 * AE);
-                if (lane == 0) a.terms[lo + r0 + row] = tm;       // per-sample loss terms of the whole pass (KL mean -> kl_coeff rule)
-                if (row == 0) RL4RS_PT(11);
-            }
-        }
-        __syncthreads();
-        RL4RS_PT(4);
-        {   // dH = dOut W2e^T, split over K: wave -> (tile t, part q); the B operand comes from the transposed copy (coalesced)
-            const int t = wave % NT1, q = wave / NT1;
-            const int kper = ((AE + parts - 1) / parts + 1) & ~1;      // even number of k per part
-            f32x16 acc;
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* drow = s_d + li * SA;
-            const int k_hi = min((q + 1) * kper, AE);
-            for (int k = q * kper; k < k_hi; k += 72) {                 // 36 loads in flight per trip (one trip for AE <= 288)
-                float wv[36];
-#pragma unroll
-                for (int u = 0; u < 36; ++u) wv[u] = a.w2t[(size_t)min(k + 2 * u + half, AE - 1) * HID + t * 32 + li];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 36; ++u) {
-                    const int kk = k + 2 * u + half;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk < k_hi ? drow[min(kk, AE - 1)] : 0.f, wv[u], acc, 0, 0, 0);
-                }
-            }
-            RL4RS_PT(12);
-            float* part = s_out + (size_t)(t * parts + q) * 1024;
-            for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + li] = acc[r];
-        }
-        __syncthreads();
-        RL4RS_PT(13);
-        for (int i = tid; i < R * HID; i += 512) {
-            const int r = i / HID, j = i - r * HID, t = j >> 5, c = j & 31;
-            float s = 0.f;
-            for (int q = 0; q < parts; ++q) s += s_out[(size_t)(t * parts + q) * 1024 + r * 32 + c];
-            const float h = s_h[r * SH + j];
-            PUB(a.dHpre[(size_t)(r0 + r) * HID + j], s * (1.f - h * h));
-        }
-        RL4RS_PT(5);
-        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
-        RL4RS_PT(6);
-        // ------------------------------------------------------------------ phase B
-        // One task = one 32x32 gradient tile (or 32 bias columns) + the Adam update of its parameters, done by a GROUP of 4
-        // waves of one workgroup: each wave reduces a quarter of the minibatch's samples (MB / 4, two trips of 16 sample
-        // pairs), the four partials meet in LDS and are summed in a fixed order, then each wave updates a quarter of the
-        // tile's parameters.
-        {
-            const double tt = (double)(a.t0 + mb + 1);
-            const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, tt)) / (1.0 - pow((double)a.b1, tt)));
-            RL4RS_PT(10);
-            const int n_t1 = (OD / 32) * NT1, n_t2 = NT1 * NT2, total = n_t1 + n_t2 + NT1 + NT2;
-            const float* obs_mb = a.obs + lo * OD;
-            const int grp = wave >> 2, q = wave & 3, spq = MB / 4;        // group of the wave, its sample quarter
-            float* s_part = s_obs + (size_t)grp * 4 * 1024;               // [4 quarters][32 x 32] per group (s_obs is free here)
-            for (int t0 = 0; t0 < total; t0 += gridDim.x * 2) {           // uniform trip count: the barriers below are workgroup-wide
-                const int task = t0 + blockIdx.x * 2 + grp;
-                const bool live = task < total;
-                const bool is_tile = task < n_t1 + n_t2;
-                const bool first = is_tile ? task < n_t1 : (task - n_t1 - n_t2) < NT1;
-                int tm = 0, tn = 0;
-                if (is_tile) {
-                    const int tl = first ? task : task - n_t1;
-                    const int tn_n = first ? NT1 : NT2;
-                    tm = tl / tn_n;
-                    tn = tl - tm * tn_n;
-                } else {
-                    const int tl = task - n_t1 - n_t2;
-                    tn = first ? tl : tl - NT1;
-                }
-                const int Nc = first ? HID : AE;
-                const int j = tn * 32 + li;
-                const bool j_ok = j < Nc;
-                const int jc = j_ok ? j : Nc - 1;
-                if (live && is_tile) {
-                    // quarter of A^T B over the samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut
-                    const float* A = first ? obs_mb : a.H;
-                    const float* B = first ? a.dHpre : a.dOut;
-                    const int lda = first ? OD : HID, ldb = Nc;
-                    const int m = tm * 32 + li;
-                    f32x16 acc;
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    for (int n = q * spq; n < (q + 1) * spq; n += 32) {
-                        float av[16], bv[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int nn = n + 2 * u + half;
-                            av[u] = A[(size_t)nn * lda + m];
-                            bv[u] = B[(size_t)nn * ldb + jc];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-                    }
-                    for (int r = 0; r < 16; ++r) s_part[q * 1024 + r * 64 + lane] = acc[r];
-                } else if (live) {
-                    // quarter of the bias column sums: lanes = 32 columns x 2 sample parities
-                    const float* X = first ? a.dHpre : a.dOut;
-                    float sum = 0.f;
-                    for (int n = q * spq + half; n < (q + 1) * spq; n += 32) {
-                        float x[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) x[u] = X[(size_t)(n + 2 * u) * Nc + jc];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) sum += x[u];
-                    }
-                    s_part[q * 1024 + lane] = sum;
-                }
-                RL4RS_PT(9);
-                __syncthreads();
-                if (live && is_tile) {
-                    // wave q owns accumulator registers 4q .. 4q+3 of the tile
-                    if (j_ok) {
-                        const size_t base = first ? 0 : (size_t)OD * HID + HID;
-                        size_t idx[4];
-                        float g[4], pp[4], mm[4], vv[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int r = 4 * q + c;
-                            idx[c] = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * Nc + j;
-                            pp[c] = a.prm[idx[c]]; mm[c] = a.am[idx[c]]; vv[c] = a.av[idx[c]];
-                            g[c] = ((s_part[r * 64 + lane] + s_part[1024 + r * 64 + lane]) + s_part[2048 + r * 64 + lane]) +
-                                   s_part[3072 + r * 64 + lane];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float mi = a.b1 * mm[c] + (1.f - a.b1) * g[c];
-                            const float vi = a.b2 * vv[c] + (1.f - a.b2) * g[c] * g[c];
-                            a.grad[idx[c]] = g[c];
-                            if (!a.apply) continue;
-                            a.am[idx[c]] = mi;
-                            a.av[idx[c]] = vi;
-                            const float pn = pp[c] - lr_t * mi / (sqrtf(vi) + a.eps);
-                            PUB(a.prm[idx[c]], pn);
-                            if (!first) {
-                                const int r = 4 * q + c;
-                                PUB(a.w2t[(size_t)j * HID + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], pn);
-                            }
-                        }
-                    }
-                } else if (live && q == 0 && half == 0 && j_ok) {
-                    float sum = 0.f;
-                    for (int qq = 0; qq < 4; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
-                    const size_t idx = (first ? (size_t)OD * HID : (size_t)OD * HID + HID + (size_t)HID * AE) + j;
-                    a.grad[idx] = sum;
-                    if (a.apply) {
-                        const float mi = a.b1 * a.am[idx] + (1.f - a.b1) * sum;
-                        const float vi = a.b2 * a.av[idx] + (1.f - a.b2) * sum * sum;
-                        a.am[idx] = mi;
-                        a.av[idx] = vi;
-                        PUB(a.prm[idx], a.prm[idx] - lr_t * mi / (sqrtf(vi) + a.eps));
-                    }
-                }
-                __syncthreads();                                          // s_part is rewritten by the next trip
-            }
-        }
-        RL4RS_PT(7);
-        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { prefetch(mb + 1); })) return;
-        RL4RS_PT(8);
-    }
-}
+#include "ppo_pass.hpp"
 
 
 // -------------------------------------------------------------------------------------------------
@@ -1335,7 +902,7 @@ struct rl4rs_policy {
     bool train_attr, pass_launched, tile_attr[3];
     int pass_resident_wgs;     // workgroups of k_ppo_pass the device can hold at once (-1 = not queried yet)
     // rl4rs_policy_set_option (include/rl4rs_hip.h RL4RS_POLICY_OPT_*): kernel-path selection for A/B runs and tests
-    bool opt_tile, opt_ppo_fused;
+    bool opt_tile, opt_ppo_fused, opt_ppo_std;
     int opt_ppo_rows, opt_resident_cap;
     std::vector<void*> owned;
 };
@@ -1364,7 +931,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->train_attr = false;
     p->pass_launched = false;
     p->pass_resident_wgs = -1;
-    p->opt_tile = true; p->opt_ppo_fused = true; p->opt_ppo_rows = 8; p->opt_resident_cap = -1;
+    p->opt_tile = true; p->opt_ppo_fused = true; p->opt_ppo_std = true; p->opt_ppo_rows = 8; p->opt_resident_cap = -1;
     p->dead_host = nullptr;
     p->tile_attr[0] = p->tile_attr[1] = p->tile_attr[2] = false;
     int rc;
@@ -1730,6 +1297,9 @@ struct PpoCall {
 
 size_t pass_smem_bytes(const PolDims& d) { return (size_t)32 * ((d.OD | 1) + (d.HID | 1) + 2 * (d.AE | 1) + d.A + 5 + d.W) * 4; }
 
+// The compile-time instantiation of the pass (ppo_pass.hpp: STD) covers the shape every BASELINE.json configuration runs
+bool pass_is_std(const rl4rs_policy* p, int minibatch);
+
 int pass_rows_per_wg(const rl4rs_policy* p) {
     // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
     // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
@@ -1740,6 +1310,11 @@ int pass_rows_per_wg(const rl4rs_policy* p) {
 // k_ppo_pass's dynamic-LDS opt-in is a property of the FUNCTION, not of a handle: raised once per process to the most any
 // policy shape may ask for (160 KB minus the kernel's few bytes of static LDS), never lowered - two handles of different
 // shapes cannot undercut each other.  Residency is still computed per handle with that handle's real LDS size.
+bool pass_is_std(const rl4rs_policy* p, int minibatch) {
+    const PolDims& d = p->d;
+    return p->opt_ppo_std && d.OD == 256 && d.HID == 64 && d.A == 284 && d.AE == 285 && d.W == 9 && pass_rows_per_wg(p) == 8 && minibatch % 256 == 0;
+}
+
 constexpr size_t PASS_SMEM_MAX = (size_t)160 * 1024 - 64;
 bool pass_opt_in() {
     // once per DEVICE (the attribute is per device and function), guarded: see raise_dyn_smem
@@ -1750,10 +1325,11 @@ bool pass_opt_in() {
     for (auto& e : done)
         if (e.first == dev) return e.second;
     bool ok = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ppo_pass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
-        (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
-        ok = false;
-    }
+    for (const void* fn : {reinterpret_cast<const void*>(&k_ppo_pass<false>), reinterpret_cast<const void*>(&k_ppo_pass<true>)})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
+            (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
+            ok = false;
+        }
     done.emplace_back(dev, ok);
     return ok;
 }
@@ -1779,7 +1355,8 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
         // blocks per CU: the runtime's occupancy answer, capped by what the LDS alone admits (160 KB per CU); if the query itself
         // is refused (it is for some > 64 KB dynamic-LDS shapes) the LDS bound with one 512-thread block per CU minimum stands in
         const int by_lds = (int)((size_t)160 * 1024 / (smem ? smem : 1));
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ppo_pass), 512, smem) != hipSuccess || per_cu <= 0) {
+        // (both instantiations: 512 threads at <= 256 registers and the same LDS - one answer serves either)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ppo_pass<false>), 512, smem) != hipSuccess || per_cu <= 0) {
             (void)hipGetLastError();          // do not leave a sticky error for the next launch check
             per_cu = by_lds > 0 ? 1 : 0;
         }
@@ -1821,7 +1398,8 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
         return RL4RS_ESTATE;
     }
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
-    hipLaunchKernelGGL(k_ppo_pass, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
+    if (pass_is_std(p, c.minibatch)) hipLaunchKernelGGL(k_ppo_pass<true>, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
+    else hipLaunchKernelGGL(k_ppo_pass<false>, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
     RL4RS_LAUNCH_CHECK();
     p->pass_launched = true;
 #ifdef RL4RS_PASS_TRACE
@@ -1958,6 +1536,7 @@ int rl4rs_policy_set_option(rl4rs_policy* p, int32_t which, int32_t value) {
             RL4RS_REQUIRE(value == 8 || value == 16 || value == 32, "policy_set_option: PPO_ROWS must be 8, 16 or 32 (got %d)", value);
             p->opt_ppo_rows = value; p->pass_resident_wgs = -1; break;
         case RL4RS_POLICY_OPT_RESIDENT_WGS: p->opt_resident_cap = value; p->pass_resident_wgs = -1; break;
+        case RL4RS_POLICY_OPT_PPO_STD: p->opt_ppo_std = value != 0; break;
         default: set_error("policy_set_option: unknown option %d", which); return RL4RS_EINVAL;
     }
     return RL4RS_OK;

@@ -229,14 +229,14 @@ int launch_pack_frag_slice(const float* w, int64_t ld, int k_off, int K, int N, 
 
 template <int NH>
 static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
-    static bool attr = false;
     const size_t smem = (size_t)(2 * 32 * (NH + 4) + 32 * (f.L + 1) + 32) * 4;
-    if (!attr) {
-        // the opt-in belongs to the FUNCTION, not to a call: raised once to the most any admitted shape needs (L = 64), so a
-        // short sequence launched first cannot leave the limit below what a longer one asks for later
+    {
+        // the opt-in belongs to the FUNCTION (and the device), not to a call: raised to the most any admitted shape needs (L = 64), so
+        // a short sequence launched first cannot leave the limit below what a longer one asks for later.  Asked on every launch:
+        // raise_dyn_smem is a cached lookup keyed by (device, function) - a process-wide `static bool` here skipped the second GPU
+        // of a process, whose launch then failed above the 64 KB default
         int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur<NH, true, 2, 0, true>), (size_t)(2 * 32 * (NH + 4) + 32 * 65 + 32) * 4);
         if (rca) return rca;
-        attr = true;
     }
     RecurArgs a;
     memset(&a, 0, sizeof(a));
@@ -253,11 +253,9 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
     if (recur_train_small(f.N, f.S)) {
         for (int s = 0; s < f.S; ++s)
             if (!a.sv_r[s] || !a.sv_u[s] || !a.sv_c[s] || !a.sv_h[s] || !a.sv_rh[s]) { set_error("recur_train_fwd: a saved-tensor pointer is NULL"); return RL4RS_EINVAL; }
-        static bool attr8 = false;
-        if (!attr8) {
+        {
             int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_fwd<NH>), recur8_fwd_smem(NH, 64));
             if (rca) return rca;
-            attr8 = true;
         }
         hipLaunchKernelGGL((k_recur8_fwd<NH>), dim3((f.N + 7) / 8, f.S), dim3(320), recur8_fwd_smem(NH, f.L), st, a);
         RL4RS_LAUNCH_CHECK();
@@ -281,12 +279,10 @@ int launch_recur_train_fwd(const RecurTrainFwd& f, hipStream_t st) {
 
 template <int NH>
 static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
-    static bool attr = false;
     const size_t smem = recur_bwd_smem(NH, b.L);
-    if (!attr) {          // per function, once, for the longest admitted sequence (see recur_train_fwd_t)
+    {                     // per (device, function), for the longest admitted sequence (see recur_train_fwd_t)
         int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur_bwd<NH>), recur_bwd_smem(NH, 64));
         if (rca) return rca;
-        attr = true;
     }
     RecurBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -298,11 +294,9 @@ static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
     }
     a.ld_g = b.ld_g; a.ld_c = b.ld_c; a.hard = b.hard;
     if (recur_train_small(b.N, b.S)) {
-        static bool attr8 = false;
-        if (!attr8) {
+        {
             int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_bwd<NH>), recur8_bwd_smem(NH, 64));
             if (rca) return rca;
-            attr8 = true;
         }
         hipLaunchKernelGGL((k_recur8_bwd<NH>), dim3((b.N + 7) / 8, b.S), dim3(320), recur8_bwd_smem(NH, b.L), st, a);
         RL4RS_LAUNCH_CHECK();

@@ -1183,7 +1183,7 @@ class DevicePolicy(object):
             self.set_option(k.strip(), int(v))
 
     def set_option(self, name, value):
-        """Kernel-path selection of this handle (rl4rs_policy_set_option): 'tile', 'ppo_fused', 'ppo_rows', 'resident_wgs'."""
+        """Kernel-path selection of this handle (rl4rs_policy_set_option): 'tile', 'ppo_fused', 'ppo_rows', 'resident_wgs', 'ppo_std'."""
         if name not in _lib.POLICY_OPTS:
             raise ValueError("unknown policy option %r; known: %s" % (name, sorted(_lib.POLICY_OPTS)))
         check(self.lib.rl4rs_policy_set_option(self.h, _lib.POLICY_OPTS[name], int(value)))

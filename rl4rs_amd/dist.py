@@ -230,23 +230,28 @@ def allreduce_rows_mean_(table_grad, ids, cap=None):
     buf = torch.full((cap + 1,), -1, dtype=torch.int64, device=dev)
     buf.scatter_(0, slot, srt)
     my_ids = buf[:cap].contiguous()
+    flagged = torch.cat([my_ids, overflow.to(torch.int64).reshape(1)])        # the rank's overflow bit travels with its ids
     valid = my_ids >= 0
     safe = my_ids.clamp_min(0)
     my_rows = table_grad.index_select(0, safe) * valid[:, None].to(table_grad.dtype)
     my_rows = torch.where(overflow, torch.full_like(my_rows, float('nan')), my_rows)
-    _OVERFLOW[dev] = overflow if _OVERFLOW.get(dev) is None else (_OVERFLOW[dev] | overflow)
     stage = _needs_host_staging(table_grad)
     if stage:
-        my_ids, my_rows = my_ids.cpu(), my_rows.cpu()
-    all_ids = [torch.empty_like(my_ids) for _ in range(W)]
+        flagged, my_rows = flagged.cpu(), my_rows.cpu()
+    all_ids = [torch.empty_like(flagged) for _ in range(W)]
     all_rows = [torch.empty_like(my_rows) for _ in range(W)]
-    dist.all_gather(all_ids, my_ids)
+    dist.all_gather(all_ids, flagged)
     dist.all_gather(all_rows, my_rows)
     table_grad.index_fill_(0, safe, 0.0)                          # (padding names row 0: zero already unless touched, and then listed)
     inv = 1.0 / W
+    # the overflow flag is GLOBAL: every rank's bit rides behind its ids, so all ranks raise ROW_OVERFLOW_MESSAGE at the same
+    # settle (a rank-local flag left the others carrying NaN tables into a collective the raising rank had already left - ADVICE r5)
     for r in range(W):                       # fixed order: every rank performs the same sequence of additions
-        i_r = all_ids[r].to(dev).clamp_min(0)                     # padded entries carry zero rows: they add 0 to row 0
+        got = all_ids[r].to(dev)
+        overflow = overflow | (got[cap] != 0)
+        i_r = got[:cap].clamp_min(0)                              # padded entries carry zero rows: they add 0 to row 0
         table_grad.index_add_(0, i_r, all_rows[r].to(dev) * inv)
+    _OVERFLOW[dev] = overflow if _OVERFLOW.get(dev) is None else (_OVERFLOW[dev] | overflow)
     return table_grad
 
 

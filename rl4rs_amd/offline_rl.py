@@ -111,12 +111,16 @@ class _ModelIO(object):
             if sp is not None:
                 blob['scalar.' + name] = np.concatenate([sp.p.cpu().numpy(), sp.m.cpu().numpy(), sp.v.cpu().numpy(), [float(sp.t)]])
         rs = getattr(self, 'reward_scaler', None)
+        if isinstance(rs, str):
+            # a scaler given by name ('standard', as batchrl_trainer builds CQL-conti) has no statistics until fit_mdp fits it on the
+            # dataset: nothing to save - a learner that never trained on scaled rewards is saved as one without a scaler
+            rs = None
         if rs is not None:
             blob['reward_scaler'] = np.array([rs.mean, rs.std, rs.eps], dtype=np.float64)
         with open(fname, 'wb') as f:
             np.savez(f, **blob)
 
-    def load_model(self, fname):
+    def load_model(self, fname, legacy=True):
         with np.load(fname) as z:
             cls = str(z['__class__'])
             if cls != type(self).__name__:
@@ -141,8 +145,14 @@ class _ModelIO(object):
                 if not hasattr(self, 'reward_scaler'):
                     raise ValueError('%s carries a reward scaler, %s has none' % (fname, type(self).__name__))
                 self.reward_scaler = StandardRewardScaler.from_stats(*[float(x) for x in z['reward_scaler']])
-            elif getattr(self, 'reward_scaler', None) is not None:
-                raise ValueError('%s was saved without a reward scaler, this learner has one' % fname)
+            elif getattr(self, 'reward_scaler', None) is not None and not isinstance(self.reward_scaler, str):
+                # files written before the scaler travelled with the model (or by a learner whose named scaler was never fitted): the
+                # learner keeps ITS scaler - loud, not fatal (legacy=False turns it back into an error)
+                if not legacy:
+                    raise ValueError('%s was saved without a reward scaler, this learner has one' % fname)
+                import warnings
+                warnings.warn('%s was saved without a reward scaler; keeping this learner\'s (mean %.6g, std %.6g) - make sure it is the '
+                              'scale the file was trained on' % (fname, self.reward_scaler.mean, self.reward_scaler.std))
 
     def fit_mdp(self, data, n_epochs=1, discrete_action=None, **kw):
         """``fit`` on MDPDataset-style arrays (the dict ``offline.generate_offline_dataset`` returns) for ``n_epochs`` passes over its
@@ -333,6 +343,20 @@ def init_amlp_params(obs_dim, act_dim, out_dim, hidden1=256, hidden2=256, seed=0
     return p
 
 
+def _check_transitions(device, D, E, obs, act, rew, nxt, ter):
+    """The one-call updates hand raw pointers to the library (which only knows the row count): everything DeviceAMLP._rows asserts
+    on the per-phase path is asserted here - device, float32, shapes [B, D] / [B, E] / [B] - before any data_ptr() is taken."""
+    B = obs.shape[0]
+    for name, t, shape in (('observations', obs, (B, D)), ('actions', act, (B, E)), ('rewards', rew, (B,)),
+                           ('next observations', nxt, (B, D)), ('terminals', ter, (B,))):
+        assert isinstance(t, torch.Tensor) and t.is_cuda and (device.index is None or t.device.index == device.index), \
+            '%s must be a tensor on %s' % (name, device)
+        assert t.dtype == torch.float32, '%s must be float32 (got %s)' % (name, t.dtype)
+        assert tuple(t.shape) == shape or (len(shape) == 1 and tuple(t.shape) == (B, 1)), \
+            '%s must have shape %s (got %s)' % (name, shape, tuple(t.shape))
+    return [t if t.is_contiguous() else t.contiguous() for t in (obs, act, rew, nxt, ter)]
+
+
 def _allreduce_group(nets):
     """Data parallel: ONE mean all-reduce for the flat gradients of a group of networks that are stepped together."""
     if not rdist.collectives_active():
@@ -443,7 +467,7 @@ class BCQ(_ModelIO):
         metrics = torch.zeros(3, dtype=torch.float32, device=self.device)
         do_rl = self.total_step >= self.rl_start_step
         do_actor = do_rl and self.total_step % self.update_actor_interval == 0
-        cont = [t if t.is_contiguous() else t.contiguous() for t in (obs, act, rew, nxt, ter)]
+        cont = _check_transitions(self.device, self.D, self.E, obs, act, rew, nxt, ter)
         st = _lib.BcqStep(*[net.h.value for net in (self.imit_enc, self.imit_dec, self.policy, self.policy_targ, self.q1, self.q2, self.q1_targ, self.q2_targ)],
                           B, n, E, L, self.beta, self.scale, self.lam, self.gamma, self.tau, self.imitator_lr, self.critic_lr, self.actor_lr,
                           1 if do_rl else 0, 1 if do_actor else 0, 1 if self.nograd == 'fp16x2' else 0, int(self.q1.H16_MIN_ROWS),
@@ -723,15 +747,27 @@ class CQL(_ModelIO):
         if ws is None:
             ws = self._ws[B] = torch.empty(int(lib.rl4rs_cql_workspace_floats(B, n, A)), dtype=torch.float32, device=self.device)
         if noise:
-            (a_t, a_tp1, a_u), (c_t, c_tp1, c_u) = noise['alpha'], noise['critic']
-            f = lambda x: x.to(device=self.device, dtype=torch.float32).reshape(-1)
-            normal = torch.cat([f(noise['eps_temp']), f(a_t), f(a_tp1), f(c_t), f(c_tp1), f(noise['eps_actor'])])
-            uniform = torch.cat([f(a_u), f(c_u)])
+            # any subset of the keys, like the per-phase path's noise.get(...): what is not given is drawn from the generator
+            def normal_part(x, rows):
+                assert x is None or x.numel() == rows * A, 'noise tensor of %d values where %d x %d are needed' % (x.numel(), rows, A)
+                return self._randn((rows, A), x).reshape(-1)
+
+            def uniform_part(x):
+                if x is None:
+                    return torch.empty(B * n * A, dtype=torch.float32, device=self.device).uniform_(-1.0, 1.0, generator=self._gen)
+                assert x.numel() == B * n * A, 'uniform noise of %d values where %d are needed' % (x.numel(), B * n * A)
+                return x.to(device=self.device, dtype=torch.float32).reshape(-1)
+
+            a_t, a_tp1, a_u = noise.get('alpha') or (None, None, None)
+            c_t, c_tp1, c_u = noise.get('critic') or (None, None, None)
+            normal = torch.cat([normal_part(noise.get('eps_temp'), B), normal_part(a_t, B * n), normal_part(a_tp1, B * n),
+                                normal_part(c_t, B * n), normal_part(c_tp1, B * n), normal_part(noise.get('eps_actor'), B)])
+            uniform = torch.cat([uniform_part(a_u), uniform_part(c_u)])
         else:
             normal = torch.randn((2 * B + 4 * B * n) * A, generator=self._gen, device=self.device, dtype=torch.float32)
             uniform = torch.empty(2 * B * n * A, dtype=torch.float32, device=self.device).uniform_(-1.0, 1.0, generator=self._gen)
         metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
-        cont = [t if t.is_contiguous() else t.contiguous() for t in (obs, act, rew, nxt, ter)]
+        cont = _check_transitions(self.device, self.D, self.A, obs, act, rew, nxt, ter)
         st = _lib.CqlStep(*[net.h.value for net in (self.policy, self.q1, self.q2, self.q1_targ, self.q2_targ)], B, n, A,
                           self.gamma, self.tau, self.actor_lr, self.critic_lr, self.temp_lr, self.alpha_lr, self.alpha_threshold, self.conservative_weight,
                           1 if self.nograd == 'fp16x2' else 0, int(self.q1.H16_MIN_ROWS), self.log_temp.t, self.log_alpha.t,

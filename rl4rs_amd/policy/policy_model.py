@@ -80,6 +80,9 @@ class policy_model(object):
         out = [self.policy.predict_value(x[lo:lo + n].contiguous(), a[lo:lo + n].contiguous()) for lo in range(0, x.shape[0], n)]
         q = out[0] if len(out) == 1 else torch.cat(out)
         scaler = getattr(self.policy, 'reward_scaler', None)
+        if isinstance(scaler, str):
+            raise ValueError("reward_scaler=%r has not been fitted (fit_mdp fits a scaler given by name on its dataset): the critics "
+                             "have no reward scale to undo yet" % scaler)
         if scaler is not None:
             q = scaler.reverse_transform(q)
         return self._out(q, obs)

@@ -174,6 +174,12 @@ def _rows_worker(rank, world, port, out):
     D.allreduce_rows_mean_(bad, ids, cap=3)
     assert torch.isnan(bad).any()
     assert bool(D.take_row_overflow('cpu'))                # ... and the flag the trainers fold into their status word is set
+    # only ONE rank overflows: the flag is global (its bit travels with the ids), so every rank raises at the same settle
+    lop = torch.zeros(H, E)
+    lop_ids = ids[:12] if rank == 0 else ids[:3]
+    lop[lop_ids] = 1.0
+    D.allreduce_rows_mean_(lop, lop_ids, cap=5)
+    assert torch.isnan(lop).any() and bool(D.take_row_overflow('cpu')), rank
     big = torch.zeros(16, 4)                               # touched rows are most of the table -> dense fallback
     big_ids = torch.arange(rank, 16, 2)
     big[big_ids] = float(rank + 1)

@@ -162,6 +162,38 @@ def test_update_as_one_library_call_equals_the_per_phase_calls(nograd):
     b.close()
 
 
+def test_one_call_update_rejects_what_the_per_phase_path_rejects():
+    """the one-call update takes raw pointers: a host tensor, a float64 reward, a bool terminal or a wrong-width observation must
+    raise before anything reaches the library (they used to become a memory fault or silent garbage)"""
+    import torch
+    B, n = 64, 8
+    a, _ = _learner_pair(63, B, n)
+    f = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    x, act, rew, ter = _batch(B, 71)
+    nx = _batch(B, 72)[0]
+    good = [f(v) for v in (x, act, rew, nx, ter)]
+    bad = [
+        [good[0].cpu()] + good[1:],
+        good[:2] + [good[2].double()] + good[3:],
+        good[:4] + [good[4] > 0.5],
+        [good[0][:, :-1]] + good[1:],
+        good[:1] + [good[1][:, :-1]] + good[2:],
+        good[:2] + [good[2][:-1]] + good[3:],
+        good[:3] + [good[3][:-1]] + good[4:],
+    ]
+    before = [net.flat_params().clone() for net in a.nets]
+    for args in bad:
+        with pytest.raises(AssertionError):
+            a.update(*args)
+    assert a.total_step == 0
+    for net, p0 in zip(a.nets, before):
+        assert torch.equal(net.flat_params(), p0)
+    a.update(*good)                                # and the well-formed batch still goes through
+    a.update(good[0], good[1], good[2].reshape(B, 1), good[3], good[4].reshape(B, 1))     # [B, 1] columns are the same memory
+    assert a.total_step == 2
+    a.close()
+
+
 def test_adam_multi_equals_separate_launches():
     """rl4rs_amlp_adam_multi (Adam of several networks + soft target updates as one launch) == rl4rs_amlp_adam_step and
     rl4rs_amlp_soft_update per network, bit for bit, over three steps; a soft-update-only entry leaves its source untouched"""

@@ -254,6 +254,39 @@ def test_update_as_one_library_call_equals_the_per_phase_calls():
     b.close()
 
 
+def test_one_call_update_validates_inputs_and_takes_partial_noise():
+    """the one-call update asserts device / dtype / shape like the per-phase path, and a noise dict with only some of
+    the keys is completed from the generator (the per-phase path reads it with noise.get) instead of raising KeyError"""
+    import torch
+    B, n = 32, 4
+    a, _ = _learner_pair(73, B, n, gamma=1.0)
+    b, _ = _learner_pair(73, B, n, gamma=1.0)
+    rs = np.random.RandomState(74)
+    f = lambda v: torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    x, act, rew, ter = _batch(B, 91)
+    nx = _batch(B, 96)[0]
+    good = [f(v) for v in (x, act, rew, nx, ter)]
+    for args in ([good[0].cpu()] + good[1:], good[:2] + [good[2].double()] + good[3:], good[:4] + [good[4] > 0.5],
+                 [good[0][:, :-1]] + good[1:], good[:1] + [good[1][:, :-1]] + good[2:]):
+        with pytest.raises(AssertionError):
+            a.update(*args)
+    assert a.total_step == 0
+    full = _noise(rs, B, n)
+    # all keys given == the same dict through the old all-or-nothing branch (b): bit-identical networks
+    a.update(*good, noise=dict(full))
+    b.update(*good, noise=full)
+    for na, nb in zip(a.nets, b.nets):
+        assert torch.equal(na.flat_params(), nb.flat_params())
+    # a partial dict: runs, and draws the rest from the learner's generator (the step differs from the fully specified one)
+    part = {'eps_temp': full['eps_temp'], 'critic': full['critic']}
+    m = a.update(*good, noise=part)
+    assert set(m) == {'critic_loss', 'actor_loss', 'temp_loss', 'alpha_loss'} and all(np.isfinite(float(v)) for v in m.values())
+    with pytest.raises(AssertionError):
+        a.update(*good, noise={'eps_temp': full['eps_temp'][:-1]})
+    a.close()
+    b.close()
+
+
 def test_fit_on_the_generated_continuous_dataset_then_knn_rollout(tmp_path):
     """'CQL-conti' end to end on one GPU as the script configures it (gamma = 1, standard reward scaler): fit the continuous
     logged-policy dataset the device env generates, then drive the env with tanh(mu(s)) through the K-NN."""

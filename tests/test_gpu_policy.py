@@ -154,6 +154,62 @@ def test_ppo_epoch_equals_minibatch_sequence():
     assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
 
 
+@pytest.mark.parametrize('MB,with_mask', [(256, True), (512, True), (256, False)])
+def test_ppo_pass_compile_time_instantiation_matches_the_runtime_one(MB, with_mask):
+    """k_ppo_pass<true> (the default shape as compile-time constants: 4-row x 64-column MFMA tiles with K split over the waves, the
+    wave's Adam operands resident in registers) against k_pass<false> (RL4RS_POLICY_OPT_PPO_STD = 0: 32x32x2 tiles, all runtime) on
+    the same pass: other summation orders, so numerical like pass-vs-chain (Adam turns rounding-level gradient entries into steps of
+    up to lr), statistics to 2e-3; and the data-parallel form (gradient of one minibatch + rl4rs_policy_adam_step) of the
+    compile-time instantiation is bit-identical to its own fused pass."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    from oracle import policy as OP
+    rs = np.random.RandomState(19)
+    N = 4 * MB + 37
+    obs, mask, bits = _data(N, rs)
+    if not with_mask:
+        mask = np.ones_like(mask)
+    flat = init_policy_params(seed=2) + (rs.randn(34973) * 0.05).astype(np.float32)
+    old_logits, old_value = OP.forward(flat, obs, mask)
+    old_lsm = OP.log_softmax(old_logits)
+    actions = np.array([rs.choice(np.nonzero(mask[i])[0]) for i in range(N)])
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    o, b, a = t(obs), (torch.from_numpy(bits).cuda() if with_mask else None), t(actions, torch.int32)
+    adv, ret = t(rs.randn(N) * 2), t(rs.randn(N) * 50 + 100)
+    olp, ov = t(old_lsm[np.arange(N), actions]), t(old_value)
+    ol = t(np.maximum(old_logits, -3.4e38).astype(np.float32))
+    kw = dict(vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2)
+    p_std, p_gen, p_dp = (DevicePolicy(256, 64, 284, max_rows=N, params=flat) for _ in range(3))
+    p_gen.set_option('ppo_std', 0)
+    s_std = s_gen = None
+    for _ in range(2):                              # two passes: the Adam step counter and the resident moments carry over
+        s_std = p_std.ppo_epoch(o, a, adv, ret, b, olp, ov, ol, minibatch=MB, lr=1e-3, **kw)
+        s_gen = p_gen.ppo_epoch(o, a, adv, ret, b, olp, ov, ol, minibatch=MB, lr=1e-3, **kw)
+    p_std.check_status()
+    p_gen.check_status()
+    w1, w2 = p_std.params().cpu().numpy().astype(np.float64), p_gen.params().cpu().numpy().astype(np.float64)
+    diff = np.abs(w1 - w2)
+    steps = 2 * (N // MB)
+    assert (diff < 2e-5).mean() > 0.999, (diff < 2e-5).mean()
+    assert diff.max() <= 2 * steps * 1e-3, diff.max()
+    moved = np.abs(w1 - flat.astype(np.float64))
+    assert np.median(diff[moved > 1e-4]) < 1e-6
+    assert np.allclose(s_std.cpu().numpy(), s_gen.cpu().numpy(), rtol=2e-3, atol=1e-3), (s_std, s_gen)
+    m1, v1, t1 = p_std.adam_state()
+    m2, v2, t2 = p_gen.adam_state()
+    assert t1 == t2 == steps
+    assert torch.allclose(m1, m2, rtol=1e-3, atol=1e-6) and torch.allclose(v1, v2, rtol=1e-3, atol=1e-9)
+    # data-parallel form of the same instantiation: bit-identical to the fused pass
+    for _ in range(2):
+        for mb in range(N // MB):
+            g, _ = p_dp.ppo_minibatch_grad(mb, o, a, adv, ret, b, olp, ov, ol, minibatch=MB, **kw)
+            p_dp.adam_step(g, lr=1e-3)
+    assert torch.equal(p_dp.params(), p_std.params())
+    m3, v3, t3 = p_dp.adam_state()
+    assert torch.equal(m3, m1) and torch.equal(v3, v1) and t3 == t1
+
+
 def test_ppo_pass_is_deterministic_over_many_minibatches():
     """The persistent pass hands activations and parameters between workgroups through two grid barriers per minibatch
     (cross-XCD L2 write-back / L1 invalidate).  A stale read would be timing dependent, so: two handles, identical state,

@@ -189,11 +189,24 @@ def test_predict_q_undoes_the_reward_scaling(tmp_path):
     path2 = os.path.join(str(tmp_path), 'cql_bare.npz')
     R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, seed=4).save_model(path2)
     with pytest.raises(ValueError):
-        other.load_model(path2)                             # trained on a scale, file without one
+        other.load_model(path2, legacy=False)               # trained on a scale, file without one: an error when asked to be strict
+    with pytest.warns(UserWarning, match='saved without a reward scaler'):
+        other.load_model(path2)                             # ... by default (files from before the scaler travelled): loud, keeps its own
+    assert (other.reward_scaler.mean, other.reward_scaler.std) == (scaler.mean, scaler.std)
     # by name: fitted on the dataset by fit_mdp
     named = R.CQL(cfg, D, batch_size=64, n_action_samples=3, gamma=1.0, reward_scaler='standard', seed=3)
     with pytest.raises(ValueError):
         named.update(*[torch.zeros(1, device='cuda')] * 5)
+    # an UNFITTED scaler given by name has no statistics - save_model writes a file without one (and such a learner
+    # loads it back), predict_q says what is wrong instead of AttributeError
+    path3 = os.path.join(str(tmp_path), 'cql_named.npz')
+    named.save_model(path3)
+    with np.load(path3) as z:
+        assert 'reward_scaler' not in z.files
+    named.load_model(path3)
+    assert named.reward_scaler == 'standard'
+    with pytest.raises(ValueError, match='has not been fitted'):
+        policy_model(named, config=cfg).predict_q(xs, a)
     data = dict(observations=x[:n].copy(), actions=acts, rewards=rewards, terminals=(np.arange(n) % 10 == 9).astype(np.float32))
     named.fit_mdp(data, n_epochs=1)
     tr = R.transitions_from_mdp(data['observations'], data['actions'], data['rewards'], data['terminals'], discrete_action=False)

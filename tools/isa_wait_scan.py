@@ -22,14 +22,16 @@ LOADS = ('global_load', 'buffer_load', 'scratch_load', 'flat_load')
 
 def scan(path):
     """serial: loads with a vmcnt(0) wait within two instructions; loops: short inner loops (<= 48 instructions) that hold a load and
-    a vmcnt(0) wait - a staging loop the compiler left as one memory round trip per iteration."""
+    a vmcnt(0) wait - a staging loop the compiler left as one memory round trip per iteration.  polls: the same two patterns when
+    every load involved is an agent-scope atomic load (``sc1``) - a spin on a flag another workgroup writes (the grid barrier of
+    k_ppo_pass) IS a round trip per look by construction; counted apart so that they do not hide a real find."""
     stats, name, window = {}, None, []
     loop_start = None
     for line in open(path):
         m = re.match(r'^(_Z\w+):', line)
         if m:
             name, window, loop_start = m.group(1), [], None
-            stats[name] = dict(serial=0, loads=0, waits0=0, spills=0, loops=0)
+            stats[name] = dict(serial=0, loads=0, waits0=0, spills=0, loops=0, polls=0)
             continue
         if name is not None and 'Inner Loop Header' in line:
             loop_start = len(window)
@@ -45,13 +47,16 @@ def scan(path):
             st['spills'] += 1
         if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
             st['waits0'] += 1
-            if any(x.startswith(LOADS) for x in window[-2:]):
-                st['serial'] += 1
+            near = [x for x in window[-2:] if x.startswith(LOADS)]
+            if near:
+                st['polls' if all(' sc1' in x for x in near) else 'serial'] += 1
         window.append(t)
         if loop_start is not None and t.startswith('s_cbranch'):
             body = window[loop_start:]
-            if len(body) <= 48 and any(x.startswith(LOADS) for x in body) and any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in body):
-                st['loops'] += 1
+            lds = [x for x in body if x.startswith(LOADS)]
+            if len(body) <= 48 and lds and any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in body):
+                if not all(' sc1' in x for x in lds):
+                    st['loops'] += 1
             loop_start = None
     return stats
 
@@ -68,12 +73,12 @@ def main():
                    os.path.join(CSRC, os.path.basename(u))] + (['-fno-slp-vectorize'] if os.path.basename(u) in NO_SLP else [])
             subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             for k, st in scan(out).items():
-                if st['serial'] >= 3 or st['spills'] or st['loops']:
-                    rows.append((st['serial'], st['spills'], st['loads'], st['waits0'], k, os.path.basename(u), st['loops']))
+                if st['serial'] >= 3 or st['spills'] or st['loops'] or st['polls']:
+                    rows.append((st['serial'], st['spills'], st['loads'], st['waits0'], k, os.path.basename(u), st['loops'], st['polls']))
     demangle = subprocess.run(['c++filt'] + [r[4] for r in rows], capture_output=True, text=True).stdout.split('\n') if rows else []
-    print('| serialised loads | one-round-trip-per-iteration loops | vector spills | loads | vmcnt(0) waits | kernel | unit |\n|---|---|---|---|---|---|---|')
+    print('| serialised loads | one-round-trip-per-iteration loops | vector spills | spin polls | loads | vmcnt(0) waits | kernel | unit |\n|---|---|---|---|---|---|---|---|')
     for r, dn in sorted(zip(rows, demangle), reverse=True):
-        print('| %d | %d | %d | %d | %d | `%s` | %s |' % (r[0], r[6], r[1], r[2], r[3], dn[:100], r[5]))
+        print('| %d | %d | %d | %d | %d | %d | `%s` | %s |' % (r[0], r[6], r[1], r[7], r[2], r[3], dn[:100], r[5]))
 
 
 if __name__ == '__main__':
