@@ -582,6 +582,18 @@ def main():
     if ranks_seen != args.gpus:
         raise SystemExit('bench.py: %d ranks joined the process group but --gpus is %d: nothing is reported' % (ranks_seen, args.gpus))
     per_rank = rdist.gather_floats(B * T * args.steps / my_elapsed, device='cuda')
+    # data-parallel training: every rank must hold the SAME learner after the same all-reduced steps - a position-weighted float64
+    # digest of each rank's parameters, gathered (equal digests on all ranks = replicas in step; the first N > 1 run on real
+    # hardware cannot be debugged from here, so the line carries the evidence)
+    param_digests = None
+    if trainer is not None:
+        nets = [trainer.policy] if hasattr(trainer, 'policy') else list(trainer.bcq.nets)
+        dig = 0.0
+        for net_ in nets:
+            p_ = (net_.params() if hasattr(net_, 'params') else net_.flat_params()).double().reshape(-1)
+            w_ = (torch.arange(p_.numel(), device=p_.device, dtype=torch.float64) % 977.0) + 1.0
+            dig += float(torch.dot(p_, w_))
+        param_digests = rdist.gather_floats(dig, device='cuda')
     prof = net.profile()
     net.set_profiling(0)
     breakdown, breakdown_steps = None, 3
@@ -685,6 +697,8 @@ def main():
             "n_gpus": world,
             "ranks_seen": ranks_seen,
             "per_rank_env_steps_per_s": [round(v, 1) for v in per_rank],
+            "param_digest_per_rank": param_digests,
+            "replicas_in_step": (None if param_digests is None else bool(max(param_digests) == min(param_digests))),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -1315,6 +1315,13 @@ bool pass_is_std(const rl4rs_policy* p, int minibatch) {
     return p->opt_ppo_std && d.OD == 256 && d.HID == 64 && d.A == 284 && d.AE == 285 && d.W == 9 && pass_rows_per_wg(p) == 8 && minibatch % 256 == 0;
 }
 
+// workgroups of one pass launch: the MB / rows that own samples; the compile-time instantiation adds workgroups that only take phase B
+// tasks until every one of its 45 tasks has a workgroup of its own (ppo_pass.hpp)
+int pass_grid(const rl4rs_policy* p, int minibatch) {
+    const int n_a = minibatch / pass_rows_per_wg(p);
+    return pass_is_std(p, minibatch) ? (n_a > 45 ? n_a : 45) : n_a;
+}
+
 constexpr size_t PASS_SMEM_MAX = (size_t)160 * 1024 - 64;
 bool pass_opt_in() {
     // once per DEVICE (the attribute is per device and function), guarded: see raise_dyn_smem
@@ -1364,7 +1371,7 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
         p->pass_resident_wgs = per_cu * cus;
         if (p->opt_resident_cap >= 0) p->pass_resident_wgs = p->opt_resident_cap;      // tests: pretend a smaller device
     }
-    return minibatch / rows <= p->pass_resident_wgs;
+    return pass_grid(p, minibatch) <= p->pass_resident_wgs;
 }
 
 // minibatches [mb_begin, mb_end) through k_ppo_pass; apply = 0 leaves the parameters alone (gradient of ONE minibatch only)
@@ -1398,8 +1405,8 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
         return RL4RS_ESTATE;
     }
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
-    if (pass_is_std(p, c.minibatch)) hipLaunchKernelGGL(k_ppo_pass<true>, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
-    else hipLaunchKernelGGL(k_ppo_pass<false>, dim3(c.minibatch / a.rows), dim3(512), pass_smem_bytes(d), st, a);
+    if (pass_is_std(p, c.minibatch)) hipLaunchKernelGGL(k_ppo_pass<true>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
+    else hipLaunchKernelGGL(k_ppo_pass<false>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
     RL4RS_LAUNCH_CHECK();
     p->pass_launched = true;
 #ifdef RL4RS_PASS_TRACE

@@ -78,17 +78,19 @@ struct PassArgs {
 // `mid` runs on every thread between the arrival and the poll: the place to REQUEST data that does not depend on what the
 // other workgroups publish - the loads fly while the barrier waits (used once per pass, for the first minibatch's inputs).
 struct NoMid { __device__ void operator()() const {} };
-template <typename Mid = NoMid>
+// DRAINED: the caller has already waited for every store another workgroup reads (each wave, before the call) and may still have
+// PRIVATE stores in flight behind them - the barrier then adds no wait of its own.
+template <typename Mid = NoMid, bool DRAINED = false>
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen, Mid mid = Mid()) {
     __shared__ unsigned s_dead;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!DRAINED || !RL4RS_PASS_WT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
     if (threadIdx.x == 0) {
 #if !RL4RS_PASS_WT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DRAINED || !RL4RS_PASS_WT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     mid();
@@ -212,12 +214,22 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         for (int u = 0; u < 36; ++u) wv[u] = bld(rs_w2t, v_w1, (k + 2 * u) * HID * 4);
     };
 
-    // ---- phase B's task map (one task = one 32x32 gradient tile or 32 bias columns + the Adam update of its parameters, done by
-    // a GROUP of 4 waves of one workgroup: each wave reduces a quarter of the minibatch's samples, the four partials meet in LDS
-    // and are summed in a fixed order, then each wave updates a quarter of the tile's parameters).  All of it scalar.
+    // ---- phase B's task map.  One task = one 32x32 gradient tile or 32 bias columns + the Adam update of its parameters, done by a
+    // group of NW waves of one workgroup: each wave reduces 1 / NW of the minibatch's samples, the partials meet in LDS and are
+    // summed in a fixed order, then each wave updates 1 / NW of the tile's parameters.  All of it scalar.
+    //   generic: NW = 4, two groups (= two tasks) per workgroup, grid = the MB / R workgroups of phase A
+    //   STD:     NW = 8, ONE task per workgroup, grid = max(MB / 8, 45): at MB = 256 thirteen extra workgroups do nothing but phase B.
+    //            With two tile tasks on 17 of 32 workgroups and 15 idle, phase B's critical path was two waves per SIMD x 32 MFMAs x
+    //            64 cycles (2 us) behind TWO dependent round trips of 32 requests per wave; one tile on eight waves is 16 sample pairs
+    //            per wave = one round trip of 32 requests, then 16 MFMAs per wave.
+    constexpr int NW = STD ? 8 : 4, NG = 8 / NW, NR = 16 / NW;            // waves per task, tasks per workgroup and trip, accumulator registers per wave
     const int n_t1 = (OD / 32) * NT1, n_t2 = NT1 * NT2, total = n_t1 + n_t2 + NT1 + NT2;
-    const int grp = wave >> 2, q = wave & 3;
-    const int spq = MB / 4;                                                          // samples per wave of a group
+    const int grp = STD ? 0 : wave >> 2, q = STD ? wave : wave & 3;
+    const int spq = MB / NW;                                              // samples per wave of a group
+    // accumulator register r of a 32x32x2 tile holds row (r & 3) + 8 (r >> 2) + 4 half; wave q owns r = NR q .. NR q + NR - 1 = rows rowbase + c (+ 4 half)
+    const int rowbase = STD ? 2 * (q & 1) + 8 * (q >> 1) : 8 * q;
+    const int n_a = MB / R;                                               // workgroups that have rows of the minibatch (phase A)
+    const bool is_a = (int)blockIdx.x < n_a;
     struct Task { bool live, is_tile, first; int tm, tn, Nc, s_e; };
     auto map_task = [&](int task) {
         Task T;
@@ -236,29 +248,32 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         }
         T.Nc = T.first ? HID : AE;
         // scalar part of the parameter offset (floats); lane part: tiles (4 half) * Nc + li [+ c * Nc], bias columns li
-        if (T.is_tile) T.s_e = (T.first ? 0 : o_w2) + (T.tm * 32 + 8 * q) * T.Nc + T.tn * 32;   // wave q owns rows c + 8q + 4 half (c = 0..3)
+        if (T.is_tile) T.s_e = (T.first ? 0 : o_w2) + (T.tm * 32 + rowbase) * T.Nc + T.tn * 32;
         else T.s_e = (T.first ? o_b1 : o_b2) + T.tn * 32;
         return T;
     };
     // Adam operands resident in registers when the task map has ONE trip (the wave updates the same parameters every minibatch)
-    const bool resident = a.apply && total <= (int)gridDim.x * 2;
-    float rp[4] = {0.f, 0.f, 0.f, 0.f}, rm[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool resident = a.apply && total <= (int)gridDim.x * NG;
+    float rp[NR], rm[NR], rv[NR];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) rp[c] = rm[c] = rv[c] = 0.f;
     if (resident) {
-        const Task T = map_task(blockIdx.x * 2 + grp);
+        const Task T = map_task(blockIdx.x * NG + grp);
         if (T.live) {                                           // (columns past Nc are past nothing harmful: never stored)
             const int v = ((T.is_tile ? 4 * half * T.Nc : 0) + li) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NR; ++c) {
                 const int so = (T.s_e + (T.is_tile ? c * T.Nc : 0)) * 4;
                 rp[c] = bld(rs_prm, v, so); rm[c] = bld(rs_am, v, so); rv[c] = bld(rs_av, v, so);
             }
         }
     }
-    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { prefetch(a.mb_begin); })) return;
+    if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { if (is_a) prefetch(a.mb_begin); })) return;
     for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
         const size_t lo = (size_t)mb * MB;
         // ------------------------------------------------------------------ phase A
         RL4RS_PT(0);
+        if (is_a) {
         if constexpr (STD) {
             // ---- the default shape on v_mfma_f32_4x4x1 (4 rows x 64 columns x 1 k per instruction): the 8 rows of the workgroup are
             // two row tiles with NO idle rows (the 32x32x2 tiles of the generic branch keep 24 of 32 rows idle, and two waves share
@@ -562,22 +577,32 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 PUB(a.dHpre[RL4RS_U((r0 + r) * HID + j)], s * (1.f - h * h));
             }
         }
+        }   // is_a
+#ifdef RL4RS_PASS_HELPER_SLEEP
+        else {
+            // workgroups without rows have nothing to do for the ~9 us of phase A: they look at the barrier late instead of polling it
+            // through the whole phase (thirteen more spinning loads on the counter's line)
+            for (int z = 0; z < RL4RS_PASS_HELPER_SLEEP; ++z) __builtin_amdgcn_s_sleep(127);
+        }
+#endif
         RL4RS_PT(5);
         if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
         RL4RS_PT(6);
         // ------------------------------------------------------------------ phase B
+        bool tile_stored = false;          // the wave's LAST stores are the 2 NR private moment stores of a tile task (scalar: the task map is)
         {
             const double tt = (double)(a.t0 + mb + 1);
             const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, tt)) / (1.0 - pow((double)a.b1, tt)));
             RL4RS_PT(10);
-            float* s_part = s_obs + (size_t)grp * 4 * 1024;               // [4 quarters][32 x 32] per group (s_obs is free here)
+            float* s_part = reinterpret_cast<float*>(smem) + (size_t)grp * NW * 1024;     // [NW partials][32 x 32] per group (the observation rows' region is free here)
             constexpr int TP = 16;      // sample pairs per trip: 32 requests in flight (one trip of 64 is SLOWER - the 64th request stalls the wave, vmcnt has 6 bits)
-            for (int t0 = 0; t0 < total; t0 += gridDim.x * 2) {           // uniform trip count: the barriers below are workgroup-wide
-                const Task T = map_task(t0 + blockIdx.x * 2 + grp);
+            for (int t0 = 0; t0 < total; t0 += gridDim.x * NG) {          // uniform trip count: the barriers below are workgroup-wide
+                const Task T = map_task(t0 + blockIdx.x * NG + grp);
+                tile_stored = false;
                 const int j = T.tn * 32 + li;
                 const bool j_ok = j < T.Nc;
                 if (T.live && T.is_tile) {
-                    // quarter of A^T B over the samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut (this minibatch's rows)
+                    // 1 / NW of A^T B over the samples; A = obs [MB, OD] or H [MB, HID], B = dHpre or dOut (this minibatch's rows)
                     const int lda = T.first ? OD : HID, ldb = T.Nc;
                     const __amdgpu_buffer_rsrc_t rs_a = T.first ? pass_rsrc(a.obs + lo * OD, (size_t)MB * OD * 4) : pass_rsrc(a.H, (size_t)MB * HID * 4);
                     const __amdgpu_buffer_rsrc_t rs_b = T.first ? pass_rsrc(a.dHpre, (size_t)MB * HID * 4) : pass_rsrc(a.dOut, (size_t)MB * AE * 4);
@@ -591,14 +616,14 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                             av[u] = bld(rs_a, v_a, (n + 2 * u) * lda * 4);
                             bw[u] = bld(rs_b, v_b, (n + 2 * u) * ldb * 4);
                         }
-                        if (n + 2 * TP >= (q + 1) * spq && t0 == 0) prefetch(mb + 1);     // behind the LAST trip's requests: nothing of phase B waits for it
+                        if (is_a && n + 2 * TP >= (q + 1) * spq && t0 == 0) prefetch(mb + 1);     // behind the LAST trip's requests: nothing of phase B waits for it
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < TP; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bw[u], acc, 0, 0, 0);
                     }
                     for (int r = 0; r < 16; ++r) s_part[q * 1024 + r * 64 + lane] = acc[r];
                 } else if (T.live) {
-                    // quarter of the bias column sums: lanes = 32 columns x 2 sample parities
+                    // 1 / NW of the bias column sums: lanes = 32 columns x 2 sample parities
                     const __amdgpu_buffer_rsrc_t rs_x = T.first ? pass_rsrc(a.dHpre, (size_t)MB * HID * 4) : pass_rsrc(a.dOut, (size_t)MB * AE * 4);
                     const int v_x = (half * T.Nc + (j_ok ? j : T.Nc - 1)) * 4;
                     float bsum = 0.f;
@@ -606,20 +631,20 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                         float x[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) x[u] = bld(rs_x, v_x, (n + 2 * u) * T.Nc * 4);
-                        if (n + 32 >= (q + 1) * spq && t0 == 0) prefetch(mb + 1);
+                        if (is_a && n + 32 >= (q + 1) * spq && t0 == 0) prefetch(mb + 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < 16; ++u) bsum += x[u];
                     }
                     s_part[q * 1024 + lane] = bsum;
-                } else if (t0 == 0) {
+                } else if (is_a && t0 == 0) {
                     prefetch(mb + 1);
                 }
                 // Adam's operands: the wave's resident copies, or (multi-trip task maps) requested here, in front of the workgroup
-                // barrier that joins the four partial sums
-                float pp[4], mm[4], vv[4];
+                // barrier that joins the partial sums
+                float pp[NR], mm[NR], vv[NR];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < NR; ++c) {
                     if (resident) { pp[c] = rp[c]; mm[c] = rm[c]; vv[c] = rv[c]; }
                     else if (a.apply && T.live) {
                         const int v = ((T.is_tile ? 4 * half * T.Nc : 0) + li) * 4, so = (T.s_e + (T.is_tile ? c * T.Nc : 0)) * 4;
@@ -630,52 +655,85 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 __syncthreads();
                 if (T.live && T.is_tile) {
                     if (j_ok) {
-                        // wave q owns accumulator registers 4q .. 4q+3 of the tile: rows tm*32 + c + 8q + 4 half, column j
+                        // wave q owns accumulator registers NR q .. NR q + NR - 1 of the tile: rows tm*32 + rowbase + c + 4 half, column j
                         const unsigned e0 = RL4RS_U(T.s_e + 4 * half * T.Nc + li);
-                        const unsigned w0 = RL4RS_U(j * HID + T.tm * 32 + 8 * q + 4 * half);       // the same elements in w2t
-                        float g[4];
+                        const unsigned w0 = RL4RS_U(j * HID + T.tm * 32 + rowbase + 4 * half);     // the same elements in w2t: NR consecutive ones
+                        float g[NR];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int r = 4 * q + c;
-                            g[c] = ((s_part[r * 64 + lane] + s_part[1024 + r * 64 + lane]) + s_part[2048 + r * 64 + lane]) +
-                                   s_part[3072 + r * 64 + lane];
+                        for (int c = 0; c < NR; ++c) {
+                            const int r = NR * q + c;
+                            float sum = s_part[r * 64 + lane];
+#pragma unroll
+                            for (int pw = 1; pw < NW; ++pw) sum += s_part[pw * 1024 + r * 64 + lane];
+                            g[c] = sum;
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        float pn[NR], mi[NR], vi[NR];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const unsigned e = e0 + RL4RS_U(c * T.Nc);
-                            const float mi = a.b1 * mm[c] + (1.f - a.b1) * g[c];
-                            const float vi = a.b2 * vv[c] + (1.f - a.b2) * g[c] * g[c];
-                            a.grad[e] = g[c];
-                            if (!a.apply) continue;
-                            a.am[e] = mi;
-                            a.av[e] = vi;
-                            const float pn = pp[c] - lr_t * mi / (sqrtf(vi) + a.eps);
-                            PUB(a.prm[e], pn);
-                            if (!T.first) PUB(a.w2t[w0 + c], pn);
-                            if (resident) { rp[c] = pn; rm[c] = mi; rv[c] = vi; }
+                        for (int c = 0; c < NR; ++c) {
+                            mi[c] = a.b1 * mm[c] + (1.f - a.b1) * g[c];
+                            vi[c] = a.b2 * vv[c] + (1.f - a.b2) * g[c] * g[c];
+                            pn[c] = pp[c] - lr_t * mi[c] / (sqrtf(vi[c]) + a.eps);
+                        }
+                        // the gradient itself leaves the kernel in the data-parallel form and for the pass's last minibatch (the API's grad_dev)
+                        if (!a.apply || mb == a.mb_end - 1) {
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) a.grad[e0 + RL4RS_U(c * T.Nc)] = g[c];
+                        }
+                        if (a.apply) {
+                            // what OTHER workgroups read (the parameters, W2e's transposed copy) goes first, write-through; the moments -
+                            // private to this wave - go last: the barrier's drain does not wait for them
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) PUB(a.prm[e0 + RL4RS_U(c * T.Nc)], pn[c]);
+                            if (!T.first) {
+                                // rows rowbase + c + 4 half of column j are NR CONSECUTIVE elements of w2t's row j: one 16- / 8-byte store
+                                // per lane (was four 4-byte stores to 64 different lines each)
+                                if constexpr (NR == 4) {
+                                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                                    const u32x4_t pk = {__builtin_bit_cast(unsigned, pn[0]), __builtin_bit_cast(unsigned, pn[1]),
+                                                        __builtin_bit_cast(unsigned, pn[2]), __builtin_bit_cast(unsigned, pn[3])};
+                                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_w2t, (int)(w0 * 4), 0, RL4RS_PASS_WT ? 16 : 0);      // aux 16 = sc1
+                                } else {
+                                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                                    const u32x2_t pk = {__builtin_bit_cast(unsigned, pn[0]), __builtin_bit_cast(unsigned, pn[1])};
+                                    __builtin_amdgcn_raw_buffer_store_b64(pk, rs_w2t, (int)(w0 * 4), 0, RL4RS_PASS_WT ? 16 : 0);
+                                }
+                            }
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) a.am[e0 + RL4RS_U(c * T.Nc)] = mi[c];
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) a.av[e0 + RL4RS_U(c * T.Nc)] = vi[c];
+                            if (resident) {
+#pragma unroll
+                                for (int c = 0; c < NR; ++c) { rp[c] = pn[c]; rm[c] = mi[c]; rv[c] = vi[c]; }
+                            }
+                            tile_stored = true;
                         }
                     }
                 } else if (T.live && q == 0 && half == 0 && j_ok) {
                     float sum = 0.f;
-                    for (int qq = 0; qq < 4; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
+                    for (int qq = 0; qq < NW; ++qq) sum += s_part[qq * 1024 + li] + s_part[qq * 1024 + 32 + li];
                     const unsigned e = RL4RS_U(T.s_e + li);
                     a.grad[e] = sum;
                     if (a.apply) {
                         const float mi = a.b1 * mm[0] + (1.f - a.b1) * sum;
                         const float vi = a.b2 * vv[0] + (1.f - a.b2) * sum * sum;
                         const float pn = pp[0] - lr_t * mi / (sqrtf(vi) + a.eps);
+                        PUB(a.prm[e], pn);
                         a.am[e] = mi;
                         a.av[e] = vi;
-                        PUB(a.prm[e], pn);
                         if (resident) { rp[0] = pn; rm[0] = mi; rv[0] = vi; }
                     }
                 }
-                __syncthreads();                                          // s_part is rewritten by the next trip
+                if (t0 + (int)gridDim.x * NG < total) __syncthreads();    // s_part is rewritten by the next trip
             }
         }
         RL4RS_PT(7);
-        if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
+        // drain what other workgroups will read, not the 2 NR moment stores behind it (vmcnt retires in order: "at most 2 NR
+        // outstanding" = everything before the moments has completed; 2 us of a minibatch were waves waiting for their own private stores)
+        if (tile_stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NR) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!grid_barrier<NoMid, true>(a.bar, a.dead_host, gridDim.x, gen)) return;
         RL4RS_PT(8);
     }
 }

@@ -230,6 +230,67 @@ def test_sparse_row_allreduce_and_broadcast_world_2():
     assert torch.equal(bc0, torch.ones(5)) and torch.equal(bc1, torch.ones(5))
 
 
+def _w8_worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from rl4rs_amd import dist as D
+    r, lr, w = D.init('gloo')
+    assert (r, w) == (rank, world)
+    lo, hi = D.shard_rows(32768, r, w)
+    floats = D.gather_floats(10.0 * r + 0.5)                  # rank order on every rank
+    t = D.max_over_ranks(1.0 + r)
+    total = D.sum_over_ranks(hi - lo)
+    g = torch.full((34973,), float(r + 1))
+    D.allreduce_mean_(g)
+    # sparse row exchange at W = 8: every rank touches its own rows plus a few shared ones (row 0 among them)
+    gen = torch.Generator().manual_seed(100 + rank)
+    H, E = 4000, 8
+    ids = torch.unique(torch.cat([torch.randint(0, H, (30,), generator=gen), torch.tensor([0, 7, 8, 9])]))
+    table = torch.zeros(H, E)
+    table[ids] = torch.randn(ids.numel(), E, generator=gen)
+    dense = table.clone()
+    D.allreduce_mean_(dense.view(-1))
+    slots = torch.cat([ids, ids[:5]])[torch.randperm(ids.numel() + 5, generator=gen)]
+    D.allreduce_rows_mean_(table, slots, cap=64)
+    path = D.LAST_ROWS_PATH
+    over = D.take_row_overflow('cpu')
+    b = torch.full((3,), float(rank))
+    D.broadcast_(b, src=5)
+    D.barrier()
+    out.put((rank, lo, hi, floats, t, total, float(g[0]), table.numpy().copy(), dense.numpy().copy(), path, bool(over), b.numpy().copy()))
+
+
+def test_world_size_8_gloo():
+    """Nothing with more than two ranks had run before round 6: the wrappers bench.py and the trainers use, at the
+    driver's 8-rank world size - contiguous balanced row blocks of the 32768-env configuration, gather order = rank order, the
+    sparse row exchange bit-identical ACROSS ranks and equal to the dense mean to float32 rounding (eight addends in a fixed rank
+    order against gloo's reduction tree), broadcast from a non-zero root."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    W = 8
+    procs = [ctx.Process(target=_w8_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(4096 * k, 4096 * (k + 1)) for k in range(W)]          # configs[3]: 8 x 4096 envs
+    for r in res:
+        assert r[3] == [10.0 * k + 0.5 for k in range(W)]
+        assert r[4] == float(W) and r[5] == 32768.0 and r[6] == 4.5
+        assert r[9] == 'sparse' and r[10] is False
+        assert (r[11] == 5.0).all()
+    t0, d0 = torch.from_numpy(res[0][7]), torch.from_numpy(res[0][8])
+    for r in res[1:]:
+        assert torch.equal(torch.from_numpy(r[7]), t0)                 # bit-identical on every rank
+    assert torch.allclose(t0, d0, rtol=1e-6, atol=1e-7) and (t0 != 0).any()
+
+
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     """`bench.py --gpus N` under a launcher whose WORLD_SIZE is not N exits non-zero before anything runs (the entry
     point used to report n_gpus = 1 for `--gpus 8` without a launcher; now it starts its own ranks, and a mismatch is an error)."""

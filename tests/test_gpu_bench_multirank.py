@@ -41,6 +41,8 @@ def test_bench_two_ranks_over_gloo(leg):
     # what the collective layer saw: both ranks joined the one process group, and each reports its own rate
     assert rec['ranks_seen'] == 2 and len(rec['per_rank_env_steps_per_s']) == 2 and min(rec['per_rank_env_steps_per_s']) > 0
     assert rec['value'] <= sum(rec['per_rank_env_steps_per_s']) * 1.001
+    if '--train' in leg:
+        assert rec['replicas_in_step'] is True, rec['param_digest_per_rank']
     if leg[:2] == ['--train', 'bcq']:
         assert rec['bcq']['updates_per_step'] == 2 and all(v == v for v in rec['bcq']['last_losses'].values())
 
@@ -58,6 +60,29 @@ def test_plain_launch_starts_its_own_ranks():
     assert len(lines) == 1, out.stdout.decode()[-2000:]
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and len(rec['per_rank_env_steps_per_s']) == 2
+
+
+@pytest.mark.parametrize('leg', [[], ['--train', 'a2c'], ['--train', 'ppo'], ['--train', 'bcq', '--bcq-updates', '2']])
+def test_plain_launch_eight_ranks(leg):
+    """The driver's 8-GPU command line shape, dry: plain ``python bench.py --gpus 8`` (no launcher) starts EIGHT ranks that share the
+    one GPU over gloo - nothing with more than two ranks had ever run.  All eight join one process group, each reports
+    its own rate, and after data-parallel training steps every rank holds the same learner (equal parameter digests)."""
+    env = dict((k, v) for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'))
+    env.update(RL4RS_DIST_BACKEND='gloo')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '256',
+           '--log-records', '700', '--no-cpu-baseline'] + leg
+    out = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['ranks_seen'] == 8 and rec['scaling'] == 'weak'
+    assert len(rec['per_rank_env_steps_per_s']) == 8 and min(rec['per_rank_env_steps_per_s']) > 0
+    assert rec['value'] <= sum(rec['per_rank_env_steps_per_s']) * 1.001
+    if leg:
+        assert len(rec['param_digest_per_rank']) == 8 and rec['replicas_in_step'] is True, rec['param_digest_per_rank']
+    else:
+        assert rec['param_digest_per_rank'] is None
 
 
 def test_more_ranks_than_gpus_over_rccl_is_refused():
