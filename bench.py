@@ -678,13 +678,15 @@ def main():
         g_rows = B * samples._env.n_complete
         g_bytes = g_rows * (cfg['dense_feature_num'] * 4 + cfg['category_feature_num'] * 4 + 32 * 4 + 10 * 4 + 36)
         g_gbs = g_bytes / (g_ms * 1e-3) / 1e9
-        gather = {"bound": "hbm", "kernel": "k_env_rows<complete>", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
-                  "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_ms,
+        # the figure that LEADS is the in-situ one (a single launch behind a whole episode-batch: cold caches, what the episode pays);
+        # the back-to-back figure (50 launches onto the same buffers: Infinity-Cache warm) is kept beside it as `burst`
+        g_situ_gbs = g_bytes / (g_situ_ms * 1e-3) / 1e9
+        gather = {"bound": "hbm", "kernel": "k_env_rows<complete>", "achieved": g_situ_gbs, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": g_situ_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_situ_ms,
                   "rows": g_rows,
-                  "in_situ": {"avg_launch_ms": g_situ_ms, "achieved": g_bytes / (g_situ_ms * 1e-3) / 1e9,
-                              "frac": g_bytes / (g_situ_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "what": "one launch behind a whole episode-batch (event pair around the single launch, mean of 5); "
-                                      "the headline figure above is 50 back-to-back launches onto the same buffers"}}
+                  "what": "one launch behind a whole episode-batch (event pair around the single launch, mean of 5)",
+                  "burst": {"avg_launch_ms": g_ms, "achieved": g_gbs, "frac": g_gbs / HBM_PEAK_GBS,
+                            "what": "50 back-to-back launches onto the same buffers (Infinity-Cache warm)"}}
         if not seq and B == 4096 and T == 9:
             # rocprofv3 WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch of this exact shape against 66.8 MB of algorithmic
             # writes + 7.5 MB of (L2-resident) reads: no wasted traffic
@@ -734,6 +736,15 @@ def main():
             out["extra"] = dict((name, extra_leg(args, workdir, rank, name))
                                 for name in ('seq_t32', 'seq_t32_ppo', 'seq_t32_a2c', 'conti', 'bcq_conti', 'all_distinct', 'compat_numpy',
                                              'compat_rllib_mask', 'compat_d3rl_mask'))
+            # the two figures VERDICT r5 asked to see beside `value`: the same workload through the API the reference's callers use
+            # (rl4rs/env/base.py:256-263: ndarray / list returns, PCIe-inclusive) and with 4096 DISTINCT user histories
+            def _v(leg):
+                x = out["extra"].get(leg)
+                return x.get('value') if isinstance(x, dict) else x
+            out["reference_api_env_steps_per_s"] = _v('compat_numpy')
+            out["reference_api_rllib_mask_env_steps_per_s"] = _v('compat_rllib_mask')
+            out["reference_api_d3rl_mask_env_steps_per_s"] = _v('compat_d3rl_mask')
+            out["all_distinct_env_steps_per_s"] = _v('all_distinct')
         if default_run and net.scorer_mode == 'fp16x2' and not args.no_fp32_leg:
             out["exact_fp32_scorer"] = extra_leg(args, workdir, rank, 'fp32')
         if args.train == 'bcq':

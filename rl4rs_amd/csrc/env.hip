@@ -375,21 +375,26 @@ __global__ __launch_bounds__(256) void k_predict_with_mask(EnvDev e, int N, cons
     if (lane == 0) out[n] = best_k;
 }
 
-// numpy float64 add.reduce order (0 + pairwise_sum, loops_utils.h.src) for n <= 128
-__device__ __forceinline__ double np_pairwise(const double* a, int n) {
+// numpy float64 add.reduce order (0 + pairwise_sum, loops_utils.h.src) for n <= 128; term(i) yields the i-th addend (the terms
+// are generated in the order the sum consumes them: no per-thread array - a `double terms[128]` was 1 040 bytes of scratch)
+template <typename Term>
+__device__ __forceinline__ double np_pairwise(Term term, int n) {
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; ++i) res = __dadd_rn(res, a[i]);
+        for (int i = 0; i < n; ++i) res = __dadd_rn(res, term(i));
         return res;
     }
     double r[8];
-    for (int j = 0; j < 8; ++j) r[j] = a[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = term(j);
     int i = 8;
-    for (; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], a[i + j]);
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], term(i + j));
+    }
     double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
                            __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __dadd_rn(res, a[i]);
+    for (; i < n; ++i) res = __dadd_rn(res, term(i));
     return res;
 }
 
@@ -445,14 +450,12 @@ __global__ void k_reward(EnvDev e, int cur, int n, int j_base, int zero_on_viola
                          const float* __restrict__ probs, const float* __restrict__ p_last, double* __restrict__ out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= e.B) return;
-    double terms[128];
     const int m = p_last ? n - 1 : n;
-    for (int j = 0; j < n; ++j) {
-        int id = e.prev[(size_t)b * e.T + j_base + j];
-        float pj = (j < m) ? probs[(size_t)b * m + j] : p_last[b];
-        terms[j] = __dmul_rn(e.price[id], (double)pj);
-    }
-    double r = np_pairwise(terms, n);
+    double r = np_pairwise([&](int j) {
+        const int id = e.prev[(size_t)b * e.T + j_base + j];
+        const float pj = (j < m) ? probs[(size_t)b * m + j] : p_last[b];
+        return __dmul_rn(e.price[id], (double)pj);
+    }, n);
     if (zero_on_violation && violation_of(e, b, cur) == 0) r = 0.0;
     out[b] = r;
 }
@@ -504,10 +507,8 @@ __global__ void k_offline_reward(EnvDev e, int cur, double* out) {
         if (cur >= e.T)
             for (int j = 0; j < e.logT; ++j) r = __dadd_rn(r, __dmul_rn(e.price[ex[j]], (double)fb[j]));
     } else if (cur % 9 == 0) {
-        double terms[128];
-        int lo = max(cur - e.P, 0), n = 0;
-        for (int j = lo; j < cur && j < e.logT; ++j) terms[n++] = __dmul_rn(e.price[ex[j]], (double)fb[j]);
-        r = np_pairwise(terms, n);
+        const int lo = max(cur - e.P, 0), n = max(min(cur, e.logT) - lo, 0);
+        r = np_pairwise([&](int j) { return __dmul_rn(e.price[ex[lo + j]], (double)fb[lo + j]); }, n);
     }
     out[b] = r;
 }

@@ -578,13 +578,6 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             }
         }
         }   // is_a
-#ifdef RL4RS_PASS_HELPER_SLEEP
-        else {
-            // workgroups without rows have nothing to do for the ~9 us of phase A: they look at the barrier late instead of polling it
-            // through the whole phase (thirteen more spinning loads on the counter's line)
-            for (int z = 0; z < RL4RS_PASS_HELPER_SLEEP; ++z) __builtin_amdgcn_s_sleep(127);
-        }
-#endif
         RL4RS_PT(5);
         if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen)) return;
         RL4RS_PT(6);

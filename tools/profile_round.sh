@@ -19,3 +19,4 @@ for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_AC
   python $repo/tools/rocpd_pmc.py $db 2>&1 | head -40 >> $out/${tag}_pmc.md
   echo >> $out/${tag}_pmc.md
 done
+python $repo/tools/pmc_mfma_busy.py $out/${tag}_pmc.md >> $out/${tag}_pmc.md 2>&1
