@@ -379,7 +379,13 @@ def extra_leg(args, workdir, rank, name, steps=3):
         dt = time.perf_counter() - t0
         tr.close()
     else:
-        dt = timed_episodes(env, T, steps, fn=episode_host if compat else None)
+        if compat:
+            # host-bound legs settle over the first episodes (page-locked blocks of the caching host allocator, python's allocator): the
+            # metric is a steady-state mean (after 3 warm-ups), so these legs warm up 3 and time 10 episode-batches
+            steps = max(steps, 10)
+            dt = timed_episodes(env, T, steps, warmup=3, fn=episode_host)
+        else:
+            dt = timed_episodes(env, T, steps)
     out = {"value": B * T * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "workload": "%s B=%d T=%d%s%s" % ('SeqSlateRecEnv-v0' if seq else 'SlateRecEnv-v0', B, T,
                                              ', continuous actions -> masked K-NN' if a.conti else '',

@@ -260,7 +260,8 @@ enum {
     RL4RS_DIEN_OPT_NO_HEAD_FUSED = 1 << 10,
     RL4RS_DIEN_OPT_CAT_V1 = 1 << 11,
     RL4RS_DIEN_OPT_NO_CAT_GROUP = 1 << 12,
-    RL4RS_DIEN_OPT_ALL = (1 << 13) - 1
+    RL4RS_DIEN_OPT_DENSE_FORK = 1 << 13,       /* the dense tower on a second stream of the handle, joined in front of the head GEMM */
+    RL4RS_DIEN_OPT_ALL = (1 << 14) - 1
 };
 
 /* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):
@@ -487,6 +488,12 @@ int rl4rs_env_step_record_host(rl4rs_stepper* s, const void* actions_dev, int32_
  * The caller has encoded the batch's sequences (rl4rs_dien_encode).  record_host may be NULL (no copies). */
 int rl4rs_env_observe_record_host(rl4rs_stepper* s, int32_t conti, uint32_t want, void* record_dev, void* record_host,
                                   void* stream);
+/* On steps without a reward forward (and on resets) the float32 observation reaches `record_host` from the epilogue of the head
+ * GEMM itself (device-visible pinned memory: hipHostGetDevicePointer must succeed on record_host, else the copy engine serves it
+ * as before) - the copy would otherwise start only when the GPU has nothing left to run.  Process-wide switch, default 0: on the
+ * boxes measured the mirror is no faster than the copy engine (13.2 against 13.1 ms per episode-batch); kept for A/B
+ * measurements.  Replaces nothing in the reference (its observations never leave host memory: rl4rs/env/slate.py:244-279). */
+int rl4rs_set_host_mirror(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * Action-masked policy net: rl4rs/nets/rllib/rllib_mask_model.py:7-64 (FC obs->hidden(tanh)->action_size

@@ -73,8 +73,10 @@ int launch_gemm_packed(const float* a, int64_t lda, const float* wp, const float
                        int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0);
 std::vector<float> pack_gemm_weight(const float* w, int64_t ldw, int K, int N);
 // fp16x2 form (scorer_mode FP16X2): weights pre-split into fp16 hi / lo fragment planes, activations split while staged
+// mirror (optional): device-visible HOST memory that receives the same output elements from the epilogue, row stride ldm
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
-                    int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0);
+                    int M, int N, int K, int act, hipStream_t st, const float* addend = nullptr, int64_t ldadd = 0,
+                    float* mirror = nullptr, int64_t ldm = 0);
 std::vector<float> pack_gemm_weight_h16(const float* w, int64_t ldw, int K, int N);
 // two chained layers in one launch (N1 <= 128, N1 % 16 == 0, N2 <= 128): c2 = act2(act1(a W1 + b1) W2 + b2)
 int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const float* bias1, int N1, int K1, int act1,
@@ -98,6 +100,11 @@ int launch_amlp_fwd_h16(const AmlpFwdH16& a, hipStream_t st);
 // applied to every kernel whose LDS size depends on a handle's shape).  Defined in env.hip.
 int raise_dyn_smem(const void* fn, size_t bytes);
 int current_device();
+
+// The NEXT rl4rs_dien_forward's observation also goes to `host_visible` (device-visible pinned host memory, [R, 256] floats) from
+// the head GEMM's epilogue - step.hip's reference-shaped records (dien.hip); dien_obs_mirror_used: did that forward take it?
+void dien_set_obs_mirror(rl4rs_dien* n, float* host_visible);
+bool dien_obs_mirror_used(const rl4rs_dien* n);
 
 // Training-mode recurrences as persistent kernels (recur_train.hpp, compiled into dien.hip; called from dientrain.hpp).
 // Arrays are per sequence input (S <= 4 inputs run in ONE launch, grid.y = S); saved tensors are [N * L, Hd] row-major.

@@ -1697,6 +1697,8 @@ struct rl4rs_dien {
     bool din_x;            // fp16x2 DIN scores through k_din_x (RL4RS_DIN=v1 keeps k_din_scores<*, true>)
     bool dense_chain;      // fp16x2 mode: both dense-tower layers in one launch (RL4RS_DENSE_FUSED=0 at create: two GEMMs)
     float* tsum;           // [max_rows, 256]: obs_b + the per-slot head tables' rows, built by k_cat_attn (table form, Cn <= 24)
+    bool dense_fork;       // RL4RS_DIEN_OPT_DENSE_FORK: the dense tower (depends on nothing before the head) on side_stream, beside the category / DIN / AUGRU launches
+    hipStream_t side_stream; hipEvent_t ev_fork, ev_join;
     bool cat_group;        // reward-sized launches (rows in groups of 8 / 9): k_cat_attn2g, one workgroup per group (RL4RS_DIEN_OPT_NO_CAT_GROUP: per row)
     bool cat_v2;           // category branch through k_cat_attn2 (half-K LDS image) when the shape allows (RL4RS_DIEN_OPT_CAT_V1: first form)
     bool cat16;            // fp16x2 mode: the Gram matrix of k_cat_attn in the split form (cat_emb inside the fp16 range)
@@ -1712,6 +1714,8 @@ struct rl4rs_dien {
     float* proj[4];        // [max_slots*L, PLD]
     // scratch
     float *allf, *dh, *q, *scores, *obs_tmp;
+    float* obs_mirror;     // rl4rs_dien_set_obs_mirror: device-visible host memory [R, OBS_DIM] for the NEXT forward's observation
+    bool obs_mirror_used;  // ... whether that forward's head kernel took it (only the fp16x2 GEMM with the table addend writes mirrors)
     std::vector<void*> owned;
     // profiling
     int profiling;         // 0 off, 1 every kernel class, 2 only the AUGRU recurrence (two event records per forward)
@@ -1876,6 +1880,8 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->cat16 = false;
     n->cat_v2 = !(opts & RL4RS_DIEN_OPT_CAT_V1);
     n->cat_group = !(opts & RL4RS_DIEN_OPT_NO_CAT_GROUP);
+    n->dense_fork = (opts & RL4RS_DIEN_OPT_DENSE_FORK) != 0;
+    n->side_stream = nullptr; n->ev_fork = nullptr; n->ev_join = nullptr;
     n->dense_chain = !(opts & RL4RS_DIEN_OPT_NO_DENSE_CHAIN);
     n->gru16 = false;
     n->gru16_attr = false;
@@ -2121,6 +2127,7 @@ int rl4rs_dien_destroy(rl4rs_dien* n) {
     for (void* p : n->owned) (void)hipFree(p);
     for (auto& e : n->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : n->pool) (void)hipEventDestroy(e);
+    if (n->side_stream) { (void)hipStreamDestroy(n->side_stream); (void)hipEventDestroy(n->ev_fork); (void)hipEventDestroy(n->ev_join); }
     delete n;
     return RL4RS_OK;
 }
@@ -2180,6 +2187,34 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
     const int off_d = S * NH2, off_c = off_d + U;
     const int ngroups = R / group;
     int rc;
+    n->obs_mirror_used = false;
+    struct MirrorOnce { rl4rs_dien* n; ~MirrorOnce() { n->obs_mirror = nullptr; } } mirror_once{n};       // one forward only
+    auto dense_tower = [&](hipStream_t s2) -> int {
+        int r2;
+        if (n->gemm16 && n->dense_chain && U <= 128 && U % 16 == 0) {      // both layers in one launch, the hidden tile stays in LDS
+            if ((r2 = launch_gemm_h16_chain(dense, n->Dn, n->dense_w1, n->dense_b1, U, n->Dn, 1, n->dense_w2, n->dense_b2,
+                                            n->allf + off_d, F, U, 1, R, s2))) return r2;
+        } else {
+            if ((r2 = scorer_gemm(n, dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, s2))) return r2;
+            if ((r2 = scorer_gemm(n, n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, s2))) return r2;
+        }
+        return RL4RS_OK;
+    };
+    // RL4RS_DIEN_OPT_DENSE_FORK: the dense tower reads only `dense` and writes its own columns of allf - it runs on a second stream
+    // of the handle from the top of the forward and is joined in front of the head GEMM (event pair owned by the handle)
+    bool forked = false;
+    if (n->dense_fork) {
+        if (!n->side_stream) {
+            RL4RS_HIP_TRY(hipStreamCreateWithFlags(&n->side_stream, hipStreamNonBlocking));
+            RL4RS_HIP_TRY(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+            RL4RS_HIP_TRY(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+        }
+        RL4RS_HIP_TRY(hipEventRecord(n->ev_fork, st));                       // (the inputs - and the previous forward's readers of allf - are ordered before this point)
+        RL4RS_HIP_TRY(hipStreamWaitEvent(n->side_stream, n->ev_fork, 0));
+        if ((rc = dense_tower(n->side_stream))) return rc;
+        RL4RS_HIP_TRY(hipEventRecord(n->ev_join, n->side_stream));
+        forked = true;
+    }
     {
         Prof p(n, KID_CAT, st);
         if (n->cat_v2 && n->cat_group && E == 128 && Cn >= 11 && Cn <= 24 && (group == 8 || group == 9)) {
@@ -2209,15 +2244,9 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         }
         RL4RS_LAUNCH_CHECK();
     }
-    {
+    if (!forked) {
         Prof p(n, KID_DENSE, st);
-        if (n->gemm16 && n->dense_chain && U <= 128 && U % 16 == 0) {      // both layers in one launch, the hidden tile stays in LDS
-            if ((rc = launch_gemm_h16_chain(dense, n->Dn, n->dense_w1, n->dense_b1, U, n->Dn, 1, n->dense_w2, n->dense_b2,
-                                            n->allf + off_d, F, U, 1, R, st))) return rc;
-        } else {
-            if ((rc = scorer_gemm(n, dense, n->Dn, n->dense_w1, n->dense_b1, n->dh, U, R, U, n->Dn, 1, st))) return rc;
-            if ((rc = scorer_gemm(n, n->dh, U, n->dense_w2, n->dense_b2, n->allf + off_d, F, R, U, U, 1, st))) return rc;
-        }
+        if ((rc = dense_tower(st))) return rc;
     }
     {
         Prof p(n, KID_DIN, st);
@@ -2326,11 +2355,16 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         RL4RS_LAUNCH_CHECK();
     }
     float* obs_out = obs ? obs : n->obs_tmp;
+    if (forked) RL4RS_HIP_TRY(hipStreamWaitEvent(st, n->ev_join, 0));
     {
         Prof p(n, KID_HEAD, st);
         if (n->ptab && n->tsum) {     // obs = ELU(allf W + [b + table rows]): the addend was built inside k_cat_attn
             const int Kh = S * NH2 + U + E;
-            if (n->gemm16) rc = launch_gemm_h16(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 1, st, n->tsum, OBS_DIM);
+            if (n->gemm16) {
+                float* mirror = (obs && n->obs_mirror) ? n->obs_mirror : nullptr;
+                rc = launch_gemm_h16(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 1, st, n->tsum, OBS_DIM, mirror, OBS_DIM);
+                n->obs_mirror_used = mirror != nullptr;
+            }
             else rc = launch_gemm_packed(n->allf, F, n->obs_w, nullptr, obs_out, OBS_DIM, R, OBS_DIM, Kh, 1, st, n->tsum, OBS_DIM);
             if (rc) return rc;
         } else if (n->ptab) {
@@ -2418,6 +2452,12 @@ int rl4rs_dien_status(rl4rs_dien* n, int32_t* flags, void* stream) {
     *flags = v ? RL4RS_DIEN_STATUS_FP16_RANGE : 0;
     return RL4RS_OK;
 }
+}  // extern "C"
+namespace rl4rs {
+void dien_set_obs_mirror(rl4rs_dien* n, float* host_visible) { if (n) n->obs_mirror = host_visible; }
+bool dien_obs_mirror_used(const rl4rs_dien* n) { return n && n->obs_mirror_used; }
+}  // namespace rl4rs
+extern "C" {
 // The status word itself (device pointer owned by the handle, != 0 <=> RL4RS_DIEN_STATUS_FP16_RANGE pending): a caller that
 // already copies a record to the host every step reads it there instead of paying rl4rs_dien_status's synchronisation.
 int rl4rs_dien_status_word(rl4rs_dien* n, int32_t** word_dev) {

@@ -565,6 +565,10 @@ __device__ __forceinline__ ghalf8_t gbuf_load_h8(__amdgpu_buffer_rsrc_t rsrc, in
 // k-blocks and the same MFMA sequence as two launches with the intermediate in HBM: bit-identical results, one launch less.
 struct G16Chain {
     const char* wp2; int kb2; const float* bias2; float* c2; int64_t ldc2; int n2; int act2;
+    // (unchained launches) second destination of the SAME output elements, row stride ldm: device-visible pinned HOST memory - the
+    // observation of a reference-shaped step leaves for the host from the head GEMM's epilogue, as its tiles finish, instead of
+    // through a device-to-host copy that can only start when the whole GEMM has ended
+    float* mirror; int64_t ldm;
 };
 
 // VEC: rows of A are 16-byte aligned (decided by the host: lda % 4 == 0 and A aligned) -> two 16-byte loads per chunk
@@ -792,6 +796,32 @@ __global__ __launch_bounds__(256) void k_gemm_h16(const float* __restrict__ A, i
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[w][r] * inv_s + bv + 0.f, act)), rs_c, c_voff,
                                                           (32 * w + (r & 3) + 8 * (r >> 2)) * ldc4, 0);
         }
+        if (chain.mirror) {
+            // the same values (recomputed from the registers: same expression, same bits) to the host block
+            const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(chain.mirror + (size_t)m0 * chain.ldm, 0,
+                                                                                  (int)((((int64_t)rows_here - 1) * chain.ldm + N) * 4), 0x00020000);
+            const int ldm4 = (int)chain.ldm * 4, m_voff = (4 * half * (int)chain.ldm + col) * 4;
+            if (addend) {
+                const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(addend + (size_t)m0 * ldadd), 0,
+                                                                                      (int)((((int64_t)rows_here - 1) * ldadd + N) * 4), 0x00020000);
+                const int ldd4 = (int)ldadd * 4, d_voff = (4 * half * (int)ldadd + col) * 4;
+#pragma unroll
+                for (int w = 0; w < WM; ++w)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float ad = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, d_voff, (32 * w + (r & 3) + 8 * (r >> 2)) * ldd4, 0));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[w][r] * inv_s + bv + ad, act)), rs_m, m_voff,
+                                                              (32 * w + (r & 3) + 8 * (r >> 2)) * ldm4, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int w = 0; w < WM; ++w)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(acc[w][r] * inv_s + bv + 0.f, act)), rs_m, m_voff,
+                                                              (32 * w + (r & 3) + 8 * (r >> 2)) * ldm4, 0);
+            }
+        }
     }
 }
 
@@ -968,8 +998,9 @@ static int launch_gemm_h16_impl(const float* a, int64_t lda, const float* wp16, 
                                 int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, G16Chain chain);
 
 int launch_gemm_h16(const float* a, int64_t lda, const float* wp16, const float* bias, float* c, int64_t ldc,
-                    int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd) {
+                    int M, int N, int K, int act, hipStream_t st, const float* addend, int64_t ldadd, float* mirror, int64_t ldm) {
     G16Chain none = {};
+    none.mirror = mirror; none.ldm = ldm;
     return launch_gemm_h16_impl(a, lda, wp16, bias, c, ldc, M, N, K, act, st, addend, ldadd, none);
 }
 
@@ -980,7 +1011,7 @@ int launch_gemm_h16_chain(const float* a, int64_t lda, const float* wp1, const f
         set_error("gemm_h16_chain: unsupported widths %d -> %d", N1, N2);
         return RL4RS_EINVAL;
     }
-    G16Chain ch = {reinterpret_cast<const char*>(wp2), (N1 + 15) / 16, bias2, c2, ldc2, N2, act2};
+    G16Chain ch = {reinterpret_cast<const char*>(wp2), (N1 + 15) / 16, bias2, c2, ldc2, N2, act2, nullptr, 0};
     return launch_gemm_h16_impl(a, lda, wp1, bias1, nullptr, 0, M, N1, K1, act1, st, nullptr, 0, ch);
 }
 

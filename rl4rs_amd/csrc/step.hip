@@ -39,6 +39,12 @@ int scorer_encode(rl4rs_stepper* s, int q, const int32_t* ids, int n, void* stre
     return s->dien ? rl4rs_dien_encode(s->dien, q, ids, n, 0, stream) : rl4rs_simnet_encode(s->simnet, q, ids, n, 0, stream);
 }
 
+// rl4rs_set_host_mirror(1): the head GEMM's epilogue writes the observation to the pinned host block itself.  OFF by default:
+// measured on one box, 2 alternating pairs of 12 episode-batches (profiles/r06h_host_mirror.txt): 13.10 / 13.16 ms with the copy
+// engine, 13.20 / 13.21 ms with the mirror - stores to host memory drain no faster than the copy engine moves the same 4 MB, and
+// the GEMM's waves hold their CUs while they do.
+int g_host_mirror = 0;
+
 int ensure_copy_stream(rl4rs_stepper* s) {
     if (!s->copy_stream) {
         RL4RS_HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
@@ -275,7 +281,23 @@ static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, 
     const int64_t obs_off = L.obs_d3rl >= 0 ? L.obs_d3rl : L.obs;
     const int64_t obs_bytes = L.obs_d3rl >= 0 ? (int64_t)B * L.d3rl_cols * 8 : (int64_t)B * L.obs_dim * 4;
     bool obs_sent = false;
+    // Steps without a reward forward (and resets): the observation is the LAST thing computed, so a device-to-host copy of its
+    // 4 MB could only start when the GPU has nothing left to do (85 us at PCIe rate per step, GPU idle).  The head GEMM's epilogue
+    // writes it to the pinned host block itself, tile by tile while the GEMM runs (k_gemm_h16's mirror destination): what is
+    // left for the copy engine is the few KB around it.  (Reward steps overlap the copy with the reward forward instead; the
+    // float64 d3rlpy rows are assembled by a kernel of their own and keep the copy.)
+    bool mirror_armed = false;
+    if (H && g_host_mirror && s->dien && reward_step != 1 && L.obs_d3rl < 0) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, H + L.obs, 0) == hipSuccess && dp) {
+            rl4rs::dien_set_obs_mirror(s->dien, reinterpret_cast<float*>(dp));
+            mirror_armed = true;
+        } else {
+            (void)hipGetLastError();          // not mapped for the device: the copy path below serves it
+        }
+    }
     auto finish_obs = [&]() -> int {
+        if (mirror_armed && rl4rs::dien_obs_mirror_used(s->dien)) obs_sent = true;      // already on its way home
         if (L.obs_d3rl >= 0) {
             // masked_actions: all of prev_actions (slate.py:100-104) or the current page's columns (seqslate.py:18-23), POST-act step counter
             const int cur_after = cur + 1, T = s->cfg.max_steps, P = s->cfg.page_items;
@@ -342,6 +364,11 @@ static int step_record(rl4rs_stepper* s, bool observe, const void* actions_dev, 
         }
         if (early) RL4RS_HIP_TRY(hipStreamWaitEvent(st, s->ev_copied, 0));     // one wait on `stream` covers every copy (the copy stream is in order)
     }
+    return RL4RS_OK;
+}
+
+int rl4rs_set_host_mirror(int32_t on) {
+    g_host_mirror = on ? 1 : 0;
     return RL4RS_OK;
 }
 

@@ -425,7 +425,9 @@ class DeviceStepper(object):
             kind = 0
         self._last_record = (L, rec)
         nb = int(L.host_bytes)
-        host = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
+        # the page-locked block of this record: the one the PREVIOUS call set aside while its kernels ran (same size), else a fresh one
+        spare = self.__dict__.pop('_spare_block', None)
+        host = spare if (spare is not None and spare.numel() == nb) else torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)
         if a is None:
             check(self.lib.rl4rs_env_observe_record_host(self.h, 1 if conti else 0, bits, _ptr(rec), host.data_ptr(), _stream()))
         else:
@@ -452,6 +454,7 @@ class DeviceStepper(object):
         r.offline_action = view(L.offline_action, np.float64, (B, self.E)) if conti else view(L.offline_action, np.int32, (B,))
         if shadow is not None:
             shadow(r)
+        self._spare_block = torch.empty(nb, dtype=torch.uint8, device='cpu', pin_memory=True)      # in the GPU's shadow: the next record's block
         wait_stream()
         return r
 

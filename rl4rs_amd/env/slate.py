@@ -680,6 +680,7 @@ class SlateRecEnv(RecSimBase):
                 if masked:
                     built['obs'] = self._mask_dicts(rec)
                 built['done'] = [1 if last else 0] * self.batch_size
+                built['zero'] = [0] * self.batch_size            # the reward of a step on which none is due (slate.py:284)
                 if cur_after < self.max_steps and cur_after < samples._exposed_len_min:
                     samples._next_offline = ((samples._batch_version, cur_after),
                                              samples._offline_from_host(cur_after, conti, None if conti else stepper.offline_action_view()))
@@ -706,7 +707,7 @@ class SlateRecEnv(RecSimBase):
             obs = built['obs'] if masked else r.obs
             if self.config.get('copy_outputs', False):
                 obs = self._copied_obs(r, masked)
-            reward = r.reward.tolist() if due else [0] * self.batch_size
+            reward = r.reward.tolist() if due else built['zero']
         if first_of_page:                                   # the library re-encoded the second sequence input
             samples._seq1_version += 1
             self._encoded_seq1 = samples._seq1_version

@@ -33,6 +33,26 @@ def step_record(self, actions, conti=False, want=(), shadow=None):
     r = orig_sr(self, actions, conti=conti, want=want, shadow=sh)
     return r
 D.DeviceStepper.step_record = step_record
+# finer marks: wait return -> env.step return (post), env.step entry -> library call entry (pre), the library call itself (launches)
+_lib_mod = D._lib.load()
+_orig_call = _lib_mod.rl4rs_env_step_record_host
+marks = {}
+def _call(*x):
+    t0 = time.perf_counter()
+    if 'step_entry' in marks:
+        acc['pre (step entry -> library call)'] = acc.get('pre (step entry -> library call)', 0.0) + t0 - marks['step_entry']
+    r = _orig_call(*x)
+    tick('library call (launches)', t0)
+    return r
+class _Shim(object):
+    def __getattr__(self, k):
+        return _call if k == 'rl4rs_env_step_record_host' else getattr(_lib_mod, k)
+_wait2 = D.wait_stream
+def wait_stream2(*x, **k):
+    r = _wait2(*x, **k)
+    marks['wait_done'] = time.perf_counter()
+    return r
+D.wait_stream = wait_stream2
 
 EPISODES = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 per_episode = []
@@ -43,7 +63,12 @@ for ep in range(EPISODES + 2):
     t0 = time.perf_counter(); env.reset(); tick('reset', t0)
     for _ in range(T):
         t0 = time.perf_counter(); act = env.offline_action; tick('offline_action', t0)
-        t0 = time.perf_counter(); env.step(act); tick('step_total', t0)
+        t0 = time.perf_counter(); marks['step_entry'] = t0
+        if getattr(env.sim, '_stepper', None) is not None and not isinstance(env.sim._stepper.lib, _Shim):
+            env.sim._stepper.lib = _Shim()
+        env.step(act); tick('step_total', t0)
+        if 'wait_done' in marks:
+            acc['post (wait done -> step returns)'] = acc.get('post (wait done -> step returns)', 0.0) + time.perf_counter() - marks['wait_done']
     per_episode.append(round((time.perf_counter() - te) * 1e3, 2))
 torch.cuda.synchronize()
 tot = (time.perf_counter() - T0) / EPISODES * 1e3
