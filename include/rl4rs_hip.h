@@ -681,7 +681,8 @@ int rl4rs_simtrain_step(rl4rs_simtrain* tr, int32_t N, const float* dense_dev, c
 /* Row-tile form of the persistent training recurrences (the GRU / AUGRU layers of rl4rs_dientrain_* and of the lstm family of
  * rl4rs_simtrain_*; reference: model.fit with batch_size 256, script/supervised_train.py:12-46): 0 = automatic (8-row workgroups
  * on v_mfma_f32_4x4x1 while 32-row ones would occupy fewer than half of the CUs - a 256-sample minibatch is 64 workgroups
- * instead of 16), 8 or 32 = pinned.  Process-wide; same arithmetic up to the summation order of a dot product. */
+ * instead of 16; hidden width 256 goes on to 4-row workgroups - 128 of them - while the 8-row ones would), 4 (hidden width 256;
+ * other widths take 8), 8 or 32 = pinned.  Process-wide; same arithmetic up to the summation order of a dot product. */
 int rl4rs_recur_train_set_rows(int32_t rows);
 
 typedef struct rl4rs_dientrain rl4rs_dientrain;

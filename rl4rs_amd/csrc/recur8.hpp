@@ -35,10 +35,14 @@ namespace rl4rs {
 // registers, then go to an LDS stage the matrix waves take their accumulators' initial values from) and copies the saved r, u,
 // r*h, c, h tiles of a step from LDS to memory.  The matrix waves issue no global load but their weight ring and no global store:
 // vmcnt retires in order, so every x load or store in their queue was a wait in front of the ring (9.9 -> 8.x us per AUGRU step).
-template <int NH>
+// RWS = rows per workgroup: 8 (two 4-row tiles) or, NH = 256 only, 4 (ONE tile per wave: half the MFMAs per step against the same
+// weight stream - a 256-sample minibatch x 2 inputs is 128 workgroups; round 6).
+template <int NH, int RWS = 8>
 __global__ __launch_bounds__(320) void k_recur8_fwd(RecurArgs a) {
     using namespace r8;
-    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB = NH / 8, NQ = NH / 4, LDH = NH + 4, NWT = NH / 32, ST = RW * NH;
+    constexpr int RW = RWS;                                       // (shadows r8::RW)
+    static_assert(RWS == 8 || (RWS == 4 && NH == 256), "rows per workgroup");
+    constexpr int NCW = NH / 64, MTW = (NH == 256) ? RWS / 4 : 1, KB = NH / 8, NQ = NH / 4, LDH = NH + 4, NWT = NH / 32, ST = RW * NH;
     constexpr int P1 = (2 * MTW >= 4) ? 1 : 2, P2 = 4 / MTW;     // accumulator chains per (gate, tile) in phase 1 / 2
     static_assert(NH == 128 || NH == 256, "hidden width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(320) void k_recur8_fwd(RecurArgs a) {
     }
 }
 
-inline size_t recur8_fwd_smem(int NH, int L) { return (size_t)(2 * 8 * (NH + 4) + 6 * 8 * NH + 8 * (L + 1)) * 4; }
+inline size_t recur8_fwd_smem(int NH, int L, int rows = 8) { return (size_t)(2 * rows * (NH + 4) + 6 * rows * NH + rows * (L + 1)) * 4; }
 
 // ----------------------------------------------------------------------------------------------------------------- backward
 // RecurBwdArgs as k_recur_bwd<NH> takes them; the same per-step equations (header of recur_train.hpp).
@@ -216,16 +220,18 @@ inline size_t recur8_fwd_smem(int NH, int L) { return (size_t)(2 * 8 * (NH + 4) 
 // at the top of every step and use them at once - a full memory round trip in front of each step's first product (16.7 us per
 // AUGRU step against 9.9 us forwards with the same MFMA count), and vmcnt retires in order, so requesting them earlier from the
 // same wave would only move the stall into the weight ring.  The loader's waits are its own.
-template <int NH>
+template <int NH, int RWS = 8>
 __global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
     using namespace r8;
-    constexpr int NCW = NH / 64, MTW = (NH == 256) ? 2 : 1, KB1 = NH / 8, KB2 = 2 * NH / 8, NQ1 = NH / 4, NQ2 = 2 * NH / 4;
+    constexpr int RW = RWS;                                       // (shadows r8::RW; see k_recur8_fwd)
+    static_assert(RWS == 8 || (RWS == 4 && NH == 256), "rows per workgroup");
+    constexpr int NCW = NH / 64, MTW = (NH == 256) ? RWS / 4 : 1, KB1 = NH / 8, KB2 = 2 * NH / 8, NQ1 = NH / 4, NQ2 = 2 * NH / 4;
     constexpr int LDA = NH + 4, LDG = 2 * NH + 4, PC = 4 / MTW;        // accumulator chains per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tA = reinterpret_cast<float*>(smem);          // [8][LDA]   dAc (A operand of the first product)
     float* tG = tA + RW * LDA;                           // [8][LDG]   [dAg_r | dAg_u] (A operand of the second product)
     float* s_att = tG + RW * LDG;                        // [8][L + 1]
-    float* s_red = s_att + RW * (a.L + 1);               // [NCW][8]   per-wave partial row sums of -dup u
+    float* s_red = s_att + RW * (a.L + 1);               // [NCW][RW]  per-wave partial row sums of -dup u
     float* stage = s_red + NCW * RW;                     // [5][8][NH] R, U, C, H_prev, upstream of the step about to be processed
     constexpr int ST = RW * NH, LDR = NH + 8;
     float* s_rv = stage + 5 * ST;                        // [8][LDR]   -dup u of every (row, column): the loader wave sums the rows
@@ -273,15 +279,15 @@ __global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
         for (int t = L - 1; t >= 0; --t) {
             __syncthreads();                             // the matrix waves have taken step t out of the stage
             if (aug && a.d_score[sq]) {
-                // d a_t of a row = sum over ALL hidden columns of -dup u: 8 lanes per row, NH / 8 values each, then three shuffle
-                // steps - a fixed order, off the matrix waves' critical path
-                const int r = lane >> 3, c0 = lane & 7;
+                // d a_t of a row = sum over ALL hidden columns of -dup u: 64 / RW lanes per row, NH / LPR values each, then log2(LPR)
+                // shuffle steps - a fixed order, off the matrix waves' critical path
+                constexpr int LPR = 64 / RW;
+                const int r = lane / LPR, c0 = lane % LPR;
                 float sum = 0.f;
 #pragma unroll 8
-                for (int j = 0; j < NH / 8; ++j) sum += s_rv[r * LDR + c0 + 8 * j];
-                sum += __shfl_xor(sum, 4);
-                sum += __shfl_xor(sum, 2);
-                sum += __shfl_xor(sum, 1);
+                for (int j = 0; j < NH / LPR; ++j) sum += s_rv[r * LDR + c0 + LPR * j];
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
                 if (c0 == 0 && row0 + r < a.n_rows) a.d_score[sq][(size_t)(row0 + r) * L + t] = sum;
             }
             if (t > 0) deposit();                        // step t - 1, requested during step t + 1
@@ -401,6 +407,8 @@ __global__ __launch_bounds__(320) void k_recur8_bwd(RecurBwdArgs a) {
     }
 }
 
-inline size_t recur8_bwd_smem(int NH, int L) { return (size_t)(8 * (NH + 4) + 8 * (2 * NH + 4) + 8 * (L + 1) + (NH / 64) * 8 + 5 * 8 * NH + 8 * (NH + 8)) * 4; }
+inline size_t recur8_bwd_smem(int NH, int L, int rows = 8) {
+    return (size_t)(rows * (NH + 4) + rows * (2 * NH + 4) + rows * (L + 1) + (NH / 64) * rows + 5 * rows * NH + rows * (NH + 8)) * 4;
+}
 
 }  // namespace rl4rs

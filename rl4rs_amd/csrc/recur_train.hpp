@@ -205,9 +205,16 @@ static int recur_train_n_cu() {
     return n_cu;
 }
 static bool recur_train_small(int N, int S) {
-    if (g_recur_train_rows == 8) return true;
+    if (g_recur_train_rows == 8 || g_recur_train_rows == 4) return true;
     if (g_recur_train_rows == 32) return false;
     return (int64_t)((N + 31) / 32) * S * 2 <= recur_train_n_cu();
+}
+// ... and, among the small forms, 4 rows per workgroup (NH = 256 only: one 4-row tile per wave, half the MFMAs of a step against the
+// same weight stream) while 8-row workgroups would occupy fewer than half of the CUs; rl4rs_recur_train_set_rows(4 / 8) pins it
+static bool recur_train_rows4(int NH, int N, int S) {
+    if (NH != 256 || g_recur_train_rows == 8) return false;
+    if (g_recur_train_rows == 4) return true;
+    return (int64_t)((N + 7) / 8) * S * 2 <= recur_train_n_cu();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -253,6 +260,15 @@ static int recur_train_fwd_t(const RecurTrainFwd& f, hipStream_t st) {
     if (recur_train_small(f.N, f.S)) {
         for (int s = 0; s < f.S; ++s)
             if (!a.sv_r[s] || !a.sv_u[s] || !a.sv_c[s] || !a.sv_h[s] || !a.sv_rh[s]) { set_error("recur_train_fwd: a saved-tensor pointer is NULL"); return RL4RS_EINVAL; }
+        if constexpr (NH == 256) {
+            if (recur_train_rows4(NH, f.N, f.S)) {
+                int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_fwd<NH, 4>), recur8_fwd_smem(NH, 64, 4));
+                if (rca) return rca;
+                hipLaunchKernelGGL((k_recur8_fwd<NH, 4>), dim3((f.N + 3) / 4, f.S), dim3(320), recur8_fwd_smem(NH, f.L, 4), st, a);
+                RL4RS_LAUNCH_CHECK();
+                return RL4RS_OK;
+            }
+        }
         {
             int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_fwd<NH>), recur8_fwd_smem(NH, 64));
             if (rca) return rca;
@@ -294,6 +310,15 @@ static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
     }
     a.ld_g = b.ld_g; a.ld_c = b.ld_c; a.hard = b.hard;
     if (recur_train_small(b.N, b.S)) {
+        if constexpr (NH == 256) {
+            if (recur_train_rows4(NH, b.N, b.S)) {
+                int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_bwd<NH, 4>), recur8_bwd_smem(NH, 64, 4));
+                if (rca) return rca;
+                hipLaunchKernelGGL((k_recur8_bwd<NH, 4>), dim3((b.N + 3) / 4, b.S), dim3(320), recur8_bwd_smem(NH, b.L, 4), st, a);
+                RL4RS_LAUNCH_CHECK();
+                return RL4RS_OK;
+            }
+        }
         {
             int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_recur8_bwd<NH>), recur8_bwd_smem(NH, 64));
             if (rca) return rca;
@@ -311,7 +336,7 @@ static int recur_train_bwd_t(const RecurTrainBwd& b, hipStream_t st) {
 
 // include/rl4rs_hip.h: pin the row-tile form of the persistent training recurrences (0 automatic, 8, 32); returns the previous value
 extern "C" int rl4rs_recur_train_set_rows(int32_t rows) {
-    if (rows != 0 && rows != 8 && rows != 32) { rl4rs::set_error("rl4rs_recur_train_set_rows: %d (0 = automatic, 8, 32)", rows); return RL4RS_EINVAL; }
+    if (rows != 0 && rows != 4 && rows != 8 && rows != 32) { rl4rs::set_error("rl4rs_recur_train_set_rows: %d (0 = automatic, 4, 8, 32)", rows); return RL4RS_EINVAL; }
     rl4rs::g_recur_train_rows = rows;
     return RL4RS_OK;
 }

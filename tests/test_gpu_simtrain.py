@@ -189,10 +189,12 @@ def test_dien_gradients_match_autograd(rate):
     _check_dien_gradients(rate, 40)
 
 
-@pytest.mark.parametrize('rows', [8, 32])
+@pytest.mark.parametrize('rows', [4, 8, 32])
 @pytest.mark.parametrize('N', [40, 43, 72])
 def test_dien_gradients_in_both_recurrence_tile_forms(recur_rows, rows, N):
-    """the first GRU (Hd = 128) and the AUGRU (Hd = 256) with their BPTT through the 8-row and the 32-row persistent kernels;
+    """the first GRU (Hd = 128) and the AUGRU (Hd = 256) with their BPTT through the 8-row and the 32-row persistent kernels
+    (rows = 4: the AUGRU in 4-row workgroups - one 4-row tile per wave - and the first GRU, whose width has no such form, in 8-row ones;
+    N = 43: ragged last tile of every form);
     N = 72: 4 608 (row, step) pairs - the sample-axis reductions of the recurrent layers' weight gradients ([256 x 512], [512 x 64],
     ...) take the LDS-tiled 128 x 128 form (k_gemm_tn_t128, from 4 096 samples) with its chunk sum"""
     recur_rows(rows)
