@@ -689,6 +689,11 @@ typedef struct rl4rs_dientrain rl4rs_dientrain;
 int rl4rs_dientrain_create(const rl4rs_dien_cfg* cfg, const rl4rs_dien_weights* w, int32_t max_batch, void* stream,
                            rl4rs_dientrain** out);
 int rl4rs_dientrain_destroy(rl4rs_dientrain* tr);
+/* The launch chains that follow a recurrent layer (parameter-gradient reductions, the attention MLP's forward / backward) of the
+ * ODD sequence inputs run on a second stream of the handle, beside the even inputs' (each ~35 small launches; own scratch; joined in
+ * front of the next recurrent launch).  Process-wide switch, default 1; 0 = everything on the caller's stream (A/B measurements).
+ * Same kernels on the same operands either way (the embedding-table gradient takes float atomics from both). */
+int rl4rs_dientrain_set_fork(int32_t on);
 int rl4rs_dientrain_params(rl4rs_dientrain* tr, float** params_dev, float** grad_dev, int64_t* count);
 int rl4rs_dientrain_masks(rl4rs_dientrain* tr, uint8_t** mask1_dev, uint8_t** mask2_dev);
 int rl4rs_dientrain_grad(rl4rs_dientrain* tr, int32_t N, const float* dense_dev, const int32_t* cat_dev,

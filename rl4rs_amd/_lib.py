@@ -194,6 +194,7 @@ SIGNATURES = {
     'rl4rs_recur_train_set_rows': (_I, [_I32]),
     'rl4rs_dientrain_create': (_I, [C.POINTER(DienCfg), C.POINTER(DienWeights), _I32, _P, C.POINTER(_P)]),
     'rl4rs_dientrain_destroy': (_I, [_P]),
+    'rl4rs_dientrain_set_fork': (_I, [_I32]),
     'rl4rs_dientrain_params': (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     'rl4rs_dientrain_masks': (_I, [_P, C.POINTER(_P), C.POINTER(_P)]),
     'rl4rs_dientrain_grad': (_I, [_P, _I32, _P, _P, C.POINTER(_P), _P, C.c_float, C.c_uint32, C.c_uint32, _P, _P]),

@@ -167,7 +167,19 @@ struct rl4rs_dientrain {
     float *s_tmpw, *loss_rows, *lr_dummy;
     int64_t adam_t;
     std::vector<void*> owned;
+    // Round 6: the work that follows a recurrent layer is a chain of ~35 small launches PER SEQUENCE INPUT (sample-axis reductions,
+    // transposes, the attention MLP): 570 + 570 + 280 + 280 us of a 3.97 ms step, most of them far from filling the chip.  The odd
+    // inputs' chains run on a second stream with their own scratch, beside the even ones' (rl4rs_dientrain_set_fork(0): one stream).
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    TrainCtx cx2;
+    float *hprev2, *dX2, *d_hid2b, *d_hid1b, *d_inp2, *dq2;
 };
+
+static int g_dientrain_fork = 1;
+
+// scratch of one stream's per-input chains
+struct InputScratch { TrainCtx* cx; float *hprev, *dX, *d_hid2, *d_hid1, *d_inp, *dq; };
 
 namespace {
 
@@ -230,7 +242,7 @@ int layer_backward(rl4rs_dientrain* t, int N, int which, const float* const* up_
 // Parameter gradients and the gradient of the layer input of one cell from its pre-activation gradients (sample-axis GEMM
 // reductions over all N * L (row, step) pairs).  Accumulates dXin [N*L, E] INTO dXin_acc (accumulate) or overwrites it.
 int cell_backward_post(rl4rs_dientrain* t, int N, const CellSave& cl, const float* Xin, const float* dAg, const float* dAc,
-                       float* dXin_acc, bool accumulate, hipStream_t st) {
+                       float* dXin_acc, bool accumulate, hipStream_t st, const InputScratch& sc) {
     const int E = t->c.emb_size, L = t->c.maxlen, Hd = cl.Hd;
     const float* Wg = t->params + t->off[cl.pgw];
     const float* Wc = t->params + t->off[cl.pgw + 2];
@@ -241,19 +253,19 @@ int cell_backward_post(rl4rs_dientrain* t, int N, const CellSave& cl, const floa
     int rc;
     const dim3 b256(256);
     const int Ns = N * L;
-    hipLaunchKernelGGL(k_shift_prev_w, dim3((Ns * Hd + 255) / 256), b256, 0, st, cl.Hs, t->hprev, N, Hd, L);
+    hipLaunchKernelGGL(k_shift_prev_w, dim3((Ns * Hd + 255) / 256), b256, 0, st, cl.Hs, sc.hprev, N, Hd, L);
     // gate_w = [x rows ; h rows] x 2Hd columns, cand_w likewise x Hd columns
     // (the bias gradients = column sums of dAg / dAc ride on the x-side reductions, whose first tile row holds those values anyway)
-    st_tn_cs(t->cx, st, Xin, E, E, dAg, 2 * Hd, 2 * Hd, Ns, gWg, gbg);
-    st_tn(t->cx, st, t->hprev, Hd, Hd, dAg, 2 * Hd, 2 * Hd, Ns, gWg + (size_t)E * 2 * Hd);
-    st_tn_cs(t->cx, st, Xin, E, E, dAc, Hd, Hd, Ns, gWc, gbc);
-    st_tn(t->cx, st, cl.RH, Hd, Hd, dAc, Hd, Hd, Ns, gWc + (size_t)E * Hd);
+    st_tn_cs(*sc.cx, st, Xin, E, E, dAg, 2 * Hd, 2 * Hd, Ns, gWg, gbg);
+    st_tn(*sc.cx, st, sc.hprev, Hd, Hd, dAg, 2 * Hd, 2 * Hd, Ns, gWg + (size_t)E * 2 * Hd);
+    st_tn_cs(*sc.cx, st, Xin, E, E, dAc, Hd, Hd, Ns, gWc, gbc);
+    st_tn(*sc.cx, st, cl.RH, Hd, Hd, dAc, Hd, Hd, Ns, gWc + (size_t)E * Hd);
     // gradient of the layer input: dAg Wg[:E]^T + dAc Wc[:E]^T
-    float* dst = accumulate ? t->dX : dXin_acc;
-    if ((rc = st_back(t->cx, st, dAg, 2 * Hd, 2 * Hd, Wg, 2 * Hd, E, dst, E, Ns))) return rc;
-    if (accumulate) hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, t->dX, Ns * E);
-    if ((rc = st_back(t->cx, st, dAc, Hd, Hd, Wc, Hd, E, t->dX, E, Ns))) return rc;
-    hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, t->dX, Ns * E);
+    float* dst = accumulate ? sc.dX : dXin_acc;
+    if ((rc = st_back(*sc.cx, st, dAg, 2 * Hd, 2 * Hd, Wg, 2 * Hd, E, dst, E, Ns))) return rc;
+    if (accumulate) hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, sc.dX, Ns * E);
+    if ((rc = st_back(*sc.cx, st, dAc, Hd, Hd, Wc, Hd, E, sc.dX, E, Ns))) return rc;
+    hipLaunchKernelGGL(k_add_inplace, dim3((Ns * E + 255) / 256), b256, 0, st, dXin_acc, sc.dX, Ns * E);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
 }
@@ -262,9 +274,15 @@ int cell_backward_post(rl4rs_dientrain* t, int N, const CellSave& cl, const floa
 
 extern "C" {
 
+int rl4rs_dientrain_set_fork(int32_t on) {
+    g_dientrain_fork = on ? 1 : 0;
+    return RL4RS_OK;
+}
+
 int rl4rs_dientrain_destroy(rl4rs_dientrain* t) {
     if (!t) return RL4RS_OK;
     for (void* q : t->owned) (void)hipFree(q);
+    if (t->side) { (void)hipStreamDestroy(t->side); (void)hipEventDestroy(t->ev_fork); (void)hipEventDestroy(t->ev_join); }
     delete t;
     return RL4RS_OK;
 }
@@ -374,6 +392,20 @@ int rl4rs_dientrain_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w,
     DT_FAIL(al(&t->cx.wt, wmax));
     DT_FAIL(al(&t->cx.part, (size_t)nz_all * wmax));
     t->cx.part_cap = (size_t)nz_all * wmax;
+    // the second stream's scratch (only per-input reductions run there: the widest is the AUGRU's [3E x 4E] gate gradient)
+    t->side = nullptr; t->ev_fork = nullptr; t->ev_join = nullptr;
+    if (S > 1) {
+        const int64_t wmax2 = (int64_t)3 * E * 4 * E;
+        t->cx2.chunk = 512;
+        DT_FAIL(al(&t->cx2.wt, wmax2));
+        DT_FAIL(al(&t->cx2.part, (size_t)nz_all * wmax2));
+        t->cx2.part_cap = (size_t)nz_all * wmax2;
+        DT_FAIL(al(&t->hprev2, Ns * NH2)); DT_FAIL(al(&t->dX2, Ns * E)); DT_FAIL(al(&t->d_hid2b, Ns * 16)); DT_FAIL(al(&t->d_hid1b, Ns * 64));
+        DT_FAIL(al(&t->d_inp2, Ns * 4 * E)); DT_FAIL(al(&t->dq2, B * E));
+        DT_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+        DT_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+        DT_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    }
     DT_HIP(hipStreamSynchronize(st));
 #undef DT_HIP
 #undef DT_FAIL
@@ -426,14 +458,31 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
         Xs[s] = t->X[s]; Ks[s] = t->gru[s].Hs; scs[s] = t->score[s];
     }
     if ((rc = layer_forward(t, N, 0, Xs, nullptr, st))) return rc;         // first GRU of every sequence input: one launch
+    // the chains of the odd sequence inputs on the second stream (fork / join = one event each way)
+    const bool two = t->side != nullptr && g_dientrain_fork && S > 1;
+    auto fork = [&]() -> int {
+        if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_fork, st)); RL4RS_HIP_TRY(hipStreamWaitEvent(t->side, t->ev_fork, 0)); }
+        return RL4RS_OK;
+    };
+    auto join = [&]() -> int {
+        if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_join, t->side)); RL4RS_HIP_TRY(hipStreamWaitEvent(st, t->ev_join, 0)); }
+        return RL4RS_OK;
+    };
+    auto stream_of = [&](int s) { return (two && (s & 1)) ? t->side : st; };
+    const InputScratch sc_main = {&t->cx, t->hprev, t->dX, t->d_hid2, t->d_hid1, t->d_inp, t->dq};
+    const InputScratch sc_side = {&t->cx2, t->hprev2, t->dX2, t->d_hid2b, t->d_hid1b, t->d_inp2, t->dq2};
+    auto scratch_of = [&](int s) -> const InputScratch& { return (two && (s & 1)) ? sc_side : sc_main; };
+    if ((rc = fork())) return rc;
     for (int s = 0; s < S; ++s) {
         const int pb = DP_SEQ0 + s * DP_PER_SEQ;
+        hipStream_t ss = stream_of(s);
         const float* Kk = t->gru[s].Hs;                                     // keys = first-GRU states [N*L, E]
-        hipLaunchKernelGGL(k_att_inp, ew(Ns * E), b256, 0, st, t->q, Kk, t->inp[s], N, L, E);
-        if ((rc = launch_gemm_f32(t->inp[s], 4 * E, P + o[pb + DQ_ATT_W1], 64, P + o[pb + DQ_ATT_B1], t->hid1[s], 64, Ns, 64, 4 * E, 2, st))) return rc;
-        if ((rc = launch_gemm_f32(t->hid1[s], 64, P + o[pb + DQ_ATT_W2], 16, P + o[pb + DQ_ATT_B2], t->hid2[s], 16, Ns, 16, 64, 2, st))) return rc;
-        if ((rc = launch_gemm_f32(t->hid2[s], 16, P + o[pb + DQ_ATT_W3], 1, P + o[pb + DQ_ATT_B3], t->score[s], 1, Ns, 1, 16, 0, st))) return rc;
+        hipLaunchKernelGGL(k_att_inp, ew(Ns * E), b256, 0, ss, t->q, Kk, t->inp[s], N, L, E);
+        if ((rc = launch_gemm_f32(t->inp[s], 4 * E, P + o[pb + DQ_ATT_W1], 64, P + o[pb + DQ_ATT_B1], t->hid1[s], 64, Ns, 64, 4 * E, 2, ss))) return rc;
+        if ((rc = launch_gemm_f32(t->hid1[s], 64, P + o[pb + DQ_ATT_W2], 16, P + o[pb + DQ_ATT_B2], t->hid2[s], 16, Ns, 16, 64, 2, ss))) return rc;
+        if ((rc = launch_gemm_f32(t->hid2[s], 16, P + o[pb + DQ_ATT_W3], 1, P + o[pb + DQ_ATT_B3], t->score[s], 1, Ns, 1, 16, 0, ss))) return rc;
     }
+    if ((rc = join())) return rc;
     if ((rc = layer_forward(t, N, 1, Ks, scs, st))) return rc;              // AUGRU of every sequence input: one launch
     for (int s = 0; s < S; ++s)
         RL4RS_HIP_TRY(hipMemcpy2DAsync(t->allf + s * NH2, (size_t)F * 4, t->aug[s].Hs + (size_t)(L - 1) * NH2, (size_t)L * NH2 * 4,
@@ -457,6 +506,7 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
     RL4RS_HIP_TRY(hipMemsetAsync(G + o[DP_CAT_EMB], 0, (size_t)H * E * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(G + o[DP_SEQ_EMB], 0, (size_t)H * E * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(t->dq, 0, (size_t)N * E * 4, st));
+    if (two) RL4RS_HIP_TRY(hipMemsetAsync(t->dq2, 0, (size_t)N * E * 4, st));
     st_tn(t->cx, st, t->obs, 256, 256, t->d_logits, K, K, N, G + o[DP_OUT_W]);
     st_cs(t->cx, st, t->d_logits, K, K, N, G + o[DP_OUT_B]);
     if ((rc = st_back(t->cx, st, t->d_logits, K, K, P + o[DP_OUT_W], K, 256, t->d_obs, 256, N))) return rc;
@@ -482,34 +532,43 @@ int rl4rs_dientrain_grad(rl4rs_dientrain* t, int32_t N, const float* dense, cons
     const float* dKs[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int s = 0; s < S; ++s) { ups[s] = t->d_allf + s * NH2; dKs[s] = t->dK[s]; }
     if ((rc = layer_backward(t, N, 1, ups, (int64_t)F, nullptr, scs, st))) return rc;
+    if ((rc = fork())) return rc;
     for (int s = 0; s < S; ++s) {
         const int pb = DP_SEQ0 + s * DP_PER_SEQ;
+        hipStream_t ss = stream_of(s);
+        const InputScratch& sc = scratch_of(s);
         const float* Kk = t->gru[s].Hs;
         float* d_score = t->d_score[s];
         float* dK = t->dK[s];
         // AUGRU parameter gradients; the gradient of its inputs (= the keys) starts dK
-        if ((rc = cell_backward_post(t, N, t->aug[s], Kk, t->dAg[s], t->dAc[s], dK, false, st))) return rc;
+        if ((rc = cell_backward_post(t, N, t->aug[s], Kk, t->dAg[s], t->dAc[s], dK, false, ss, sc))) return rc;
         // attention MLP (LocalActivationUnit, att_hidden_units = (64, 16), sigmoid; raw score)
-        st_tn(t->cx, st, t->hid2[s], 16, 16, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_W3]);
-        st_cs(t->cx, st, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_B3]);
-        if ((rc = st_back(t->cx, st, d_score, 1, 1, P + o[pb + DQ_ATT_W3], 1, 16, t->d_hid2, 16, Ns))) return rc;
-        hipLaunchKernelGGL(k_sig_bwd, ew(Ns * 16), b256, 0, st, t->d_hid2, t->hid2[s], Ns * 16);
-        st_tn(t->cx, st, t->hid1[s], 64, 64, t->d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_W2]);
-        st_cs(t->cx, st, t->d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_B2]);
-        if ((rc = st_back(t->cx, st, t->d_hid2, 16, 16, P + o[pb + DQ_ATT_W2], 16, 64, t->d_hid1, 64, Ns))) return rc;
-        hipLaunchKernelGGL(k_sig_bwd, ew(Ns * 64), b256, 0, st, t->d_hid1, t->hid1[s], Ns * 64);
-        st_tn(t->cx, st, t->inp[s], 4 * E, 4 * E, t->d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_W1]);
-        st_cs(t->cx, st, t->d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_B1]);
-        if ((rc = st_back(t->cx, st, t->d_hid1, 64, 64, P + o[pb + DQ_ATT_W1], 64, 4 * E, t->d_inp, 4 * E, Ns))) return rc;
-        hipLaunchKernelGGL(k_att_inp_bwd, ew(N * E), b256, 0, st, t->d_inp, t->q, Kk, dK, t->dq, N, L, E);
+        st_tn(*sc.cx, ss, t->hid2[s], 16, 16, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_W3]);
+        st_cs(*sc.cx, ss, d_score, 1, 1, Ns, G + o[pb + DQ_ATT_B3]);
+        if ((rc = st_back(*sc.cx, ss, d_score, 1, 1, P + o[pb + DQ_ATT_W3], 1, 16, sc.d_hid2, 16, Ns))) return rc;
+        hipLaunchKernelGGL(k_sig_bwd, ew(Ns * 16), b256, 0, ss, sc.d_hid2, t->hid2[s], Ns * 16);
+        st_tn(*sc.cx, ss, t->hid1[s], 64, 64, sc.d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_W2]);
+        st_cs(*sc.cx, ss, sc.d_hid2, 16, 16, Ns, G + o[pb + DQ_ATT_B2]);
+        if ((rc = st_back(*sc.cx, ss, sc.d_hid2, 16, 16, P + o[pb + DQ_ATT_W2], 16, 64, sc.d_hid1, 64, Ns))) return rc;
+        hipLaunchKernelGGL(k_sig_bwd, ew(Ns * 64), b256, 0, ss, sc.d_hid1, t->hid1[s], Ns * 64);
+        st_tn(*sc.cx, ss, t->inp[s], 4 * E, 4 * E, sc.d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_W1]);
+        st_cs(*sc.cx, ss, sc.d_hid1, 64, 64, Ns, G + o[pb + DQ_ATT_B1]);
+        if ((rc = st_back(*sc.cx, ss, sc.d_hid1, 64, 64, P + o[pb + DQ_ATT_W1], 64, 4 * E, sc.d_inp, 4 * E, Ns))) return rc;
+        hipLaunchKernelGGL(k_att_inp_bwd, ew(N * E), b256, 0, ss, sc.d_inp, t->q, Kk, dK, sc.dq, N, L, E);
     }
+    if ((rc = join())) return rc;
     // first GRU of every input in one launch: every state has an upstream gradient (it is a key and an AUGRU input)
     if ((rc = layer_backward(t, N, 0, nullptr, 0, dKs, nullptr, st))) return rc;
+    if ((rc = fork())) return rc;
     for (int s = 0; s < S; ++s) {
-        // its inputs are embedding rows
-        if ((rc = cell_backward_post(t, N, t->gru[s], t->X[s], t->dAg[s], t->dAc[s], t->d_inp /* scratch [N*L, E] */, false, st))) return rc;
-        hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, seq[s], N, L, H, E, t->d_inp, (int64_t)L * E, G + o[DP_SEQ_EMB]);
+        hipStream_t ss = stream_of(s);
+        const InputScratch& sc = scratch_of(s);
+        // its inputs are embedding rows (the table gradient takes float atomics from both streams)
+        if ((rc = cell_backward_post(t, N, t->gru[s], t->X[s], t->dAg[s], t->dAc[s], sc.d_inp /* scratch [N*L, E] */, false, ss, sc))) return rc;
+        hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, ss, seq[s], N, L, H, E, sc.d_inp, (int64_t)L * E, G + o[DP_SEQ_EMB]);
     }
+    if ((rc = join())) return rc;
+    if (two) hipLaunchKernelGGL(k_add_inplace, ew(N * E), b256, 0, st, t->dq, t->dq2, N * E);      // the query gradient of the odd inputs
     hipLaunchKernelGGL(k_emb_mean_bwd, g4, b256, 0, st, t->ids10, N, 10, H, E, t->dq, (int64_t)E, G + o[DP_SEQ_EMB]);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;

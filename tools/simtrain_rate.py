@@ -20,6 +20,7 @@ seqs = [t(rs.randint(0, 284, size=(N, 64)).astype(np.int32)) for _ in range(2)]
 # RECUR_ROWS=8|32 pins the row-tile form of the persistent recurrences (default: automatic); ALGOS=lstm,dien restricts the families
 from rl4rs_amd import _lib
 _lib.check(_lib.load().rl4rs_recur_train_set_rows(int(os.environ.get('RECUR_ROWS', '0'))))
+_lib.check(_lib.load().rl4rs_dientrain_set_fork(int(os.environ.get('DIEN_FORK', '1'))))        # DIEN_FORK=0: per-input chains on one stream
 for algo in os.environ.get('ALGOS', 'dnn,widedeep,lstm,dien').split(','):
     if algo == 'dien':
         tr = DeviceDienTrainer(CFG, init_dien_weights(CFG, seed=1), max_batch=N)
