@@ -176,7 +176,6 @@ struct rl4rs_dientrain {
     float *hprev2, *dX2, *d_hid2b, *d_hid1b, *d_inp2, *dq2;
 };
 
-static int g_dientrain_fork = 1;
 
 // scratch of one stream's per-input chains
 struct InputScratch { TrainCtx* cx; float *hprev, *dX, *d_hid2, *d_hid1, *d_inp, *dq; };

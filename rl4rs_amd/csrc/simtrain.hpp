@@ -195,6 +195,8 @@ struct GruSave {
     const int32_t* ids;
 };
 
+static int g_dientrain_fork = 1;       // rl4rs_dientrain_set_fork: per-input launch chains on two streams (dien and lstm trainers)
+
 struct rl4rs_simtrain {
     rl4rs_simnet_cfg c;
     int64_t n_params;
@@ -211,7 +213,15 @@ struct rl4rs_simtrain {
     float *g_dA, *g_dX, *g_hprev, *g_G, *g_Gh, *g_dh, *g_dhp, *g_dhg, *g_drh, *g_zero, *g_uzrT, *g_uhT, *g_tmpw;
     int32_t* g_iota;                   // 0, 1, 2, ... (persistent recurrence kernels, recur_train.hpp); NULL: step-by-step form
     std::vector<void*> owned;
+    // lstm, round 6: the category GRU (its own length: its own persistent launches) and the LAST sequence GRU's gradient chain run on
+    // a second stream with their own scratch, beside the sequence GRUs' launches and the other chains (rl4rs_dientrain_set_fork(0):
+    // one stream)
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_mid, ev_join;
+    float *g_dX2, *g_hprev2, *g_tmpw2, *wt2, *part2;
+    size_t part_cap2;
 };
+struct GruScratch { float *dX, *hprev, *tmpw, *wt, *part; size_t part_cap; };
 
 namespace {
 
@@ -376,7 +386,7 @@ int gru_backward_launch_multi(rl4rs_simtrain* t, int N, GruSave* const* gs, cons
 
 // use_dA != NULL: the recurrence already ran (gru_backward_launch_multi) and left the gate gradients there - only the
 // parameter gradients and the embedding scatter remain
-int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t ld_up, float* use_dA, hipStream_t st) {
+int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t ld_up, float* use_dA, hipStream_t st, const GruScratch& sc) {
     const int E = t->c.emb_size, U = t->c.hidden_units, H = t->c.category_hash_size, len = g.len;
     const float* K = t->params + t->off[g.pk];
     const float* Rw = t->params + t->off[g.pk + 1];
@@ -410,15 +420,15 @@ int gru_backward(rl4rs_simtrain* t, int N, GruSave& g, const float* up, int64_t 
     }
     // parameter gradients over all (row, step) samples
     const int Ns = N * len;
-    hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, t->g_hprev, N, U, len);
-    const TrainCtx cx = {t->chunk, t->part, t->wt, t->part_cap};
+    hipLaunchKernelGGL(k_shift_prev, dim3((Ns * U + 255) / 256), b256, 0, st, g.H, sc.hprev, N, U, len);
+    const TrainCtx cx = {t->chunk, sc.part, sc.wt, sc.part_cap};
     st_tn_cs(cx, st, g.X, E, E, dA, 3 * U, 3 * U, Ns, gK, gb);
-    st_tn(cx, st, t->g_hprev, U, U, dA, 3 * U, 2 * U, Ns, t->g_tmpw);                                   // [U, 2U]
-    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, t->g_tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
-    st_tn(cx, st, g.RH, U, U, dA + 2 * U, 3 * U, U, Ns, t->g_tmpw);                                      // [U, U]
-    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR + 2 * U, (size_t)3 * U * 4, t->g_tmpw, (size_t)U * 4, (size_t)U * 4, U, hipMemcpyDeviceToDevice, st));
-    if ((rc = st_back(cx, st, dA, 3 * U, 3 * U, K, 3 * U, E, t->g_dX, E, Ns))) return rc;
-    hipLaunchKernelGGL(k_emb_flatten_bwd, dim3((N + 3) / 4), b256, 0, st, g.ids, N, len, H, E, t->g_dX, (int64_t)len * E,
+    st_tn(cx, st, sc.hprev, U, U, dA, 3 * U, 2 * U, Ns, sc.tmpw);                                   // [U, 2U]
+    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR, (size_t)3 * U * 4, sc.tmpw, (size_t)2 * U * 4, (size_t)2 * U * 4, U, hipMemcpyDeviceToDevice, st));
+    st_tn(cx, st, g.RH, U, U, dA + 2 * U, 3 * U, U, Ns, sc.tmpw);                                      // [U, U]
+    RL4RS_HIP_TRY(hipMemcpy2DAsync(gR + 2 * U, (size_t)3 * U * 4, sc.tmpw, (size_t)U * 4, (size_t)U * 4, U, hipMemcpyDeviceToDevice, st));
+    if ((rc = st_back(cx, st, dA, 3 * U, 3 * U, K, 3 * U, E, sc.dX, E, Ns))) return rc;
+    hipLaunchKernelGGL(k_emb_flatten_bwd, dim3((N + 3) / 4), b256, 0, st, g.ids, N, len, H, E, sc.dX, (int64_t)len * E,
                        t->grad + t->off[g.emb]);
     RL4RS_LAUNCH_CHECK();
     return RL4RS_OK;
@@ -431,6 +441,7 @@ extern "C" {
 int rl4rs_simtrain_destroy(rl4rs_simtrain* t) {
     if (!t) return RL4RS_OK;
     for (void* q : t->owned) (void)hipFree(q);
+    if (t->side) { (void)hipStreamDestroy(t->side); (void)hipEventDestroy(t->ev_fork); (void)hipEventDestroy(t->ev_mid); (void)hipEventDestroy(t->ev_join); }
     delete t;
     return RL4RS_OK;
 }
@@ -546,6 +557,16 @@ int rl4rs_simtrain_create(const rl4rs_simnet_cfg* c, const rl4rs_simnet_weights*
         ST_FAIL(al(&t->g_dhg, B * U)); ST_FAIL(al(&t->g_drh, B * U)); ST_FAIL(al(&t->g_zero, B * U));
         ST_FAIL(al(&t->g_uzrT, 2 * U * U)); ST_FAIL(al(&t->g_uhT, U * U)); ST_FAIL(al(&t->g_tmpw, U * 2 * U));
         ST_HIP(hipMemsetAsync(t->g_zero, 0, B * U * 4, st));
+        {   // second stream + its scratch (only GRU gradient chains run there: widest reduction [E x 3U] / [U x 3U])
+            const int64_t wmax2 = (E > U ? E : U) * 3 * U;
+            ST_FAIL(al(&t->g_dX2, nm * E)); ST_FAIL(al(&t->g_hprev2, nm * U)); ST_FAIL(al(&t->g_tmpw2, U * 2 * U));
+            ST_FAIL(al(&t->wt2, wmax2)); ST_FAIL(al(&t->part2, (size_t)nz_all * wmax2));
+            t->part_cap2 = (size_t)nz_all * wmax2;
+            ST_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+            ST_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+            ST_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
+            ST_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        }
         {
             float* p; ST_FAIL(al(&p, B)); t->g_iota = reinterpret_cast<int32_t*>(p);
             std::vector<int32_t> io(B);
@@ -630,12 +651,17 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         for (int g = 0; g <= S; ++g) t->gru[g].ids = g == 0 ? cat : seq[g - 1];
         const bool pers = gru_persistent(t, N, t->gru[0].len) && gru_persistent(t, N, t->gru[1].len);
         if (pers) {
-            // persistent recurrence kernels: the category GRU alone (its own length), the sequence GRUs together in ONE launch
+            // persistent recurrence kernels: the category GRU alone (its own length), the sequence GRUs together in ONE launch - the
+            // two launches (32 + 64 workgroups at batch 256) and their input chains side by side on two streams
+            const bool two = t->side != nullptr && g_dientrain_fork;
+            hipStream_t s2nd = two ? t->side : st;
+            if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_fork, st)); RL4RS_HIP_TRY(hipStreamWaitEvent(t->side, t->ev_fork, 0)); }
             GruSave* one[1] = {&t->gru[0]};
-            if ((rc = gru_forward_multi(t, N, one, 1, st))) return rc;
+            if ((rc = gru_forward_multi(t, N, one, 1, s2nd))) return rc;
             GruSave* seqs[4];
             for (int s2 = 0; s2 < S; ++s2) seqs[s2] = &t->gru[1 + s2];
             if ((rc = gru_forward_multi(t, N, seqs, S, st))) return rc;
+            if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_join, t->side)); RL4RS_HIP_TRY(hipStreamWaitEvent(st, t->ev_join, 0)); }
         }
         for (int g = 0; g <= S; ++g) {
             if (!pers && (rc = gru_forward(t, N, t->gru[g], st))) return rc;
@@ -692,19 +718,31 @@ int rl4rs_simtrain_grad(rl4rs_simtrain* t, int32_t N, const float* dense, const 
         RL4RS_HIP_TRY(hipMemsetAsync(G + o[SP_SEQ_EMB], 0, (size_t)H * E * 4, st));
         hipLaunchKernelGGL(k_emb_flatten_bwd, g4, b256, 0, st, cat, N, Cn, H, E, t->d_feat + S * U + 2 * U, (int64_t)FCK, G + o[SP_CAT_EMB]);
         const bool pers = gru_persistent(t, N, t->gru[0].len) && gru_persistent(t, N, t->gru[1].len);
+        const GruScratch sc_main = {t->g_dX, t->g_hprev, t->g_tmpw, t->wt, t->part, t->part_cap};
+        const GruScratch sc_side = {t->g_dX2, t->g_hprev2, t->g_tmpw2, t->wt2, t->part2, t->part_cap2};
+        const bool two = pers && t->side != nullptr && g_dientrain_fork;
+        hipStream_t s2nd = two ? t->side : st;
+        if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_fork, st)); RL4RS_HIP_TRY(hipStreamWaitEvent(t->side, t->ev_fork, 0)); }
         if (pers) {
+            // second stream: the category GRU's BPTT launch and its gradient chain; first stream: the sequence GRUs' launch
             GruSave* one[1] = {&t->gru[0]};
             const float* up0[1] = {t->d_feat + S * U + U};
-            if ((rc = gru_backward_launch_multi(t, N, one, up0, (int64_t)FCK, 1, st))) return rc;
+            if ((rc = gru_backward_launch_multi(t, N, one, up0, (int64_t)FCK, 1, s2nd))) return rc;
             GruSave* seqs[4];
             const float* ups[4];
             for (int s2 = 0; s2 < S; ++s2) { seqs[s2] = &t->gru[1 + s2]; ups[s2] = t->d_feat + s2 * U; }
             if ((rc = gru_backward_launch_multi(t, N, seqs, ups, (int64_t)FCK, S, st))) return rc;
+            if (two) RL4RS_HIP_TRY(hipEventRecord(t->ev_mid, st));           // the sequence GRUs' gate gradients exist from here on
         }
         for (int g = 0; g <= S; ++g) {
             const int off = g == 0 ? S * U + U : (g - 1) * U;
-            if ((rc = gru_backward(t, N, t->gru[g], t->d_feat + off, (int64_t)FCK, pers ? t->gru[g].dA : (float*)nullptr, st))) return rc;
+            // chains: category GRU and the LAST sequence GRU on the second stream (the latter behind the sequence launch), the rest here
+            const bool on_side = two && (g == 0 || (g == S && S > 1));
+            if (on_side && g == S) RL4RS_HIP_TRY(hipStreamWaitEvent(t->side, t->ev_mid, 0));
+            if ((rc = gru_backward(t, N, t->gru[g], t->d_feat + off, (int64_t)FCK, pers ? t->gru[g].dA : (float*)nullptr, on_side ? t->side : st,
+                                   on_side ? sc_side : sc_main))) return rc;
         }
+        if (two) { RL4RS_HIP_TRY(hipEventRecord(t->ev_join, t->side)); RL4RS_HIP_TRY(hipStreamWaitEvent(st, t->ev_join, 0)); }
     } else {
         hipLaunchKernelGGL(k_elu_bwd, ew(N * 256), b256, 0, st, t->d_obs, (int64_t)256, t->obs, (int64_t)256, (const uint8_t*)nullptr, 0.f, N * 256, 256);
         tn(t->a1, 256, 256, t->d_obs, 256, 256, G + o[SP_OBS_W]);
