@@ -271,6 +271,15 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     if (!grid_barrier(a.bar, a.dead_host, gridDim.x, gen, [&]() { if (is_a) prefetch(a.mb_begin); })) return;
     for (int mb = a.mb_begin; mb < a.mb_end; ++mb) {
         const size_t lo = (size_t)mb * MB;
+        // An opaque zero, new in every iteration: every scalar offset / descriptor below is formed from it, so none of them is
+        // loop-invariant.  Left invariant, LLVM hoists all ~200 of them out of the minibatch loop, runs out of SGPRs and parks them
+        // in VGPR lanes: 355 v_writelane in front of the loop and 649 v_readlane - VALU instructions, each in front of the load it
+        // feeds - per minibatch and wave (the code object's "SGPR spills").  An s_add in place costs nothing.
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const int wz = wave + z;
+        const __amdgpu_buffer_rsrc_t rs_prm = pass_rsrc(a.prm + z, (size_t)n_prm * 4), rs_am = pass_rsrc(a.am + z, (size_t)n_prm * 4),
+                                     rs_av = pass_rsrc(a.av + z, (size_t)n_prm * 4), rs_w2t = pass_rsrc(a.w2t + z, (size_t)HID * AE * 4);
         // ------------------------------------------------------------------ phase A
         RL4RS_PT(0);
         if (is_a) {
@@ -293,12 +302,12 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             const int vl = lane * 4;
             float bv1[32], bv2[32], bv2t[8], wv[36], b2v[5];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) bv1[u] = bld(rs_prm, vl, (wave * 32 + u) * 256);                       // W1 rows wave*32 .. +31
-            const float b1v = bld(rs_prm, vl, o_b1 * 4);
+            for (int u = 0; u < 32; ++u) bv1[u] = bld(rs_prm, vl, (wz * 32 + u) * 256);                       // W1 rows wave*32 .. +31
+            const float b1v = bld(rs_prm, vl, (o_b1 + z) * 4);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) b2v[i] = bld(rs_prm, vl, (o_b2 + 64 * i) * 4);                          // (past the buffer: 0)
+            for (int i = 0; i < 5; ++i) b2v[i] = bld(rs_prm, vl, (o_b2 + 64 * i + z) * 4);                          // (past the buffer: 0)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bv2t[u] = bld(rs_prm, vl, (o_w2 + (wave * 8 + u) * 285 + 256) * 4);     // W2e rows wave*8 .. +7, columns 256 ..
+            for (int u = 0; u < 8; ++u) bv2t[u] = bld(rs_prm, vl, (o_w2 + (wz * 8 + u) * 285 + 256) * 4);     // W2e rows wave*8 .. +7, columns 256 ..
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PF_OBS; ++u) s_x[(u * 2 + (tid >> 8)) * 260 + (tid & 255)] = pf_obs[u];       // i = tid + 512 u -> row i / 256
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             slice(s_x + (lane & 3) * 260 + wave * 32, 260, std::integral_constant<int, 8>(), bv1, o0, o1);
             // layer 2's main operand (column tile wave & 3, K half wave >> 2) flies during the partial-sum exchange and the tanh
 #pragma unroll
-            for (int u = 0; u < 32; ++u) bv2[u] = bld(rs_prm, vl, (o_w2 + ((wave >> 2) * 32 + u) * 285 + (wave & 3) * 64) * 4);
+            for (int u = 0; u < 32; ++u) bv2[u] = bld(rs_prm, vl, (o_w2 + ((wz >> 2) * 32 + u) * 285 + (wz & 3) * 64) * 4);
             __builtin_amdgcn_sched_barrier(0);
             put(s_p + wave * 512, 64, o0, o1);
             __syncthreads();
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             slice(s_hh + (lane & 3) * 68 + wave * 8, 68, std::integral_constant<int, 2>(), bv2t, t0, t1);
             // dH's operand (rows 36 w .. of the transposed W2e; rows >= 285 are past the buffer: 0) flies during the row losses
 #pragma unroll
-            for (int u = 0; u < 36; ++u) wv[u] = bld(rs_w2t, vl, (wave * 36 + u) * 256);
+            for (int u = 0; u < 36; ++u) wv[u] = bld(rs_w2t, vl, (wz * 36 + u) * 256);
             __builtin_amdgcn_sched_barrier(0);
             put(s_p + (wave >> 2) * 2048 + (wave & 3) * 64, 256, o0, o1);
             put(s_p + 4096 + wave * 512, 64, t0, t1);
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                     const int v_a = (half * lda + T.tm * 32 + li) * 4, v_b = (half * ldb + (j_ok ? j : T.Nc - 1)) * 4;
                     f32x16 acc;
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    for (int n = q * spq; n < (q + 1) * spq; n += 2 * TP) {
+                    for (int n = q * spq + z; n < (q + 1) * spq; n += 2 * TP) {
                         float av[TP], bw[TP];
 #pragma unroll
                         for (int u = 0; u < TP; ++u) {
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                     const __amdgpu_buffer_rsrc_t rs_x = T.first ? pass_rsrc(a.dHpre, (size_t)MB * HID * 4) : pass_rsrc(a.dOut, (size_t)MB * AE * 4);
                     const int v_x = (half * T.Nc + (j_ok ? j : T.Nc - 1)) * 4;
                     float bsum = 0.f;
-                    for (int n = q * spq; n < (q + 1) * spq; n += 32) {
+                    for (int n = q * spq + z; n < (q + 1) * spq; n += 32) {
                         float x[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) x[u] = bld(rs_x, v_x, (n + 2 * u) * T.Nc * 4);
