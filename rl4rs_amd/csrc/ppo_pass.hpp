@@ -426,7 +426,8 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             }
         } else {
             float bv1[32], bv2[32];
-            load_w1(q1 * (OD / parts), bv1);
+            const int q1z = q1 + z;                       // (loop-variant: see `z`)
+            load_w1(q1z * (OD / parts), bv1);
             const float b1v = bld(rs_prm, (tid % HID) * 4, o_b1 * 4);
             __builtin_amdgcn_sched_barrier(0);
             if (can_pf) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             __syncthreads();
             RL4RS_PT(1);
             {   // layer 1, split over K: wave -> (tile t1, part q1)
-                const int kper = OD / parts, kb = q1 * kper, ke = kb + kper;
+                const int kper = OD / parts, kb = q1z * kper, ke = kb + kper;
                 f32x16 acc;
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 for (int k = kb;;) {                                        // one memory round trip per 64 k (kper % 64 == 0)
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                         }
                     }
             };
-            for (int t = wave; t < NT2; t += 8) l2_tile(t, bv2, 0.f, false);
+            for (int t = wz; t < NT2; t += 8) l2_tile(t, bv2, 0.f, false);
             __syncthreads();
             RL4RS_PT(3);
             {   // row losses: wave w takes rows w, w + 8, ...
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 f32x16 acc;
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 const float* drow = s_d + li * SA;
-                const int kb = q1 * kper_h, k_hi = min(kb + kper_h, AE);
+                const int kb = q1z * kper_h, k_hi = min(kb + kper_h, AE);
                 for (int k = kb; k < k_hi; k += 72) {                       // 36 loads in flight per trip (one trip for AE <= 288)
                     load_w2t(k, wv);
                     __builtin_amdgcn_sched_barrier(0);
