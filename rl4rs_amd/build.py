@@ -12,7 +12,7 @@ SOURCES = ['env.hip', 'gemm.hip', 'dien.hip', 'augru_x.hip', 'policy.hip', 'reco
 # same-box A/B: k_cat_attn2 -8 %, k_din_x -2 %, end to end +0.7 %).  The other units keep it (the learners' element-wise and
 # reduction kernels are 1 - 4 % faster with it) - and so does augru_x.hip: k_augru_x<2,4,2> sits at the register limit and spills without it.
 NO_SLP = ('dien.hip', 'gemm.hip')
-HEADERS = ['common.hpp', 'recur_args.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'recur8.hpp', 'mfma4.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', 'amlp_fused.hpp', 'ppo_pass.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
+HEADERS = ['common.hpp', 'recur_args.hpp', 'augru_x.hpp', 'din_x.hpp', 'recur_train.hpp', 'recur8.hpp', 'mfma4.hpp', 'simnet.hpp', 'gather_kernels.hpp', 'simtrain.hpp', 'dientrain.hpp', 'rawtrain.hpp', 'qlearn.hpp', 'contirl.hpp', 'amlp_fused.hpp', 'ppo_pass.hpp', 'policy_tile_std.hpp', os.path.join('..', '..', 'include', 'rl4rs_hip.h')]
 
 
 def _stale():

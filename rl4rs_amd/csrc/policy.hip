@@ -886,6 +886,8 @@ __global__ __launch_bounds__(512) void k_policy_tile(TileArgs a) {
     }
 }
 
+#include "policy_tile_std.hpp"
+
 }  // namespace rl4rs
 
 using namespace rl4rs;
@@ -1010,8 +1012,20 @@ bool tile_fits(const rl4rs_policy* p) {
 size_t tile_smem(const PolDims& d, int mode) {
     return (size_t)(8 * ((d.OD | 1) + (d.HID | 1) + (mode == 2 ? 2 : 1) * (d.AE | 1) + d.W) + 8 * 1024) * 4;
 }
+// the default shape takes the 4x4x1 form (policy_tile_std.hpp); RL4RS_POLICY_OPT_PPO_STD = 0 keeps the 32x32x2 one for A/B runs
+bool tile_is_std(const rl4rs_policy* p) {
+    const PolDims& d = p->d;
+    return p->opt_ppo_std && d.OD == 256 && d.HID == 64 && d.A == 284 && d.AE == 285 && d.W == 9;
+}
 template <int MODE>
 int launch_policy_tile(rl4rs_policy* p, const TileArgs& a, hipStream_t st) {
+    if (tile_is_std(p)) {
+        int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_policy_tile_std<MODE>), TILE_STD_SMEM);      // (72 KB: above the 64 KB default)
+        if (rca) return rca;
+        hipLaunchKernelGGL(k_policy_tile_std<MODE>, dim3((a.N + 7) / 8), dim3(512), TILE_STD_SMEM, st, a);
+        RL4RS_LAUNCH_CHECK();
+        return RL4RS_OK;
+    }
     const size_t smem = tile_smem(p->d, MODE);
     if (!p->tile_attr[MODE]) {       // per-function limit, only ever raised (policies of different shapes share the kernel)
         int rca = raise_dyn_smem(reinterpret_cast<const void*>(&k_policy_tile<MODE>), smem);

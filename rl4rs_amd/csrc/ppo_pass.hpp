@@ -128,6 +128,32 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t rs, int voff, int so
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 
+// one K slice of [8 rows] x [64 columns] on 4x4x1 MFMAs: A rows from LDS (16-byte reads of 4 consecutive k of row lane % 4 of each
+// 4-row tile), NQ quads of k, B = bw[k] (the wave's register per k: W[k][lane]); two accumulator chains per row tile
+template <int NQ>
+__device__ __forceinline__ void std_slice(const float* arow, int stride, const float (&bw)[4 * NQ], f32x4_t& o0, f32x4_t& o1) {
+    f32x4_t c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+    for (int qd = 0; qd < NQ; ++qd) {
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(arow + 4 * qd), a1 = *reinterpret_cast<const f32x4_t*>(arow + 4 * stride + 4 * qd);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj], bw[4 * qd + jj], c00, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj], bw[4 * qd + jj], c10, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj + 1], bw[4 * qd + jj + 1], c01, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj + 1], bw[4 * qd + jj + 1], c11, 0, 0, 0);
+        }
+    }
+    o0 = c00 + c01;
+    o1 = c10 + c11;
+}
+// register i of lane l = out[row i][column l]
+__device__ __forceinline__ void std_put(float* dst, int ld, int lane, const f32x4_t& o0, const f32x4_t& o1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dst[i * ld + lane] = o0[i]; dst[(4 + i) * ld + lane] = o1[i]; }
+}
+
+
 // STD: OD = 256, HID = 64, A = 284 (AE = 285, W = 9), R = 8 rows per workgroup, MB % 256 == 0 - everything constant folds.
 template <bool STD>
 __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
@@ -321,37 +347,14 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             }
             __syncthreads();
             RL4RS_PT(1);
-            // one K slice of [8 rows] x [64 columns]: A rows from LDS (16-byte reads of 4 consecutive k of row lane % 4 of each row
-            // tile), NQ quads of k, two accumulator chains per row tile; returns the two row tiles' sums
-            auto slice = [&](const float* arow, int stride, auto nq_tag, const float* bw, f32x4_t& o0, f32x4_t& o1) {
-                constexpr int NQ = decltype(nq_tag)::value;
-                f32x4_t c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
-#pragma unroll
-                for (int qd = 0; qd < NQ; ++qd) {
-                    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(arow + 4 * qd), a1 = *reinterpret_cast<const f32x4_t*>(arow + 4 * stride + 4 * qd);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj += 2) {
-                        c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj], bw[4 * qd + jj], c00, 0, 0, 0);
-                        c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj], bw[4 * qd + jj], c10, 0, 0, 0);
-                        c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj + 1], bw[4 * qd + jj + 1], c01, 0, 0, 0);
-                        c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj + 1], bw[4 * qd + jj + 1], c11, 0, 0, 0);
-                    }
-                }
-                o0 = c00 + c01;
-                o1 = c10 + c11;
-            };
-            auto put = [&](float* dst, int ld, const f32x4_t& o0, const f32x4_t& o1) {       // register i of lane l = out[row i][column l]
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { dst[i * ld + lane] = o0[i]; dst[(4 + i) * ld + lane] = o1[i]; }
-            };
             f32x4_t o0, o1;
             // layer 1: wave w multiplies k in [32 w, 32 w + 32)
-            slice(s_x + (lane & 3) * 260 + wave * 32, 260, std::integral_constant<int, 8>(), bv1, o0, o1);
+            std_slice<8>(s_x + (lane & 3) * 260 + wave * 32, 260, bv1, o0, o1);
             // layer 2's main operand (column tile wave & 3, K half wave >> 2) flies during the partial-sum exchange and the tanh
 #pragma unroll
             for (int u = 0; u < 32; ++u) bv2[u] = bld(rs_prm, vl, (o_w2 + ((wz >> 2) * 32 + u) * 285 + (wz & 3) * 64) * 4);
             __builtin_amdgcn_sched_barrier(0);
-            put(s_p + wave * 512, 64, o0, o1);
+            std_put(s_p + wave * 512, 64, lane, o0, o1);
             __syncthreads();
             {   // thread = (row wave, column lane)
                 float sum = b1v;
@@ -364,15 +367,15 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             __syncthreads();
             RL4RS_PT(2);
             // layer 2: columns 0..255 as 4 tiles x 2 K halves (one per wave), columns 256..284 split over K eight ways
-            slice(s_hh + (lane & 3) * 68 + (wave >> 2) * 32, 68, std::integral_constant<int, 8>(), bv2, o0, o1);
+            std_slice<8>(s_hh + (lane & 3) * 68 + (wave >> 2) * 32, 68, bv2, o0, o1);
             f32x4_t t0, t1;
-            slice(s_hh + (lane & 3) * 68 + wave * 8, 68, std::integral_constant<int, 2>(), bv2t, t0, t1);
+            std_slice<2>(s_hh + (lane & 3) * 68 + wave * 8, 68, bv2t, t0, t1);
             // dH's operand (rows 36 w .. of the transposed W2e; rows >= 285 are past the buffer: 0) flies during the row losses
 #pragma unroll
             for (int u = 0; u < 36; ++u) wv[u] = bld(rs_w2t, vl, (wz * 36 + u) * 256);
             __builtin_amdgcn_sched_barrier(0);
-            put(s_p + (wave >> 2) * 2048 + (wave & 3) * 64, 256, o0, o1);
-            put(s_p + 4096 + wave * 512, 64, t0, t1);
+            std_put(s_p + (wave >> 2) * 2048 + (wave & 3) * 64, 256, lane, o0, o1);
+            std_put(s_p + 4096 + wave * 512, 64, lane, t0, t1);
             __syncthreads();
             RL4RS_PT(3);
             {   // row losses: wave w owns row w - it first joins the partial sums of its row (+ bias, + action mask)
@@ -412,9 +415,9 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             __syncthreads();
             RL4RS_PT(4);
             // dH = dOut W2e^T: wave w multiplies k in [36 w, 36 w + 36)
-            slice(s_g + (lane & 3) * 288 + wave * 36, 288, std::integral_constant<int, 9>(), wv, o0, o1);
+            std_slice<9>(s_g + (lane & 3) * 288 + wave * 36, 288, wv, o0, o1);
             RL4RS_PT(12);
-            put(s_p + wave * 512, 64, o0, o1);
+            std_put(s_p + wave * 512, 64, lane, o0, o1);
             __syncthreads();
             RL4RS_PT(13);
             {

@@ -154,6 +154,52 @@ def test_ppo_epoch_equals_minibatch_sequence():
     assert not torch.equal(p1.params().cpu(), torch.from_numpy(flat))
 
 
+@pytest.mark.parametrize('N,with_mask', [(4096, True), (1003, True), (517, False), (5, True)])
+def test_tile_kernels_of_the_default_shape_match_the_generic_ones(N, with_mask):
+    """k_policy_tile_std<0 / 1 / 2> (the default shape on 4-row x 64-column MFMA tiles, policy_tile_std.hpp) against k_policy_tile (32x32x2
+    tiles, RL4RS_POLICY_OPT_PPO_STD = 0): act with the same seed (masked logits to 2e-5, identical draws wherever the top two Gumbel
+    scores are not within rounding of each other - counted, at most a handful), evaluate, and the A2C / PPO gradient; ragged last
+    workgroups (N % 8 != 0), with and without a mask; and act / evaluate against the float64 restatement."""
+    import torch
+    from rl4rs_amd.device import DevicePolicy
+    from rl4rs_amd.nets.policy import init_policy_params
+    from oracle import policy as OP
+    rs = np.random.RandomState(N)
+    obs, mask, bits = _data(N, rs)
+    if not with_mask:
+        mask = np.ones_like(mask)
+    flat = init_policy_params(seed=6) + (rs.randn(34973) * 0.05).astype(np.float32)
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    o, b = t(obs), (torch.from_numpy(bits).cuda() if with_mask else None)
+    std = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+    gen = DevicePolicy(256, 64, 284, max_rows=N, params=flat)
+    gen.set_option('ppo_std', 0)
+    a1, lp1, v1, e1, lg1 = std.act(o, mask_bits=b, seed=11, step=3, want_logits=True)
+    a2, lp2, v2, e2, lg2 = gen.act(o, mask_bits=b, seed=11, step=3, want_logits=True)
+    ref_logits, ref_value = OP.forward(flat, obs, mask)
+    live = mask.astype(bool)
+    assert np.abs(lg1.cpu().numpy()[live] - ref_logits[live]).max() < 5e-5 and np.abs(v1.cpu().numpy() - ref_value).max() < 5e-5
+    assert np.abs(lg1.cpu().numpy()[live] - lg2.cpu().numpy()[live]).max() < 2e-5
+    assert (lg1.cpu().numpy()[~live] < -1e38).all()
+    assert mask[np.arange(N), a1.cpu().numpy()].all()                                   # never a masked action
+    assert (a1 != a2).sum().item() <= max(2, N // 500), (a1 != a2).sum().item()
+    same = (a1 == a2).cpu().numpy()
+    assert np.allclose(lp1.cpu().numpy()[same], lp2.cpu().numpy()[same], atol=2e-5) and torch.allclose(v1, v2, atol=2e-5) and torch.allclose(e1, e2, atol=2e-5)
+    l1, w1, n1, _ = std.evaluate(o, a2, mask_bits=b)
+    l2, w2, n2, _ = gen.evaluate(o, a2, mask_bits=b)
+    assert torch.allclose(l1, l2, atol=2e-5) and torch.allclose(w1, w2, atol=2e-5) and torch.allclose(n1, n2, atol=2e-5)
+    lsm = OP.log_softmax(ref_logits)
+    assert np.abs(l1.cpu().numpy() - lsm[np.arange(N), a2.cpu().numpy()]).max() < 5e-5
+    adv, ret = t(rs.randn(N) * 2), t(rs.randn(N) * 10 + 5)
+    for algo, kw in ((0, dict(vf_coeff=0.5, ent_coeff=0.01)),
+                     (1, dict(old_logp=l2, old_value=w2, old_logits=torch.clamp(lg2, min=-3.4e38), vf_coeff=0.5, ent_coeff=0.01, kl_coeff=0.2))):
+        g1, s1 = std.loss_grad(algo, o, a2, adv, ret, mask_bits=b, **kw)
+        g2, s2 = gen.loss_grad(algo, o, a2, adv, ret, mask_bits=b, **kw)
+        scale = max(1.0, g2.abs().max().item())
+        assert (g1 - g2).abs().max().item() < 2e-5 * scale * max(1, N // 256), (algo, (g1 - g2).abs().max().item(), scale)
+        assert torch.allclose(s1, s2, rtol=2e-4, atol=2e-3), (s1, s2)
+
+
 @pytest.mark.parametrize('MB,with_mask', [(256, True), (512, True), (256, False)])
 def test_ppo_pass_compile_time_instantiation_matches_the_runtime_one(MB, with_mask):
     """k_ppo_pass<true> (the default shape as compile-time constants: 4-row x 64-column MFMA tiles with K split over the waves, the
