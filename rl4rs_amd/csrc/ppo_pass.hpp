@@ -80,21 +80,52 @@ struct PassArgs {
 struct NoMid { __device__ void operator()() const {} };
 // DRAINED: the caller has already waited for every store another workgroup reads (each wave, before the call) and may still have
 // PRIVATE stores in flight behind them - the barrier then adds no wait of its own.
+//
+// Arrival, grids of up to 63 workgroups (RL4RS_PASS_FLAGS): every workgroup publishes its generation number in a word of ITS OWN
+// (bar[64 + workgroup], write-through) and wave 0 looks at all of them with ONE load per poll (lane l reads workgroup l's word,
+// lane 63 the timeout flag) - arrivals no longer queue up as read-modify-writes of one address.  Larger grids: the counter.
+#ifndef RL4RS_PASS_FLAGS
+#define RL4RS_PASS_FLAGS 1
+#endif
 template <typename Mid = NoMid, bool DRAINED = false>
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned* dead_host, unsigned nwg, unsigned& gen, Mid mid = Mid()) {
     __shared__ unsigned s_dead;
     if (!DRAINED || !RL4RS_PASS_WT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
+    const bool flags = RL4RS_PASS_FLAGS && RL4RS_PASS_WT && nwg <= 63u;
     if (threadIdx.x == 0) {
 #if !RL4RS_PASS_WT
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
         if (!DRAINED || !RL4RS_PASS_WT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags) __hip_atomic_store(bar + 64 + blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     mid();
-    if (threadIdx.x == 0) {
+    if (flags) {
+        if (threadIdx.x < 64) {
+            // bounded wait (~seconds): if the workgroups are not all resident the pass gives up instead of hanging the device
+            const unsigned lane = threadIdx.x;
+            unsigned* word = lane == 63u ? bar + 1 : bar + 64 + (lane < nwg ? lane : 0u);
+            unsigned spins = 0, dead = 0;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool here = lane == 63u || lane >= nwg || v >= gen;
+                dead = __builtin_amdgcn_readlane(lane == 63u ? v : 0u, 63);
+                if (__builtin_amdgcn_ballot_w64(here) == ~0ull || dead) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (dead_host) __hip_atomic_store(dead_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            if (lane == 0) s_dead = dead;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    } else if (threadIdx.x == 0) {
         const unsigned target = gen * nwg;
         // bounded wait (~seconds): if the workgroups are not all resident (a tool that serialises workgroups, a shared GPU)
         // the pass gives up instead of hanging the device - bar[1] is raised and rl4rs_policy_ppo_epoch reports it
