@@ -952,8 +952,8 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     if ((rc = alloc(&p->part, part_n))) return rc;
     if ((rc = alloc(&p->sumsq, 4))) return rc;
     if ((rc = alloc(&p->w2t, (size_t)hidden * p->d.AE))) return rc;
-    // bar[0] arrival counter, bar[1] sticky timeout flag, bar[64 .. 127] one arrival word per workgroup (grids of up to 63: ppo_pass.hpp)
-    { float* b4; if ((rc = alloc(&b4, 128))) return rc; p->bar = reinterpret_cast<unsigned*>(b4); }
+    // bar[0] arrival counter, bar[1] sticky timeout flag, bar[64 .. 315] one arrival word per workgroup (grids of up to 252: ppo_pass.hpp)
+    { float* b4; if ((rc = alloc(&b4, 320))) return rc; p->bar = reinterpret_cast<unsigned*>(b4); }
     float* t4;
     if ((rc = alloc(&t4, (size_t)max_rows * 4))) return rc;
     p->terms = reinterpret_cast<float4*>(t4);
@@ -961,7 +961,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     RL4RS_HIP_TRY(hipMemcpyAsync(p->params, params_host, (size_t)p->n_params * 4, hipMemcpyHostToDevice, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_m, 0, (size_t)p->n_params * 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->adam_v, 0, (size_t)p->n_params * 4, st));
-    RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 128 * 4, st));
+    RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 320 * 4, st));
     RL4RS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->dead_host), 64, hipHostMallocDefault));
     *p->dead_host = 0u;
     RL4RS_HIP_TRY(hipStreamSynchronize(st));
@@ -1420,7 +1420,7 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
         return RL4RS_ESTATE;
     }
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
-    RL4RS_HIP_TRY(hipMemsetAsync(p->bar + 64, 0, 64 * 4, st));         // (the per-workgroup arrival words count from 1 in every launch)
+    RL4RS_HIP_TRY(hipMemsetAsync(p->bar + 64, 0, 256 * 4, st));         // (the per-workgroup arrival words count from 1 in every launch)
     if (pass_is_std(p, c.minibatch)) hipLaunchKernelGGL(k_ppo_pass<true>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
     else hipLaunchKernelGGL(k_ppo_pass<false>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
     RL4RS_LAUNCH_CHECK();
