@@ -29,13 +29,13 @@ MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 # fp16x2 (k_augru_x): raw FETCH_SIZE 185.0 MB per obs-sized / 214.3 MB per reward-sized launch, x the factor calibrated on this
 # kernel's own LDS-DMA stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for
 # the 64-row form), + WRITE_SIZE 8.2 / 65.5 MB: (10 x 324.6 + 494.1) / 11.  fp32 (k_recur): not re-measured since round 1.
-TRAFFIC_SOURCE_FILE = 'profiles/r05q_pmc.md'
+TRAFFIC_SOURCE_FILE = 'profiles/r06p_pmc.md'
 TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 3.40e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
 TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (324.6 MB) + 1 reward-sized (494.1 MB) launches of an episode-batch; "
                 "rocprofv3 FETCH_SIZE x the factor calibrated on this kernel's stream (profiles/r02_fetch_calibration.md) + WRITE_SIZE, "
                 "arithmetic in the header of profiles/r05q_pmc.md; algorithmic bytes = 1746 distinct histories x 64 steps x 768 f32 = "
                 "343 MB read + 8.4 / 67 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
-GATHER_TRAFFIC_B = 6.48e7           # k_env_rows<2>: WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch (profiles/r04f_pmc.md; r05q_pmc.md: unchanged)
+GATHER_TRAFFIC_B = 6.48e7           # k_env_rows<2>: WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch (profiles/r04f_pmc.md; r05q_pmc.md, r06p_pmc.md: unchanged)
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
