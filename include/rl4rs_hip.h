@@ -577,7 +577,8 @@ int rl4rs_policy_status_words(rl4rs_policy* pol, uint32_t** words_dev);
  * Kernel-path selection of ONE handle, for A/B measurements and tests (defaults in brackets):
  *   TILE          [1] 0 = one-wave-per-sample forward / loss kernels instead of k_policy_tile
  *   PPO_FUSED     [1] 0 = per-minibatch kernel chain instead of the persistent k_ppo_pass
- *   PPO_ROWS      [8] samples per workgroup of k_ppo_pass: 8, 16 or 32
+ *   PPO_ROWS      [automatic] samples per workgroup of k_ppo_pass: 8, 16 or 32 pin the all-runtime instantiation's (automatic: 8);
+ *                     where the compile-time instantiation applies: 4 or 8 (automatic: 4 while MB / 4 <= 126 workgroups, else 8)
  *   RESIDENT_WGS [-1] >= 0: pretend the device holds only this many workgroups of k_ppo_pass at once (co-residency tests)
  *   PPO_STD       [1] 0 = the all-runtime instantiation of k_ppo_pass even at the default shape (256 -> 64 -> 284 + 1, 8 rows,
  *                     minibatch % 256 == 0), which otherwise runs the compile-time one (bit-identical results) */

@@ -946,7 +946,7 @@ int rl4rs_policy_create(int32_t obs_dim, int32_t hidden, int32_t action_size, in
     p->train_attr = false;
     p->pass_launched = false;
     p->pass_resident_wgs = -1;
-    p->opt_tile = true; p->opt_ppo_fused = true; p->opt_ppo_std = true; p->opt_ppo_rows = 8; p->opt_resident_cap = -1;
+    p->opt_tile = true; p->opt_ppo_fused = true; p->opt_ppo_std = true; p->opt_ppo_rows = 0; p->opt_resident_cap = -1;
     p->dead_host = nullptr;
     p->tile_attr[0] = p->tile_attr[1] = p->tile_attr[2] = false;
     int rc;
@@ -1334,9 +1334,17 @@ bool pass_is_std(const rl4rs_policy* p, int minibatch);
 
 int pass_rows_per_wg(const rl4rs_policy* p) {
     // rows per workgroup: the per-row loss code is the longest stretch of phase A, so it is spread over as many compute units
-    // as the minibatch allows (8 rows = one row per wave); the MFMA tiles stay 32 rows tall and mostly idle, which is free here
-    // (RL4RS_POLICY_OPT_PPO_ROWS = 16 / 32 for A/B runs)
+    // as the minibatch allows (8 rows = one row per wave; RL4RS_POLICY_OPT_PPO_ROWS = 16 / 32 for A/B runs of the all-runtime form;
+    // 4 = the compile-time form's 4-row workgroups - one row per SIMD - where that form applies, 8 elsewhere)
     return (p->opt_ppo_rows == 32 || p->opt_ppo_rows == 16) ? p->opt_ppo_rows : 8;
+}
+// rows per workgroup of the compile-time instantiation (pass_is_std): 4 while MB / 4 workgroups still meet at the arrival-word
+// barrier (<= 126: MB = 256 is 19.4 us per minibatch against 20.6 with 8 rows; MB = 512 would be 128 workgroups on the counter
+// barrier: 23.7 against 22.3), 8 beyond; RL4RS_POLICY_OPT_PPO_ROWS = 4 / 8 pins it
+int pass_std_rows(const rl4rs_policy* p, int minibatch) {
+    if (p->opt_ppo_rows == 4) return 4;
+    if (p->opt_ppo_rows == 8) return 8;
+    return minibatch / 4 <= 126 ? 4 : 8;
 }
 
 // k_ppo_pass's dynamic-LDS opt-in is a property of the FUNCTION, not of a handle: raised once per process to the most any
@@ -1350,8 +1358,11 @@ bool pass_is_std(const rl4rs_policy* p, int minibatch) {
 // workgroups of one pass launch: the MB / rows that own samples; the compile-time instantiation adds workgroups that only take phase B
 // tasks until every one of its 45 tasks has a workgroup of its own (ppo_pass.hpp)
 int pass_grid(const rl4rs_policy* p, int minibatch) {
-    const int n_a = minibatch / pass_rows_per_wg(p);
-    return pass_is_std(p, minibatch) ? (n_a > 45 ? n_a : 45) : n_a;
+    if (pass_is_std(p, minibatch)) {
+        const int n_a = minibatch / pass_std_rows(p, minibatch);
+        return n_a > 45 ? n_a : 45;
+    }
+    return minibatch / pass_rows_per_wg(p);
 }
 
 constexpr size_t PASS_SMEM_MAX = (size_t)160 * 1024 - 64;
@@ -1364,7 +1375,8 @@ bool pass_opt_in() {
     for (auto& e : done)
         if (e.first == dev) return e.second;
     bool ok = true;
-    for (const void* fn : {reinterpret_cast<const void*>(&k_ppo_pass<false>), reinterpret_cast<const void*>(&k_ppo_pass<true>)})
+    for (const void* fn : {reinterpret_cast<const void*>(&k_ppo_pass<false, 8>), reinterpret_cast<const void*>(&k_ppo_pass<true, 8>),
+                           reinterpret_cast<const void*>(&k_ppo_pass<true, 4>)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS_SMEM_MAX) != hipSuccess) {
             (void)hipGetLastError();          // no sticky error for the next launch check: the caller takes the per-minibatch kernels
             ok = false;
@@ -1395,7 +1407,7 @@ bool pass_fits(rl4rs_policy* p, int minibatch, float grad_clip) {
         // is refused (it is for some > 64 KB dynamic-LDS shapes) the LDS bound with one 512-thread block per CU minimum stands in
         const int by_lds = (int)((size_t)160 * 1024 / (smem ? smem : 1));
         // (both instantiations: 512 threads at <= 256 registers and the same LDS - one answer serves either)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ppo_pass<false>), 512, smem) != hipSuccess || per_cu <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ppo_pass<false, 8>), 512, smem) != hipSuccess || per_cu <= 0) {
             (void)hipGetLastError();          // do not leave a sticky error for the next launch check
             per_cu = by_lds > 0 ? 1 : 0;
         }
@@ -1438,8 +1450,12 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
     }
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar, 0, 4, st));
     RL4RS_HIP_TRY(hipMemsetAsync(p->bar + 64, 0, 256 * 4, st));         // (the per-workgroup arrival words count from 1 in every launch)
-    if (pass_is_std(p, c.minibatch)) hipLaunchKernelGGL(k_ppo_pass<true>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
-    else hipLaunchKernelGGL(k_ppo_pass<false>, dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
+    if (pass_is_std(p, c.minibatch)) {
+        if (pass_std_rows(p, c.minibatch) == 4) hipLaunchKernelGGL((k_ppo_pass<true, 4>), dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
+        else hipLaunchKernelGGL((k_ppo_pass<true, 8>), dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
+    } else {
+        hipLaunchKernelGGL((k_ppo_pass<false, 8>), dim3(pass_grid(p, c.minibatch)), dim3(512), pass_smem_bytes(d), st, a);
+    }
     RL4RS_LAUNCH_CHECK();
     p->pass_launched = true;
 #ifdef RL4RS_PASS_TRACE
@@ -1453,6 +1469,7 @@ int launch_ppo_pass(rl4rs_policy* p, const PpoCall& c, int mb_begin, int mb_end,
                 (double)(h[5] - h[13]) / 2400.0);
         fprintf(stderr, "  lr_t %.2f  tile-loop %.2f  adam %.2f | first loss row %.2f\n", (double)(h[10] - h[6]) / 2400.0,
                 (double)(h[9] - h[10]) / 2400.0, (double)(h[7] - h[9]) / 2400.0, (double)(h[11] - h[3]) / 2400.0);
+        fprintf(stderr, "  row loss: join %.2f  lse %.2f  loss %.2f\n", (double)(h[14] - h[3]) / 2400.0, (double)(h[15] - h[14]) / 2400.0, (double)(h[11] - h[15]) / 2400.0);
     }
 #endif
     return RL4RS_OK;
@@ -1573,7 +1590,7 @@ int rl4rs_policy_set_option(rl4rs_policy* p, int32_t which, int32_t value) {
         case RL4RS_POLICY_OPT_TILE: p->opt_tile = value != 0; break;
         case RL4RS_POLICY_OPT_PPO_FUSED: p->opt_ppo_fused = value != 0; break;
         case RL4RS_POLICY_OPT_PPO_ROWS:
-            RL4RS_REQUIRE(value == 8 || value == 16 || value == 32, "policy_set_option: PPO_ROWS must be 8, 16 or 32 (got %d)", value);
+            RL4RS_REQUIRE(value == 4 || value == 8 || value == 16 || value == 32, "policy_set_option: PPO_ROWS must be 4, 8, 16 or 32 (got %d)", value);
             p->opt_ppo_rows = value; p->pass_resident_wgs = -1; break;
         case RL4RS_POLICY_OPT_RESIDENT_WGS: p->opt_resident_cap = value; p->pass_resident_wgs = -1; break;
         case RL4RS_POLICY_OPT_PPO_STD: p->opt_ppo_std = value != 0; break;

@@ -163,33 +163,55 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t rs, int voff, int so
 
 // one K slice of [8 rows] x [64 columns] on 4x4x1 MFMAs: A rows from LDS (16-byte reads of 4 consecutive k of row lane % 4 of each
 // 4-row tile), NQ quads of k, B = bw[k] (the wave's register per k: W[k][lane]); two accumulator chains per row tile
-template <int NQ>
+// MT = row tiles (2: rows 0 .. 7; 1: rows 0 .. 3 only - the 4-row workgroups of k_ppo_pass<true, 4>: o1 stays zero, four chains on the one tile)
+template <int NQ, int MT = 2>
 __device__ __forceinline__ void std_slice(const float* arow, int stride, const float (&bw)[4 * NQ], f32x4_t& o0, f32x4_t& o1) {
     f32x4_t c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00, c11 = c00;
 #pragma unroll
     for (int qd = 0; qd < NQ; ++qd) {
-        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(arow + 4 * qd), a1 = *reinterpret_cast<const f32x4_t*>(arow + 4 * stride + 4 * qd);
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(arow + 4 * qd);
+        if constexpr (MT == 2) {
+            const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(arow + 4 * stride + 4 * qd);
 #pragma unroll
-        for (int jj = 0; jj < 4; jj += 2) {
-            c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj], bw[4 * qd + jj], c00, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj], bw[4 * qd + jj], c10, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj + 1], bw[4 * qd + jj + 1], c01, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj + 1], bw[4 * qd + jj + 1], c11, 0, 0, 0);
+            for (int jj = 0; jj < 4; jj += 2) {
+                c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj], bw[4 * qd + jj], c00, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj], bw[4 * qd + jj], c10, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[jj + 1], bw[4 * qd + jj + 1], c01, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[jj + 1], bw[4 * qd + jj + 1], c11, 0, 0, 0);
+            }
+        } else {
+            c00 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[0], bw[4 * qd + 0], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[1], bw[4 * qd + 1], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[2], bw[4 * qd + 2], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[3], bw[4 * qd + 3], c11, 0, 0, 0);
         }
     }
-    o0 = c00 + c01;
-    o1 = c10 + c11;
+    if constexpr (MT == 2) {
+        o0 = c00 + c01;
+        o1 = c10 + c11;
+    } else {
+        o0 = (c00 + c01) + (c10 + c11);
+        o1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 }
 // register i of lane l = out[row i][column l]
+template <int MT = 2>
 __device__ __forceinline__ void std_put(float* dst, int ld, int lane, const f32x4_t& o0, const f32x4_t& o1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dst[i * ld + lane] = o0[i]; dst[(4 + i) * ld + lane] = o1[i]; }
+    for (int i = 0; i < 4; ++i) {
+        dst[i * ld + lane] = o0[i];
+        if (MT == 2) dst[(4 + i) * ld + lane] = o1[i];
+    }
 }
 
 
 // STD: OD = 256, HID = 64, A = 284 (AE = 285, W = 9), R = 8 rows per workgroup, MB % 256 == 0 - everything constant folds.
-template <bool STD>
+// SR (STD only): rows per workgroup, 8 or 4.  Four rows = one 4-row MFMA tile per stage (half the matrix work of a workgroup) and one
+// row loss per SIMD instead of two sharing it; the LDS layout stays that of eight rows (rows 4 .. 7 unused).
+template <bool STD, int SR = 8>
 __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
+    static_assert(SR == 8 || (STD && SR == 4), "rows per workgroup of the compile-time form");
+    constexpr int MT = SR / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PolDims d = a.d;
     if (STD) { d.OD = 256; d.HID = 64; d.A = 284; d.AE = 285; d.W = 9; }
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
     const __amdgpu_buffer_rsrc_t rs_prm = pass_rsrc(a.prm, (size_t)n_prm * 4), rs_am = pass_rsrc(a.am, (size_t)n_prm * 4),
                                  rs_av = pass_rsrc(a.av, (size_t)n_prm * 4), rs_w2t = pass_rsrc(a.w2t, (size_t)HID * AE * 4);
     const int NT1 = HID / 32, NT2 = (AE + 31) / 32, parts = 8 / NT1;
-    const int R = STD ? 8 : a.rows;          // samples of this workgroup (8, 16 or 32): rows R..31 of every MFMA tile are idle
+    const int R = STD ? SR : a.rows;         // samples of this workgroup (8, 16 or 32; compile-time form: SR): rows R..31 of every 32x32x2 tile are idle
     const int r0 = blockIdx.x * R;
     const int t1 = wave % NT1, q1 = wave / NT1;                      // layer-1 / dH role of the wave: column tile, K part
     unsigned gen = 0;
@@ -245,9 +267,9 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
         // descriptors over exactly this workgroup's rows: a lane past the end reads 0 (and does not store it)
         const __amdgpu_buffer_rsrc_t rs_o = pass_rsrc(a.obs + ln * OD, (size_t)R * OD * 4), rs_l = pass_rsrc(a.L.old_logits + ln * d.A, (size_t)R * d.A * 4);
 #pragma unroll
-        for (int u = 0; u < PF_OBS; ++u) pf_obs[u] = bld(rs_o, tid * 4, 2048 * u);
+        for (int u = 0; u < (STD ? PF_OBS * SR / 8 : PF_OBS); ++u) pf_obs[u] = bld(rs_o, tid * 4, 2048 * u);
 #pragma unroll
-        for (int u = 0; u < PF_OLD; ++u) pf_old[u] = bld(rs_l, tid * 4, 2048 * u);
+        for (int u = 0; u < ((STD && SR == 4) ? 3 : PF_OLD); ++u) pf_old[u] = bld(rs_l, tid * 4, 2048 * u);
         if (a.mask) pf_mask = __builtin_amdgcn_raw_buffer_load_b32(pass_rsrc(a.mask + ln * d.W, (size_t)R * d.W * 4), tid * 4, 0, 0);
         pf_act = (int)__builtin_amdgcn_raw_buffer_load_b32(pass_rsrc(a.L.actions + ln, (size_t)R * 4), tid * 4, 0, 0);
         pf_sc[0] = bld(pass_rsrc(a.L.adv + ln, (size_t)R * 4), tid * 4, 0);
@@ -369,12 +391,12 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             for (int u = 0; u < 8; ++u) bv2t[u] = bld(rs_prm, vl, (o_w2 + (wz * 8 + u) * 285 + 256) * 4);     // W2e rows wave*8 .. +7, columns 256 ..
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < PF_OBS; ++u) s_x[(u * 2 + (tid >> 8)) * 260 + (tid & 255)] = pf_obs[u];       // i = tid + 512 u -> row i / 256
+            for (int u = 0; u < PF_OBS * SR / 8; ++u) s_x[(u * 2 + (tid >> 8)) * 260 + (tid & 255)] = pf_obs[u];       // i = tid + 512 u -> row i / 256
 #pragma unroll
             for (int u = 0; u < PF_OLD; ++u)
-                if (tid + 512 * u < 8 * 284) s_ol[tid + 512 * u] = pf_old[u];
-            if (a.mask && tid < 72) s_mk[tid] = pf_mask;
-            if (tid < 8) {
+                if (tid + 512 * u < SR * 284) s_ol[tid + 512 * u] = pf_old[u];
+            if (a.mask && tid < SR * 9) s_mk[tid] = pf_mask;
+            if (tid < SR) {
                 reinterpret_cast<int32_t*>(s_s5)[tid] = pf_act;
                 s_s5[32 + tid] = pf_sc[0]; s_s5[64 + tid] = pf_sc[1]; s_s5[96 + tid] = pf_sc[2]; s_s5[128 + tid] = pf_sc[3];
             }
@@ -382,14 +404,14 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             RL4RS_PT(1);
             f32x4_t o0, o1;
             // layer 1: wave w multiplies k in [32 w, 32 w + 32)
-            std_slice<8>(s_x + (lane & 3) * 260 + wave * 32, 260, bv1, o0, o1);
+            std_slice<8, MT>(s_x + (lane & 3) * 260 + wave * 32, 260, bv1, o0, o1);
             // layer 2's main operand (column tile wave & 3, K half wave >> 2) flies during the partial-sum exchange and the tanh
 #pragma unroll
             for (int u = 0; u < 32; ++u) bv2[u] = bld(rs_prm, vl, (o_w2 + ((wz >> 2) * 32 + u) * 285 + (wz & 3) * 64) * 4);
             __builtin_amdgcn_sched_barrier(0);
-            std_put(s_p + wave * 512, 64, lane, o0, o1);
+            std_put<MT>(s_p + wave * 512, 64, lane, o0, o1);
             __syncthreads();
-            {   // thread = (row wave, column lane)
+            if (wave < SR) {   // thread = (row wave, column lane)
                 float sum = b1v;
 #pragma unroll
                 for (int pp = 0; pp < 8; ++pp) sum += s_p[pp * 512 + wave * 64 + lane];
@@ -400,18 +422,18 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             __syncthreads();
             RL4RS_PT(2);
             // layer 2: columns 0..255 as 4 tiles x 2 K halves (one per wave), columns 256..284 split over K eight ways
-            std_slice<8>(s_hh + (lane & 3) * 68 + (wave >> 2) * 32, 68, bv2, o0, o1);
+            std_slice<8, MT>(s_hh + (lane & 3) * 68 + (wave >> 2) * 32, 68, bv2, o0, o1);
             f32x4_t t0, t1;
-            std_slice<2>(s_hh + (lane & 3) * 68 + wave * 8, 68, bv2t, t0, t1);
+            std_slice<2, MT>(s_hh + (lane & 3) * 68 + wave * 8, 68, bv2t, t0, t1);
             // dH's operand (rows 36 w .. of the transposed W2e; rows >= 285 are past the buffer: 0) flies during the row losses
 #pragma unroll
             for (int u = 0; u < 36; ++u) wv[u] = bld(rs_w2t, vl, (wz * 36 + u) * 256);
             __builtin_amdgcn_sched_barrier(0);
-            std_put(s_p + (wave >> 2) * 2048 + (wave & 3) * 64, 256, lane, o0, o1);
-            std_put(s_p + 4096 + wave * 512, 64, lane, t0, t1);
+            std_put<MT>(s_p + (wave >> 2) * 2048 + (wave & 3) * 64, 256, lane, o0, o1);
+            std_put<MT>(s_p + 4096 + wave * 512, 64, lane, t0, t1);
             __syncthreads();
             RL4RS_PT(3);
-            {   // row losses: wave w owns row w - it first joins the partial sums of its row (+ bias, + action mask)
+            if (wave < SR) {   // row losses: wave w owns row w - it first joins the partial sums of its row (+ bias, + action mask)
                 float* so = s_lg + wave * 288;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
@@ -432,6 +454,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 if (lane < 3) s_g[wave * 288 + 285 + lane] = 0.f;
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (wave == 0) RL4RS_PT(14);
                 LossArgs L = a.L;                      // inputs from the LDS copies, indexed by the row within the tile
                 L.actions = reinterpret_cast<const int32_t*>(s_s5); L.adv = s_s5 + 32; L.ret = s_s5 + 64; L.old_logp = s_s5 + 96;
                 L.old_value = s_s5 + 128; L.old_logits = s_ol;
@@ -441,6 +464,7 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
                 float se = 0.f;
                 for (int c = lane; c < 284; c += 64) se += expf(so[c] - mx);
                 const float lse = mx + logf(wave_sum(se));
+                if (wave == 0) RL4RS_PT(15);
                 const float4 tm = policy_row_loss<RL4RS_PASS_WT != 0>(d, L, so, lse, wave, lane, s_g + wave * 288, a.dOut + (size_t)r0 * AE);
                 if (lane == 0) a.terms[lo + r0 + wave] = tm;       // per-sample loss terms of the whole pass (KL mean -> kl_coeff rule)
                 if (wave == 0) RL4RS_PT(11);
@@ -448,12 +472,12 @@ __global__ __launch_bounds__(512) void k_ppo_pass(PassArgs a) {
             __syncthreads();
             RL4RS_PT(4);
             // dH = dOut W2e^T: wave w multiplies k in [36 w, 36 w + 36)
-            std_slice<9>(s_g + (lane & 3) * 288 + wave * 36, 288, wv, o0, o1);
+            std_slice<9, MT>(s_g + (lane & 3) * 288 + wave * 36, 288, wv, o0, o1);
             RL4RS_PT(12);
-            std_put(s_p + wave * 512, 64, lane, o0, o1);
+            std_put<MT>(s_p + wave * 512, 64, lane, o0, o1);
             __syncthreads();
             RL4RS_PT(13);
-            {
+            if (wave < SR) {
                 float sum = 0.f;
 #pragma unroll
                 for (int pp = 0; pp < 8; ++pp) sum += s_p[pp * 512 + wave * 64 + lane];

@@ -200,13 +200,14 @@ def test_tile_kernels_of_the_default_shape_match_the_generic_ones(N, with_mask):
         assert torch.allclose(s1, s2, rtol=2e-4, atol=2e-3), (s1, s2)
 
 
-@pytest.mark.parametrize('MB,with_mask', [(256, True), (512, True), (256, False)])
-def test_ppo_pass_compile_time_instantiation_matches_the_runtime_one(MB, with_mask):
+@pytest.mark.parametrize('MB,with_mask,rows', [(256, True, None), (512, True, None), (256, False, None), (256, True, 8), (512, True, 4)])
+def test_ppo_pass_compile_time_instantiation_matches_the_runtime_one(MB, with_mask, rows):
     """k_ppo_pass<true> (the default shape as compile-time constants: 4-row x 64-column MFMA tiles with K split over the waves, the
     wave's Adam operands resident in registers) against k_pass<false> (RL4RS_POLICY_OPT_PPO_STD = 0: 32x32x2 tiles, all runtime) on
     the same pass: other summation orders, so numerical like pass-vs-chain (Adam turns rounding-level gradient entries into steps of
     up to lr), statistics to 2e-3; and the data-parallel form (gradient of one minibatch + rl4rs_policy_adam_step) of the
-    compile-time instantiation is bit-identical to its own fused pass."""
+    compile-time instantiation is bit-identical to its own fused pass.  rows: 4- or 8-row workgroups of the compile-time form pinned
+    (automatic: 4 at MB = 256 - 64 workgroups -, 8 at MB = 512)."""
     import torch
     from rl4rs_amd.device import DevicePolicy
     from rl4rs_amd.nets.policy import init_policy_params
@@ -228,6 +229,9 @@ def test_ppo_pass_compile_time_instantiation_matches_the_runtime_one(MB, with_ma
     kw = dict(vf_coeff=0.5, ent_coeff=0.01, clip=0.3, vf_clip=500.0, kl_coeff=0.2)
     p_std, p_gen, p_dp = (DevicePolicy(256, 64, 284, max_rows=N, params=flat) for _ in range(3))
     p_gen.set_option('ppo_std', 0)
+    if rows is not None:
+        p_std.set_option('ppo_rows', rows)
+        p_dp.set_option('ppo_rows', rows)
     s_std = s_gen = None
     for _ in range(2):                              # two passes: the Adam step counter and the resident moments carry over
         s_std = p_std.ppo_epoch(o, a, adv, ret, b, olp, ov, ol, minibatch=MB, lr=1e-3, **kw)
