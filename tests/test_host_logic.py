@@ -172,9 +172,12 @@ def test_native_record_parser_matches_python_parser():
         with pytest.raises(_lib.Rl4rsHipError):
             parse_records_native([bad], 64, log_steps=9)
     big = synth.make_records(4000, pages=1, seed=5)
-    t = time.time(); RecordColumns(big, 64); tp = time.time() - t
-    t = time.time(); parse_records_native(big, 64); tn = time.time() - t
-    assert tn < tp
+    def best_of(fn, n=3):                   # best of three: a busy host must not decide this
+        best = float('inf')
+        for _ in range(n):
+            t = time.time(); fn(big, 64); best = min(best, time.time() - t)
+        return best
+    assert best_of(parse_records_native) < best_of(RecordColumns)
 
 
 def test_fileutil_lookup_helpers(tmp_path):
