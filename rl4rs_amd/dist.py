@@ -47,6 +47,20 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def ranks_sharing_device():
+    """How many ranks of this node run on the SAME GPU as this one: 1 in the product configuration (one process per GPU over RCCL);
+    more only in the dry runs that put several gloo ranks on one GPU (tests/test_gpu_bench_multirank.py: eight ranks on a 1-GPU
+    box).  A persistent kernel with a grid barrier (k_ppo_pass) needs all of its workgroups resident at once, which a GPU shared by
+    several processes does not promise: the trainer divides the kernel's co-residency budget by this number."""
+    import torch
+    _, _, world = dist_env()
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev <= 0 or local_world <= n_dev:
+        return 1
+    return -(-local_world // n_dev)
+
+
 def shard_seed(base_seed, rank):
     """Per-rank seed of the synthetic log / sampling stream (seed = 1000 + rank)."""
     return int(base_seed) + int(rank)

@@ -319,6 +319,12 @@ class Trainer(_DeferredStats):
             raise ValueError("PPO needs at least one full minibatch per train call: %d rollouts x batch_size x max_steps = %d < "
                              "minibatch = %d" % (self.R, N, minibatch))
         self.policy = D.DevicePolicy(256, hidden, self.A, max_rows=N, seed=init_seed)
+        share = rdist.ranks_sharing_device()
+        if share > 1:
+            # several ranks on ONE GPU (gloo dry runs only): the persistent PPO pass may use its grid barrier only while the grids of
+            # all the processes on the device fit together, one workgroup per CU; beyond that the per-minibatch kernels run
+            n_cu = torch.cuda.get_device_properties(self.policy.device).multi_processor_count
+            self.policy.set_option('resident_wgs', n_cu // share)
         self.iteration = 0
         self._rollouts = 0
         dev = self.policy.device

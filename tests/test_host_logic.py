@@ -330,3 +330,22 @@ def test_cache_window_with_blank_lines_matches_the_line_by_line_loop(tmp_path):
             want = ref.window(cache)
             assert db.sample_list == want, (trial, lines, cache)
             assert [file_lines[r].rstrip() if r >= 0 else '' for r in db.sample_rows] == want
+
+
+def test_ranks_sharing_device(monkeypatch):
+    """rl4rs_amd/dist.py::ranks_sharing_device: 1 in the product configuration (one process per GPU), ceil(local ranks / GPUs) when a
+    dry run puts more ranks on a node than it has GPUs (the trainer then shrinks the persistent PPO pass's co-residency budget)."""
+    import torch
+    from rl4rs_amd import dist as rdist
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    assert rdist.ranks_sharing_device() == 1
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    for world, n_dev, want in ((8, 8, 1), (8, 1, 8), (8, 3, 3), (2, 1, 2), (1, 1, 1), (4, 8, 1)):
+        monkeypatch.setenv('WORLD_SIZE', str(world))
+        monkeypatch.setattr(torch.cuda, 'device_count', lambda n=n_dev: n)
+        assert rdist.ranks_sharing_device() == want, (world, n_dev)
+    monkeypatch.setenv('WORLD_SIZE', '16')                  # two nodes of eight: LOCAL_WORLD_SIZE decides
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    assert rdist.ranks_sharing_device() == 1
