@@ -358,3 +358,43 @@ def test_the_bench_configuration_itself(tmp_path):
         viol = st.get_violation()
         assert (r[viol == 0] == 0).all() and (r[viol == 1] > 0).all()
         env.sim.model.device_net.check_status()
+
+
+def test_four_times_the_baseline_batch_equals_its_chunks(tmp_path):
+    """Beyond BASELINE.json's size (one GPU has the memory for far bigger shards): B = 16 384 envs with 16 384 DISTINCT user
+    histories - 64-row AUGRU workgroups for the observation launches too, a 3.2 GB sequence cache per input, 147 456 complete
+    rows in the reward forward - against the same records run as four batches of 4096: every observation of every step and
+    every reward bit-identical (rows are independent and the kernels batch-position invariant, so this is a size-independent
+    check of the big launch geometry; the 4096-env batches are the ones the tests above pin to the oracle).  One step further,
+    32 768 distinct histories, the per-input cache would pass the 4 GB a 32-bit buffer offset can address: refused when the
+    scorer handle is created, loudly - more envs than that per GPU are several env handles."""
+    import torch
+    import rl4rs_amd
+    from rl4rs_amd import synth, _lib
+    from rl4rs_amd.env.slate import SlateRecEnv, SlateState
+    BIG, CH, T = 16384, 4096, 9
+    d = str(tmp_path)
+    text = synth.make_catalog_text(seed=1234)
+    synth.write_text(os.path.join(d, 'c.csv'), text)
+    recs = synth.make_records(2 * BIG, seed=1000, illegal_frac=0.05, special_ids=synth.special_ids_from_text(text))
+
+    def episode(rs):
+        synth.write_records(os.path.join(d, 'log.csv'), rs)
+        env = rl4rs_amd.make('SlateRecEnv-v0', recsim=SlateRecEnv(_full_cfg(d, len(rs), T, rs), state_cls=SlateState))
+        out = [env.reset(reset_file=True).clone()]
+        for t in range(T):
+            obs, reward, done, info = env.step(env.offline_action)
+            out.append(obs.clone())
+        res = torch.stack(out).cpu(), reward.clone().cpu()
+        del env
+        torch.cuda.empty_cache()
+        return res
+
+    big_obs, big_r = episode(recs[:BIG])
+    assert torch.isfinite(big_obs).all() and torch.isfinite(big_r).all() and float(big_r.abs().max()) > 0
+    for k in range(0, BIG, CH):
+        o, r = episode(recs[k:k + CH])
+        assert torch.equal(o, big_obs[:, k:k + CH]), k
+        assert torch.equal(r, big_r[k:k + CH]), k
+    with pytest.raises(_lib.Rl4rsHipError, match='4 GB'):
+        episode(recs)
