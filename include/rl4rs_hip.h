@@ -261,7 +261,9 @@ enum {
     RL4RS_DIEN_OPT_CAT_V1 = 1 << 11,
     RL4RS_DIEN_OPT_NO_CAT_GROUP = 1 << 12,
     RL4RS_DIEN_OPT_DENSE_FORK = 1 << 13,       /* the dense tower on a second stream of the handle, joined in front of the head GEMM */
-    RL4RS_DIEN_OPT_ALL = (1 << 14) - 1
+    RL4RS_DIEN_OPT_NO_GRU_PAD = 1 << 14,       /* first GRU: compute the steps on leading zero ids (front padding) per row instead of
+                                                  taking them from the handle's table of pad states (bit-identical either way) */
+    RL4RS_DIEN_OPT_ALL = (1 << 15) - 1
 };
 
 /* Every mode accumulates in fp32 and meets the fp32 parity bar against the fp64 oracle (same measured error):

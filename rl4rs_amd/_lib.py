@@ -33,7 +33,7 @@ class DienCfg(C.Structure):
 # include/rl4rs_hip.h RL4RS_DIEN_OPT_*: kernel-path selection of one scorer handle (config['scorer_kernels'])
 DIEN_OPTS = {'augru_h16': 1 << 0, 'augru_rows32': 1 << 1, 'augru_rows64': 1 << 2, 'din_v1': 1 << 3, 'no_din16': 1 << 4,
              'no_gru16': 1 << 5, 'no_gemm16': 1 << 6, 'no_cat16': 1 << 7, 'no_dense_chain': 1 << 8, 'no_head_tables': 1 << 9,
-             'no_head_fused': 1 << 10, 'cat_v1': 1 << 11, 'no_cat_group': 1 << 12, 'dense_fork': 1 << 13}
+             'no_head_fused': 1 << 10, 'cat_v1': 1 << 11, 'no_cat_group': 1 << 12, 'dense_fork': 1 << 13, 'no_gru_pad': 1 << 14}
 POLICY_OPTS = {'tile': 0, 'ppo_fused': 1, 'ppo_rows': 2, 'resident_wgs': 3, 'ppo_std': 4}          # RL4RS_POLICY_OPT_*
 ENV_OPTS = {'rows_variant': 0}                                                       # RL4RS_ENV_OPT_*
 

@@ -1261,13 +1261,57 @@ __global__ __launch_bounds__(256) void k_gru_h16(RecurArgs a) {
     float ug[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h_own[r] = 0.f;
-    load_x(acc_r, 0, 0);
-    load_x(acc_u, 0, 1);
-    load_x(acc_c, 0, 2);
+    // Leading zero ids (front padding): the state after k steps on id 0 from h = 0 does not depend on the row, so a workgroup whose
+    // rows ALL start with t0 zeros takes those t0 states from the handle's table (computed by this kernel on one all-zero row when
+    // the handle was created: the kernels are batch-position invariant, so the table holds the very bits each row would compute)
+    // and runs steps t0 .. L - 1 only.  SeqSlate's second sequence input - the items exposed on earlier pages, 9 / 18 / 27 ids behind
+    // 55 / 46 / 37 zeros, re-encoded for all envs at every page end - is the case this is for.
+    int t0 = 0;
+    if (a.pad) {                                                          // (uniform)
+        __shared__ int s_lead[32];
+        __shared__ int s_t0;
+        if (tid < 32) s_lead[tid] = L;
+        if (tid == 0) s_t0 = L;
+        __syncthreads();
+        {
+            const int r = tid >> 3, c = tid & 7, cl = (L + 7) >> 3;       // 8 threads per row, a chunk of the row's ids each
+            int first = L;
+            for (int t = min(L, (c + 1) * cl) - 1; t >= c * cl; --t)
+                if (s_ids[r * LDT + t] != 0) first = t;
+            if (first < L) atomicMin(&s_lead[r], first);
+        }
+        __syncthreads();
+        if (tid < 32) atomicMin(&s_t0, s_lead[tid]);                      // (rows past n_rows repeat the last valid row)
+        __syncthreads();
+        t0 = __builtin_amdgcn_readfirstlane(s_t0);
+        if (t0 > 0) {
+            const float hv = a.pad[(size_t)(t0 - 1) * NH + col];
+            const _Float16 vh = (_Float16)hv, vl = (_Float16)(hv - (float)vh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h_own[r] = hv;
+                hp_hi[crow(r, half) * LDP + col] = vh;
+                hp_lo[crow(r, half) * LDP + col] = vl;
+            }
+#pragma unroll 1
+            for (int t = 0; t < t0; ++t) {
+                const unsigned v = __builtin_bit_cast(unsigned, a.pad[(size_t)t * NH + col]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rs_o, o_voff, (((r & 3) + 8 * (r >> 2)) * L + t) * old4, 0);
+            }
+            __syncthreads();
+        }
+    }
+    if (t0 < L) {
+        load_x(acc_r, t0, 0);
+        load_x(acc_u, t0, 1);
+        load_x(acc_c, t0, 2);
+    }
     const int aoff = li * LDP + half * 8;
 
 #pragma unroll 1
-    for (int t = 0; t < L; ++t) {
+    for (int t = t0; t < L; ++t) {
         // ---- slot R: acc_r += h Wr
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -1688,6 +1732,7 @@ struct rl4rs_dien {
     float* augru_wg16[4];  // fp16 hi/lo planes of the same fragments (optional fp16x2 mode)
     float* augru_wc16[4];
     float* gru_wg16[4];    // first GRU, fp16 hi/lo planes (k_gru_h16)
+    float* gru_pad[4];     // k_gru_h16: [L][E] states after 1 .. L leading zero ids (RecurArgs::pad), NULL = off (RL4RS_DIEN_OPT_NO_GRU_PAD)
     float* gru_wc16[4];
     bool gru16, gru16_attr;
     bool fp16x2;
@@ -2093,6 +2138,28 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     AL(obs_tmp, (size_t)c->max_rows * OBS_DIM);
     n->tsum = nullptr;
     if (n->ptab && Cn <= 24 && !(opts & RL4RS_DIEN_OPT_NO_HEAD_FUSED)) AL(tsum, (size_t)c->max_rows * OBS_DIM);
+    // first GRU: the states after 1 .. L leading zero ids, per sequence input (RecurArgs::pad) - the kernel itself on ONE all-zero row
+    for (int s = 0; s < 4; ++s) n->gru_pad[s] = nullptr;
+    if (n->gru16 && !(opts & RL4RS_DIEN_OPT_NO_GRU_PAD)) {
+        float* zero_ids = nullptr;                       // L zero int32 ids (all-zero bits either way)
+        if ((rc = alloc_f(n, &zero_ids, (size_t)L)) != RL4RS_OK) return rc;
+        RL4RS_HIP_TRY(hipMemsetAsync(zero_ids, 0, (size_t)L * 4, st));
+        const size_t smem16 = (((size_t)4 * 32 * (128 + 8) * 2 + (size_t)32 * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * 8 * 2048;
+        if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_gru_h16), smem16))) return rc;
+        n->gru16_attr = true;
+        for (int s = 0; s < S; ++s) {
+            AL(gru_pad[s], (size_t)L * E);
+            RecurArgs a;
+            memset(&a, 0, sizeof(a));
+            a.n_rows = 1; a.L = L; a.group = 1;
+            a.xbase[0] = n->embw1[s]; a.xld = 3 * E; a.xoff = 0; a.xbytes = (int64_t)H * 3 * E * 4;
+            a.ids = reinterpret_cast<const int32_t*>(zero_ids);
+            a.wg[0] = n->gru_wg16[s]; a.wc[0] = n->gru_wc16[s];
+            a.out = n->gru_pad[s]; a.out_ld = E; a.slot_base = 0;
+            hipLaunchKernelGGL(k_gru_h16, dim3(1, 1), dim3(256), smem16, st, a);
+            RL4RS_LAUNCH_CHECK();
+        }
+    }
 #undef UP
 #undef AL
     // LDS opt-in above the 64 KB default where needed
@@ -2150,6 +2217,7 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
         a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.out_seq_off = 0; a.slot_base = slot_base;
         if (n->gru16) {
             a.wg[0] = n->gru_wg16[s]; a.wc[0] = n->gru_wc16[s];
+            a.pad = n->gru_pad[s];
             const size_t smem16 = (((size_t)4 * 32 * (128 + 8) * 2 + (size_t)32 * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * 8 * 2048;
             if (!n->gru16_attr) {
                 int rc16 = raise_dyn_smem(reinterpret_cast<const void*>(&k_gru_h16), smem16);

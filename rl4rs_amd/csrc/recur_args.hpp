@@ -55,6 +55,10 @@ struct RecurArgs {
     int steps;                   // debug: run only the first `steps` recurrence steps (0 = all L)
     const int32_t* order;        // k_augru_x: processing order of the row groups (NULL = identity)
     int final_only;              // GRU mode: write only the last state, to out[(slot_base + row) * out_ld + out_off]
+    // k_gru_h16: [L][NH] - row t = the state after t + 1 steps on item id 0 from h = 0 (the same for every row: pad_sequences pads in
+    // FRONT, rl4rs/utils/datautil.py:44).  A workgroup whose rows all start with at least t0 zero ids copies rows 0 .. t0 - 1 of this
+    // table into their outputs and starts the recurrence at step t0 from row t0 - 1.  NULL = every step is computed.
+    const float* pad;
     // fp16x2 AUGRU kernels: every 32-column tile of the reset / update / candidate weight matrices (and the same columns of the
     // cached x-side projections, biases folded) is stored multiplied by its own power of two s (rl4rs_dien_create: max |w| * s in
     // [2^13, 2^14) over the tile), so the fp16 hi + lo split keeps its 22 bits whatever the scale of a checkpoint's weights, no

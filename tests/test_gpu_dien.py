@@ -598,3 +598,54 @@ def test_trained_like_model_stays_within_the_margins(scorer_precision):
             assert mode == 'fp16x2' or v[mode]['poisoned_rows'] == 0
             assert v[mode]['obs_abs'] < 5e-5 and v[mode]['prob_abs'] < 5e-6, (name, mode, out)
     assert out['variants']['trained']['fp16x2']['poisoned_rows'] == 0
+
+
+def test_first_gru_pad_table_is_bit_identical(scorer_precision):
+    """k_gru_h16 takes the steps on LEADING zero ids (pad_sequences pads in front, rl4rs/utils/datautil.py:44) from the handle's
+    table of pad states when all 32 rows of a workgroup share them (RecurArgs::pad), instead of computing them per row
+    (scorer_kernels='no_gru_pad').  Workgroups of every kind - a common prefix of 55 / 46 / 37 zeros as SeqSlate's second input
+    has at its page ends, mixed prefix lengths, all-zero rows only, no prefix at all, zeros in the MIDDLE of a row, a ragged last
+    workgroup - must give the same h1 cache and the same forward, bit for bit."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only: the exact-fp32 first GRU has no pad table')
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien, DIEN_H1
+    cfg = dict(CFG, scorer_precision=scorer_precision)
+    w = init_dien_weights(cfg, seed=8, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(11)
+    blocks = []
+    for lead in (55, 46, 37):                                # one workgroup each: the same prefix on every row
+        b = rs.randint(1, 284, size=(32, 64)); b[:, :lead] = 0; blocks.append(b)
+    b = rs.randint(1, 284, size=(32, 64))                    # mixed prefixes, the shortest is 7
+    for r in range(32):
+        b[r, :7 + (r * 5) % 50] = 0
+    blocks.append(b)
+    blocks.append(np.zeros((32, 64), dtype=np.int64))        # nothing but padding
+    blocks.append(rs.randint(1, 284, size=(32, 64)))         # no padding
+    b = rs.randint(1, 284, size=(32, 64)); b[:, :12] = 0; b[:, 30:40] = 0; b[3, 12] = 0; blocks.append(b)    # zeros further in are ordinary steps
+    b = rs.randint(1, 284, size=(13, 64)); b[:, :60] = 0; blocks.append(b)                                   # ragged tail
+    seq1 = np.concatenate(blocks).astype(np.int32)
+    R = seq1.shape[0]
+    seq0 = rs.randint(0, 284, size=(R, 64)).astype(np.int32)
+    seq0[: R // 2, :33] = 0
+    dense = np.abs(rs.randn(R, 432) * 3).astype(np.float32)
+    cat = rs.randint(0, cfg['category_hash_size'], size=(R, 21)).astype(np.int32)
+    cat[:, 10:] = rs.randint(0, 284, size=(R, 11))
+
+    def run(kernels):
+        net = DeviceDien(dict(cfg, scorer_kernels=kernels), w, max_rows=R, max_slots=R + 40)
+        net.encode(0, torch.from_numpy(seq0).cuda(), 0)
+        net.encode(1, torch.from_numpy(seq1).cuda(), 0)
+        net.encode(1, torch.from_numpy(np.ascontiguousarray(seq1[:40])).cuda(), R)        # a second call at a slot offset
+        h1 = net.snapshot(DIEN_H1, R)[:R].clone()            # (sequence input 0's cache; the slots behind R are never written)
+        sl = torch.arange(R, dtype=torch.int32).repeat(2, 1).contiguous().cuda()
+        obs, p = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), sl, True, True)
+        obs, p = obs.clone(), p.clone()
+        net.close()
+        return h1, obs, p
+
+    h1a, oa, pa = run('')
+    h1b, ob, pb = run('no_gru_pad')
+    assert torch.isfinite(oa).all() and torch.isfinite(pa).all()
+    assert torch.equal(h1a, h1b) and torch.equal(oa, ob) and torch.equal(pa, pb)
