@@ -19,14 +19,17 @@ int augru_x_prepare() {
     int rc;
     if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), augru_x_smem(1)))) return rc;
     if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), augru_x_smem(2)))) return rc;
+    if ((rc = raise_dyn_smem(reinterpret_cast<const void*>(&k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING, true>), augru_x_smem(1)))) return rc;
     return 0;
 }
 
 // rows_per_wg = 32: grid (ceil(n_rows / 32), S);  64: grid (n_rows / 64, S) - the caller has checked the 64-row form's conditions
 void augru_x_launch(int rows_per_wg, int n_seq, hipStream_t st, const RecurArgs& a) {
     const dim3 block(512);
-    if (rows_per_wg == 64)
+    if (rows_per_wg == 64)      // (the 64-row form with the redirect - 256 registers, no spill - measured flat on SeqSlate and 0.3 % slower on the headline: not instantiated)
         hipLaunchKernelGGL((k_augru_x<2, RL4RS_X2_NRES, RL4RS_X2_RING>), dim3(a.n_rows / 64, n_seq), block, augru_x_smem(2), st, a);
+    else if (a.lead[0])       // the handle keeps a pad slot and the leading-zero counts of its cache slots (RecurArgs::lead)
+        hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING, true>), dim3((a.n_rows + 31) / 32, n_seq), block, augru_x_smem(1), st, a);
     else
         hipLaunchKernelGGL((k_augru_x<1, RL4RS_X_NRES, RL4RS_X_RING>), dim3((a.n_rows + 31) / 32, n_seq), block, augru_x_smem(1), st, a);
 }

@@ -116,7 +116,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // rows come in groups of 8 consecutive rows per cache slot (the reward forward: 8 complete-state rows per env): every weight
 // fragment feeds two row tiles (half the weight bytes per row through the L1 return path), and the 8 distinct projection rows
 // of the workgroup are staged once (1 KB per gate and wave, one DMA instruction).
-template <int MT, int NRES, int RING>
+// PAD (instantiated for MT = 1): steps below a row's count of leading zero ids read the projections of the pad slot (RecurArgs::lead / pad_slot).
+template <int MT, int NRES, int RING, bool PAD = false>
 __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
     using namespace xk;
     constexpr int NH = 256, KB = 16, PLANE = 32 * NH * 2;          // bytes per plane (16 KB)
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         return a.order ? a.order[p / a.group] * a.group + p % a.group : p;
     };
     int dma_off[4];
+    int pad_delta[4] = {0, 0, 0, 0}, lead_j[4] = {0, 0, 0, 0};     // PAD: (pad slot - own slot) in bytes, leading zero ids of the lane's row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // MT = 1: row r = 8j + l/8, rotated chunk.  MT = 2 (only j = 0 is used): lane l fetches chunk l%8 of distinct row d = l/8,
@@ -168,7 +170,12 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
         const int r = MT == 1 ? 8 * j + (lane >> 3) : 8 * (lane >> 3);
         const int gr = phys(row0 + r);
         const int c = MT == 1 ? (((lane & 7) - (r >> 1)) & 7) : (lane & 7);
-        dma_off[j] = (int)((uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group] * (uint32_t)L * (uint32_t)xld4) + c * 16;
+        const uint32_t slot = (uint32_t)a.slots[(size_t)sq * a.slots_stride + gr / a.group];
+        dma_off[j] = (int)(slot * (uint32_t)L * (uint32_t)xld4) + c * 16;
+        if constexpr (PAD) {
+            lead_j[j] = a.lead[sq][slot];
+            pad_delta[j] = (int)(((uint32_t)a.pad_slot - slot) * (uint32_t)L * (uint32_t)xld4);
+        }
     }
     const float* att_row[MT];
 #pragma unroll
@@ -179,9 +186,12 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int j = 0; j < (MT == 1 ? 4 : 1); ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * (STG / 3) + j * 1024), 16, dma_off[j],
+            for (int j = 0; j < (MT == 1 ? 4 : 1); ++j) {
+                int voff = dma_off[j];
+                if constexpr (PAD) voff += t < lead_j[j] ? pad_delta[j] : 0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * (STG / 3) + j * 1024), 16, voff,
                                                          t * xld4 + xs_base + g * NH * 4, 0, 0);
+            }
     };
     auto x_read = [&](f32x16& dst, int g, int m) {                 // staged projection rows -> accumulator (MFMA C-in)
         const int rot = half + (li >> 1);

@@ -1281,7 +1281,10 @@ __global__ __launch_bounds__(256) void k_gru_h16(RecurArgs a) {
             if (first < L) atomicMin(&s_lead[r], first);
         }
         __syncthreads();
-        if (tid < 32) atomicMin(&s_t0, s_lead[tid]);                      // (rows past n_rows repeat the last valid row)
+        if (tid < 32) {
+            atomicMin(&s_t0, s_lead[tid]);                                // (rows past n_rows repeat the last valid row)
+            if (a.lead_out && row0 + tid < a.n_rows) a.lead_out[a.slot_base + row0 + tid] = s_lead[tid];
+        }
         __syncthreads();
         t0 = __builtin_amdgcn_readfirstlane(s_t0);
         if (t0 > 0) {
@@ -1402,6 +1405,9 @@ struct DinArgs {
     float* scores; int64_t scores_stride;           // [n_seq][scores_stride] rows of L
     const int32_t* order;        // processing order of the row groups (NULL = identity): rl4rs_dien_set_row_order
     unsigned long long* trace;   // -DRL4RS_DINX_TRACE timing experiments only
+    // k_din_x: leading zero ids of the sequence in every cache slot and the slot of the all-zero sequence (RecurArgs::lead / pad_slot):
+    // the steps of a row's front padding read the pad slot's states and projections - the same bytes, shared by all rows.  NULL = off
+    const int32_t* lead[4]; int pad_slot;
 };
 
 template <bool STAGE, bool H16>
@@ -1733,6 +1739,7 @@ struct rl4rs_dien {
     float* augru_wc16[4];
     float* gru_wg16[4];    // first GRU, fp16 hi/lo planes (k_gru_h16)
     float* gru_pad[4];     // k_gru_h16: [L][E] states after 1 .. L leading zero ids (RecurArgs::pad), NULL = off (RL4RS_DIEN_OPT_NO_GRU_PAD)
+    int32_t* lead[4];      // [max_slots + 1] leading zero ids of the sequence in every cache slot (k_gru_h16 writes, k_augru_x<.., PAD> reads); slot max_slots = the all-zero sequence
     float* gru_wc16[4];
     bool gru16, gru16_attr;
     bool fp16x2;
@@ -1862,7 +1869,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     RL4RS_REQUIRE(c->category_feature_num >= 1 && c->category_feature_num <= 32, "dien: category_feature_num must be in 1..32");
     RL4RS_REQUIRE(c->max_rows > 0 && c->max_slots > 0 && c->category_hash_size > 0 && c->dense_feature_num > 0,
                   "dien: bad sizes");
-    RL4RS_REQUIRE((int64_t)c->max_slots * c->maxlen * (ATT_H1 + 6 * c->emb_size) * 4 < (int64_t)0x7fffffff * 2,
+    RL4RS_REQUIRE(((int64_t)c->max_slots + 1) * c->maxlen * (ATT_H1 + 6 * c->emb_size) * 4 < (int64_t)0x7fffffff * 2,      // (+ 1: the pad slot)
                   "dien: max_slots=%d too large: the per-input sequence cache must stay below 4 GB (32-bit buffer offsets)",
                   c->max_slots);
     RL4RS_REQUIRE((int64_t)c->category_hash_size * 3 * c->emb_size * 4 < (int64_t)0x7fffffff * 2,
@@ -2120,10 +2127,10 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             keep.push_back(pack_frag_h16(hs.data(), NH2, 0, NH2, NH2));
             UP(augru_wc16[s], keep.back().data(), keep.back().size());
         }
-        AL(h1[s], (size_t)c->max_slots * L * E);
+        AL(h1[s], ((size_t)c->max_slots + 1) * L * E);                  // (+ 1 everywhere: slot max_slots holds the all-zero sequence)
         n->h1f[s] = nullptr;
-        if (n->fp16x2 && n->din16 && n->din_x && E == 128 && L <= 64) AL(h1f[s], (size_t)c->max_slots * ((L + 31) / 32) * 32 * E);
-        AL(proj[s], (size_t)c->max_slots * L * PLD);
+        if (n->fp16x2 && n->din16 && n->din_x && E == 128 && L <= 64) AL(h1f[s], ((size_t)c->max_slots + 1) * ((L + 31) / 32) * 32 * E);
+        AL(proj[s], ((size_t)c->max_slots + 1) * L * PLD);
     }
     keep.push_back(pack_w(wac_all.data(), S * ATT_H1, E, S * ATT_H1));
     UP(w1ac_all, keep.back().data(), keep.back().size());
@@ -2139,7 +2146,7 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
     n->tsum = nullptr;
     if (n->ptab && Cn <= 24 && !(opts & RL4RS_DIEN_OPT_NO_HEAD_FUSED)) AL(tsum, (size_t)c->max_rows * OBS_DIM);
     // first GRU: the states after 1 .. L leading zero ids, per sequence input (RecurArgs::pad) - the kernel itself on ONE all-zero row
-    for (int s = 0; s < 4; ++s) n->gru_pad[s] = nullptr;
+    for (int s = 0; s < 4; ++s) { n->gru_pad[s] = nullptr; n->lead[s] = nullptr; }
     if (n->gru16 && !(opts & RL4RS_DIEN_OPT_NO_GRU_PAD)) {
         float* zero_ids = nullptr;                       // L zero int32 ids (all-zero bits either way)
         if ((rc = alloc_f(n, &zero_ids, (size_t)L)) != RL4RS_OK) return rc;
@@ -2158,6 +2165,20 @@ int rl4rs_dien_create(const rl4rs_dien_cfg* c, const rl4rs_dien_weights* w, void
             a.out = n->gru_pad[s]; a.out_ld = E; a.slot_base = 0;
             hipLaunchKernelGGL(k_gru_h16, dim3(1, 1), dim3(256), smem16, st, a);
             RL4RS_LAUNCH_CHECK();
+            // ... and the cache slot of the all-zero sequence (slot max_slots): states, fragment copy, projections - what encode does
+            const int P = c->max_slots;
+            RL4RS_HIP_TRY(hipMemcpyAsync(n->h1[s] + (size_t)P * L * E, n->gru_pad[s], (size_t)L * E * 4, hipMemcpyDeviceToDevice, st));
+            if (n->h1f[s]) {
+                const int64_t pieces = (int64_t)((L + 31) / 32) * 1024;
+                hipLaunchKernelGGL(k_h1_frag, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, n->h1[s], n->h1f[s], P, 1, L);
+                RL4RS_LAUNCH_CHECK();
+            }
+            if ((rc = scorer_gemm(n, n->h1[s] + (size_t)P * L * E, E, n->wproj[s], n->bproj[s], n->proj[s] + (size_t)P * L * n->PLD, n->PLD,
+                                  L, n->PLD, E, 0, st))) return rc;
+            float* lead_f = nullptr;
+            if ((rc = alloc_f(n, &lead_f, (size_t)c->max_slots + 1)) != RL4RS_OK) return rc;
+            RL4RS_HIP_TRY(hipMemsetAsync(lead_f, 0, ((size_t)c->max_slots + 1) * 4, st));
+            n->lead[s] = reinterpret_cast<int32_t*>(lead_f);
         }
     }
 #undef UP
@@ -2217,7 +2238,7 @@ int rl4rs_dien_encode(rl4rs_dien* n, int32_t s, const int32_t* ids, int32_t cnt,
         a.out = n->h1[s]; a.out_ld = E; a.out_off = 0; a.out_seq_off = 0; a.slot_base = slot_base;
         if (n->gru16) {
             a.wg[0] = n->gru_wg16[s]; a.wc[0] = n->gru_wc16[s];
-            a.pad = n->gru_pad[s];
+            a.pad = n->gru_pad[s]; a.lead_out = n->lead[s];
             const size_t smem16 = (((size_t)4 * 32 * (128 + 8) * 2 + (size_t)32 * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * 8 * 2048;
             if (!n->gru16_attr) {
                 int rc16 = raise_dyn_smem(reinterpret_cast<const void*>(&k_gru_h16), smem16);
@@ -2331,6 +2352,8 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         }
         a.scores = n->scores; a.scores_stride = (int64_t)n->c.max_rows * L;
         a.order = (n->row_order && n->row_order_n == ngroups) ? n->row_order : nullptr;
+        for (int s = 0; s < S; ++s) a.lead[s] = n->lead[s];
+        a.pad_slot = n->c.max_slots;
 #ifdef RL4RS_DINX_TRACE      // timing experiments only (tools/dinx_trace.py)
         {
             static unsigned long long* din_trace = nullptr;
@@ -2367,8 +2390,10 @@ int rl4rs_dien_forward(rl4rs_dien* n, int32_t R, int32_t group, const float* den
         RecurArgs a;
         memset(&a, 0, sizeof(a));
         a.n_rows = R; a.L = L; a.group = group;
-        a.xld = n->PLD; a.xoff = ATT_H1; a.xbytes = (int64_t)n->c.max_slots * L * n->PLD * 4;
+        a.xld = n->PLD; a.xoff = ATT_H1; a.xbytes = ((int64_t)n->c.max_slots + 1) * L * n->PLD * 4;
         a.ids = nullptr; a.slots = slots; a.slots_stride = ngroups;
+        for (int s = 0; s < S; ++s) a.lead[s] = n->lead[s];
+        a.pad_slot = n->c.max_slots;
         for (int s = 0; s < S; ++s) { a.xbase[s] = n->proj[s]; a.wg[s] = n->augru_wg[s]; a.wc[s] = n->augru_wc[s]; }
         a.att = n->scores; a.att_stride = (int64_t)n->c.max_rows * L;
         a.out = n->allf; a.out_ld = F; a.out_off = 0; a.out_seq_off = NH2; a.slot_base = 0;

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
 #else
         const int slot = a.slots[(size_t)sq * a.slots_stride + gs];
 #endif
+        const int lead = a.lead[sq] ? a.lead[sq][slot] : 0;
         __builtin_amdgcn_wave_barrier();
         // the row's q and q-side term are requested here and staged in LDS inside the first tile, behind that tile's own
         // requests: one memory round trip at the start of a row instead of two
@@ -128,8 +129,9 @@ __global__ __launch_bounds__(512, RL4RS_DINX_WPE) void k_din_x(DinArgs a, int ro
             DINX_TR((j / NW) * 2 + n, 0);
             const int t = n * 32 + li;
             const int tc = min(t, L - 1);                  // steps >= L re-read the last row (results never stored)
-            const float* hp = a.h1f[sq] + (((size_t)slot * ntile + n) * KB * 64 + lane) * 8;
-            const float* akp = a.proj[sq] + ((size_t)slot * L + tc) * a.pld;
+            const int slot_t = t < lead ? a.pad_slot : slot;      // (a lane = a step of the tile: front padding comes from the pad slot)
+            const float* hp = a.h1f[sq] + (((size_t)slot_t * ntile + n) * KB * 64 + lane) * 8;
+            const float* akp = a.proj[sq] + ((size_t)slot_t * L + tc) * a.pld;
             float4 hr[RL4RS_DINX_RING][2];
             auto ldh = [&](int s, int kb) {
                 hr[s][0] = *reinterpret_cast<const float4*>(hp + kb * 512);

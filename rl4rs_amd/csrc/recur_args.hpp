@@ -59,6 +59,13 @@ struct RecurArgs {
     // FRONT, rl4rs/utils/datautil.py:44).  A workgroup whose rows all start with at least t0 zero ids copies rows 0 .. t0 - 1 of this
     // table into their outputs and starts the recurrence at step t0 from row t0 - 1.  NULL = every step is computed.
     const float* pad;
+    int32_t* lead_out;           // k_gru_h16 (with pad): [slot] the number of leading zero ids of every encoded row
+    // k_augru_x<.., PAD = true>: lead[sq][slot] as written by k_gru_h16, pad_slot = the cache slot that holds the projections of the
+    // all-zero sequence.  Step t of a row whose sequence starts with more than t zero ids reads the pad slot's row t instead of its
+    // own (the same bytes: the first GRU's state after t + 1 zero ids does not depend on the row) - 4096 envs then share ONE copy of
+    // their padding's projections in L2 instead of streaming 4096 identical ones from HBM.
+    const int32_t* lead[4];
+    int pad_slot;
     // fp16x2 AUGRU kernels: every 32-column tile of the reset / update / candidate weight matrices (and the same columns of the
     // cached x-side projections, biases folded) is stored multiplied by its own power of two s (rl4rs_dien_create: max |w| * s in
     // [2^13, 2^14) over the tile), so the fp16 hi + lo split keeps its 22 bits whatever the scale of a checkpoint's weights, no
