@@ -24,18 +24,19 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per AUGRU launch of the default workload, from the round's PMC passes (profiles/r05q_pmc.md, arithmetic in its header;
-# the same values as profiles/r04f_pmc.md).
-# fp16x2 (k_augru_x): raw FETCH_SIZE 185.0 MB per obs-sized / 214.3 MB per reward-sized launch, x the factor calibrated on this
-# kernel's own LDS-DMA stream against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for
-# the 64-row form), + WRITE_SIZE 8.2 / 65.5 MB: (10 x 324.6 + 494.1) / 11.  fp32 (k_recur): not re-measured since round 1.
-TRAFFIC_SOURCE_FILE = 'profiles/r06p_pmc.md'
-TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 3.40e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
-TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (324.6 MB) + 1 reward-sized (494.1 MB) launches of an episode-batch; "
+# HBM bytes per AUGRU launch of the default workload, from the round's PMC passes (profiles/r06zzd_pmc.md, arithmetic in its header).
+# fp16x2 (k_augru_x): raw FETCH_SIZE 142.7 MB per obs-sized / 214.3 MB per reward-sized launch (the obs-sized form reads a row's front
+# padding from ONE shared cache slot since round 6: 185.0 MB before), x the factor calibrated on this kernel's own LDS-DMA stream
+# against a known byte count (profiles/r02_fetch_calibration.md: 1.71 for the 32-row form, 2.00 for the 64-row form), + WRITE_SIZE
+# 8.2 / 65.5 MB: (10 x 252.2 + 494.1) / 11.  fp32 (k_recur): not re-measured since round 1.
+TRAFFIC_SOURCE_FILE = 'profiles/r06zzd_pmc.md'
+TRAFFIC_B_PER_LAUNCH = {'fp32': None, 'fp16x2': 2.74e8}      # fp32 kernel: not re-measured since the row-order hint (r01e: 8.96e8)
+TRAFFIC_NOTE = ("B/launch, launch-weighted over the 10 obs-sized (252.2 MB) + 1 reward-sized (494.1 MB) launches of an episode-batch; "
                 "rocprofv3 FETCH_SIZE x the factor calibrated on this kernel's stream (profiles/r02_fetch_calibration.md) + WRITE_SIZE, "
-                "arithmetic in the header of profiles/r05q_pmc.md; algorithmic bytes = 1746 distinct histories x 64 steps x 768 f32 = "
-                "343 MB read + 8.4 / 67 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
-GATHER_TRAFFIC_B = 6.48e7           # k_env_rows<2>: WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch (profiles/r04f_pmc.md; r05q_pmc.md, r06p_pmc.md: unchanged)
+                "arithmetic in the header of profiles/r06zzd_pmc.md; algorithmic bytes of an obs-sized launch = 1746 distinct histories x "
+                "~48 non-padding steps x 768 f32 = 259 MB read (the front padding of all rows comes from one shared slot; 343 MB with "
+                "every row's own padding) + 8.4 MB written: with the row-order hint the duplicate env rows of one history hit in L2")
+GATHER_TRAFFIC_B = 6.48e7           # k_env_rows<2>: WRITE_SIZE 64.15 MB + FETCH_SIZE 0.65 MB per launch (profiles/r04f_pmc.md; r05q_pmc.md, r06p_pmc.md, r06zzd_pmc.md: unchanged)
 MFMA_F16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec
 
