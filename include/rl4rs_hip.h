@@ -314,7 +314,11 @@ int rl4rs_dien_status_word(rl4rs_dien* net, int32_t** word_dev);
 
 /* Encode `n` id sequences of sequence input `s` into cache slots [slot_base, slot_base+n):
  * embedding lookup + first GRU over all maxlen steps (utils.py:119-120) and the input-side
- * projections of the attention MLP / AUGRU that depend only on it.  ids_dev [n, maxlen] int32. */
+ * projections of the attention MLP / AUGRU that depend only on it.  ids_dev [n, maxlen] int32.
+ * Front padding (rl4rs/utils/datautil.py:44: pad_sequences pads in FRONT): the states after k leading zero ids are the same for
+ * every sequence, so (FP16X2 mode, unless RL4RS_DIEN_OPT_NO_GRU_PAD) the handle keeps them in a table and in one extra cache slot
+ * behind max_slots; encode starts every 32-row block at its shortest zero prefix and records each slot's prefix length, and the
+ * forward's AUGRU / DIN kernels read the steps of a row's prefix from that one slot.  Bit-identical to computing them per row. */
 int rl4rs_dien_encode(rl4rs_dien* net, int32_t s, const int32_t* ids_dev, int32_t n,
                       int32_t slot_base, void* stream);
 
