@@ -40,6 +40,12 @@ constexpr int gate(int i) { return i < 8 ? 0 : (i < 24 ? 1 : (i < 40 ? 2 : 0)); 
 constexpr int kb(int i) { return i < 8 ? 8 + i : (i < 24 ? i - 8 : (i < 40 ? i - 24 : i - 40)); }
 constexpr bool from_rh(int i) { return i >= 24 && i < 40; }  // B operand: r*h planes (candidate) or h planes
 constexpr bool after_barrier(int i) { return i == 0 || i == 24 || i == 40; }
+#ifndef RL4RS_X_DMA_AUX
+#define RL4RS_X_DMA_AUX 2        // cache-policy bits of the projection DMA (1 sc0, 2 nt, 16 sc1).  nt: a projection row is used once (by the
+                                // envs of one history, which run side by side), so it should not push the weight fragments - re-read 64
+                                // times per launch - out of L2.  Same-box A/B, 5 alternating pairs: 11.41 -> 11.32 ms per episode-batch
+                                // (+0.8 %), SeqSlate T=32 38.55 -> 38.12 ms (+1.1 %); sc0 flat, nt|sc0 like nt.  0 = round 2 .. 5's default
+#endif
 #ifndef RL4RS_X_AB
 #define RL4RS_X_AB 0            // timing ablations (results are WRONG when non-zero): 1 no epilogue math, 2 no weight streaming,
 #endif                          // 4 no projection DMA / reads, 8 no state-fragment reads, 16 no barriers
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(512) void k_augru_x(RecurArgs a) {
                 int voff = dma_off[j];
                 if constexpr (PAD) voff += t < lead_j[j] ? pad_delta[j] : 0;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(stage + g * (STG / 3) + j * 1024), 16, voff,
-                                                         t * xld4 + xs_base + g * NH * 4, 0, 0);
+                                                         t * xld4 + xs_base + g * NH * 4, 0, RL4RS_X_DMA_AUX);
             }
     };
     auto x_read = [&](f32x16& dst, int g, int m) {                 // staged projection rows -> accumulator (MFMA C-in)
