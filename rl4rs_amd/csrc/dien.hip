@@ -1366,7 +1366,12 @@ __global__ __launch_bounds__(256) void k_gru_h16(RecurArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float c = gate_tanh(acc_c[r]);
-            const float hn = __builtin_fmaf(ug[r], h_own[r] - c, c);     // u h + (1-u) c
+            float hn = __builtin_fmaf(ug[r], h_own[r] - c, c);           // u h + (1-u) c
+            // the planes are a function of the ROUNDED fp32 state: left alone, the compiler fuses the fma with the conversion
+            // (v_fma_mixlo_f16: one rounding of the exact result to fp16), and the hi plane then differs from (_Float16)hn in the
+            // rare double-rounding cases - which made a state taken from the pad table (split from its fp32 value above) differ
+            // from the same state computed here, one fp32 ulp a step later, for one element in ~8000
+            asm volatile("" : "+v"(hn));
             h_own[r] = hn;
             const _Float16 vh = (_Float16)hn;
             hp_hi[crow(r, half) * LDP + col] = vh;

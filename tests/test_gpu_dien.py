@@ -649,3 +649,43 @@ def test_first_gru_pad_table_is_bit_identical(scorer_precision):
     h1b, ob, pb = run('no_gru_pad')
     assert torch.isfinite(oa).all() and torch.isfinite(pa).all()
     assert torch.equal(h1a, h1b) and torch.equal(oa, ob) and torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize('L', [33, 16])
+def test_pad_table_at_other_sequence_lengths(scorer_precision, L):
+    """The pad-state table / pad slot (test above) at maxlen 33 and 16 (one ragged 32-step tile, half a tile) with three sequence
+    inputs: front-padded rows against the fp64 oracle and, bit for bit, against scorer_kernels='no_gru_pad'."""
+    if scorer_precision != 'fp16x2':
+        pytest.skip('fp16x2 only: the exact-fp32 first GRU has no pad table')
+    import torch
+    from rl4rs_amd.nets.dien import init_dien_weights
+    from rl4rs_amd.device import DeviceDien
+    from oracle.dien import OracleDien
+    cfg = dict(CFG, scorer_precision=scorer_precision, maxlen=L, seq_num=3)
+    w = init_dien_weights(cfg, seed=9, emb_scale=0.5, bias_noise=0.2)
+    rs = np.random.RandomState(L)
+    R, S = 70, 3
+    seq = rs.randint(1, 284, size=(R, S, L)).astype(np.int32)
+    for r in range(R):
+        seq[r, 0, :(r * 3) % (L + 1)] = 0                     # every prefix length incl. 0 and L
+        seq[r, 1, :L - 2] = 0                                 # the same long prefix on every row
+    seq[:, 2, :] = 0                                          # a constant all-zero input
+    dense = np.abs(rs.randn(R, 432) * 3).astype(np.float32)
+    cat = rs.randint(0, cfg['category_hash_size'], size=(R, 21)).astype(np.int32)
+
+    def run(kernels):
+        net = DeviceDien(dict(cfg, scorer_kernels=kernels), w, max_rows=R, max_slots=R)
+        for s in range(S):
+            net.encode(s, torch.from_numpy(np.ascontiguousarray(seq[:, s])).cuda(), 0)
+        sl = torch.arange(R, dtype=torch.int32).repeat(S, 1).contiguous().cuda()
+        obs, p = net.forward(R, 1, torch.from_numpy(dense).cuda(), torch.from_numpy(cat).cuda(), sl, True, True)
+        obs, p = obs.clone(), p.clone()
+        net.close()
+        return obs, p
+
+    oa, pa = run('')
+    ob, pb = run('no_gru_pad')
+    assert torch.equal(oa, ob) and torch.equal(pa, pb)
+    orc = OracleDien(w, cfg, np.float64)
+    assert np.abs(oa.cpu().numpy() - orc.obs(seq, dense, cat)).max() < 5e-5
+    assert np.abs(pa.cpu().numpy() - orc.reward_probs(seq, dense, cat)[:, 1]).max() < 5e-6
