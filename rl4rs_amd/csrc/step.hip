@@ -74,8 +74,9 @@ int after_act(rl4rs_stepper* s, int cur_before, float* obs, double* reward, uint
     rl4rs_env* e = s->env;
     const int B = s->cfg.batch_size;
     int rc;
-    if (s->cfg.is_seq && cur_before % s->cfg.page_items == 0) {
-        // first act of a page: the second sequence input (items of the previous pages, seqslate.py:107-108) changed
+    if (s->cfg.is_seq && cur_before > 0 && cur_before % s->cfg.page_items == 0) {
+        // first act of a page: the second sequence input (items of the previous pages, seqslate.py:107-108) changed - on every page
+        // but the first (prev_actions[:0] is the [0] the episode started with: nothing to re-encode)
         for (int q = 1; q < s->seq_num; ++q)
             if ((rc = scorer_encode(s, q, s->seq1, B, stream))) return rc;
     }

@@ -44,8 +44,9 @@ class SeqSlateState(SlateState):
 
     def act(self, actions):
         env = self._live()
-        if env.cur_steps % self.page_items == 0:
-            # the second sequence input (items of the previous pages) changes on the first act of a page
+        if env.cur_steps > 0 and env.cur_steps % self.page_items == 0:
+            # the second sequence input (items of the previous pages, seqslate.py:107-108) changes on the first act of a page - of
+            # every page but the first: `prev_actions[:0]` is the same [0] the episode started with
             self._seq1_version += 1
         SlateState.act(self, actions)
 

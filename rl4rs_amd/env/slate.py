@@ -475,20 +475,26 @@ class SlateRecEnv(RecSimBase):
             if hasattr(net, 'set_row_order'):
                 net.set_row_order(None if self.config.get('no_row_order', False) else getattr(samples, '_row_order', None))
         if samples.is_seq:
-            if self._encoded_seq1 != samples._seq1_version:
-                p1, _ = env.buffer_ptr(D.BUF_SEQ1)
-                for s in range(1, net.S):
-                    net.encode(s, (p1, B), 0)
-                self._encoded_seq1 = samples._seq1_version
             if self._slots is None or self._slots[0] != 'seq':
                 self._slots = ('seq', torch.arange(B, dtype=torch.int32, device=env.device).repeat(net.S, 1).contiguous())
                 self._slots_hist = None
+                self._seq_tab_own = True
+            if samples._seq1_version == 0 and not self.config.get('no_seq_zero_slot', False):
+                # the whole first page the second sequence input is the constant [0] (seqslate.py:107: prev_actions[:0]): ONE shared
+                # slot like SlateState's, instead of encoding B identical all-zero rows at every reset
+                self._ensure_zero_slot(net, env, B)
+                if self._seq_tab_own:
+                    self._slots[1][1:].fill_(B)
+                    self._seq_tab_own = False
+            else:
+                if self._encoded_seq1 != samples._seq1_version:
+                    p1, _ = env.buffer_ptr(D.BUF_SEQ1)
+                    for s in range(1, net.S):
+                        net.encode(s, (p1, B), 0)
+                    self._encoded_seq1 = samples._seq1_version
+                self._seq_slots_own(env, B)
         else:
-            if not getattr(self.model, 'zero_slot_ready', False):
-                z = torch.zeros((1, net.L), dtype=torch.int32, device=env.device)
-                for s in range(1, net.S):
-                    net.encode(s, z, B)                     # the constant [0] sequence: ONE shared slot
-                self.model.zero_slot_ready = True
+            self._ensure_zero_slot(net, env, B)
             if self._slots is None or self._slots[0] != 'slate':
                 sl = torch.full((net.S, B), B, dtype=torch.int32, device=env.device)
                 sl[0] = torch.arange(B, dtype=torch.int32, device=env.device)
@@ -498,6 +504,22 @@ class SlateRecEnv(RecSimBase):
             self._slots[1][0].copy_(hu[1] if hu is not None else torch.arange(B, dtype=torch.int32, device=env.device))
             self._slots_hist = samples._batch_version
         return net, self._slots[1]
+
+    def _ensure_zero_slot(self, net, env, B):
+        import torch
+        if not getattr(self.model, 'zero_slot_ready', False):
+            z = torch.zeros((1, net.L), dtype=torch.int32, device=env.device)
+            for s in range(1, net.S):
+                net.encode(s, z, B)                         # the constant [0] sequence: ONE shared slot (index B)
+            self.model.zero_slot_ready = True
+
+    def _seq_slots_own(self, env, B):
+        """SeqSlate from the second page on: every env's second sequence input has a slot of its own (rows 1.. of the slot table,
+        in place - the fused step holds the table's address)."""
+        import torch
+        if not getattr(self, '_seq_tab_own', True):
+            self._slots[1][1:] = torch.arange(B, dtype=torch.int32, device=env.device)
+            self._seq_tab_own = True
 
     # -- obs -----------------------------------------------------------------------------------
     def obs_fn(self, state):
@@ -650,7 +672,9 @@ class SlateRecEnv(RecSimBase):
         if not self._fused_ok(samples):
             return RecSimBase._step(self, samples, action, **kwargs)
         env, net, stepper = self._stepper_for(samples)
-        first_of_page = samples.is_seq and env.cur_steps % samples.page_items == 0
+        first_of_page = samples.is_seq and env.cur_steps > 0 and env.cur_steps % samples.page_items == 0      # (the first page starts with the [0] it had at reset)
+        if first_of_page:
+            self._seq_slots_own(env, self.batch_size)       # the library re-encodes every env's second input into its own slot
         conti = bool(self.config.get("support_conti_env", False))
         last = kwargs['step'] >= self.max_steps - 1
         masked = self.config.get("support_rllib_mask", False)
